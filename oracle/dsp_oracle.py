@@ -1,0 +1,537 @@
+"""CPU oracle for the batched spectral hot path -- TEST INFRASTRUCTURE ONLY.
+
+This module is a numpy/scipy float64 restatement of the reference algorithms
+(dsptoolbox 0.8, read-only at /root/reference).  It is the *checker* for the
+HIP product path and the `cpu_baseline` leg of bench.py.  Nothing under
+`dsptoolbox_amd/` may import it; only `tests/`, `__graft_entry__.smoke()` and
+`bench.py --cpu-baseline` do.
+
+Parity status: PINNED.  Every function below is compared against outputs of
+the real reference (imported in the build container by `oracle/gen_golden.py`)
+stored in `tests/golden/*.npz`; see `tests/test_oracle_golden.py`.
+
+Each function cites the reference file:line it follows.  Plain ndarrays in,
+plain ndarrays out; scalings are passed by *name* ("FFTBackward", ...) so the
+oracle does not depend on the product's enums.
+"""
+
+from __future__ import annotations
+
+import numpy as np
+from scipy.fft import next_fast_len, rfft as sp_rfft
+from scipy.signal import oaconvolve
+from scipy.signal.windows import get_window
+
+AMPLITUDE_SCALINGS = (
+    "AmplitudeSpectrum",
+    "AmplitudeSpectralDensity",
+    "FFTBackward",
+    "FFTForward",
+    "FFTOrthogonal",
+)
+PHYSICAL_SCALINGS = (
+    "AmplitudeSpectrum",
+    "AmplitudeSpectralDensity",
+    "PowerSpectrum",
+    "PowerSpectralDensity",
+)
+ALL_SCALINGS = AMPLITUDE_SCALINGS + ("PowerSpectrum", "PowerSpectralDensity")
+
+
+# --------------------------------------------------------------------------
+# scaling algebra  (dsptoolbox/standard/enums.py:21-229)
+# --------------------------------------------------------------------------
+def fft_norm(scaling: str) -> str:
+    """enums.py:53-75"""
+    if scaling == "FFTForward":
+        return "forward"
+    if scaling == "FFTOrthogonal":
+        return "ortho"
+    return "backward"
+
+
+def is_amplitude_scaling(scaling: str) -> bool:
+    """enums.py:77-92"""
+    return scaling in AMPLITUDE_SCALINGS
+
+
+def has_physical_units(scaling: str) -> bool:
+    """enums.py:109-123"""
+    return scaling in PHYSICAL_SCALINGS
+
+
+def get_scaling_factor(scaling: str, length: int, fs_hz: int, window):
+    """enums.py:183-229 (returns an array, like the reference)."""
+    if scaling == "FFTBackward":
+        return np.atleast_1d(1.0)
+    if scaling == "FFTForward":
+        return np.atleast_1d(1.0 / length)
+    if scaling == "FFTOrthogonal":
+        return np.atleast_1d((1.0 / length) ** 0.5)
+    if scaling in ("AmplitudeSpectralDensity", "PowerSpectralDensity"):
+        if window is None:
+            factor = (2 / length / fs_hz) ** 0.5
+        else:
+            factor = (2 / np.sum(window**2, axis=0, keepdims=True) / fs_hz) ** 0.5
+    else:
+        if window is None:
+            factor = 2**0.5 / length
+        else:
+            factor = 2**0.5 / np.sum(window, axis=0, keepdims=True)
+    if is_amplitude_scaling(scaling):
+        return np.atleast_1d(factor)
+    return np.atleast_1d(factor**2.0)
+
+
+def conversion_factor(src: str, dst: str, length: int, fs_hz: int, window):
+    """enums.py:141-181"""
+    fin = get_scaling_factor(src, length, fs_hz, window).astype(np.float64)
+    fout = get_scaling_factor(dst, length, fs_hz, window).astype(np.float64)
+    if not (is_amplitude_scaling(src) ^ is_amplitude_scaling(dst)):
+        return fout / fin
+    if is_amplitude_scaling(src):
+        fin = fin**2.0
+    else:
+        fout = fout**2.0
+    return fout / fin
+
+
+# --------------------------------------------------------------------------
+# framing  (helpers/other.py:181-259, standard/_framed_signal_representation.py:9-67)
+# --------------------------------------------------------------------------
+def compute_number_frames(window_length: int, step: int, signal_length: int,
+                          zero_padding: bool):
+    """helpers/other.py:181-213"""
+    if zero_padding:
+        n_frames = int(np.ceil(signal_length / step))
+        padding = window_length - int(signal_length % step)
+    else:
+        padding = 0
+        n_frames = int(np.ceil((signal_length - window_length) / step))
+    return n_frames, padding
+
+
+def get_framed_signal(td: np.ndarray, window_length: int, step: int,
+                      keep_last_frames: bool = True) -> np.ndarray:
+    """_framed_signal_representation.py:9-67 -> (W, F, C) float64 copy."""
+    assert td.ndim == 2
+    n_frames, pad = compute_number_frames(window_length, step, td.shape[0],
+                                          keep_last_frames)
+    tdp = np.concatenate([td, np.zeros((pad, td.shape[1]))], axis=0)
+    idx = np.arange(window_length)[:, None] + step * np.arange(n_frames)[None, :]
+    return tdp[idx, :].astype(np.float64, copy=True)
+
+
+# --------------------------------------------------------------------------
+# Welch  (standard/_spectral_methods.py:10-173)
+# --------------------------------------------------------------------------
+def welch(x, y, fs_hz: int, window_spec, window_length_samples: int,
+          overlap_percent: float, detrend: bool, average: str, scaling: str):
+    """Auto (y is None) or cross spectrum.  x,y: (N,) or (N,C)."""
+    auto = y is None
+    x = np.asarray(x, dtype=np.float64).squeeze()
+    if not auto:
+        y = np.asarray(y, dtype=np.float64).squeeze()
+        assert x.shape == y.shape
+    multi = x.ndim == 2
+    assert window_length_samples in [2**k for k in range(3, 19)]
+    assert 0 <= overlap_percent < 100
+    assert average in ("mean", "median")
+    window = get_window(window_spec, window_length_samples, fftbins=True)
+    overlap = int(overlap_percent / 100 * window_length_samples)  # :106 truncation
+    step = window_length_samples - overlap
+    if not multi:
+        x = x[:, None]
+        if not auto:
+            y = y[:, None]
+    xf = get_framed_signal(x, window_length_samples, step) * window[:, None, None]
+    if detrend:  # :136-139, AFTER windowing
+        xf = xf - np.mean(xf, axis=0)
+    X = np.fft.rfft(xf, axis=0, norm=fft_norm(scaling))
+    if auto:
+        sp = np.abs(X) ** 2.0
+    else:
+        yf = get_framed_signal(y, window_length_samples, step) * window[:, None, None]
+        if detrend:
+            yf = yf - np.mean(yf, axis=0)
+        sp = X.conjugate() * np.fft.rfft(yf, axis=0, norm=fft_norm(scaling))
+    if average == "mean":
+        csd = np.mean(sp, axis=1)
+    else:  # :153-162
+        csd = np.median(sp.real, axis=1) + 1j * np.median(sp.imag, axis=1)
+        n = sp.shape[1] if sp.shape[1] % 2 == 1 else sp.shape[1] - 1
+        csd = csd / np.sum((-1) ** (n + 1) / n)
+    if has_physical_units(scaling):  # :165-168
+        csd = csd * get_scaling_factor(scaling, window_length_samples, fs_hz, window)
+        csd[np.array([0, -1]), ...] /= 2
+    if is_amplitude_scaling(scaling):  # :170-171
+        csd = np.sqrt(csd)
+    if not multi:
+        csd = csd[:, 0]
+    return csd
+
+
+def compute_transfer_function(y, x, fs_hz: int, window_length_samples: int,
+                              mode: str, window_spec="hann",
+                              overlap_percent: float = 50.0, detrend: bool = True,
+                              average: str = "mean", scaling: str = "FFTBackward"):
+    """transfer_functions/transfer_functions.py:419-539.
+    y: (N,Cy) output, x: (N,1) or (N,Cy) input.  Returns (tf complex128 (B,Cy),
+    coherence float64 (B,Cy)).  Keeps the reference's per-channel loop."""
+    y = np.asarray(y, dtype=np.float64)
+    x = np.asarray(x, dtype=np.float64)
+    assert x.shape[0] == y.shape[0]
+    multichannel = x.shape[1] == 1
+    if not multichannel:
+        assert x.shape[1] == y.shape[1]
+    kw = dict(fs_hz=fs_hz, window_spec=window_spec,
+              window_length_samples=window_length_samples,
+              overlap_percent=overlap_percent, detrend=detrend, average=average,
+              scaling=scaling)
+    B = window_length_samples // 2 + 1
+    tf = np.zeros((B, y.shape[1]), dtype=np.complex128)
+    coh = np.zeros((B, y.shape[1]))
+    if multichannel:
+        G_xx = welch(x[:, 0], None, **kw)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        for n in range(y.shape[1]):
+            G_yy = welch(y[:, n], None, **kw)
+            ni = 0 if multichannel else n
+            if not multichannel:
+                G_xx = welch(x[:, ni], None, **kw)
+            if mode == "H2":
+                G_yx = welch(y[:, n], x[:, ni], **kw)
+            G_xy = welch(x[:, ni], y[:, n], **kw)
+            if mode == "H1":
+                tf[:, n] = G_xy / G_xx
+            elif mode == "H2":
+                tf[:, n] = G_yy / G_yx
+            elif mode == "H3":
+                tf[:, n] = G_xy / np.abs(G_xy) * (G_yy / G_xx) ** 0.5
+            else:
+                raise ValueError("Unsupported transfer function type")
+            coh[:, n] = np.abs(G_xy) ** 2 / G_xx / G_yy
+    return tf, coh
+
+
+def compute_transfer_function_batched(y, x, fs_hz, window_length_samples, mode,
+                                      window_spec="hann", overlap_percent=50.0,
+                                      detrend=True, scaling="FFTBackward",
+                                      workers=1):
+    """Same numbers as compute_transfer_function (mean average only) but with
+    one framing + one rFFT batch per signal; used as the multi-core CPU
+    baseline.  Checked against the per-channel form in tests."""
+    y = np.asarray(y, dtype=np.float64)
+    x = np.asarray(x, dtype=np.float64)
+    W = window_length_samples
+    window = get_window(window_spec, W, fftbins=True)
+    step = W - int(overlap_percent / 100 * W)
+
+    def spec(sig):
+        f = get_framed_signal(sig, W, step) * window[:, None, None]
+        if detrend:
+            f -= np.mean(f, axis=0)
+        return sp_rfft(f, axis=0, norm=fft_norm(scaling), workers=workers)
+
+    X, Y = spec(x), spec(y)
+
+    def finish(S):
+        if has_physical_units(scaling):
+            S = S * get_scaling_factor(scaling, W, fs_hz, window)
+            S[np.array([0, -1]), ...] /= 2
+        return np.sqrt(S) if is_amplitude_scaling(scaling) else S
+
+    G_xx = finish(np.mean(np.abs(X) ** 2, axis=1))
+    G_yy = finish(np.mean(np.abs(Y) ** 2, axis=1))
+    G_xy = finish(np.mean(X.conj() * Y, axis=1).astype(np.complex128))
+    with np.errstate(divide="ignore", invalid="ignore"):
+        if mode == "H1":
+            tf = G_xy / G_xx
+        elif mode == "H2":
+            tf = G_yy / finish(np.mean(Y.conj() * X, axis=1).astype(np.complex128))
+        elif mode == "H3":
+            tf = G_xy / np.abs(G_xy) * (G_yy / G_xx) ** 0.5
+        else:
+            raise ValueError("Unsupported transfer function type")
+        coh = np.abs(G_xy) ** 2 / G_xx / G_yy
+    return tf, coh
+
+
+# --------------------------------------------------------------------------
+# STFT  (standard/_spectral_methods.py:176-282)
+# --------------------------------------------------------------------------
+def stft(x, fs_hz: int, window_length_samples: int, window_spec,
+         overlap_percent: float, fft_length_samples, detrend: bool,
+         padding: bool, scaling: str):
+    x = np.asarray(x, dtype=np.float64)
+    assert window_length_samples in [2**k for k in range(4, 17)]
+    assert 0 <= overlap_percent < 100
+    if fft_length_samples is None:
+        fft_length_samples = window_length_samples
+    window = get_window(window_spec, window_length_samples, fftbins=True)
+    overlap = int(overlap_percent / 100 * window_length_samples + 0.5)  # :247 rounding
+    step = window_length_samples - overlap
+    if padding:
+        x = np.pad(x, ((overlap, overlap), (0, 0)))
+    tx = get_framed_signal(x, window_length_samples, step, True)
+    tx *= window[:, None, None]
+    if detrend:
+        tx -= np.mean(tx, axis=0)
+    out = np.fft.rfft(tx, axis=0, n=fft_length_samples, norm=fft_norm(scaling))
+    if has_physical_units(scaling):  # :271-278
+        out[0, ...] /= 2**0.5
+        if fft_length_samples % 2 == 0:
+            out[-1, ...] /= 2**0.5
+        factor = get_scaling_factor(scaling, fft_length_samples, fs_hz, window)
+        if not is_amplitude_scaling(scaling):
+            out = np.abs(out) ** 2.0
+        out = out * factor
+    time_s = np.linspace(0, len(x) / fs_hz, out.shape[1])
+    freqs_hz = np.fft.rfftfreq(len(window), 1 / fs_hz)
+    return time_s, freqs_hz, out
+
+
+# --------------------------------------------------------------------------
+# CSM  (standard/_spectral_methods.py:285-443)
+# --------------------------------------------------------------------------
+def csm_welch(td, fs_hz: int, window_length_samples: int, window_spec,
+              overlap_percent: float, detrend: bool, average: str, scaling: str):
+    """Reference-faithful pair loop (:351-369)."""
+    td = np.asarray(td, dtype=np.float64)
+    C = td.shape[1]
+    csm = np.zeros((window_length_samples // 2 + 1, C, C), dtype=np.complex128)
+    for i1 in range(C):
+        for i2 in range(i1, C):
+            csm[:, i2, i1] = welch(td[:, i1], td[:, i2] if i1 != i2 else None,
+                                   fs_hz, window_spec, window_length_samples,
+                                   overlap_percent, detrend, average, scaling)
+            if i1 == i2:
+                csm[:, i1, i2] *= 0.5
+    csm += np.swapaxes(csm, 1, 2).conjugate()
+    f = np.fft.rfftfreq(window_length_samples, 1 / fs_hz)
+    return f, csm
+
+
+def csm_welch_batched(td, fs_hz, window_length_samples, window_spec,
+                      overlap_percent, detrend, scaling, workers=1):
+    """(1/F) sum_f x x^H per bin + the same finish as welch(); equals csm_welch
+    (mean average) -- checked in tests.  Multi-core CPU baseline."""
+    td = np.asarray(td, dtype=np.float64)
+    W = window_length_samples
+    window = get_window(window_spec, W, fftbins=True)
+    step = W - int(overlap_percent / 100 * W)
+    fr = get_framed_signal(td, W, step) * window[:, None, None]
+    if detrend:
+        fr -= np.mean(fr, axis=0)
+    X = sp_rfft(fr, axis=0, norm=fft_norm(scaling), workers=workers)  # (B,F,C)
+    # csm[b, i2, i1] = mean_f conj(X[b,f,i1]) X[b,f,i2]
+    S = np.einsum("bfi,bfj->bji", X.conj(), X) / X.shape[1]
+    if has_physical_units(scaling):
+        S = S * get_scaling_factor(scaling, W, fs_hz, window)
+        S[np.array([0, -1]), ...] /= 2
+    if is_amplitude_scaling(scaling):
+        # the reference takes sqrt of the lower triangle (i2 >= i1) and mirrors
+        # its conjugate; for a Hermitian S this equals the element-wise
+        # principal root except on the negative real axis.
+        low = np.tril(np.ones(S.shape[1:], dtype=bool))
+        R = np.where(low[None], np.sqrt(S), 0)
+        d = np.einsum("bii->bi", R).copy()
+        R = R + np.swapaxes(R, 1, 2).conjugate()
+        np.einsum("bii->bi", R)[...] = d
+        S = R
+    return np.fft.rfftfreq(W, 1 / fs_hz), S
+
+
+def csm_fft(spectrum, scaling: str, window, fs_hz: int):
+    """_spectral_methods.py:374-443; `spectrum` is the FFTBackward rFFT (B,C)."""
+    spectrum = np.asarray(spectrum, dtype=np.complex128)
+    C = spectrum.shape[1]
+    csm = np.zeros((spectrum.shape[0], C, C), dtype=np.complex128)
+    for i1 in range(C):
+        for i2 in range(i1, C):
+            csm[:, i2, i1] = spectrum[:, i1].conjugate() * spectrum[:, i2]
+            if i1 == i2:
+                csm[:, i1, i2] *= 0.5
+    csm += np.swapaxes(csm, 1, 2).conjugate()
+    if scaling == "FFTBackward":
+        return csm
+    csm[np.array([0, -1]), ...] /= 2.0
+    # NOTE reference passes `spectrum.shape[0] // 2 + 1` as the length (:436)
+    factor = conversion_factor("FFTBackward", scaling, spectrum.shape[0] // 2 + 1,
+                               fs_hz, window)[:, None]
+    factor = np.repeat(factor, C, axis=-1)
+    csm *= factor[None, ...]
+    if is_amplitude_scaling(scaling):
+        csm = np.sqrt(csm)
+    return csm
+
+
+# --------------------------------------------------------------------------
+# whole-signal spectrum (classes/signal.py:899-938, helpers/spectrum_utilities.py:268-328)
+# --------------------------------------------------------------------------
+def spectrum_fft(td, fs_hz: int, scaling: str = "FFTBackward",
+                 pad_to_fast_length: bool = True):
+    td = np.asarray(td, dtype=np.float64)
+    n = next_fast_len(td.shape[0], True) if pad_to_fast_length else td.shape[0]
+    sp = sp_rfft(td, axis=0, norm=fft_norm(scaling), n=n)
+    if has_physical_units(scaling):
+        factor = get_scaling_factor(scaling, n, fs_hz, None)
+        sp[0] /= 2**0.5
+        if n % 2 == 0:
+            sp[-1] /= 2**0.5
+        if not is_amplitude_scaling(scaling):
+            sp = np.abs(sp) ** 2
+        sp = sp * factor
+    return np.fft.rfftfreq(n, 1 / fs_hz), sp
+
+
+# --------------------------------------------------------------------------
+# spectral deconvolution
+# --------------------------------------------------------------------------
+def to_db(x, amplitude_input: bool):
+    """helpers/gain_and_level.py:158-200 (default clipping)."""
+    factor = 20.0 if amplitude_input else 10.0
+    tiny = float(np.finfo(np.float64).smallest_normal)
+    return factor * np.log10(np.clip(np.abs(x), a_min=tiny, a_max=None))
+
+
+def find_frequencies_above_threshold(spec, f, threshold_db):
+    """helpers/other.py:34-41"""
+    d = to_db(spec, True)
+    d = d - np.max(d)
+    fr = f[d > threshold_db]
+    return [fr[0], fr[-1]]
+
+
+def find_nearest_points_index_in_vector(points, vector):
+    """helpers/other.py:9-31"""
+    points = np.atleast_1d(np.array(points))
+    return np.array([np.argmin(np.abs(p - vector)) for p in points], dtype=np.int_)
+
+
+def tukey_like_window_hann(points, window_length: int, inverse: bool):
+    """helpers/windows.py:8-76 with Window.Hann, at_start=True."""
+    i0, i1, i2, i3 = [int(i) for i in points]
+    nl = i1 - i0
+    low = get_window("hann", nl * 2, fftbins=True)[:nl] if nl > 0 else np.ones(nl)
+    nh = i3 - i2
+    high = get_window("hann", nh * 2, fftbins=True)[nh:] if nh > 1 else np.ones(nh)
+    w = np.concatenate((np.zeros(i0), low, np.ones(i2 - i1), high,
+                        np.zeros(window_length - i3)))
+    return 1 - w if inverse else w
+
+
+def regularization_eps(denum_fft_ch0, freqs_hz, fs_hz, start_stop_hz, threshold_db):
+    """transfer_functions.py:152-167 + _transfer_functions.py:31-35.
+    Returns (eps (B,), start_stop_hz (4,))."""
+    if start_stop_hz is None:
+        start_stop_hz = find_frequencies_above_threshold(denum_fft_ch0, freqs_hz,
+                                                         threshold_db)
+    if len(start_stop_hz) == 2:
+        start_stop_hz = np.array([
+            start_stop_hz[0] / np.sqrt(2), start_stop_hz[0], start_stop_hz[1],
+            np.min([start_stop_hz[1] * np.sqrt(2), fs_hz / 2])])
+    elif len(start_stop_hz) != 4:
+        raise ValueError("start_stop_hz vector should have 2 or 4 values")
+    ids = find_nearest_points_index_in_vector(start_stop_hz, freqs_hz)
+    eps = tukey_like_window_hann(ids, len(freqs_hz), True) * 10 ** (30 / 20)
+    return eps, np.asarray(start_stop_hz)
+
+
+def spectral_deconvolve(y, x, fs_hz: int, apply_regularization: bool = True,
+                        start_stop_hz=None, threshold_db: float = -30.0,
+                        padding: bool = False, keep_original_length: bool = False):
+    """transfer_functions.py:61-184 with default spectrum parameters
+    (FFTBackward, pad_to_fast_length=True).  y (N,C); x (N,1|C) -> (N|2N, C)."""
+    y = np.asarray(y, dtype=np.float64)
+    x = np.asarray(x, dtype=np.float64)
+    assert y.shape[0] == x.shape[0]
+    multichannel = x.shape[1] == 1
+    if not multichannel:
+        assert x.shape[1] == y.shape[1]
+    if not apply_regularization:
+        assert start_stop_hz is None
+    N0 = y.shape[0]
+    if padding:
+        y = np.concatenate([y, np.zeros_like(y)], axis=0)
+        x = np.concatenate([x, np.zeros_like(x)], axis=0)
+    L = next_fast_len(y.shape[0], True)
+    den = sp_rfft(x, axis=0, n=L)
+    num = sp_rfft(y, axis=0, n=L)
+    freqs = np.fft.rfftfreq(L, 1 / fs_hz)
+    nt = y.shape[0]
+    out = np.zeros_like(y)
+    eps = None
+    for n in range(y.shape[1]):
+        nd = 0 if multichannel else n
+        if apply_regularization:
+            if eps is None:  # band derived ONCE, from the first denominator used
+                eps, start_stop_hz = regularization_eps(den[:, nd], freqs, fs_hz,
+                                                        start_stop_hz, threshold_db)
+            reg = den[:, nd].conj() / (np.abs(den[:, nd]) ** 2 + eps)
+            out[:, n] = np.fft.irfft(num[:, n] * reg, n=nt)
+        else:
+            out[:, n] = np.fft.irfft(np.divide(num[:, n], den[:, nd]), n=nt)
+    if padding and keep_original_length:
+        out = out[:N0]
+    return out
+
+
+# --------------------------------------------------------------------------
+# FIR filtering (classes/filter_helpers.py:288-503)
+# --------------------------------------------------------------------------
+def lfilter_fir(b, x):
+    """filter_helpers.py:454-503 without zi: oaconvolve(...)[:N]."""
+    b = np.asarray(b, dtype=np.float64).squeeze()
+    x = np.asarray(x, dtype=np.float64)
+    if x.ndim < 2:
+        x = x[:, None]
+    return oaconvolve(x, b[:, None], mode="full", axes=0)[: x.shape[0], :]
+
+
+def filter_fir_on_channels(b, td, channels=None):
+    """filter_helpers.py:288-382 FIR branch: selected channels filtered, the
+    rest bypassed."""
+    td = np.asarray(td, dtype=np.float64)
+    out = td.copy()
+    if channels is None:
+        channels = np.arange(td.shape[1])
+    channels = np.atleast_1d(channels)
+    out[:, channels] = lfilter_fir(b, td[:, channels])
+    return out
+
+
+def filterbank_fir(taps_list, td, mode: str):
+    """filter_helpers.py:385-451.  Parallel -> (N, C, K) stack of band outputs;
+    Sequential / Summed -> (N, C)."""
+    td = np.asarray(td, dtype=np.float64)
+    if mode == "Parallel":
+        return np.stack([lfilter_fir(b, td) for b in taps_list], axis=-1)
+    if mode == "Sequential":
+        out = td.copy()
+        for b in taps_list:
+            out = lfilter_fir(b, out)
+        return out
+    if mode == "Summed":
+        acc = np.zeros((td.shape[0], td.shape[1], len(taps_list)))
+        for n, b in enumerate(taps_list):
+            acc[:, :, n] = lfilter_fir(b, td)
+        return np.sum(acc, axis=-1)
+    raise ValueError("Invalid filter bank apply mode")
+
+
+# --------------------------------------------------------------------------
+# parity metrics (max-norm relative and relative L2)
+# --------------------------------------------------------------------------
+def rel_max(a, b) -> float:
+    a = np.asarray(a)
+    b = np.asarray(b)
+    den = float(np.max(np.abs(b)))
+    return float(np.max(np.abs(a - b))) / (den if den > 0 else 1.0)
+
+
+def rel_l2(a, b) -> float:
+    a = np.asarray(a)
+    b = np.asarray(b)
+    den = float(np.linalg.norm(b.ravel()))
+    return float(np.linalg.norm((a - b).ravel())) / (den if den > 0 else 1.0)

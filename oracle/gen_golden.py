@@ -1,0 +1,312 @@
+"""Generate golden vectors by RUNNING THE REFERENCE (dsptoolbox 0.8).
+
+Runs only in the build container, where /root/reference exists.  The reference
+never travels: only the seeded inputs and the outputs it produced are written,
+as small .npz fixtures under tests/golden/.  Re-run with
+
+    python oracle/gen_golden.py
+
+Recorded skew: the reference pins numpy~=2.4 / scipy~=1.17 and python>=3.11;
+this container has python 3.10, numpy 2.2.6, scipy 1.15.3.  The import recipe
+is SURVEY.md section 8(c): alias typing.Self, register placeholder modules for the
+absent audio-IO / plotting packages (never touched by the hot path).
+"""
+
+from __future__ import annotations
+
+import json
+import os
+import sys
+
+import numpy as np
+
+REF = "/root/reference"
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
+
+
+def import_reference():
+    import typing
+    from unittest.mock import MagicMock
+
+    import typing_extensions
+
+    sys.dont_write_bytecode = True
+    typing.Self = typing_extensions.Self
+    for m in ("soundfile", "sounddevice", "seaborn"):
+        sys.modules[m] = MagicMock()
+    import matplotlib
+
+    matplotlib.use("Agg")
+    sys.path.insert(0, REF)
+    import dsptoolbox as dsp
+
+    return dsp
+
+
+def save(name, meta, arrays):
+    os.makedirs(OUT, exist_ok=True)
+    meta = dict(meta)
+    meta["generator"] = "oracle/gen_golden.py"
+    meta["reference"] = "dsptoolbox 0.8 source @ /root/reference"
+    import scipy
+
+    meta["numpy"] = np.__version__
+    meta["scipy"] = scipy.__version__
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, meta=np.array(json.dumps(meta)), **arrays)
+    print(f"{name}: {os.path.getsize(path) / 1024:.1f} KiB, {len(meta['cases'])} cases")
+
+
+def main():
+    dsp = import_reference()
+    from dsptoolbox.standard._spectral_methods import _welch
+    from dsptoolbox.standard._framed_signal_representation import _get_framed_signal
+    from dsptoolbox.helpers.other import _compute_number_frames
+    from dsptoolbox.standard.enums import (SpectrumScaling, SpectrumMethod, Window,
+                                           FilterBankMode, FilterPassType)
+    from dsptoolbox.transfer_functions.enums import TransferFunctionType
+
+    S = SpectrumScaling
+    fs = 48000
+    import warnings
+
+    warnings.simplefilter("ignore")
+
+    # ------------------------------------------------------------ framing
+    cases, arrs = [], {}
+    rng = np.random.default_rng(11)
+    for i, (N, W, hop, keep) in enumerate([(1000, 64, 32, True), (1024, 64, 32, True),
+                                           (1000, 64, 48, True), (1000, 64, 32, False),
+                                           (130, 128, 64, True), (777, 256, 64, False)]):
+        x = rng.standard_normal((N, 2))
+        fr = _get_framed_signal(x.copy(), W, hop, keep)
+        nf, pad = _compute_number_frames(W, hop, N, keep)
+        cases.append(dict(N=N, W=W, hop=hop, keep=keep, n_frames=int(nf), pad=int(pad)))
+        arrs[f"in_{i}"] = x
+        arrs[f"out_{i}"] = fr
+    save("framing", dict(cases=cases), arrs)
+
+    # ------------------------------------------------------------ welch
+    rng = np.random.default_rng(12)
+    xw = rng.standard_normal((16384, 3)) * 0.3
+    xw[:, 1] += 0.25  # DC offset exercises detrend
+    xw[:, 2] = np.convolve(xw[:, 0], rng.standard_normal(32) * 0.3)[:16384] + 0.01 * xw[:, 2]
+    xr = xw[:10000]  # ragged: N % hop != 0
+    cases, arrs = [], {"x": xw}
+    combos = []
+    for sc in S:
+        combos.append((1024, 50, True, "mean", sc, "hann", "full"))
+    combos += [
+        (256, 0, True, "mean", S.FFTBackward, "hann", "full"),
+        (256, 75, False, "mean", S.PowerSpectralDensity, "hann", "full"),
+        (256, 50, False, "mean", S.FFTBackward, "hamming", "full"),
+        (1024, 33, True, "mean", S.AmplitudeSpectrum, "blackman", "ragged"),
+        (1024, 50, True, "mean", S.FFTBackward, "hann", "ragged"),
+        (512, 50, False, "mean", S.PowerSpectrum, "boxcar", "ragged"),
+        (1024, 50, True, "median", S.FFTBackward, "hann", "full"),
+        (256, 50, False, "median", S.PowerSpectralDensity, "hann", "ragged"),
+        (4096, 50, True, "mean", S.FFTBackward, "hann", "full"),
+        (8, 50, True, "mean", S.FFTBackward, "hann", "ragged"),
+    ]
+    wmap = {"hann": Window.Hann, "hamming": Window.Hamming, "blackman": Window.Blackman,
+            "boxcar": Window.Boxcar}
+    for i, (W, ov, det, avg, sc, win, which) in enumerate(combos):
+        data = xw if which == "full" else xr
+        auto = _welch(data.copy(), None, fs, wmap[win], W, ov, det, avg, sc)
+        cross = _welch(data[:, 0].copy(), data[:, 2].copy(), fs, wmap[win], W, ov, det, avg, sc)
+        cases.append(dict(W=W, overlap=ov, detrend=det, average=avg, scaling=sc.name,
+                          window=win, data=which))
+        arrs[f"auto_{i}"] = auto
+        arrs[f"cross_{i}"] = cross
+    save("welch", dict(cases=cases, fs=fs, ragged_len=10000,
+                       cross="x[:,0] vs x[:,2]"), arrs)
+
+    # ------------------------------------------------------------ transfer functions
+    rng = np.random.default_rng(13)
+    N = 8000
+    xin = rng.standard_normal((N, 3)) * 0.2
+    h = rng.standard_normal((3, 24)) * np.exp(-np.arange(24) / 6.0)
+    yout = np.stack([np.convolve(xin[:, c], h[c])[:N] for c in range(3)], axis=1)
+    yout += 0.02 * rng.standard_normal((N, 3))
+    y1 = np.stack([np.convolve(xin[:, 0], h[c])[:N] for c in range(3)], axis=1)
+    y1 += 0.02 * rng.standard_normal((N, 3))
+    cases, arrs = [], {"x": xin, "y_multi": yout, "y_single": y1}
+    i = 0
+    for mode in TransferFunctionType:
+        for sc in (S.FFTBackward, S.PowerSpectralDensity, S.AmplitudeSpectrum, S.PowerSpectrum):
+            for single in (True, False):
+                for det, ov, W in ((True, 50, 512), (False, 75, 256)):
+                    inp = dsp.Signal(None, xin[:, :1].copy() if single else xin.copy(), fs)
+                    out = dsp.Signal(None, (y1 if single else yout).copy(), fs)
+                    inp.set_spectrum_parameters(window_length_samples=1024,
+                                                window_type=Window.Hann, overlap_percent=ov,
+                                                detrend=det, average="mean", scaling=sc)
+                    sp = dsp.transfer_functions.compute_transfer_function(out, inp, W, mode)
+                    cases.append(dict(mode=mode.name, scaling=sc.name, single_input=single,
+                                      detrend=det, overlap=ov, W=W))
+                    arrs[f"f_{i}"] = np.asarray(sp.frequency_vector_hz)
+                    arrs[f"tf_{i}"] = np.asarray(sp.spectral_data)
+                    arrs[f"coh_{i}"] = np.asarray(sp.coherence)
+                    i += 1
+    save("transfer_function", dict(cases=cases, fs=fs), arrs)
+
+    # ------------------------------------------------------------ stft
+    rng = np.random.default_rng(14)
+    xs = rng.standard_normal((3000, 2)) * 0.4 + 0.1
+    cases, arrs = [], {"x": xs}
+    combos = [(256, 50, None, False, True, sc) for sc in S]
+    combos += [
+        (256, 50, None, False, False, S.FFTBackward),
+        (256, 75, 512, False, True, S.FFTBackward),
+        (256, 33, 128, True, True, S.FFTBackward),
+        (128, 0, None, True, False, S.AmplitudeSpectralDensity),
+        (1024, 50, 2048, False, True, S.PowerSpectrum),
+        (16, 50, None, False, True, S.FFTBackward),
+    ]
+    for i, (W, ov, nfft, det, pad, sc) in enumerate(combos):
+        s = dsp.Signal(None, xs.copy(), fs)
+        s.set_spectrogram_parameters(window_length_samples=W, window_type=Window.Hann,
+                                     overlap_percent=ov, fft_length_samples=nfft,
+                                     detrend=det, padding=pad, scaling=sc)
+        t, f, st = s.get_spectrogram()
+        cases.append(dict(W=W, overlap=ov, fft_length=nfft, detrend=det, padding=pad,
+                          scaling=sc.name))
+        arrs[f"t_{i}"] = t
+        arrs[f"f_{i}"] = f
+        arrs[f"stft_{i}"] = st
+    save("stft", dict(cases=cases, fs=fs), arrs)
+
+    # ------------------------------------------------------------ csm
+    rng = np.random.default_rng(15)
+    common = rng.standard_normal(4096)
+    xc = 0.1 * rng.standard_normal((4096, 5)) + 0.2 * common[:, None]
+    cases, arrs = [], {"x": xc}
+    combos = [("welch", 256, 50, True, sc) for sc in S]
+    combos += [("welch", 512, 75, False, S.FFTBackward), ("welch", 64, 0, False, S.PowerSpectralDensity)]
+    combos += [("fft", None, None, None, sc) for sc in (S.FFTBackward, S.PowerSpectralDensity,
+                                                       S.AmplitudeSpectrum)]
+    for i, (meth, W, ov, det, sc) in enumerate(combos):
+        s = dsp.Signal(None, xc.copy() if meth == "welch" else xc[:1000, :3].copy(), fs)
+        if meth == "welch":
+            s.set_spectrum_parameters(method=SpectrumMethod.WelchPeriodogram,
+                                      window_length_samples=W, overlap_percent=ov, detrend=det,
+                                      scaling=sc)
+        else:
+            s.set_spectrum_parameters(method=SpectrumMethod.FFT, scaling=sc)
+        f, csm = s.get_csm()
+        cases.append(dict(method=meth, W=W, overlap=ov, detrend=det, scaling=sc.name,
+                          data="x" if meth == "welch" else "x[:1000,:3]"))
+        arrs[f"f_{i}"] = f
+        arrs[f"csm_{i}"] = csm
+    save("csm", dict(cases=cases, fs=fs), arrs)
+
+    # ------------------------------------------------------------ whole-signal spectrum
+    rng = np.random.default_rng(16)
+    xf = rng.standard_normal((3000, 2)) * 0.3
+    cases, arrs = [], {"x": xf}
+    i = 0
+    for sc in S:
+        for fast in (True, False):
+            s = dsp.Signal(None, xf[:2999].copy() if not fast else xf.copy(), fs)
+            s.set_spectrum_parameters(method=SpectrumMethod.FFT, scaling=sc,
+                                      pad_to_fast_length=fast)
+            f, sp = s.get_spectrum()
+            cases.append(dict(scaling=sc.name, pad_to_fast_length=fast,
+                              n=2999 if not fast else 3000))
+            arrs[f"f_{i}"] = f
+            arrs[f"sp_{i}"] = sp
+            i += 1
+    save("spectrum_fft", dict(cases=cases, fs=fs), arrs)
+
+    # ------------------------------------------------------------ deconvolution
+    rng = np.random.default_rng(17)
+    cases, arrs = [], {}
+
+    def sweep(n):
+        t = np.arange(n) / fs
+        T = n / fs
+        k = np.log(20000.0 / 20.0)
+        return 0.5 * np.sin(2 * np.pi * 20.0 * T / k * (np.exp(t / T * k) - 1.0))
+
+    for tag, n in (("p2", 4096), ("np2", 6000)):
+        xsw = sweep(n)
+        hh = rng.standard_normal((2, 64)) * np.exp(-np.arange(64) / 10.0)
+        yy = np.stack([np.convolve(xsw, hh[c])[:n] for c in range(2)], axis=1)
+        yy += 1e-3 * rng.standard_normal(yy.shape)
+        x2 = np.stack([xsw, 0.7 * sweep(n) + 1e-3 * rng.standard_normal(n)], axis=1)
+        arrs[f"x_{tag}"] = xsw[:, None]
+        arrs[f"x2_{tag}"] = x2
+        arrs[f"y_{tag}"] = yy
+    variants = [
+        dict(data="p2", den="mono", reg=True, ss=None, thr=-30.0, pad=False, keep=False),
+        dict(data="p2", den="multi", reg=True, ss=None, thr=-30.0, pad=False, keep=False),
+        dict(data="p2", den="mono", reg=True, ss=[100.0, 15000.0], thr=-30.0, pad=False, keep=False),
+        dict(data="p2", den="mono", reg=True, ss=[50.0, 100.0, 12000.0, 18000.0], thr=-30.0,
+             pad=False, keep=False),
+        dict(data="p2", den="mono", reg=False, ss=None, thr=-30.0, pad=False, keep=False),
+        dict(data="p2", den="mono", reg=True, ss=None, thr=-20.0, pad=True, keep=False),
+        dict(data="p2", den="mono", reg=False, ss=None, thr=-30.0, pad=True, keep=True),
+        dict(data="np2", den="mono", reg=True, ss=None, thr=-30.0, pad=False, keep=False),
+        dict(data="np2", den="multi", reg=False, ss=None, thr=-30.0, pad=True, keep=True),
+    ]
+    for i, v in enumerate(variants):
+        tag = v["data"]
+        inp = dsp.Signal(None, (arrs[f"x_{tag}"] if v["den"] == "mono" else arrs[f"x2_{tag}"]).copy(), fs)
+        out = dsp.Signal(None, arrs[f"y_{tag}"].copy(), fs)
+        ir = dsp.transfer_functions.spectral_deconvolve(
+            out, inp, apply_regularization=v["reg"], start_stop_hz=v["ss"],
+            threshold_db=v["thr"], padding=v["pad"], keep_original_length=v["keep"])
+        assert type(ir).__name__ == "ImpulseResponse"
+        cases.append(v)
+        arrs[f"ir_{i}"] = ir.time_data
+    save("deconvolve", dict(cases=cases, fs=fs), arrs)
+
+    # ------------------------------------------------------------ FIR / filter bank
+    rng = np.random.default_rng(18)
+    cases, arrs = [], {}
+    xa = rng.standard_normal((4096, 2)) * 0.1
+    xb = rng.standard_normal((30000, 2)) * 0.1
+    arrs["x_a"], arrs["x_b"] = xa, xb
+    i = 0
+    for order, cutoff, ptype in ((150, 3000.0, FilterPassType.Lowpass),
+                                 (4096, [500.0, 4000.0], FilterPassType.Bandpass)):
+        flt = dsp.Filter.fir_filter(order, cutoff, ptype, fs)
+        b = flt.ba[0]
+        for which, data in (("a", xa), ("b", xb)):
+            for ch in (None, [1]):
+                if which == "b" and ((order == 150) == (ch is None)):
+                    continue  # keep the fixture small
+                s = dsp.Signal(None, data.copy(), fs)
+                o = flt.filter_signal(s, channels=ch)
+                cases.append(dict(kind="filter", order=order, data=which,
+                                  channels=ch, taps_key=f"b_{order}"))
+                arrs[f"b_{order}"] = b
+                arrs[f"y_{i}"] = o.time_data
+                i += 1
+    # filter bank: three FIR band filters
+    bank_taps = []
+    flts = []
+    for (lo, hi) in ((100.0, 800.0), (800.0, 3000.0), (3000.0, 12000.0)):
+        f_ = dsp.Filter.fir_filter(300, [lo, hi], FilterPassType.Bandpass, fs)
+        flts.append(f_)
+        bank_taps.append(f_.ba[0])
+    arrs["bank_taps"] = np.stack(bank_taps)
+    fb = dsp.FilterBank(flts)
+    for mode in FilterBankMode:
+        s = dsp.Signal(None, xa.copy(), fs)
+        o = fb.filter_signal(s, mode)
+        if mode == FilterBankMode.Parallel:
+            td = o.get_all_time_data()[0] if isinstance(o.get_all_time_data(), tuple) else o.get_all_time_data()
+            arrs[f"y_{i}"] = np.asarray(td)
+            shape_note = "get_all_time_data()"
+        else:
+            arrs[f"y_{i}"] = o.time_data
+            shape_note = "time_data"
+        cases.append(dict(kind="bank", mode=mode.name, data="a", note=shape_note,
+                          out_type=type(o).__name__))
+        i += 1
+    save("fir", dict(cases=cases, fs=fs), arrs)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,143 @@
+"""The CPU oracle must reproduce the REAL reference's outputs (tests/golden/,
+made by oracle/gen_golden.py from dsptoolbox 0.8) to float64 rounding.  This is
+what pins the oracle; the GPU parity tests then compare the HIP path to it."""
+
+import numpy as np
+import pytest
+
+from oracle import dsp_oracle as orc
+from conftest import load_golden
+
+TOL = 5e-13  # float64 round-off; observed <= 1e-14
+
+
+def close(a, b, tol=TOL, skip_dc=False):
+    a, b = np.asarray(a), np.asarray(b)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    if skip_dc:
+        a, b = a[1:], b[1:]
+    fin = np.isfinite(b)
+    assert np.array_equal(fin, np.isfinite(a))
+    err = np.max(np.abs(a[fin] - b[fin])) / max(np.max(np.abs(b[fin])), 1e-300)
+    assert err < tol, err
+
+
+def test_framing():
+    meta, z = load_golden("framing")
+    for i, c in enumerate(meta["cases"]):
+        nf, pad = orc.compute_number_frames(c["W"], c["hop"], c["N"], c["keep"])
+        assert (nf, pad) == (c["n_frames"], c["pad"])
+        fr = orc.get_framed_signal(z[f"in_{i}"], c["W"], c["hop"], c["keep"])
+        assert np.array_equal(fr, z[f"out_{i}"])
+
+
+def test_welch():
+    meta, z = load_golden("welch")
+    x = z["x"]
+    for i, c in enumerate(meta["cases"]):
+        d = x if c["data"] == "full" else x[: meta["ragged_len"]]
+        a = orc.welch(d, None, meta["fs"], c["window"], c["W"], c["overlap"], c["detrend"],
+                      c["average"], c["scaling"])
+        k = orc.welch(d[:, 0], d[:, 2], meta["fs"], c["window"], c["W"], c["overlap"],
+                      c["detrend"], c["average"], c["scaling"])
+        # detrend makes the DC bin 0/0-type noise in the reference itself
+        close(a, z[f"auto_{i}"], skip_dc=c["detrend"])
+        close(k, z[f"cross_{i}"], skip_dc=c["detrend"])
+        assert a.dtype == z[f"auto_{i}"].dtype
+
+
+def test_transfer_function_both_forms():
+    meta, z = load_golden("transfer_function")
+    for i, c in enumerate(meta["cases"]):
+        x = z["x"][:, :1] if c["single_input"] else z["x"]
+        y = z["y_single"] if c["single_input"] else z["y_multi"]
+        kw = dict(window_spec="hann", overlap_percent=c["overlap"], detrend=c["detrend"],
+                  scaling=c["scaling"])
+        tf, coh = orc.compute_transfer_function(y, x, meta["fs"], c["W"], c["mode"],
+                                                average="mean", **kw)
+        close(tf, z[f"tf_{i}"], skip_dc=c["detrend"], tol=1e-11)
+        close(coh, z[f"coh_{i}"], skip_dc=c["detrend"], tol=1e-11)
+        tf2, coh2 = orc.compute_transfer_function_batched(y, x, meta["fs"], c["W"],
+                                                          c["mode"], **kw)
+        close(tf2, z[f"tf_{i}"], skip_dc=c["detrend"], tol=1e-11)
+        close(coh2, z[f"coh_{i}"], skip_dc=c["detrend"], tol=1e-11)
+        assert np.array_equal(np.fft.rfftfreq(c["W"], 1 / meta["fs"]), z[f"f_{i}"])
+
+
+def test_stft():
+    meta, z = load_golden("stft")
+    for i, c in enumerate(meta["cases"]):
+        t, f, s = orc.stft(z["x"], meta["fs"], c["W"], "hann", c["overlap"], c["fft_length"],
+                           c["detrend"], c["padding"], c["scaling"])
+        close(t, z[f"t_{i}"])
+        close(f, z[f"f_{i}"])
+        close(s, z[f"stft_{i}"])
+        assert s.dtype == z[f"stft_{i}"].dtype
+
+
+def test_csm():
+    meta, z = load_golden("csm")
+    for i, c in enumerate(meta["cases"]):
+        if c["method"] == "welch":
+            f, csm = orc.csm_welch(z["x"], meta["fs"], c["W"], "hann", c["overlap"],
+                                   c["detrend"], "mean", c["scaling"])
+            close(csm, z[f"csm_{i}"], skip_dc=c["detrend"])
+            f2, csm2 = orc.csm_welch_batched(z["x"], meta["fs"], c["W"], "hann", c["overlap"],
+                                             c["detrend"], c["scaling"])
+            close(csm2, z[f"csm_{i}"], skip_dc=c["detrend"], tol=1e-11)
+        else:
+            x = z["x"][:1000, :3]
+            f, sp = orc.spectrum_fft(x, meta["fs"], "FFTBackward", True)
+            csm = orc.csm_fft(sp, c["scaling"], None, meta["fs"])
+            close(csm, z[f"csm_{i}"])
+        close(f, z[f"f_{i}"])
+
+
+def test_spectrum_fft():
+    meta, z = load_golden("spectrum_fft")
+    for i, c in enumerate(meta["cases"]):
+        f, sp = orc.spectrum_fft(z["x"][: c["n"]], meta["fs"], c["scaling"],
+                                 c["pad_to_fast_length"])
+        close(f, z[f"f_{i}"])
+        close(sp, z[f"sp_{i}"])
+        assert sp.dtype == z[f"sp_{i}"].dtype
+
+
+def test_deconvolve():
+    meta, z = load_golden("deconvolve")
+    for i, c in enumerate(meta["cases"]):
+        tag = c["data"]
+        x = z[f"x_{tag}"] if c["den"] == "mono" else z[f"x2_{tag}"]
+        ir = orc.spectral_deconvolve(z[f"y_{tag}"], x, meta["fs"], c["reg"], c["ss"],
+                                     c["thr"], c["pad"], c["keep"])
+        close(ir, z[f"ir_{i}"], tol=1e-10)
+
+
+def test_fir():
+    meta, z = load_golden("fir")
+    for i, c in enumerate(meta["cases"]):
+        x = z["x_" + c["data"]]
+        if c["kind"] == "filter":
+            y = orc.filter_fir_on_channels(z[c["taps_key"]], x, c["channels"])
+            close(y, z[f"y_{i}"], tol=1e-12)
+        else:
+            y = orc.filterbank_fir(list(z["bank_taps"]), x, c["mode"])
+            ref = z[f"y_{i}"]
+            if c["mode"] == "Parallel":
+                # reference MultiBandSignal.get_all_time_data(): (N, bands, C)
+                assert c["out_type"] == "MultiBandSignal"
+                ref = np.transpose(ref, (0, 2, 1))
+            close(y, ref, tol=1e-12)
+
+
+@pytest.mark.parametrize("mode", ["H1", "H2", "H3"])
+def test_property_linearity_of_h1(mode):
+    """Scaling the output by g scales H by g and leaves coherence unchanged."""
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((4096, 1))
+    y = np.stack([np.convolve(x[:, 0], [1.0, 0.5, -0.2])[:4096]], axis=1)
+    y += 0.05 * rng.standard_normal(y.shape)
+    tf, coh = orc.compute_transfer_function(y, x, 48000, 256, mode, scaling="PowerSpectrum")
+    tf2, coh2 = orc.compute_transfer_function(3 * y, x, 48000, 256, mode, scaling="PowerSpectrum")
+    close(tf2[1:], 3 * tf[1:], tol=1e-11)
+    close(coh2[1:], coh[1:], tol=1e-11)
