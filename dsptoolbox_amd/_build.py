@@ -1,0 +1,40 @@
+"""Build the HIP library in-tree:  python -m dsptoolbox_amd._build [--force]."""
+
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB_DIR = os.path.join(HERE, "lib")
+LIB_PATH = os.path.join(LIB_DIR, "libdsptoolbox_amd.so")
+SOURCES = [os.path.join(CSRC, "api.hip")]
+
+
+def _newest_source_mtime() -> float:
+    newest = 0.0
+    for root in (CSRC, os.path.join(HERE, "..", "include")):
+        for dp, _, files in os.walk(root):
+            for f in files:
+                if f.endswith((".hip", ".hpp", ".h")):
+                    newest = max(newest, os.path.getmtime(os.path.join(dp, f)))
+    return newest
+
+
+def build_library(force: bool = False, verbose: bool = True) -> str:
+    """hipcc --offload-arch=gfx950 -> dsptoolbox_amd/lib/libdsptoolbox_amd.so"""
+    os.makedirs(LIB_DIR, exist_ok=True)
+    if (not force and os.path.exists(LIB_PATH)
+            and os.path.getmtime(LIB_PATH) >= _newest_source_mtime()):
+        return LIB_PATH
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
+           "-o", LIB_PATH] + SOURCES + ["-ldl"]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    print(build_library(force="--force" in sys.argv))

@@ -1,0 +1,217 @@
+"""ctypes binding of the C-ABI in include/dsptoolbox_amd.h.
+
+The HIP library is the product: if it is missing, or there is no GPU, every
+compute call raises -- there is no CPU fallback anywhere in this package.
+"""
+
+import ctypes as C
+import os
+import threading
+
+import numpy as np
+
+from ._build import LIB_PATH
+
+c32_p = C.c_void_p  # ds_c32* (numpy complex64 buffers)
+f32_p = C.c_void_p
+ctx_p = C.c_void_p
+i64 = C.c_int64
+
+SIGNATURES = {
+    "ds_version": (C.c_int, []),
+    "ds_device_count": (C.c_int, []),
+    "ds_init": (C.c_int, [C.c_int, C.POINTER(ctx_p)]),
+    "ds_destroy": (None, [ctx_p]),
+    "ds_last_error": (C.c_char_p, [ctx_p]),
+    "ds_malloc": (C.c_int, [ctx_p, C.POINTER(C.c_void_p), C.c_size_t]),
+    "ds_free": (C.c_int, [ctx_p, C.c_void_p]),
+    "ds_upload": (C.c_int, [ctx_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "ds_download": (C.c_int, [ctx_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "ds_memset": (C.c_int, [ctx_p, C.c_void_p, C.c_int, C.c_size_t]),
+    "ds_sync": (C.c_int, [ctx_p]),
+    "ds_timer_start": (C.c_int, [ctx_p]),
+    "ds_timer_stop": (C.c_int, [ctx_p, C.POINTER(C.c_float)]),
+    "ds_max_fft_len": (C.c_int, []),
+    "ds_stft_r2c_dev": (C.c_int, [ctx_p, f32_p, i64, C.c_int, i64, C.c_int, C.c_int, C.c_int, i64,
+                                  C.c_int, f32_p, C.c_int, C.c_float, C.c_float, C.c_int, c32_p]),
+    "ds_stft_r2c": (C.c_int, [ctx_p, f32_p, i64, C.c_int, C.c_int, C.c_int, C.c_int, i64, C.c_int,
+                              f32_p, C.c_int, C.c_float, C.c_float, C.c_int, c32_p]),
+    "ds_welch_tf_dev": (C.c_int, [ctx_p, f32_p, C.c_int, i64, f32_p, C.c_int, i64, i64, C.c_int,
+                                  C.c_int, C.c_int, f32_p, C.c_int, C.c_int, C.c_int, C.c_double,
+                                  C.c_double, C.c_int, c32_p, f32_p]),
+    "ds_welch_tf": (C.c_int, [ctx_p, f32_p, C.c_int, f32_p, C.c_int, i64, C.c_int, C.c_int, C.c_int,
+                              f32_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int,
+                              c32_p, f32_p]),
+    "ds_welch_psd_dev": (C.c_int, [ctx_p, f32_p, C.c_int, i64, i64, C.c_int, C.c_int, C.c_int, f32_p,
+                                   C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, f32_p]),
+    "ds_welch_psd": (C.c_int, [ctx_p, f32_p, C.c_int, i64, C.c_int, C.c_int, C.c_int, f32_p, C.c_int,
+                               C.c_int, C.c_double, C.c_double, C.c_int, f32_p]),
+    "ds_welch_csd": (C.c_int, [ctx_p, f32_p, f32_p, C.c_int, i64, C.c_int, C.c_int, C.c_int, f32_p,
+                               C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, c32_p]),
+    "ds_csm_dev": (C.c_int, [ctx_p, f32_p, C.c_int, i64, i64, C.c_int, C.c_int, C.c_int, f32_p,
+                             C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, c32_p]),
+    "ds_csm": (C.c_int, [ctx_p, f32_p, C.c_int, i64, C.c_int, C.c_int, C.c_int, f32_p, C.c_int,
+                         C.c_int, C.c_double, C.c_double, C.c_int, c32_p]),
+    "ds_rfft_dev": (C.c_int, [ctx_p, f32_p, C.c_int, i64, i64, C.c_int, C.c_float, c32_p]),
+    "ds_rfft": (C.c_int, [ctx_p, f32_p, C.c_int, i64, C.c_int, C.c_float, c32_p]),
+    "ds_deconv_inverse_dev": (C.c_int, [ctx_p, c32_p, C.c_int, C.c_int, f32_p, c32_p]),
+    "ds_deconv_dev": (C.c_int, [ctx_p, f32_p, C.c_int, C.c_int, i64, i64, C.c_int, c32_p, C.c_int,
+                                i64, i64, f32_p]),
+    "ds_deconv": (C.c_int, [ctx_p, f32_p, C.c_int, C.c_int, i64, C.c_int, c32_p, C.c_int, i64, f32_p]),
+    "ds_fir_ola_dev": (C.c_int, [ctx_p, f32_p, C.c_int, i64, i64, f32_p, C.c_int, C.c_int, C.c_int,
+                                 f32_p, i64]),
+    "ds_fir_ola": (C.c_int, [ctx_p, f32_p, C.c_int, i64, f32_p, C.c_int, C.c_int, C.c_int, f32_p]),
+    "ds_comm_unique_id": (C.c_int, [C.c_char_p]),
+    "ds_comm_init": (C.c_int, [ctx_p, C.c_int, C.c_int, C.c_char_p]),
+    "ds_bcast": (C.c_int, [ctx_p, C.c_void_p, C.c_size_t, C.c_int]),
+    "ds_comm_destroy": (C.c_int, [ctx_p]),
+}
+
+_lib = None
+_lock = threading.Lock()
+
+
+class DeviceError(RuntimeError):
+    """Raised for every non-zero return of the HIP library."""
+
+
+def load_library(path: str | None = None):
+    """Load libdsptoolbox_amd.so and bind every symbol of the header.  Raises if
+    the library has not been built (python -m dsptoolbox_amd._build)."""
+    global _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        path = path or os.environ.get("DSPTOOLBOX_AMD_LIB", LIB_PATH)
+        if not os.path.exists(path):
+            raise DeviceError(
+                f"{path} not found: the HIP extension is required (no CPU fallback). "
+                "Build it with `python -m dsptoolbox_amd._build`.")
+        lib = C.CDLL(path)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+        return lib
+
+
+class Context:
+    """One ds_ctx: one device, one HIP stream."""
+
+    def __init__(self, device: int | None = None):
+        self.lib = load_library()
+        if device is None:
+            device = int(os.environ.get("LOCAL_RANK", "0"))
+            n = self.lib.ds_device_count()
+            if n > 0:
+                device %= n
+        h = ctx_p()
+        rc = self.lib.ds_init(int(device), C.byref(h))
+        if rc != 0:
+            msg = self.lib.ds_last_error(None)
+            raise DeviceError(f"ds_init({device}) failed [{rc}]: {msg.decode() if msg else ''}")
+        self.handle = h
+        self.device = device
+
+    def check(self, rc: int, what: str = ""):
+        if rc == 0:
+            return
+        msg = self.lib.ds_last_error(self.handle)
+        text = f"{what} failed [{rc}]: {msg.decode() if msg else ''}"
+        if rc == -2:
+            raise NotImplementedError(text)
+        if rc == -1:
+            raise ValueError(text)
+        raise DeviceError(text)
+
+    # ---- raw device memory -------------------------------------------------
+    def malloc(self, nbytes: int) -> int:
+        p = C.c_void_p()
+        self.check(self.lib.ds_malloc(self.handle, C.byref(p), nbytes), "ds_malloc")
+        return p.value
+
+    def free(self, dptr: int):
+        self.check(self.lib.ds_free(self.handle, C.c_void_p(dptr)), "ds_free")
+
+    def upload(self, dptr: int, arr: np.ndarray):
+        arr = np.ascontiguousarray(arr)
+        self.check(self.lib.ds_upload(self.handle, C.c_void_p(dptr), arr.ctypes.data, arr.nbytes),
+                   "ds_upload")
+
+    def download(self, dptr: int, arr: np.ndarray):
+        assert arr.flags.c_contiguous
+        self.check(self.lib.ds_download(self.handle, arr.ctypes.data, C.c_void_p(dptr), arr.nbytes),
+                   "ds_download")
+
+    def to_device(self, arr: np.ndarray) -> int:
+        arr = np.ascontiguousarray(arr)
+        d = self.malloc(arr.nbytes)
+        self.upload(d, arr)
+        return d
+
+    def sync(self):
+        self.check(self.lib.ds_sync(self.handle), "ds_sync")
+
+    def timer_start(self):
+        self.check(self.lib.ds_timer_start(self.handle), "ds_timer_start")
+
+    def timer_stop(self) -> float:
+        ms = C.c_float()
+        self.check(self.lib.ds_timer_stop(self.handle, C.byref(ms)), "ds_timer_stop")
+        return float(ms.value)
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.ds_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_default_ctx = None
+
+
+def get_context() -> Context:
+    """Process-wide default context (device = LOCAL_RANK, one process per GPU)."""
+    global _default_ctx
+    if _default_ctx is None:
+        _default_ctx = Context()
+    return _default_ctx
+
+
+class DeviceBuffer:
+    """Owned device allocation (freed explicitly or at garbage collection)."""
+
+    def __init__(self, ctx: Context, nbytes: int):
+        self.ctx = ctx
+        self.nbytes = int(nbytes)
+        self.ptr = ctx.malloc(self.nbytes)
+
+    @classmethod
+    def from_array(cls, ctx: Context, arr: np.ndarray) -> "DeviceBuffer":
+        arr = np.ascontiguousarray(arr)
+        buf = cls(ctx, arr.nbytes)
+        ctx.upload(buf.ptr, arr)
+        return buf
+
+    def to_array(self, shape, dtype) -> np.ndarray:
+        out = np.empty(shape, dtype=dtype)
+        assert out.nbytes <= self.nbytes
+        self.ctx.download(self.ptr, out)
+        return out
+
+    def free(self):
+        if self.ptr is not None and self.ctx.handle:
+            self.ctx.free(self.ptr)
+        self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass

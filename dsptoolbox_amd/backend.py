@@ -1,0 +1,296 @@
+"""Host shim: the reference's private numeric backends, same
+names and argument meaning, executed by the HIP library through ctypes.
+
+    _welch        <- dsptoolbox/standard/_spectral_methods.py:10-173
+    _stft         <- dsptoolbox/standard/_spectral_methods.py:176-282
+    _csm_welch    <- dsptoolbox/standard/_spectral_methods.py:285-371
+    _lfilter_fir  <- dsptoolbox/classes/filter_helpers.py:454-503
+    welch_transfer_function  <- the per-channel _welch loop of
+                     transfer_functions/transfer_functions.py:476-534, fused
+    rfft_spectrum <- scipy.fft.rfft call of classes/signal.py:899-911
+    spectral_division <- transfer_functions/_transfer_functions.py:19-42
+
+Arrays cross the boundary as (samples, channels) float64 like in the
+reference; the shim transposes to planar fp32, the device computes in
+fp32/complex64 (finish() in fp64) and results are cast back to
+float64/complex128.  Anything the device path does not implement raises
+NotImplementedError -- nothing is silently computed on the CPU.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+from warnings import warn
+
+import numpy as np
+from scipy.signal import check_COLA
+from scipy.signal.windows import get_window
+
+from ._lib import DeviceBuffer, get_context
+from .standard.enums import SpectrumScaling, Window
+
+DS_TF = {"H1": 1, "H2": 2, "H3": 3}
+DS_FB_PARALLEL, DS_FB_SEQUENTIAL, DS_FB_SUMMED = 1, 2, 3
+
+
+def _planar_f32(x: np.ndarray) -> np.ndarray:
+    """(N, C) float64 -> (C, N) float32 C-contiguous."""
+    x = np.asarray(x)
+    if x.ndim == 1:
+        x = x[:, None]
+    return np.ascontiguousarray(x.T, dtype=np.float32)
+
+
+def _ptr(a: np.ndarray):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _window_array(window_type, length: int) -> np.ndarray:
+    spec = window_type.to_scipy_format() if isinstance(window_type, Window) else window_type
+    return get_window(spec, length, fftbins=True)
+
+
+def _finish_params(scaling: SpectrumScaling, W: int, fs_hz: int, window: np.ndarray):
+    """(amp_sqrt, norm_scale, factor, halve_edges) of _welch's tail (:141-171)."""
+    norm = scaling.fft_norm()
+    norm_scale = 1.0 if norm == "backward" else (1.0 / W**2 if norm == "forward" else 1.0 / W)
+    phys = scaling.has_physical_units()
+    factor = float(np.asarray(scaling.get_scaling_factor(W, fs_hz, window)).ravel()[0]) if phys else 1.0
+    return int(scaling.is_amplitude_scaling()), float(norm_scale), factor, int(phys)
+
+
+def _welch_checks(window_length_samples, overlap_percent, average):
+    assert window_length_samples in [2**k for k in range(3, 19)], (
+        "Window length should be a power of 2 between [8, 262_144] or [2**3, 2**18]")
+    assert overlap_percent >= 0 and overlap_percent < 100, \
+        "overlap_percent should be between 0 and 100"
+    assert average in ("mean", "median"), f"{average} is not valid. Use either mean or median"
+    if average == "median":
+        raise NotImplementedError(
+            "median averaging is not built on the GPU path yet (needs per-frame spectra)")
+
+
+def _welch_framing(n_samples: int, W: int, overlap_percent: float, window: np.ndarray):
+    overlap = int(overlap_percent / 100 * W)  # truncation, _spectral_methods.py:106
+    hop = W - overlap
+    if not check_COLA(window, nperseg=len(window), noverlap=overlap):
+        warn("Selected window type and overlap do not meet the constant "
+             "overlap and add constraint! Results might be distorted")
+    n_frames = int(np.ceil(n_samples / hop))  # helpers/other.py:206
+    return hop, n_frames
+
+
+def _welch(x, y, fs_hz: int, window_type, window_length_samples: int, overlap_percent: float,
+           detrend: bool, average: str, scaling: SpectrumScaling):
+    """Welch auto (y None) or cross spectrum; shapes as in the reference."""
+    auto = y is None
+    x = np.asarray(x).squeeze()
+    if not auto:
+        y = np.asarray(y).squeeze()
+        assert x.shape == y.shape, "Shapes of data do not match"
+    assert x.ndim <= 2, f"{x.shape} are too many dimensions. Use flat arrays or 2D-Arrays instead"
+    multi = x.ndim == 2
+    _welch_checks(window_length_samples, overlap_percent, average)
+    W = int(window_length_samples)
+    window = _window_array(window_type, W)
+    hop, n_frames = _welch_framing(x.shape[0], W, overlap_percent, window)
+    amp, norm_scale, factor, phys = _finish_params(scaling, W, fs_hz, window)
+    ctx = get_context()
+    xp = _planar_f32(x)
+    n_ch, n = xp.shape
+    w32 = window.astype(np.float32)
+    B = W // 2 + 1
+    if auto:
+        out = np.empty((B, n_ch), dtype=np.float32)
+        ctx.check(ctx.lib.ds_welch_psd(ctx.handle, _ptr(xp), n_ch, n, W, hop, n_frames, _ptr(w32),
+                                       int(bool(detrend)), amp, norm_scale, factor, phys, _ptr(out)),
+                  "ds_welch_psd")
+        res = out.astype(np.float64)
+    else:
+        yp = _planar_f32(y)
+        out = np.empty((B, n_ch), dtype=np.complex64)
+        ctx.check(ctx.lib.ds_welch_csd(ctx.handle, _ptr(xp), _ptr(yp), n_ch, n, W, hop, n_frames,
+                                       _ptr(w32), int(bool(detrend)), amp, norm_scale, factor, phys,
+                                       _ptr(out)), "ds_welch_csd")
+        res = out.astype(np.complex128)
+    return res if multi else res[:, 0]
+
+
+def welch_transfer_function(output_td, input_td, fs_hz: int, window_length_samples: int, mode: str,
+                            window_type=Window.Hann, overlap_percent: float = 50.0,
+                            detrend: bool = True, average: str = "mean",
+                            scaling: SpectrumScaling = SpectrumScaling.FFTBackward):
+    """H1/H2/H3 + coherence for every output channel in one device call.
+    output_td (N, Cy); input_td (N, 1) or (N, Cy).  -> (tf complex128 (B, Cy),
+    coherence float64 (B, Cy))."""
+    _welch_checks(window_length_samples, overlap_percent, average)
+    if mode not in DS_TF:
+        raise ValueError("Unsupported transfer function type")
+    W = int(window_length_samples)
+    window = _window_array(window_type, W)
+    yp, xp = _planar_f32(output_td), _planar_f32(input_td)
+    n_cy, n = yp.shape
+    n_cx = xp.shape[0]
+    assert xp.shape[1] == n, "Signal lengths do not match"
+    hop, n_frames = _welch_framing(n, W, overlap_percent, window)
+    amp, norm_scale, factor, phys = _finish_params(scaling, W, fs_hz, window)
+    w32 = window.astype(np.float32)
+    B = W // 2 + 1
+    tf = np.empty((B, n_cy), dtype=np.complex64)
+    coh = np.empty((B, n_cy), dtype=np.float32)
+    ctx = get_context()
+    ctx.check(ctx.lib.ds_welch_tf(ctx.handle, _ptr(xp), n_cx, _ptr(yp), n_cy, n, W, hop, n_frames,
+                                  _ptr(w32), int(bool(detrend)), DS_TF[mode], amp, norm_scale, factor,
+                                  phys, _ptr(tf), _ptr(coh)), "ds_welch_tf")
+    return tf.astype(np.complex128), coh.astype(np.float64)
+
+
+def _stft(x, fs_hz: int, window_length_samples: int, window_type, overlap_percent: float,
+          fft_length_samples, detrend: bool, padding: bool, scaling: SpectrumScaling):
+    """-> (time_s (F,), freqs_hz (B,), stft (B', F, C))."""
+    assert window_length_samples in [2**k for k in range(4, 17)], (
+        "Window length should be a power of 2 between [16, 65536] or [2**4, 2**16]")
+    assert overlap_percent >= 0 and overlap_percent < 100, \
+        "overlap_percent should be between 0 and 100"
+    W = int(window_length_samples)
+    nfft = W if fft_length_samples is None else int(fft_length_samples)
+    if nfft & (nfft - 1) or nfft < 8:
+        raise NotImplementedError("fft_length_samples must be a power of two >= 8 on the GPU path")
+    window = _window_array(window_type, W)
+    overlap = int(overlap_percent / 100 * W + 0.5)  # rounding, _spectral_methods.py:247
+    hop = W - overlap
+    if not check_COLA(window, nperseg=len(window), noverlap=overlap):
+        warn("Selected window type and overlap do not meet the constant "
+             "overlap and add constraint! Results might be distorted")
+    xp = _planar_f32(x)
+    n_ch, n = xp.shape
+    pad_front = overlap if padding else 0
+    n_padded = n + 2 * pad_front
+    n_frames = int(np.ceil(n_padded / hop))
+    if scaling.has_physical_units():
+        scale = float(np.asarray(scaling.get_scaling_factor(nfft, fs_hz, window)).ravel()[0])
+        edge = 2**-0.5
+        power = int(not scaling.is_amplitude_scaling())
+    else:
+        norm = scaling.fft_norm()
+        scale = 1.0 if norm == "backward" else (1.0 / nfft if norm == "forward" else nfft**-0.5)
+        edge, power = 1.0, 0
+    B = nfft // 2 + 1
+    out = np.empty((B, n_frames, n_ch), dtype=np.complex64)
+    w32 = window.astype(np.float32)
+    ctx = get_context()
+    ctx.check(ctx.lib.ds_stft_r2c(ctx.handle, _ptr(xp), n, n_ch, W, hop, nfft, pad_front, n_frames,
+                                  _ptr(w32), int(bool(detrend)), scale, edge, power, _ptr(out)),
+              "ds_stft_r2c")
+    stft = out.real.astype(np.float64) if power else out.astype(np.complex128)
+    time_s = np.linspace(0, n_padded / fs_hz, n_frames)
+    freqs_hz = np.fft.rfftfreq(W, 1 / fs_hz)
+    return time_s, freqs_hz, stft
+
+
+def _csm_welch(time_data, sampling_rate_hz: int, window_length_samples: int, window_type,
+               overlap_percent, detrend: bool, average: str, scaling: SpectrumScaling):
+    """-> (f (B,), csm (B, C, C) complex128)."""
+    _welch_checks(window_length_samples, overlap_percent, average)
+    W = int(window_length_samples)
+    window = _window_array(window_type, W)
+    xp = _planar_f32(time_data)
+    n_ch, n = xp.shape
+    hop, n_frames = _welch_framing(n, W, overlap_percent, window)
+    amp, norm_scale, factor, phys = _finish_params(scaling, W, sampling_rate_hz, window)
+    B = W // 2 + 1
+    out = np.empty((B, n_ch, n_ch), dtype=np.complex64)
+    w32 = window.astype(np.float32)
+    ctx = get_context()
+    ctx.check(ctx.lib.ds_csm(ctx.handle, _ptr(xp), n_ch, n, W, hop, n_frames, _ptr(w32),
+                             int(bool(detrend)), amp, norm_scale, factor, phys, _ptr(out)), "ds_csm")
+    return np.fft.rfftfreq(W, 1 / sampling_rate_hz), out.astype(np.complex128)
+
+
+def rfft_spectrum(time_data, n_fft: int, scale: float = 1.0):
+    """rfft(time_data, n=n_fft, axis=0) * scale -> (n_fft/2+1, C) complex128."""
+    xp = _planar_f32(time_data)
+    n_ch, n = xp.shape
+    if n_fft & (n_fft - 1):
+        raise NotImplementedError(
+            f"whole-signal FFT length {n_fft} is not a power of two: not built on the GPU path yet")
+    out = np.empty((n_fft // 2 + 1, n_ch), dtype=np.complex64)
+    ctx = get_context()
+    ctx.check(ctx.lib.ds_rfft(ctx.handle, _ptr(xp), n_ch, n, int(n_fft), float(scale), _ptr(out)),
+              "ds_rfft")
+    return out.astype(np.complex128)
+
+
+def spectral_division(num_td, n_fft: int, inverse_spectrum, n_out: int):
+    """irfft(rfft(num_td, n_fft) * inverse_spectrum, n_fft)[:n_out] per channel.
+    num_td (N, C) or (M, N, C) for a batch of M items; inverse_spectrum (B,)
+    shared or (B, C) per channel.  -> same leading shape, float64."""
+    num_td = np.asarray(num_td)
+    batched = num_td.ndim == 3
+    items = num_td if batched else num_td[None]
+    m, n, n_ch = items.shape
+    yp = np.ascontiguousarray(np.transpose(items, (0, 2, 1)), dtype=np.float32)  # (M, C, N)
+    r = np.asarray(inverse_spectrum)
+    per_channel = r.ndim == 2
+    rp = np.ascontiguousarray(r.T if per_channel else r, dtype=np.complex64)  # (C, B) or (B,)
+    assert rp.shape[-1] == n_fft // 2 + 1, "Frequency vector does not match"
+    out = np.empty((m, n_ch, n_out), dtype=np.float32)
+    ctx = get_context()
+    ctx.check(ctx.lib.ds_deconv(ctx.handle, _ptr(yp), m, n_ch, n, int(n_fft), _ptr(rp),
+                                int(per_channel), int(n_out), _ptr(out)), "ds_deconv")
+    res = np.transpose(out, (0, 2, 1)).astype(np.float64)
+    return res if batched else res[0]
+
+
+def regularized_inverse(denum_spectrum, eps=None):
+    """conj(X)/(|X|^2+eps) (regularised) or 1/X, on the device.  denum_spectrum
+    (B, C) complex; eps (B,) or None.  -> (B, C) complex128."""
+    xs = np.ascontiguousarray(denum_spectrum, dtype=np.complex64)
+    nb, n_ch = xs.shape
+    ctx = get_context()
+    d_x = DeviceBuffer.from_array(ctx, xs)
+    d_e = DeviceBuffer.from_array(ctx, np.ascontiguousarray(eps, dtype=np.float32)) if eps is not None else None
+    d_r = DeviceBuffer(ctx, xs.nbytes)
+    ctx.check(ctx.lib.ds_deconv_inverse_dev(ctx.handle, C.c_void_p(d_x.ptr), n_ch, nb,
+                                            C.c_void_p(d_e.ptr) if d_e else None,
+                                            C.c_void_p(d_r.ptr)), "ds_deconv_inverse")
+    r = d_r.to_array((n_ch, nb), np.complex64)
+    for d in (d_x, d_e, d_r):
+        if d is not None:
+            d.free()
+    return r.T.astype(np.complex128)
+
+
+def fir_filter_bank(x, taps_list, mode: int):
+    """x (N, C); taps_list K arrays of equal length T.  Parallel -> (K, N, C);
+    Sequential / Summed -> (N, C).  float64."""
+    xp = _planar_f32(x)
+    n_ch, n = xp.shape
+    taps = np.ascontiguousarray(np.stack([np.asarray(t, dtype=np.float64) for t in taps_list]),
+                                dtype=np.float32)
+    k, t = taps.shape
+    out = np.empty(((k if mode == DS_FB_PARALLEL else 1), n_ch, n), dtype=np.float32)
+    ctx = get_context()
+    ctx.check(ctx.lib.ds_fir_ola(ctx.handle, _ptr(xp), n_ch, n, _ptr(taps), k, t, int(mode),
+                                 _ptr(out)), "ds_fir_ola")
+    res = np.transpose(out, (0, 2, 1)).astype(np.float64)
+    return res if mode == DS_FB_PARALLEL else res[0]
+
+
+def _lfilter_fir(b, a, x, zi=None, axis: int = 0):
+    """Causal FIR filtering y = (x * b)[:N] along axis 0."""
+    a = np.atleast_1d(a)
+    assert len(a) == 1, f"{a} is not valid. It has to be 1 in order to be a valid FIR filter"
+    b = np.asarray(b)
+    if b.ndim != 1:
+        b = np.squeeze(b)
+        assert b.ndim == 1, "FIR Filters for audio must be 1D-arrays"
+    if zi is not None:
+        raise NotImplementedError("filter state (zi) is not built on the GPU path yet")
+    if np.iscomplexobj(b) or np.iscomplexobj(x):
+        raise NotImplementedError("complex FIR filtering is not built on the GPU path yet")
+    x = np.asarray(x)
+    if x.ndim < 2:
+        x = x[..., None]
+    assert x.ndim == 2, "Filtering only works on 2D-arrays"
+    return fir_filter_bank(x, [b], DS_FB_PARALLEL)[0]

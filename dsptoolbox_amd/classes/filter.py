@@ -1,0 +1,138 @@
+"""Filter: FIR part of dsptoolbox/classes/filter.py (fir_filter :189-235,
+from_ba :237-260, ba setter :485-529, is_fir :460-470, filter_signal :648-743).
+FIR filtering runs on the device as FFT block convolution
+(dsptoolbox_amd.backend.fir_filter_bank).  IIR / SOS / zpk filters, filter state
+(zi) and zero-phase filtering are recursive or two-pass operations outside the
+FFT-batchable hot path; they raise NotImplementedError."""
+
+from copy import deepcopy
+from warnings import warn
+
+import numpy as np
+import scipy.signal as sig
+
+from .. import backend
+from ..standard.enums import FilterCoefficientsType, FilterPassType, Window
+from .signal import Signal
+
+
+class Filter:
+    def __init__(self, filter_coefficients: dict, sampling_rate_hz: int):
+        self.warning_if_complex = True
+        self.sampling_rate_hz = sampling_rate_hz
+        assert ((FilterCoefficientsType.Ba in filter_coefficients)
+                ^ (FilterCoefficientsType.Sos in filter_coefficients)
+                ^ (FilterCoefficientsType.Zpk in filter_coefficients)), (
+            "Only (and at least) one type of filter coefficients should be passed to create a filter")
+        if FilterCoefficientsType.Ba not in filter_coefficients:
+            raise NotImplementedError(
+                "only ba (FIR) coefficients are supported on the GPU path; SOS / zpk filters are "
+                "recursive and outside the FFT-batchable hot path")
+        b, a = filter_coefficients[FilterCoefficientsType.Ba]
+        self.ba = [np.atleast_1d(b), np.atleast_1d(a)]
+
+    @staticmethod
+    def fir_filter(order: int, frequency_hz, type_of_pass: FilterPassType, sampling_rate_hz: int,
+                   window: Window = Window.Hamming) -> "Filter":
+        """FIR design with scipy.signal.firwin (order = taps - 1)."""
+        win = (window if window is not None else Window.Hamming).to_scipy_format()
+        b = sig.firwin(numtaps=order + 1, cutoff=frequency_hz, window=win,
+                       pass_zero=type_of_pass.to_str(), fs=sampling_rate_hz)
+        return Filter({FilterCoefficientsType.Ba: [b, np.asarray([1.0])]}, sampling_rate_hz)
+
+    @staticmethod
+    def from_ba(b, a, sampling_rate_hz: int) -> "Filter":
+        return Filter({FilterCoefficientsType.Ba: [b, a]}, sampling_rate_hz)
+
+    @property
+    def sampling_rate_hz(self) -> int:
+        return self.__sampling_rate_hz
+
+    @sampling_rate_hz.setter
+    def sampling_rate_hz(self, new_sampling_rate_hz):
+        assert type(new_sampling_rate_hz) is int, "Sampling rate can only be an integer"
+        self.__sampling_rate_hz = new_sampling_rate_hz
+
+    @property
+    def warning_if_complex(self) -> bool:
+        return self.__warning_if_complex
+
+    @warning_if_complex.setter
+    def warning_if_complex(self, new_warning):
+        assert type(new_warning) is bool, "This attribute must be of boolean type"
+        self.__warning_if_complex = new_warning
+
+    @property
+    def has_sos(self) -> bool:
+        return False
+
+    @property
+    def is_iir(self) -> bool:
+        a = self.ba[1]
+        return not (len(a) == 1 and a[0] == 1.0)
+
+    @property
+    def is_fir(self) -> bool:
+        return not self.is_iir
+
+    @property
+    def order(self) -> int:
+        return max(len(self.ba[0]), len(self.ba[1])) - 1
+
+    def __len__(self):
+        return self.order + 1
+
+    @property
+    def ba(self):
+        return self.__ba
+
+    @ba.setter
+    def ba(self, new_ba):
+        ba = list(new_ba)
+        assert len(ba) == 2, "ba coefficients must be a list of length two"
+        for ind in range(2):
+            coeff = np.atleast_1d(ba[ind])
+            assert coeff.ndim == 1
+            ba[ind] = coeff.astype(np.complex128 if np.issubdtype(coeff.dtype, np.complexfloating)
+                                   else np.float64)
+        b, a = ba
+        a = np.atleast_1d(np.trim_zeros(a.copy(), "b"))
+        if len(a) == 1:  # FIR: normalise
+            b = b / a[0]
+            a = a / a[0]
+            self.__ba = [b, a]
+        else:
+            self.__ba = ba
+
+    @property
+    def metadata(self) -> dict:
+        return dict(sampling_rate_hz=self.sampling_rate_hz, order=self.order,
+                    filter_type="fir" if self.is_fir else "iir")
+
+    def filter_signal(self, signal: Signal, channels=None, activate_zi: bool = False,
+                      zero_phase: bool = False) -> Signal:
+        """Filter the selected channels (the others are bypassed) and return a new Signal."""
+        assert self.sampling_rate_hz == signal.sampling_rate_hz, "Sampling rates do not match"
+        assert not (activate_zi and zero_phase), (
+            "Filter initial and final values cannot be updated when filtering with zero-phase")
+        if channels is None:
+            channels = np.arange(signal.number_of_channels)
+        else:
+            channels = np.atleast_1d(np.squeeze(channels))
+            assert channels.ndim == 1, "channels can be only a 1D-array or an int"
+            assert all(channels < signal.number_of_channels), (
+                f"Selected channels ({channels}) are not valid for the signal with "
+                f"{signal.number_of_channels} channels")
+        if activate_zi or zero_phase:
+            raise NotImplementedError("zi / zero-phase filtering is not built on the GPU path yet")
+        if not self.is_fir:
+            raise NotImplementedError("IIR filtering is outside the FFT-batchable GPU hot path")
+        if self.order > signal.time_data.shape[0]:
+            warn("Filter is longer than signal, results might be meaningless!")
+        new_time_data = signal.time_data.copy()
+        new_time_data[:, channels] = backend._lfilter_fir(self.ba[0], self.ba[1],
+                                                          signal.time_data[:, channels])
+        return signal.copy_with_new_time_data(new_time_data)
+
+    def copy(self) -> "Filter":
+        return deepcopy(self)

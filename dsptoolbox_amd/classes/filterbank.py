@@ -1,0 +1,110 @@
+"""FilterBank (API mirror of dsptoolbox/classes/filterbank.py: ctor :33-66,
+filter_signal :415-477, and the loop of filter_helpers.py:385-451).
+A bank of equal-length FIR filters is applied in ONE device call: every input
+block is transformed once and all band filters are applied on chip."""
+
+from copy import deepcopy
+
+import numpy as np
+
+from .. import backend
+from ..standard.enums import FilterBankMode
+from .filter import Filter
+from .multibandsignal import MultiBandSignal
+from .signal import Signal
+
+
+class FilterBank:
+    def __init__(self, filters=None, same_sampling_rate: bool = True, info=None):
+        self.same_sampling_rate = same_sampling_rate
+        self.filters = filters if filters is not None else []
+        self.info = info if info is not None else {}
+
+    @property
+    def filters(self):
+        return self.__filters
+
+    @filters.setter
+    def filters(self, new_filters):
+        assert type(new_filters) is list, "Filters have to be passed as a list"
+        for f in new_filters:
+            assert isinstance(f, Filter), f"{type(f)} is not a valid filter type"
+        if new_filters and self.same_sampling_rate:
+            fs = new_filters[0].sampling_rate_hz
+            assert all(f.sampling_rate_hz == fs for f in new_filters), \
+                "Not all filters have the same sampling rate"
+        self.__filters = new_filters
+
+    @property
+    def sampling_rate_hz(self):
+        if self.same_sampling_rate:
+            return self.filters[0].sampling_rate_hz
+        return [f.sampling_rate_hz for f in self.filters]
+
+    @property
+    def same_sampling_rate(self) -> bool:
+        return self.__same_sampling_rate
+
+    @same_sampling_rate.setter
+    def same_sampling_rate(self, new_same):
+        assert type(new_same) is bool, "Same sampling rate attribute must be a boolean"
+        self.__same_sampling_rate = new_same
+
+    @property
+    def number_of_filters(self) -> int:
+        return len(self.filters)
+
+    def __len__(self):
+        return len(self.filters)
+
+    def __iter__(self):
+        return iter(self.filters)
+
+    def add_filter(self, filt: Filter, index: int = -1):
+        fl = list(self.filters)
+        fl.insert(len(fl) if index == -1 else index, filt)
+        self.filters = fl
+        return self
+
+    def remove_filter(self, index: int = -1, return_filter: bool = False):
+        fl = list(self.filters)
+        f = fl.pop(index)
+        self.filters = fl
+        return f if return_filter else self
+
+    def copy(self):
+        return deepcopy(self)
+
+    def filter_signal(self, signal: Signal, mode: FilterBankMode, activate_zi: bool = False,
+                      zero_phase: bool = False):
+        """Parallel -> MultiBandSignal; Sequential / Summed -> Signal."""
+        if type(signal) is MultiBandSignal:
+            raise TypeError("This method only supports Signal objects. Use "
+                            "filter_multiband_signal() for multirate parallel filtering")
+        if mode in (FilterBankMode.Sequential, FilterBankMode.Summed):
+            assert self.same_sampling_rate, \
+                "Multirate filtering is not valid for sequential or summed filtering"
+        assert np.all(signal.sampling_rate_hz == self.sampling_rate_hz), \
+            "Sampling rates do not match"
+        if zero_phase:
+            assert not activate_zi, "Zero-phase filtering and zi cannot be used at the same time"
+        if activate_zi or zero_phase:
+            raise NotImplementedError("zi / zero-phase filtering is not built on the GPU path yet")
+        if mode not in (FilterBankMode.Parallel, FilterBankMode.Sequential, FilterBankMode.Summed):
+            raise ValueError("Invalid filter bank apply mode")
+        for f in self.filters:
+            if not f.is_fir:
+                raise NotImplementedError("IIR filters are outside the FFT-batchable GPU hot path")
+        taps = [f.ba[0] for f in self.filters]
+        n_taps = max(len(t) for t in taps)
+        # zero-extending a FIR filter at the end does not change its output
+        taps = [np.concatenate([t, np.zeros(n_taps - len(t))]) for t in taps]
+        ds_mode = {FilterBankMode.Parallel: backend.DS_FB_PARALLEL,
+                   FilterBankMode.Sequential: backend.DS_FB_SEQUENTIAL,
+                   FilterBankMode.Summed: backend.DS_FB_SUMMED}[mode]
+        y = backend.fir_filter_bank(signal.time_data, taps, ds_mode)
+        if mode == FilterBankMode.Parallel:
+            bands = [signal.copy_with_new_time_data(np.ascontiguousarray(y[k]))
+                     for k in range(len(taps))]
+            return MultiBandSignal(bands, same_sampling_rate=self.same_sampling_rate)
+        return signal.copy_with_new_time_data(y)

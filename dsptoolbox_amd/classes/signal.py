@@ -1,0 +1,344 @@
+"""Signal container with the hot-path getters
+(API mirror of dsptoolbox/classes/signal.py: ctor :57-115, time_data setter
+:222-301, set_spectrum_parameters :497-588, set_spectrogram_parameters
+:706-773, get_spectrum :861-946, get_csm :948-1007, get_spectrogram
+:1009-1056, copy_with_new_time_data :1647-1680).
+
+Spectra, cross-spectral matrices and spectrograms are computed by the HIP
+library (dsptoolbox_amd.backend).  File IO, plotting, smoothing and time
+windows of the reference class are outside the hot path and not provided.
+"""
+
+from copy import deepcopy
+from warnings import warn
+
+import numpy as np
+from scipy.fft import next_fast_len
+
+from .. import backend
+from ..standard.enums import SpectrumMethod, SpectrumScaling, Window
+from ._multichannel_data import MultichannelData
+
+
+class Signal(MultichannelData):
+    def __init__(self, path=None, time_data=None, sampling_rate_hz=None,
+                 constrain_amplitude: bool = False, activate_cache: bool = False):
+        self.constrain_amplitude = constrain_amplitude
+        self.calibrated_signal = False
+        self.activate_cache = activate_cache
+        self.__update_state()
+        if path is not None:
+            raise NotImplementedError(
+                "audio file reading is outside the GPU hot path; pass time_data and sampling_rate_hz")
+        assert time_data is not None, \
+            "Either a path to an audio file or a time vector has to be passed"
+        assert sampling_rate_hz is not None, "A sampling rate should be passed!"
+        self.sampling_rate_hz = sampling_rate_hz
+        self.time_data = time_data
+        self.set_spectrum_parameters()
+        self.set_spectrogram_parameters()
+
+    @staticmethod
+    def from_time_data(time_data, sampling_rate_hz: int, constrain_amplitude: bool = True):
+        return Signal(None, time_data, sampling_rate_hz, constrain_amplitude)
+
+    def __update_state(self):
+        self.__spectrum_state_update = True
+        self.__csm_state_update = True
+        self.__spectrogram_state_update = True
+        self.__time_vector_update = True
+
+    # ---- properties --------------------------------------------------------
+    @property
+    def time_data(self) -> np.ndarray:
+        return self.__time_data
+
+    @time_data.setter
+    def time_data(self, new_time_data):
+        new_time_data = np.atleast_2d(new_time_data).squeeze()
+        assert new_time_data.ndim <= 2, (
+            f"{new_time_data.ndim} are too many dimensions for time data. "
+            "Dimensions should be [time samples, channels]")
+        if new_time_data.ndim < 2:
+            new_time_data = new_time_data[..., None]
+        if new_time_data.shape[1] > new_time_data.shape[0]:  # more samples than channels, always
+            new_time_data = new_time_data.T
+        if np.iscomplexobj(new_time_data):
+            new_imag = np.imag(new_time_data)
+            new_time_data = np.real(new_time_data)
+        else:
+            new_imag = None
+        self.__amplitude_scale_factor = 1.0
+        if self.constrain_amplitude:
+            peak = np.max(np.abs(new_time_data))
+            if new_imag is not None:
+                peak = max(peak, np.max(np.abs(new_imag)))
+            if peak > 1.0:
+                new_time_data = new_time_data / peak
+                warn("Signal was over 0 dBFS, normalizing to 0 dBFS peak level was triggered")
+                if new_imag is not None:
+                    new_imag = new_imag / peak
+                self.__amplitude_scale_factor = 1.0 / peak
+        self.__time_data = new_time_data
+        self.time_data_imaginary = new_imag
+        self.__update_state()
+        self.clear_time_window()
+
+    @property
+    def amplitude_scale_factor(self) -> float:
+        return self.__amplitude_scale_factor
+
+    @property
+    def sampling_rate_hz(self) -> int:
+        return self.__sampling_rate_hz
+
+    @sampling_rate_hz.setter
+    def sampling_rate_hz(self, new_sampling_rate_hz):
+        assert type(new_sampling_rate_hz) is int, "Sampling rate can only be an integer"
+        self.__sampling_rate_hz = new_sampling_rate_hz
+        self.__update_state()
+
+    @property
+    def length_seconds(self) -> float:
+        return len(self) / self.sampling_rate_hz
+
+    @property
+    def length_samples(self) -> int:
+        return len(self)
+
+    @property
+    def time_vector_s(self) -> np.ndarray:
+        if self.__time_vector_update:
+            self.__time_vector_update = False
+            self.__time_vector_s = np.linspace(0, len(self.time_data) / self.sampling_rate_hz,
+                                               len(self.time_data))
+        return self.__time_vector_s
+
+    @property
+    def time_data_imaginary(self):
+        return self.__time_data_imaginary
+
+    @time_data_imaginary.setter
+    def time_data_imaginary(self, new_imag):
+        if new_imag is not None:
+            assert new_imag.shape == self.__time_data.shape, \
+                "Shape of imaginary part time data does not match"
+        self.__time_data_imaginary = new_imag
+
+    @property
+    def is_complex_signal(self) -> bool:
+        return self.time_data_imaginary is not None
+
+    @property
+    def constrain_amplitude(self) -> bool:
+        return self.__constrain_amplitude
+
+    @constrain_amplitude.setter
+    def constrain_amplitude(self, nca):
+        assert type(nca) is bool, "constrain_amplitude must be of type boolean"
+        self.__constrain_amplitude = nca
+        if nca and hasattr(self, "time_data"):
+            self.time_data = self.time_data
+
+    @property
+    def calibrated_signal(self) -> bool:
+        return self.__calibrated_signal
+
+    @calibrated_signal.setter
+    def calibrated_signal(self, ncs):
+        assert type(ncs) is bool, "calibrated_signal must be of type boolean"
+        self.__calibrated_signal = ncs
+
+    @property
+    def metadata(self) -> dict:
+        return dict(sampling_rate_hz=self.sampling_rate_hz,
+                    number_of_channels=self.number_of_channels,
+                    signal_length_samples=self.length_samples,
+                    signal_length_seconds=self.length_seconds,
+                    constrain_amplitude=self.constrain_amplitude,
+                    amplitude_scale_factor=self.amplitude_scale_factor,
+                    is_complex_signal=self.is_complex_signal)
+
+    def __len__(self):
+        return self.time_data.shape[0]
+
+    def __iter__(self):
+        return iter([self.time_data[:, x] for x in range(self.number_of_channels)])
+
+    # ---- parameters ----------------------------------------------------------
+    def set_spectrum_parameters(self, method: SpectrumMethod = SpectrumMethod.WelchPeriodogram,
+                                smoothing: int = 0, pad_to_fast_length: bool = True,
+                                window_length_samples: int = 1024,
+                                window_type: Window = Window.Hann, overlap_percent: float = 50,
+                                detrend: bool = True, average: str = "mean",
+                                scaling: SpectrumScaling = SpectrumScaling.FFTBackward):
+        new = dict(method=method, smoothing=smoothing, pad_to_fast_length=pad_to_fast_length,
+                   window_length_samples=window_length_samples, window_type=window_type,
+                   overlap_percent=overlap_percent, detrend=detrend, average=average,
+                   scaling=scaling)
+        if not hasattr(self, "_spectrum_parameters"):
+            self._spectrum_parameters = new
+            self.__spectrum_state_update = True
+        elif not all(self._spectrum_parameters[k] == new[k] for k in self._spectrum_parameters):
+            self._spectrum_parameters = new
+            self.__spectrum_state_update = True
+            self.__csm_state_update = True
+        return self
+
+    @property
+    def spectrum_scaling(self) -> SpectrumScaling:
+        return self._spectrum_parameters["scaling"]
+
+    @spectrum_scaling.setter
+    def spectrum_scaling(self, new_scaling: SpectrumScaling):
+        assert isinstance(new_scaling, SpectrumScaling)
+        self._spectrum_parameters["scaling"] = new_scaling
+        self.__spectrum_state_update = True
+        self.__csm_state_update = True
+
+    @property
+    def spectrum_method(self) -> SpectrumMethod:
+        return self._spectrum_parameters["method"]
+
+    @spectrum_method.setter
+    def spectrum_method(self, new_method: SpectrumMethod):
+        assert isinstance(new_method, SpectrumMethod)
+        self._spectrum_parameters["method"] = new_method
+        self.__spectrum_state_update = True
+        self.__csm_state_update = True
+
+    @property
+    def spectrum_smoothing(self) -> float:
+        return self._spectrum_parameters["smoothing"]
+
+    @spectrum_smoothing.setter
+    def spectrum_smoothing(self, new_smoothing):
+        assert new_smoothing >= 0.0, "Smoothing must be positive or zero"
+        self._spectrum_parameters["smoothing"] = float(new_smoothing)
+
+    def set_spectrogram_parameters(self, window_length_samples: int = 1024,
+                                   window_type: Window = Window.Hann,
+                                   overlap_percent: float = 50.0, fft_length_samples=None,
+                                   detrend: bool = False, padding: bool = True,
+                                   scaling: SpectrumScaling = SpectrumScaling.FFTBackward):
+        new = dict(window_length_samples=window_length_samples, window_type=window_type,
+                   overlap_percent=overlap_percent, fft_length_samples=fft_length_samples,
+                   detrend=detrend, padding=padding, scaling=scaling)
+        if not hasattr(self, "_spectrogram_parameters"):
+            self._spectrogram_parameters = new
+            self.__spectrogram_state_update = True
+        elif not all(self._spectrogram_parameters[k] == new[k]
+                     for k in self._spectrogram_parameters):
+            self._spectrogram_parameters = new
+            self.__spectrogram_state_update = True
+        return self
+
+    def clear_time_window(self):
+        if hasattr(self, "window"):
+            del self.window
+        return self
+
+    # ---- getters (device) ------------------------------------------------------
+    def get_spectrum(self, force_computation=False):
+        """-> (freqs_hz, spectrum) with the stored spectrum parameters."""
+        if not (not hasattr(self, "spectrum") or self.__spectrum_state_update
+                or force_computation):
+            return self.spectrum[0].copy(), self.spectrum[1].copy()
+        par = self._spectrum_parameters
+        if self.spectrum_method == SpectrumMethod.WelchPeriodogram:
+            spectrum = backend._welch(self.time_data, None, self.sampling_rate_hz,
+                                      par["window_type"], par["window_length_samples"],
+                                      par["overlap_percent"], par["detrend"], par["average"],
+                                      par["scaling"])
+            if spectrum.ndim == 1:
+                spectrum = spectrum[:, None]
+            fft_length = par["window_length_samples"]
+        else:
+            fft_length = (next_fast_len(self.length_samples, True)
+                          if par["pad_to_fast_length"] else self.length_samples)
+            if par["smoothing"] != 0:
+                raise NotImplementedError("spectrum smoothing is outside the GPU hot path")
+            if hasattr(self, "window"):
+                raise NotImplementedError("time-windowed signals are outside the GPU hot path")
+            scaling = self.spectrum_scaling
+            norm = scaling.fft_norm()
+            scale = 1.0 if norm == "backward" else (
+                1.0 / fft_length if norm == "forward" else fft_length**-0.5)
+            spectrum = backend.rfft_spectrum(self.time_data, fft_length, scale)
+            if scaling.has_physical_units():
+                # helpers/spectrum_utilities.py:268-328 (per-bin scalars on the device result)
+                factor = scaling.get_scaling_factor(fft_length, self.sampling_rate_hz, None)
+                spectrum[0] /= 2**0.5
+                if fft_length % 2 == 0:
+                    spectrum[-1] /= 2**0.5
+                if not scaling.is_amplitude_scaling():
+                    spectrum = np.abs(spectrum) ** 2
+                spectrum = spectrum * factor
+        freqs = np.fft.rfftfreq(fft_length, 1 / self.sampling_rate_hz)
+        if self.activate_cache:
+            self.spectrum = [freqs.copy(), spectrum.copy()]
+            self.__spectrum_state_update = False
+        return freqs, spectrum
+
+    def get_csm(self, force_computation=False):
+        """-> (freqs_hz, csm (bins, channels, channels))."""
+        assert self.number_of_channels > 1, (
+            "Cross spectral matrix can only be computed when at least two channels are available")
+        if not (not hasattr(self, "csm") or force_computation or self.__csm_state_update):
+            return self.csm[0].copy(), self.csm[1].copy()
+        par = self._spectrum_parameters
+        if self.spectrum_method == SpectrumMethod.WelchPeriodogram:
+            f, csm = backend._csm_welch(self.time_data, self.sampling_rate_hz,
+                                        par["window_length_samples"], par["window_type"],
+                                        par["overlap_percent"], par["detrend"], par["average"],
+                                        par["scaling"])
+        else:
+            raise NotImplementedError(
+                "get_csm with SpectrumMethod.FFT (single-frame outer product) is not built on "
+                "the GPU path yet")
+        if self.activate_cache:
+            self.csm = [f.copy(), csm.copy()]
+            self.__csm_state_update = False
+        return f, csm
+
+    def get_spectrogram(self, force_computation: bool = False):
+        """-> (time_s, freqs_hz, stft (bins, frames, channels))."""
+        if not (not hasattr(self, "spectrogram") or force_computation
+                or self.__spectrogram_state_update):
+            return tuple(a.copy() for a in self.spectrogram)
+        par = self._spectrogram_parameters
+        out = backend._stft(self.time_data, self.sampling_rate_hz, par["window_length_samples"],
+                            par["window_type"], par["overlap_percent"],
+                            par["fft_length_samples"], par["detrend"], par["padding"],
+                            par["scaling"])
+        self.__spectrogram_state_update = False
+        if self.activate_cache:
+            self.spectrogram = deepcopy(out)
+        return out[0], out[1], out[2]
+
+    # ---- copies ---------------------------------------------------------------
+    def copy(self):
+        return deepcopy(self)
+
+    def _get_data(self):
+        return self.time_data
+
+    def _set_data(self, data) -> None:
+        self.time_data = data
+
+    def _create_copy_with_new_data(self, data):
+        return self.copy_with_new_time_data(data)
+
+    def _update_state(self) -> None:
+        self.__update_state()
+
+    def copy_with_new_time_data(self, new_time_data) -> "Signal":
+        if isinstance(new_time_data, np.ndarray) and new_time_data.base is not None:
+            new_time_data = new_time_data.copy()  # the new signal owns its samples
+        new_signal = Signal.from_time_data(new_time_data, self.sampling_rate_hz,
+                                           self.constrain_amplitude)
+        new_signal.calibrated_signal = self.calibrated_signal
+        new_signal.activate_cache = self.activate_cache
+        new_signal._spectrum_parameters = deepcopy(self._spectrum_parameters)
+        new_signal._spectrogram_parameters = deepcopy(self._spectrogram_parameters)
+        return new_signal

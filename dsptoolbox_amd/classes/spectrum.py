@@ -1,0 +1,106 @@
+"""Spectrum container returned by compute_transfer_function
+(API mirror of dsptoolbox/classes/spectrum.py: ctor :31-53, setters :138-269,
+set_coherence :871-885).  Interpolation, smoothing and plotting of the
+reference class are outside the hot path."""
+
+from copy import deepcopy
+
+import numpy as np
+
+from ..standard.enums import SpectrumType
+from ._multichannel_data import MultichannelData
+
+
+class Spectrum(MultichannelData):
+    def __init__(self, frequency_vector_hz, spectral_data):
+        self.frequency_vector_hz = frequency_vector_hz
+        self.spectral_data = spectral_data
+
+    @staticmethod
+    def from_signal(sig, complex: bool = False) -> "Spectrum":
+        if complex:
+            assert sig.spectrum_scaling.outputs_complex_spectrum(sig.spectrum_method), \
+                "Method or scaling do not deliver a complex spectrum"
+        f, sp = sig.get_spectrum()
+        if complex:
+            assert np.iscomplexobj(sp), "Spectrum of signal is not complex"
+            return Spectrum(f, sp)
+        return Spectrum(f, np.abs(sp) if sig.spectrum_scaling.is_amplitude_scaling()
+                        else np.abs(sp) ** 0.5)
+
+    @property
+    def frequency_vector_hz(self):
+        return self.__frequency_vector_hz
+
+    @frequency_vector_hz.setter
+    def frequency_vector_hz(self, new_freqs):
+        assert not np.iscomplexobj(new_freqs), "Complex frequencies are invalid"
+        f = np.atleast_1d(new_freqs).astype(np.float64)
+        assert f.ndim == 1, "Frequency vector can only have a single dimension"
+        assert np.all(f >= 0.0), "Negative frequencies are not supported"
+        assert np.all(np.ediff1d(f) > 0.0), "Frequency vector is not strictly ascending"
+        self.__frequency_vector_hz = f
+
+    @property
+    def number_frequency_bins(self) -> int:
+        return len(self.frequency_vector_hz)
+
+    @property
+    def length_frequency_bins(self) -> int:
+        return self.number_frequency_bins
+
+    @property
+    def spectral_data(self):
+        return self.__spectral_data
+
+    @spectral_data.setter
+    def spectral_data(self, new_data):
+        data = np.atleast_2d(new_data)
+        assert data.ndim == 2, "Spectral data must have two dimensions"
+        if data.shape[0] < data.shape[1]:
+            data = data.T
+        assert data.shape[0] == self.number_frequency_bins, \
+            "Spectral data and frequency vector lengths do not match"
+        is_magnitude = np.isrealobj(data)
+        self.__spectral_data = data.astype(np.float64 if is_magnitude else np.complex128)
+        if self.is_magnitude:
+            assert np.all(self.__spectral_data >= 0.0), \
+                "No negative values are allowed for the magnitude spectrum"
+
+    @property
+    def is_magnitude(self) -> bool:
+        return np.isrealobj(self.__spectral_data)
+
+    @property
+    def is_complex(self) -> bool:
+        return not self.is_magnitude
+
+    @property
+    def spectrum_type(self) -> SpectrumType:
+        return SpectrumType.Magnitude if self.is_magnitude else SpectrumType.Complex
+
+    @property
+    def has_coherence(self) -> bool:
+        return hasattr(self, "coherence")
+
+    def set_coherence(self, coherence):
+        assert coherence.shape == self.spectral_data.shape, \
+            "Length of signals and given coherence do not match"
+        assert not np.iscomplexobj(coherence), "Coherence cannot be complex"
+        self.coherence = coherence
+
+    def copy(self) -> "Spectrum":
+        return deepcopy(self)
+
+    def _get_data(self):
+        return self.spectral_data
+
+    def _set_data(self, data) -> None:
+        self.spectral_data = data
+
+    def _create_copy_with_new_data(self, data):
+        new = Spectrum(self.frequency_vector_hz.copy(), data)
+        return new
+
+    def _update_state(self) -> None:
+        pass

@@ -1,0 +1,706 @@
+// C-ABI of dsptoolbox_amd (see include/dsptoolbox_amd.h): context, memory,
+// plan (twiddle) cache, launch logic.  gfx950 only.
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/dsptoolbox_amd.h"
+#include "kernels_finish.hpp"
+#include "kernels_generic.hpp"
+#include "kernels_welch4096.hpp"
+
+using namespace dsk;
+
+static thread_local std::string g_err;
+
+struct ds_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::string err;
+    std::map<int, float2*> tw;  // twiddle tables by length
+    void* ws = nullptr;         // kernel workspace (spectra, partials)
+    size_t ws_bytes = 0;
+    void* io = nullptr;  // staging for the host-pointer entry points
+    size_t io_bytes = 0;
+    // RCCL (dlopen'ed lazily)
+    void* rccl = nullptr;
+    void* comm = nullptr;
+};
+
+static int fail(ds_ctx* c, int code, const std::string& msg) {
+    g_err = msg;
+    if (c) c->err = msg;
+    return code;
+}
+#define HIPCHK(c, expr)                                                                   \
+    do {                                                                                  \
+        hipError_t e_ = (expr);                                                           \
+        if (e_ != hipSuccess)                                                             \
+            return fail(c, DS_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+#define CHK(expr)                 \
+    do {                          \
+        int r_ = (expr);          \
+        if (r_ != DS_OK) return r_; \
+    } while (0)
+
+static bool is_pow2(int64_t n) { return n > 0 && (n & (n - 1)) == 0; }
+static const int kMaxFft = 16384, kMinFft = 8;
+
+extern "C" int ds_version(void) { return 100; }
+extern "C" int ds_max_fft_len(void) { return kMaxFft; }
+extern "C" int ds_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+extern "C" int ds_init(int device, ds_ctx** out) {
+    if (!out) return fail(nullptr, DS_ERR_ARG, "ds_init: out is null");
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+        return fail(nullptr, DS_ERR_HIP, "ds_init: no HIP device visible");
+    if (device < 0 || device >= n) return fail(nullptr, DS_ERR_ARG, "ds_init: bad device index");
+    ds_ctx* c = new ds_ctx();
+    c->device = device;
+    HIPCHK(c, hipSetDevice(device));
+    HIPCHK(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    HIPCHK(c, hipEventCreate(&c->ev0));
+    HIPCHK(c, hipEventCreate(&c->ev1));
+    *out = c;
+    return DS_OK;
+}
+
+extern "C" int ds_comm_destroy(ds_ctx* c);
+
+extern "C" void ds_destroy(ds_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    ds_comm_destroy(c);
+    (void)hipStreamSynchronize(c->stream);
+    for (auto& kv : c->tw) (void)hipFree(kv.second);
+    if (c->ws) (void)hipFree(c->ws);
+    if (c->io) (void)hipFree(c->io);
+    (void)hipEventDestroy(c->ev0);
+    (void)hipEventDestroy(c->ev1);
+    (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+extern "C" const char* ds_last_error(ds_ctx* c) { return c ? c->err.c_str() : g_err.c_str(); }
+
+extern "C" int ds_malloc(ds_ctx* c, void** dptr, size_t bytes) {
+    if (!c || !dptr) return fail(c, DS_ERR_ARG, "ds_malloc: null argument");
+    HIPCHK(c, hipSetDevice(c->device));
+    hipError_t e = hipMalloc(dptr, bytes ? bytes : 1);
+    if (e != hipSuccess) return fail(c, DS_ERR_NOMEM, std::string("hipMalloc: ") + hipGetErrorString(e));
+    return DS_OK;
+}
+extern "C" int ds_free(ds_ctx* c, void* dptr) {
+    if (!c) return fail(c, DS_ERR_ARG, "ds_free: null ctx");
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipFree(dptr));
+    return DS_OK;
+}
+extern "C" int ds_upload(ds_ctx* c, void* dst, const void* src, size_t bytes) {
+    if (!c || (bytes && (!dst || !src))) return fail(c, DS_ERR_ARG, "ds_upload: null argument");
+    HIPCHK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return DS_OK;
+}
+extern "C" int ds_download(ds_ctx* c, void* dst, const void* src, size_t bytes) {
+    if (!c || (bytes && (!dst || !src))) return fail(c, DS_ERR_ARG, "ds_download: null argument");
+    HIPCHK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return DS_OK;
+}
+extern "C" int ds_memset(ds_ctx* c, void* dst, int value, size_t bytes) {
+    if (!c) return fail(c, DS_ERR_ARG, "ds_memset: null ctx");
+    HIPCHK(c, hipMemsetAsync(dst, value, bytes, c->stream));
+    return DS_OK;
+}
+extern "C" int ds_sync(ds_ctx* c) {
+    if (!c) return fail(c, DS_ERR_ARG, "ds_sync: null ctx");
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return DS_OK;
+}
+extern "C" int ds_timer_start(ds_ctx* c) {
+    if (!c) return fail(c, DS_ERR_ARG, "ds_timer_start: null ctx");
+    HIPCHK(c, hipEventRecord(c->ev0, c->stream));
+    return DS_OK;
+}
+extern "C" int ds_timer_stop(ds_ctx* c, float* ms) {
+    if (!c || !ms) return fail(c, DS_ERR_ARG, "ds_timer_stop: null argument");
+    HIPCHK(c, hipEventRecord(c->ev1, c->stream));
+    HIPCHK(c, hipEventSynchronize(c->ev1));
+    HIPCHK(c, hipEventElapsedTime(ms, c->ev0, c->ev1));
+    return DS_OK;
+}
+
+// ---- internal helpers ------------------------------------------------------
+static int get_twiddles(ds_ctx* c, int n, const float2** out) {
+    auto it = c->tw.find(n);
+    if (it != c->tw.end()) {
+        *out = it->second;
+        return DS_OK;
+    }
+    std::vector<float2> h(n);
+    for (int m = 0; m < n; ++m) {
+        double a = -2.0 * M_PI * (double)m / (double)n;
+        h[m] = make_float2((float)std::cos(a), (float)std::sin(a));
+    }
+    float2* d = nullptr;
+    HIPCHK(c, hipMalloc((void**)&d, sizeof(float2) * n));
+    HIPCHK(c, hipMemcpyAsync(d, h.data(), sizeof(float2) * n, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->tw[n] = d;
+    *out = d;
+    return DS_OK;
+}
+
+static int reserve(ds_ctx* c, void** buf, size_t* cap, size_t bytes) {
+    if (bytes <= *cap) return DS_OK;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (*buf) HIPCHK(c, hipFree(*buf));
+    *buf = nullptr;
+    *cap = 0;
+    size_t want = bytes + bytes / 8 + 4096;
+    hipError_t e = hipMalloc(buf, want);
+    if (e != hipSuccess) return fail(c, DS_ERR_NOMEM, "workspace hipMalloc failed");
+    *cap = want;
+    return DS_OK;
+}
+
+struct Carver {  // 256-byte aligned sub-allocations out of one buffer
+    char* base;
+    size_t off = 0;
+    explicit Carver(void* b) : base((char*)b) {}
+    template <typename T>
+    T* take(size_t count) {
+        T* p = (T*)(base + off);
+        off += (count * sizeof(T) + 255) & ~size_t(255);
+        return p;
+    }
+    static size_t pad(size_t bytes) { return (bytes + 255) & ~size_t(255); }
+};
+
+template <typename K, typename A>
+static int launch(ds_ctx* c, K kernel, dim3 grid, int threads, size_t lds, const A& args) {
+    if (lds > 64 * 1024)
+        HIPCHK(c, hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kernel, grid, dim3(threads), lds, c->stream, args);
+    HIPCHK(c, hipGetLastError());
+    return DS_OK;
+}
+
+#define DISPATCH_N(n, CALL)                                                        \
+    switch (n) {                                                                   \
+        case 8: { constexpr int NN = 8; CALL; } break;                             \
+        case 16: { constexpr int NN = 16; CALL; } break;                           \
+        case 32: { constexpr int NN = 32; CALL; } break;                           \
+        case 64: { constexpr int NN = 64; CALL; } break;                           \
+        case 128: { constexpr int NN = 128; CALL; } break;                         \
+        case 256: { constexpr int NN = 256; CALL; } break;                         \
+        case 512: { constexpr int NN = 512; CALL; } break;                         \
+        case 1024: { constexpr int NN = 1024; CALL; } break;                       \
+        case 2048: { constexpr int NN = 2048; CALL; } break;                       \
+        case 4096: { constexpr int NN = 4096; CALL; } break;                       \
+        case 8192: { constexpr int NN = 8192; CALL; } break;                       \
+        case 16384: { constexpr int NN = 16384; CALL; } break;                     \
+        default: return fail(c, DS_ERR_UNSUP, "FFT length must be a power of two in [8, 16384]"); \
+    }
+
+static int check_fft_len(ds_ctx* c, int n, const char* what) {
+    if (!is_pow2(n) || n < kMinFft)
+        return fail(c, DS_ERR_ARG, std::string(what) + ": length must be a power of two >= 8");
+    if (n > kMaxFft)
+        return fail(c, DS_ERR_UNSUP, std::string(what) + ": lengths above 16384 are not built yet (LDS-resident FFT)");
+    return DS_OK;
+}
+
+// ---- STFT ------------------------------------------------------------------
+extern "C" int ds_stft_r2c_dev(ds_ctx* c, const float* x, int64_t n_samples, int n_ch, int64_t ld,
+                               int W, int hop, int nfft, int64_t pad_front, int n_frames,
+                               const float* window, int detrend, float scale, float edge_scale,
+                               int power, ds_c32* out) {
+    if (!c || !x || !out || !window) return fail(c, DS_ERR_ARG, "ds_stft_r2c: null argument");
+    if (n_ch <= 0 || n_samples <= 0 || W <= 0 || hop <= 0 || n_frames <= 0 || ld < n_samples)
+        return fail(c, DS_ERR_ARG, "ds_stft_r2c: bad shape");
+    CHK(check_fft_len(c, nfft, "ds_stft_r2c nfft"));
+    const float2* tw;
+    CHK(get_twiddles(c, nfft, &tw));
+    StftArgs a{x, n_samples, ld, pad_front, n_ch, W, hop, n_frames, detrend, power, window, tw,
+               scale, edge_scale, (float2*)out};
+    dim3 grid((unsigned)((int64_t)n_ch * ((n_frames + 1) / 2)));
+    DISPATCH_N(nfft, CHK(launch(c, k_stft<NN>, grid, Cfg<NN>::NT, Cfg<NN>::LDS_BYTES, a)));
+    return DS_OK;
+}
+
+// ---- Welch -----------------------------------------------------------------
+struct WelchPlan {
+    int n_chunks, fpc;
+};
+static WelchPlan plan_welch(int n_frames, int units) {
+    // >= ~1024 workgroups when there is enough work, <= 32 frames per fp32 chain
+    int by_len = (n_frames + 31) / 32;
+    int by_fill = (1024 + units - 1) / units;
+    int n_chunks = std::max(by_len, std::min(by_fill, (n_frames + 1) / 2));
+    n_chunks = std::max(1, n_chunks);
+    int fpc = (n_frames + n_chunks - 1) / n_chunks;
+    fpc = (fpc + 1) & ~1;  // even: frames travel in pairs in the input-spectra kernel
+    n_chunks = (n_frames + fpc - 1) / fpc;
+    return {n_chunks, fpc};
+}
+
+// kind 0: tf+coh, 1: psd of x, 2: csd of (x[c], y[c])
+static int welch_common(ds_ctx* c, int kind, const float* x, int n_cx, int64_t ldx, const float* y,
+                        int n_cy, int64_t ldy, int64_t n_samples, int W, int hop, int n_frames,
+                        const float* window, int detrend, int mode, int amp_sqrt,
+                        double norm_scale, double factor, int halve_edges, float2* out_c,
+                        float* out_r) {
+    if (!c || !x || !window) return fail(c, DS_ERR_ARG, "welch: null argument");
+    if (kind != 1 && !y) return fail(c, DS_ERR_ARG, "welch: null output-signal pointer");
+    if (n_cx <= 0 || n_samples <= 0 || hop <= 0 || hop > W || n_frames <= 0 || ldx < n_samples)
+        return fail(c, DS_ERR_ARG, "welch: bad shape");
+    if (kind != 1 && (n_cy <= 0 || ldy < n_samples || !(n_cx == 1 || n_cx == n_cy)))
+        return fail(c, DS_ERR_ARG, "welch: input must have 1 channel or as many as the output");
+    if (kind == 0 && (mode < DS_TF_H1 || mode > DS_TF_H3))
+        return fail(c, DS_ERR_ARG, "welch: unsupported transfer function type");
+    CHK(check_fft_len(c, W, "welch window length"));
+    const float2* tw;
+    CHK(get_twiddles(c, W, &tw));
+    const int nb = W / 2 + 1;
+    const int units = kind == 1 ? n_cx : (n_cy + 1) / 2;
+    WelchPlan pl = plan_welch(n_frames, units);
+    const bool need_xs = kind != 1;
+    size_t bytes = Carver::pad(sizeof(float) * (size_t)pl.n_chunks * n_cx * nb);
+    if (need_xs) {
+        bytes += Carver::pad(sizeof(float2) * (size_t)n_cx * n_frames * nb);
+        bytes += Carver::pad(sizeof(float2) * (size_t)pl.n_chunks * n_cy * nb);
+        bytes += Carver::pad(sizeof(float) * (size_t)pl.n_chunks * n_cy * nb);
+    }
+    CHK(reserve(c, &c->ws, &c->ws_bytes, bytes));
+    Carver cv(c->ws);
+    float* pxx = cv.take<float>((size_t)pl.n_chunks * n_cx * nb);
+    float2* xs = nullptr;
+    float2* pxy = nullptr;
+    float* pyy = nullptr;
+    if (need_xs) {
+        xs = cv.take<float2>((size_t)n_cx * n_frames * nb);
+        pxy = cv.take<float2>((size_t)pl.n_chunks * n_cy * nb);
+        pyy = cv.take<float>((size_t)pl.n_chunks * n_cy * nb);
+    }
+    {
+        XspecArgs a{x, n_samples, ldx, n_cx, W, hop, n_frames, detrend, pl.fpc, window, tw, xs, pxx};
+        dim3 grid(pl.n_chunks, n_cx);
+        DISPATCH_N(W, CHK(launch(c, k_xspec<NN>, grid, Cfg<NN>::NT, Cfg<NN>::LDS_BYTES, a)));
+    }
+    if (need_xs) {
+        YaccArgs a{y, n_samples, ldy, n_cy, n_cx, W, hop, n_frames, detrend, pl.fpc, window, tw, xs, pxy, pyy};
+        dim3 grid(pl.n_chunks, (n_cy + 1) / 2);
+        DISPATCH_N(W, CHK(launch(c, k_yacc<NN>, grid, Cfg<NN>::NT, Cfg<NN>::LDS_BYTES, a)));
+    }
+    WelchFinArgs f{pxx, pxy, pyy, pl.n_chunks, n_cx, n_cy, kind, mode,
+                   FinishPar{norm_scale / (double)n_frames, factor, halve_edges, amp_sqrt, nb},
+                   out_c, out_r};
+    int64_t total = (int64_t)nb * (kind == 1 ? n_cx : n_cy);
+    CHK(launch(c, k_welch_finish, dim3((unsigned)((total + 255) / 256)), 256, 0, f));
+    return DS_OK;
+}
+
+extern "C" int ds_welch_tf_dev(ds_ctx* c, const float* x, int n_cx, int64_t ldx, const float* y,
+                               int n_cy, int64_t ldy, int64_t n_samples, int W, int hop, int n_frames,
+                               const float* window, int detrend, int mode, int amp_sqrt,
+                               double norm_scale, double factor, int halve_edges, ds_c32* tf,
+                               float* coh) {
+    if (!tf || !coh) return fail(c, DS_ERR_ARG, "ds_welch_tf: null output");
+    if (c && W == 4096 && n_cx == 1 && hop == 2048 && welch4096::enabled())
+        return welch4096::run(c->stream, x, ldx, y, n_cy, ldy, n_samples, n_frames, window, detrend,
+                              mode, amp_sqrt, norm_scale, factor, halve_edges, (float2*)tf, coh);
+    return welch_common(c, 0, x, n_cx, ldx, y, n_cy, ldy, n_samples, W, hop, n_frames, window, detrend,
+                        mode, amp_sqrt, norm_scale, factor, halve_edges, (float2*)tf, coh);
+}
+extern "C" int ds_welch_psd_dev(ds_ctx* c, const float* x, int n_cx, int64_t ldx, int64_t n_samples,
+                                int W, int hop, int n_frames, const float* window, int detrend,
+                                int amp_sqrt, double norm_scale, double factor, int halve_edges,
+                                float* psd) {
+    if (!psd) return fail(c, DS_ERR_ARG, "ds_welch_psd: null output");
+    return welch_common(c, 1, x, n_cx, ldx, nullptr, 0, 0, n_samples, W, hop, n_frames, window, detrend,
+                        0, amp_sqrt, norm_scale, factor, halve_edges, nullptr, psd);
+}
+static int welch_csd_dev(ds_ctx* c, const float* x, const float* y, int n_ch, int64_t ld,
+                         int64_t n_samples, int W, int hop, int n_frames, const float* window,
+                         int detrend, int amp_sqrt, double norm_scale, double factor,
+                         int halve_edges, ds_c32* csd) {
+    return welch_common(c, 2, x, n_ch, ld, y, n_ch, ld, n_samples, W, hop, n_frames, window, detrend, 0,
+                        amp_sqrt, norm_scale, factor, halve_edges, (float2*)csd, nullptr);
+}
+
+// ---- CSM -------------------------------------------------------------------
+extern "C" int ds_csm_dev(ds_ctx* c, const float* x, int n_ch, int64_t ld, int64_t n_samples, int W,
+                          int hop, int n_frames, const float* window, int detrend, int amp_sqrt,
+                          double norm_scale, double factor, int halve_edges, ds_c32* csm) {
+    if (!c || !x || !window || !csm) return fail(c, DS_ERR_ARG, "ds_csm: null argument");
+    if (n_ch < 1 || n_samples <= 0 || hop <= 0 || hop > W || n_frames <= 0 || ld < n_samples)
+        return fail(c, DS_ERR_ARG, "ds_csm: bad shape");
+    CHK(check_fft_len(c, W, "ds_csm window length"));
+    const int nb = W / 2 + 1;
+    // the STFT buffer X[b][f][c] lives in the io workspace tail? no: own workspace
+    size_t bytes = sizeof(float2) * (size_t)nb * n_frames * n_ch;
+    CHK(reserve(c, &c->ws, &c->ws_bytes, bytes));
+    float2* X = (float2*)c->ws;
+    CHK(ds_stft_r2c_dev(c, x, n_samples, n_ch, ld, W, hop, W, 0, n_frames, window, detrend, 1.0f, 1.0f,
+                        0, (ds_c32*)X));
+    const int nt = (n_ch + 31) / 32;
+    CsmArgs a{X, n_ch, n_frames,
+              FinishPar{norm_scale / (double)n_frames, factor, halve_edges, amp_sqrt, nb},
+              (float2*)csm};
+    CHK(launch(c, k_csm_gemm, dim3(nb, nt * (nt + 1) / 2), 256, 0, a));
+    return DS_OK;
+}
+
+// ---- whole-signal rFFT, deconvolution ---------------------------------------
+extern "C" int ds_rfft_dev(ds_ctx* c, const float* x, int n_ch, int64_t ld, int64_t n_samples,
+                           int n_fft, float scale, ds_c32* spec) {
+    if (!c || !x || !spec) return fail(c, DS_ERR_ARG, "ds_rfft: null argument");
+    if (n_ch <= 0 || n_samples <= 0 || ld < n_samples || n_samples > n_fft)
+        return fail(c, DS_ERR_ARG, "ds_rfft: bad shape (n_samples must be <= n_fft)");
+    CHK(check_fft_len(c, n_fft, "ds_rfft n_fft"));
+    const float2* tw;
+    CHK(get_twiddles(c, n_fft, &tw));
+    RfftArgs a{x, n_samples, ld, n_ch, tw, scale, (float2*)spec};
+    DISPATCH_N(n_fft, CHK(launch(c, k_rfft<NN>, dim3((n_ch + 1) / 2), Cfg<NN>::NT, Cfg<NN>::LDS_BYTES, a)));
+    return DS_OK;
+}
+
+extern "C" int ds_deconv_inverse_dev(ds_ctx* c, const ds_c32* xspec, int n_ch, int n_bins,
+                                     const float* eps, ds_c32* r) {
+    if (!c || !xspec || !r || n_ch <= 0 || n_bins <= 0)
+        return fail(c, DS_ERR_ARG, "ds_deconv_inverse: bad argument");
+    int64_t total = (int64_t)n_ch * n_bins;
+    hipLaunchKernelGGL(k_deconv_inverse, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream,
+                       (const float2*)xspec, n_ch, n_bins, eps, (float2*)r);
+    HIPCHK(c, hipGetLastError());
+    return DS_OK;
+}
+
+extern "C" int ds_deconv_dev(ds_ctx* c, const float* y, int n_items, int n_ch, int64_t ld,
+                             int64_t n_samples, int n_fft, const ds_c32* r, int r_per_channel,
+                             int64_t n_out, int64_t ld_out, float* ir) {
+    if (!c || !y || !r || !ir) return fail(c, DS_ERR_ARG, "ds_deconv: null argument");
+    if (n_items <= 0 || n_ch <= 0 || n_samples <= 0 || ld < n_samples || n_samples > n_fft ||
+        n_out <= 0 || n_out > n_fft || ld_out < n_out)
+        return fail(c, DS_ERR_ARG, "ds_deconv: bad shape");
+    CHK(check_fft_len(c, n_fft, "ds_deconv n_fft"));
+    const float2* tw;
+    CHK(get_twiddles(c, n_fft, &tw));
+    DeconvArgs a{y, n_samples, ld, n_out, ld_out, n_ch, r_per_channel, tw, (const float2*)r, ir};
+    dim3 grid((n_ch + 1) / 2, n_items);
+    DISPATCH_N(n_fft, CHK(launch(c, k_deconv<NN>, grid, Cfg<NN>::NT, Cfg<NN>::LDS_BYTES, a)));
+    return DS_OK;
+}
+
+// ---- FIR ---------------------------------------------------------------------
+static int fir_block_len(int n_taps) {
+    int n = 1024;
+    while (n < 4 * n_taps && n < kMaxFft) n <<= 1;
+    return n;
+}
+
+static int fir_once(ds_ctx* c, const float* x, int n_ch, int64_t ldx, int64_t n_samples,
+                    const float* taps, int n_filt, int n_taps, float* y, int64_t ld_y) {
+    const int N = fir_block_len(n_taps);
+    if (n_taps - 1 > N / 2)
+        return fail(c, DS_ERR_UNSUP, "ds_fir_ola: more than 8193 taps needs partitioned convolution (not built yet)");
+    const float2* tw;
+    CHK(get_twiddles(c, N, &tw));
+    CHK(reserve(c, &c->ws, &c->ws_bytes, sizeof(float2) * (size_t)n_filt * N));
+    float2* hs = (float2*)c->ws;
+    {
+        FirTapsArgs a{taps, n_filt, n_taps, tw, hs};
+        DISPATCH_N(N, CHK(launch(c, k_fir_taps<NN>, dim3((n_filt + 1) / 2), Cfg<NN>::NT, Cfg<NN>::LDS_BYTES, a)));
+    }
+    const int L = N - (n_taps - 1);
+    const int64_t n_blocks = (n_samples + L - 1) / L;
+    FirArgs a{x, n_samples, ldx, ld_y, n_ch, n_filt, n_taps, tw, hs, y};
+    dim3 grid((unsigned)n_blocks, (n_ch + 1) / 2);
+    DISPATCH_N(N, CHK(launch(c, k_fir<NN>, grid, Cfg<NN>::NT, Cfg<NN>::LDS_BYTES, a)));
+    return DS_OK;
+}
+
+__global__ void k_sum_taps(const float* taps, int n_filt, int n_taps, float* out) {
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_taps) return;
+    double s = 0.0;
+    for (int k = 0; k < n_filt; ++k) s += (double)taps[(int64_t)k * n_taps + t];
+    out[t] = (float)s;
+}
+
+extern "C" int ds_fir_ola_dev(ds_ctx* c, const float* x, int n_ch, int64_t ldx, int64_t n_samples,
+                              const float* taps, int n_filt, int n_taps, int mode, float* y,
+                              int64_t ld_y) {
+    if (!c || !x || !taps || !y) return fail(c, DS_ERR_ARG, "ds_fir_ola: null argument");
+    if (n_ch <= 0 || n_samples <= 0 || n_filt <= 0 || n_taps <= 0 || ldx < n_samples || ld_y < n_samples)
+        return fail(c, DS_ERR_ARG, "ds_fir_ola: bad shape");
+    if (mode == DS_FB_PARALLEL) return fir_once(c, x, n_ch, ldx, n_samples, taps, n_filt, n_taps, y, ld_y);
+    if (mode == DS_FB_SUMMED) {
+        // sum_k (x * b_k) = x * (sum_k b_k): one filter with the summed taps
+        float* bs = nullptr;
+        HIPCHK(c, hipMalloc((void**)&bs, sizeof(float) * n_taps));
+        hipLaunchKernelGGL(k_sum_taps, dim3((n_taps + 255) / 256), dim3(256), 0, c->stream, taps, n_filt, n_taps, bs);
+        int r = fir_once(c, x, n_ch, ldx, n_samples, bs, 1, n_taps, y, ld_y);
+        (void)hipStreamSynchronize(c->stream);
+        (void)hipFree(bs);
+        return r;
+    }
+    if (mode == DS_FB_SEQUENTIAL) {
+        // cascade, each stage truncated to n_samples (causal, so identical to the reference loop)
+        float* tmp = nullptr;
+        if (n_filt > 1) HIPCHK(c, hipMalloc((void**)&tmp, sizeof(float) * (size_t)n_ch * n_samples));
+        const float* src = x;
+        int64_t lds = ldx;
+        int r = DS_OK;
+        for (int k = 0; k < n_filt && r == DS_OK; ++k) {
+            bool last = (k == n_filt - 1);
+            // ping-pong so the last stage lands in y
+            float* dst = ((n_filt - 1 - k) % 2 == 0) ? y : tmp;
+            int64_t ldd = (dst == y) ? ld_y : n_samples;
+            r = fir_once(c, src, n_ch, lds, n_samples, taps + (int64_t)k * n_taps, 1, n_taps, dst, ldd);
+            src = dst;
+            lds = ldd;
+            (void)last;
+        }
+        (void)hipStreamSynchronize(c->stream);
+        if (tmp) (void)hipFree(tmp);
+        return r;
+    }
+    return fail(c, DS_ERR_ARG, "ds_fir_ola: invalid filter bank apply mode");
+}
+
+// ---- host-pointer entry points -------------------------------------------------
+struct Stage {  // device staging out of ctx->io
+    ds_ctx* c;
+    Carver cv;
+    explicit Stage(ds_ctx* ctx) : c(ctx), cv(ctx->io) {}
+};
+static int stage_reserve(ds_ctx* c, size_t bytes) { return reserve(c, &c->io, &c->io_bytes, bytes + 4096); }
+
+extern "C" int ds_stft_r2c(ds_ctx* c, const float* x, int64_t n_samples, int n_ch, int W, int hop,
+                           int nfft, int64_t pad_front, int n_frames, const float* window, int detrend,
+                           float scale, float edge_scale, int power, ds_c32* out) {
+    if (!c || !x || !window || !out) return fail(c, DS_ERR_ARG, "ds_stft_r2c: null argument");
+    if (n_ch <= 0 || n_samples <= 0 || W <= 0 || n_frames <= 0 || nfft <= 0) return fail(c, DS_ERR_ARG, "ds_stft_r2c: bad shape");
+    size_t nx = (size_t)n_ch * n_samples, no = (size_t)(nfft / 2 + 1) * n_frames * n_ch;
+    CHK(stage_reserve(c, Carver::pad(nx * 4) + Carver::pad((size_t)W * 4) + Carver::pad(no * 8)));
+    Carver cv(c->io);
+    float* dx = cv.take<float>(nx);
+    float* dw = cv.take<float>(W);
+    float2* dout = cv.take<float2>(no);
+    CHK(ds_upload(c, dx, x, nx * 4));
+    CHK(ds_upload(c, dw, window, (size_t)W * 4));
+    CHK(ds_stft_r2c_dev(c, dx, n_samples, n_ch, n_samples, W, hop, nfft, pad_front, n_frames, dw, detrend,
+                        scale, edge_scale, power, (ds_c32*)dout));
+    return ds_download(c, out, dout, no * 8);
+}
+
+extern "C" int ds_welch_tf(ds_ctx* c, const float* x, int n_cx, const float* y, int n_cy,
+                           int64_t n_samples, int W, int hop, int n_frames, const float* window,
+                           int detrend, int mode, int amp_sqrt, double norm_scale, double factor,
+                           int halve_edges, ds_c32* tf, float* coh) {
+    if (!c || !x || !y || !window || !tf || !coh) return fail(c, DS_ERR_ARG, "ds_welch_tf: null argument");
+    if (n_cx <= 0 || n_cy <= 0 || n_samples <= 0 || W <= 0) return fail(c, DS_ERR_ARG, "ds_welch_tf: bad shape");
+    size_t nx = (size_t)n_cx * n_samples, ny = (size_t)n_cy * n_samples, no = (size_t)(W / 2 + 1) * n_cy;
+    CHK(stage_reserve(c, Carver::pad(nx * 4) + Carver::pad(ny * 4) + Carver::pad((size_t)W * 4) +
+                             Carver::pad(no * 8) + Carver::pad(no * 4)));
+    Carver cv(c->io);
+    float* dx = cv.take<float>(nx);
+    float* dy = cv.take<float>(ny);
+    float* dw = cv.take<float>(W);
+    float2* dtf = cv.take<float2>(no);
+    float* dcoh = cv.take<float>(no);
+    CHK(ds_upload(c, dx, x, nx * 4));
+    CHK(ds_upload(c, dy, y, ny * 4));
+    CHK(ds_upload(c, dw, window, (size_t)W * 4));
+    CHK(ds_welch_tf_dev(c, dx, n_cx, n_samples, dy, n_cy, n_samples, n_samples, W, hop, n_frames, dw,
+                        detrend, mode, amp_sqrt, norm_scale, factor, halve_edges, (ds_c32*)dtf, dcoh));
+    CHK(ds_download(c, tf, dtf, no * 8));
+    return ds_download(c, coh, dcoh, no * 4);
+}
+
+extern "C" int ds_welch_psd(ds_ctx* c, const float* x, int n_cx, int64_t n_samples, int W, int hop,
+                            int n_frames, const float* window, int detrend, int amp_sqrt,
+                            double norm_scale, double factor, int halve_edges, float* psd) {
+    if (!c || !x || !window || !psd) return fail(c, DS_ERR_ARG, "ds_welch_psd: null argument");
+    if (n_cx <= 0 || n_samples <= 0 || W <= 0) return fail(c, DS_ERR_ARG, "ds_welch_psd: bad shape");
+    size_t nx = (size_t)n_cx * n_samples, no = (size_t)(W / 2 + 1) * n_cx;
+    CHK(stage_reserve(c, Carver::pad(nx * 4) + Carver::pad((size_t)W * 4) + Carver::pad(no * 4)));
+    Carver cv(c->io);
+    float* dx = cv.take<float>(nx);
+    float* dw = cv.take<float>(W);
+    float* dp = cv.take<float>(no);
+    CHK(ds_upload(c, dx, x, nx * 4));
+    CHK(ds_upload(c, dw, window, (size_t)W * 4));
+    CHK(ds_welch_psd_dev(c, dx, n_cx, n_samples, n_samples, W, hop, n_frames, dw, detrend, amp_sqrt,
+                         norm_scale, factor, halve_edges, dp));
+    return ds_download(c, psd, dp, no * 4);
+}
+
+extern "C" int ds_welch_csd(ds_ctx* c, const float* x, const float* y, int n_ch, int64_t n_samples,
+                            int W, int hop, int n_frames, const float* window, int detrend,
+                            int amp_sqrt, double norm_scale, double factor, int halve_edges,
+                            ds_c32* csd) {
+    if (!c || !x || !y || !window || !csd) return fail(c, DS_ERR_ARG, "ds_welch_csd: null argument");
+    if (n_ch <= 0 || n_samples <= 0 || W <= 0) return fail(c, DS_ERR_ARG, "ds_welch_csd: bad shape");
+    size_t nx = (size_t)n_ch * n_samples, no = (size_t)(W / 2 + 1) * n_ch;
+    CHK(stage_reserve(c, 2 * Carver::pad(nx * 4) + Carver::pad((size_t)W * 4) + Carver::pad(no * 8)));
+    Carver cv(c->io);
+    float* dx = cv.take<float>(nx);
+    float* dy = cv.take<float>(nx);
+    float* dw = cv.take<float>(W);
+    float2* dc = cv.take<float2>(no);
+    CHK(ds_upload(c, dx, x, nx * 4));
+    CHK(ds_upload(c, dy, y, nx * 4));
+    CHK(ds_upload(c, dw, window, (size_t)W * 4));
+    CHK(welch_csd_dev(c, dx, dy, n_ch, n_samples, n_samples, W, hop, n_frames, dw, detrend, amp_sqrt,
+                      norm_scale, factor, halve_edges, (ds_c32*)dc));
+    return ds_download(c, csd, dc, no * 8);
+}
+
+extern "C" int ds_csm(ds_ctx* c, const float* x, int n_ch, int64_t n_samples, int W, int hop,
+                      int n_frames, const float* window, int detrend, int amp_sqrt, double norm_scale,
+                      double factor, int halve_edges, ds_c32* csm) {
+    if (!c || !x || !window || !csm) return fail(c, DS_ERR_ARG, "ds_csm: null argument");
+    if (n_ch <= 0 || n_samples <= 0 || W <= 0) return fail(c, DS_ERR_ARG, "ds_csm: bad shape");
+    size_t nx = (size_t)n_ch * n_samples, no = (size_t)(W / 2 + 1) * n_ch * n_ch;
+    CHK(stage_reserve(c, Carver::pad(nx * 4) + Carver::pad((size_t)W * 4) + Carver::pad(no * 8)));
+    Carver cv(c->io);
+    float* dx = cv.take<float>(nx);
+    float* dw = cv.take<float>(W);
+    float2* dc = cv.take<float2>(no);
+    CHK(ds_upload(c, dx, x, nx * 4));
+    CHK(ds_upload(c, dw, window, (size_t)W * 4));
+    CHK(ds_csm_dev(c, dx, n_ch, n_samples, n_samples, W, hop, n_frames, dw, detrend, amp_sqrt, norm_scale,
+                   factor, halve_edges, (ds_c32*)dc));
+    return ds_download(c, csm, dc, no * 8);
+}
+
+extern "C" int ds_rfft(ds_ctx* c, const float* x, int n_ch, int64_t n_samples, int n_fft, float scale,
+                       ds_c32* spec) {
+    if (!c || !x || !spec) return fail(c, DS_ERR_ARG, "ds_rfft: null argument");
+    if (n_ch <= 0 || n_samples <= 0 || n_fft <= 0) return fail(c, DS_ERR_ARG, "ds_rfft: bad shape");
+    size_t nx = (size_t)n_ch * n_samples, no = (size_t)(n_fft / 2 + 1) * n_ch;
+    CHK(stage_reserve(c, Carver::pad(nx * 4) + Carver::pad(no * 8)));
+    Carver cv(c->io);
+    float* dx = cv.take<float>(nx);
+    float2* ds = cv.take<float2>(no);
+    CHK(ds_upload(c, dx, x, nx * 4));
+    CHK(ds_rfft_dev(c, dx, n_ch, n_samples, n_samples, n_fft, scale, (ds_c32*)ds));
+    return ds_download(c, spec, ds, no * 8);
+}
+
+extern "C" int ds_deconv(ds_ctx* c, const float* y, int n_items, int n_ch, int64_t n_samples, int n_fft,
+                         const ds_c32* r, int r_per_channel, int64_t n_out, float* ir) {
+    if (!c || !y || !r || !ir) return fail(c, DS_ERR_ARG, "ds_deconv: null argument");
+    if (n_items <= 0 || n_ch <= 0 || n_samples <= 0 || n_fft <= 0 || n_out <= 0) return fail(c, DS_ERR_ARG, "ds_deconv: bad shape");
+    size_t ny = (size_t)n_items * n_ch * n_samples, nr = (size_t)(r_per_channel ? n_ch : 1) * (n_fft / 2 + 1),
+           no = (size_t)n_items * n_ch * n_out;
+    CHK(stage_reserve(c, Carver::pad(ny * 4) + Carver::pad(nr * 8) + Carver::pad(no * 4)));
+    Carver cv(c->io);
+    float* dy = cv.take<float>(ny);
+    float2* dr = cv.take<float2>(nr);
+    float* dir = cv.take<float>(no);
+    CHK(ds_upload(c, dy, y, ny * 4));
+    CHK(ds_upload(c, dr, r, nr * 8));
+    CHK(ds_deconv_dev(c, dy, n_items, n_ch, n_samples, n_samples, n_fft, (const ds_c32*)dr, r_per_channel,
+                      n_out, n_out, dir));
+    return ds_download(c, ir, dir, no * 4);
+}
+
+extern "C" int ds_fir_ola(ds_ctx* c, const float* x, int n_ch, int64_t n_samples, const float* taps,
+                          int n_filt, int n_taps, int mode, float* y) {
+    if (!c || !x || !taps || !y) return fail(c, DS_ERR_ARG, "ds_fir_ola: null argument");
+    if (n_ch <= 0 || n_samples <= 0 || n_filt <= 0 || n_taps <= 0) return fail(c, DS_ERR_ARG, "ds_fir_ola: bad shape");
+    size_t nx = (size_t)n_ch * n_samples, nt = (size_t)n_filt * n_taps,
+           no = (size_t)(mode == DS_FB_PARALLEL ? n_filt : 1) * n_ch * n_samples;
+    CHK(stage_reserve(c, Carver::pad(nx * 4) + Carver::pad(nt * 4) + Carver::pad(no * 4)));
+    Carver cv(c->io);
+    float* dx = cv.take<float>(nx);
+    float* dt = cv.take<float>(nt);
+    float* dy = cv.take<float>(no);
+    CHK(ds_upload(c, dx, x, nx * 4));
+    CHK(ds_upload(c, dt, taps, nt * 4));
+    CHK(ds_fir_ola_dev(c, dx, n_ch, n_samples, n_samples, dt, n_filt, n_taps, mode, dy, n_samples));
+    return ds_download(c, y, dy, no * 4);
+}
+
+// ---- RCCL (resolved at run time so the library loads on machines without it) ----
+typedef int (*nccl_getuid_t)(void*);
+struct uid128 {
+    char b[128];
+};
+typedef int (*nccl_init_rank_t)(void**, int, uid128, int);
+typedef int (*nccl_bcast_t)(const void*, void*, size_t, int, int, void*, hipStream_t);
+typedef int (*nccl_destroy_t)(void*);
+typedef const char* (*nccl_errstr_t)(int);
+
+static void* rccl_handle() {
+    static void* h = nullptr;
+    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    return h;
+}
+
+extern "C" int ds_comm_unique_id(char id_out[128]) {
+    if (!id_out) return fail(nullptr, DS_ERR_ARG, "ds_comm_unique_id: null");
+    void* h = rccl_handle();
+    if (!h) return fail(nullptr, DS_ERR_COMM, "librccl.so not found");
+    auto f = (nccl_getuid_t)dlsym(h, "ncclGetUniqueId");
+    if (!f) return fail(nullptr, DS_ERR_COMM, "ncclGetUniqueId missing");
+    int r = f(id_out);
+    return r == 0 ? DS_OK : fail(nullptr, DS_ERR_COMM, "ncclGetUniqueId failed");
+}
+
+extern "C" int ds_comm_init(ds_ctx* c, int n_ranks, int rank, const char id[128]) {
+    if (!c || !id || n_ranks <= 0 || rank < 0 || rank >= n_ranks) return fail(c, DS_ERR_ARG, "ds_comm_init: bad argument");
+    void* h = rccl_handle();
+    if (!h) return fail(c, DS_ERR_COMM, "librccl.so not found");
+    auto f = (nccl_init_rank_t)dlsym(h, "ncclCommInitRank");
+    if (!f) return fail(c, DS_ERR_COMM, "ncclCommInitRank missing");
+    HIPCHK(c, hipSetDevice(c->device));
+    uid128 u;
+    memcpy(u.b, id, 128);
+    int r = f(&c->comm, n_ranks, u, rank);
+    if (r != 0) {
+        auto es = (nccl_errstr_t)dlsym(h, "ncclGetErrorString");
+        return fail(c, DS_ERR_COMM, std::string("ncclCommInitRank: ") + (es ? es(r) : "error"));
+    }
+    c->rccl = h;
+    return DS_OK;
+}
+
+extern "C" int ds_bcast(ds_ctx* c, void* buf, size_t bytes, int root) {
+    if (!c || !buf) return fail(c, DS_ERR_ARG, "ds_bcast: null argument");
+    if (!c->comm) return fail(c, DS_ERR_COMM, "ds_bcast: communicator not initialised");
+    auto f = (nccl_bcast_t)dlsym(c->rccl, "ncclBroadcast");
+    if (!f) return fail(c, DS_ERR_COMM, "ncclBroadcast missing");
+    int r = f(buf, buf, bytes, /*ncclChar*/ 0, root, c->comm, c->stream);
+    if (r != 0) return fail(c, DS_ERR_COMM, "ncclBroadcast failed");
+    return DS_OK;
+}
+
+extern "C" int ds_comm_destroy(ds_ctx* c) {
+    if (!c || !c->comm) return DS_OK;
+    auto f = (nccl_destroy_t)dlsym(c->rccl, "ncclCommDestroy");
+    if (f) f(c->comm);
+    c->comm = nullptr;
+    return DS_OK;
+}

@@ -1,0 +1,193 @@
+// Epilogue kernels: chunk partials -> the reference's finish() (scaling, edge
+// halving, principal square root; standard/_spectral_methods.py:151-171) in
+// fp64, transfer functions and coherence
+// (transfer_functions/transfer_functions.py:525-534), and the channel x channel
+// cross-spectral-matrix GEMM on the fp32 MFMA pipe.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace dsk {
+
+struct cd {
+    double x, y;
+};
+
+__device__ __forceinline__ cd csqrt_principal(cd z) {
+    double r = hypot(z.x, z.y);
+    if (r == 0.0) return cd{0.0, z.y};
+    if (z.x >= 0.0) {
+        double t = sqrt(0.5 * (r + z.x));
+        return cd{t, z.y / (2.0 * t)};
+    }
+    double t = sqrt(0.5 * (r - z.x));
+    return cd{fabs(z.y) / (2.0 * t), copysign(t, z.y)};
+}
+
+struct FinishPar {
+    double inv;     // norm_scale / n_frames
+    double factor;  // physical-unit factor (applied when halve_edges)
+    int halve_edges, amp_sqrt, nb;
+};
+
+__device__ __forceinline__ double finish_real(double s, int b, const FinishPar& f) {
+    s *= f.inv;
+    if (f.halve_edges) {
+        s *= f.factor;
+        if (b == 0 || b == f.nb - 1) s *= 0.5;
+    }
+    return f.amp_sqrt ? sqrt(s) : s;
+}
+__device__ __forceinline__ cd finish_cplx(cd s, int b, const FinishPar& f) {
+    s.x *= f.inv;
+    s.y *= f.inv;
+    if (f.halve_edges) {
+        double e = (b == 0 || b == f.nb - 1) ? 0.5 * f.factor : f.factor;
+        s.x *= e;
+        s.y *= e;
+    }
+    return f.amp_sqrt ? csqrt_principal(s) : s;
+}
+
+// kind: 0 = transfer function + coherence, 1 = auto spectra (psd), 2 = cross spectra (csd)
+struct WelchFinArgs {
+    const float* pxx;   // [q][n_cx][nb]
+    const float2* pxy;  // [q][n_cy][nb]
+    const float* pyy;   // [q][n_cy][nb]
+    int n_chunks, n_cx, n_cy, kind, mode;
+    FinishPar fin;
+    float2* tf;  // [nb][n_cy]   (kind 0: tf, kind 2: csd)
+    float* coh;  // [nb][n_cy]   (kind 0: coherence, kind 1: psd [nb][n_cx])
+};
+
+__global__ void k_welch_finish(WelchFinArgs p) {
+    const int nb = p.fin.nb;
+    const int nc = p.kind == 1 ? p.n_cx : p.n_cy;
+    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)nb * nc) return;
+    const int b = (int)(idx / nc), c = (int)(idx % nc);
+    const int cx = p.n_cx == 1 ? 0 : c;
+    double sxx = 0.0, syy = 0.0;
+    cd sxy{0.0, 0.0};
+    for (int q = 0; q < p.n_chunks; ++q) {
+        if (p.kind != 2) sxx += (double)p.pxx[((int64_t)q * p.n_cx + cx) * nb + b];
+        if (p.kind != 1) {
+            int64_t i = ((int64_t)q * p.n_cy + c) * nb + b;
+            float2 t = p.pxy[i];
+            sxy.x += (double)t.x;
+            sxy.y += (double)t.y;
+            if (p.kind == 0) syy += (double)p.pyy[i];
+        }
+    }
+    if (p.kind == 1) {
+        p.coh[idx] = (float)finish_real(sxx, b, p.fin);
+        return;
+    }
+    cd gxy = finish_cplx(sxy, b, p.fin);
+    if (p.kind == 2) {
+        p.tf[idx] = make_float2((float)gxy.x, (float)gxy.y);
+        return;
+    }
+    double gxx = finish_real(sxx, b, p.fin), gyy = finish_real(syy, b, p.fin);
+    double axy2 = gxy.x * gxy.x + gxy.y * gxy.y;
+    cd h;
+    if (p.mode == 1) {  // H1 = Gxy / Gxx
+        h = cd{gxy.x / gxx, gxy.y / gxx};
+    } else if (p.mode == 2) {  // H2 = Gyy / Gyx, Gyx = conj(Gxy)  ->  Gyy * Gxy / |Gxy|^2
+        h = cd{gyy * gxy.x / axy2, gyy * gxy.y / axy2};
+    } else {  // H3 = Gxy/|Gxy| * sqrt(Gyy/Gxx)
+        double s = sqrt(gyy / gxx) / sqrt(axy2);
+        h = cd{gxy.x * s, gxy.y * s};
+    }
+    p.tf[idx] = make_float2((float)h.x, (float)h.y);
+    p.coh[idx] = (float)(axy2 / gxx / gyy);
+}
+
+// r[c][b] = eps ? conj(X)/(|X|^2 + eps[b]) : 1/X ; xspec is [b][c]
+__global__ void k_deconv_inverse(const float2* xspec, int n_ch, int nb, const float* eps,
+                                 float2* r) {
+    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)nb * n_ch) return;
+    int c = (int)(idx / nb), b = (int)(idx % nb);
+    float2 x = xspec[(int64_t)b * n_ch + c];
+    double xr = x.x, xi = x.y;
+    double den = xr * xr + xi * xi + (eps ? (double)eps[b] : 0.0);
+    r[idx] = make_float2((float)(xr / den), (float)(-xi / den));
+}
+
+// ---------------------------------------------------------------- CSM GEMM (fp32 MFMA)
+// X[b][f][c] (the STFT layout).  grid = (nb, n_tile_pairs), 256 threads.
+// Tile pair (I >= J) of 32 x 32 channels: G[i][j] = sum_f X_i conj(X_j) with
+//   Re += Xr_i Xr_j + Xi_i Xi_j ,  Im += Xi_i Xr_j - Xr_i Xi_j
+// as four v_mfma_f32_32x32x2_f32 per two frames; the 4 waves split the frames
+// and are combined in fp64 through LDS, followed by finish() and the
+// reference's mirror  csm[b][i2][i1] = g, csm[b][i1][i2] = conj(g)  (i2 >= i1).
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct CsmArgs {
+    const float2* X;
+    int n_ch, n_frames;
+    FinishPar fin;
+    float2* csm;
+};
+
+__global__ __launch_bounds__(256) void k_csm_gemm(CsmArgs p) {
+    __shared__ float red[4][2][16][64];
+    const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
+    const int b = blockIdx.x;
+    int I = 0;
+    {
+        int tp = blockIdx.y;
+        while ((I + 1) * (I + 2) / 2 <= tp) ++I;
+        tp -= I * (I + 1) / 2;
+        // J = tp
+        const int J = tp;
+        const int C = p.n_ch, F = p.n_frames;
+        const int ci = 32 * I + (l & 31), cj = 32 * J + (l & 31);
+        const float2* Xb = p.X + (int64_t)b * F * C;
+        f32x16 re = {0}, im = {0};
+        for (int s = w; 2 * s < F; s += 4) {
+            int f = 2 * s + (l >> 5);
+            float2 a = make_float2(0.f, 0.f), bb = make_float2(0.f, 0.f);
+            if (f < F) {
+                if (ci < C) a = Xb[(int64_t)f * C + ci];
+                if (cj < C) bb = Xb[(int64_t)f * C + cj];
+            }
+            re = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bb.x, re, 0, 0, 0);
+            re = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bb.y, re, 0, 0, 0);
+            im = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bb.x, im, 0, 0, 0);
+            im = __builtin_amdgcn_mfma_f32_32x32x2f32(-a.x, bb.y, im, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            red[w][0][r][l] = re[r];
+            red[w][1][r][l] = im[r];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const int r = w * 4 + rr;
+            cd g{0.0, 0.0};
+#pragma unroll
+            for (int ww = 0; ww < 4; ++ww) {
+                g.x += (double)red[ww][0][r][l];
+                g.y += (double)red[ww][1][r][l];
+            }
+            const int i = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), j = l & 31;
+            const int gi = 32 * I + i, gj = 32 * J + j;
+            if (gi < C && gj < C && gi >= gj) {
+                float2* out = p.csm + (int64_t)b * C * C;
+                if (gi == gj) {
+                    double d = finish_real(g.x, b, p.fin);
+                    out[(int64_t)gi * C + gj] = make_float2((float)d, 0.f);
+                } else {
+                    cd v = finish_cplx(g, b, p.fin);
+                    out[(int64_t)gi * C + gj] = make_float2((float)v.x, (float)v.y);
+                    out[(int64_t)gj * C + gi] = make_float2((float)v.x, (float)-v.y);
+                }
+            }
+        }
+    }
+}
+
+}  // namespace dsk

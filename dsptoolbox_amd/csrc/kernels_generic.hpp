@@ -1,0 +1,502 @@
+// Generic (any power-of-two length 8..16384) kernels of the spectral hot path.
+// One workgroup transforms one length-N complex FFT in LDS (fft_lds.hpp); real
+// frames travel in pairs as real/imaginary parts and are separated with the
+// Hermitian identity  A[k] = (Z[k] + conj Z[N-k])/2,  B[k] = (Z[k] - conj Z[N-k])/(2i).
+//
+// Reference semantics (dsptoolbox 0.8):
+//   framing / zero padding   helpers/other.py:181-213, _framed_signal_representation.py:9-67
+//   window, detrend-after-window, rfft   standard/_spectral_methods.py:126-148, 260-268
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "fft_lds.hpp"
+
+namespace dsk {
+using namespace dsfft;
+
+struct FrameSrc {
+    const float* base;  // channel base pointer (may be nullptr: all zeros)
+    int64_t start;      // sample index of frame sample 0 (may be negative / beyond the end)
+};
+
+// workgroup sum of a float2 (all threads get the result). red: >= 16 float2 of LDS.
+template <int NT>
+__device__ __forceinline__ float2 block_sum2(float2 s, float2* red, int tid) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        s.x += __shfl_xor(s.x, o);
+        s.y += __shfl_xor(s.y, o);
+    }
+    constexpr int NW = NT / 64;
+    if constexpr (NW > 1) {
+        if ((tid & 63) == 0) red[tid >> 6] = s;
+        __syncthreads();
+        float2 r = red[0];
+#pragma unroll
+        for (int w = 1; w < NW; ++w) {
+            r.x += red[w].x;
+            r.y += red[w].y;
+        }
+        __syncthreads();  // red reusable afterwards
+        s = r;
+    }
+    return s;
+}
+
+// Load two real frames as the real / imaginary part of the first-pass register
+// set v[i][t] = z[tid + i*NT + t*N/4]:  z[n] = a[n] w[n] + i b[n] w[n] for n < W,
+// zero beyond W or outside [0, n_samples).  Optional detrend = subtract the mean
+// over the W windowed samples (also those cropped away when W > N).
+template <int N>
+__device__ __forceinline__ void load_pair(float2 (&v)[Cfg<N>::BPT][4], FrameSrc a, FrameSrc b,
+                                          int64_t n_samples, int W,
+                                          const float* __restrict__ window, bool detrend,
+                                          float2* red, int tid) {
+    using C = Cfg<N>;
+    float2 sum = make_float2(0.f, 0.f);
+#pragma unroll
+    for (int i = 0; i < C::BPT; ++i) {
+        int j = tid + i * C::NT;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            int n = j + t * C::NB4;
+            float2 z = make_float2(0.f, 0.f);
+            if ((C::NB4 >= C::NT || j < C::NB4) && n < W) {
+                float w = window ? window[n] : 1.0f;
+                int64_t ga = a.start + n, gb = b.start + n;
+                if (a.base && ga >= 0 && ga < n_samples) z.x = a.base[ga] * w;
+                if (b.base && gb >= 0 && gb < n_samples) z.y = b.base[gb] * w;
+            }
+            v[i][t] = z;
+            sum.x += z.x;
+            sum.y += z.y;
+        }
+    }
+    if (detrend) {
+        for (int n = N + tid; n < W; n += C::NT) {  // samples cropped by nfft < W still count
+            float w = window ? window[n] : 1.0f;
+            int64_t ga = a.start + n, gb = b.start + n;
+            if (a.base && ga >= 0 && ga < n_samples) sum.x += a.base[ga] * w;
+            if (b.base && gb >= 0 && gb < n_samples) sum.y += b.base[gb] * w;
+        }
+        sum = block_sum2<C::NT>(sum, red, tid);
+        float inv = 1.0f / (float)W;
+        float2 m = make_float2(sum.x * inv, sum.y * inv);
+#pragma unroll
+        for (int i = 0; i < C::BPT; ++i) {
+            int j = tid + i * C::NT;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                int n = j + t * C::NB4;
+                if (n < W) {
+                    v[i][t].x -= m.x;
+                    v[i][t].y -= m.y;
+                }
+            }
+        }
+    }
+}
+
+// spectra of the two packed real sequences at bin k (0 <= k <= N/2), from the
+// natural-order complex spectrum in LDS
+template <int N>
+__device__ __forceinline__ void unpack_bin(const float2* __restrict__ buf, int k, float2& A,
+                                           float2& B) {
+    float2 P = buf[k];
+    float2 Qc = buf[(N - k) & (N - 1)];  // Q = conj(Qc)
+    A = make_float2(0.5f * (P.x + Qc.x), 0.5f * (P.y - Qc.y));
+    // B = -i (P - Q)/2,  P - Q = (P.x - Qc.x, P.y + Qc.y)
+    B = make_float2(0.5f * (P.y + Qc.y), -0.5f * (P.x - Qc.x));
+}
+
+template <int N>
+struct Bins {
+    static constexpr int NBINS = N / 2 + 1;
+    static constexpr int BPB = (NBINS + Cfg<N>::NT - 1) / Cfg<N>::NT;  // bins per thread
+};
+
+// ---------------------------------------------------------------- STFT
+// grid.x = n_ch * ceil(n_frames/2); out[(b*F + f)*C + c]
+struct StftArgs {
+    const float* x;
+    int64_t n_samples, ld, pad_front;
+    int n_ch, W, hop, n_frames, detrend, power;
+    const float* window;
+    const float2* tw;
+    float scale, edge_scale;
+    float2* out;
+};
+
+template <int N>
+__global__ __launch_bounds__(Cfg<N>::NT) void k_stft(StftArgs p) {
+    using C = Cfg<N>;
+    extern __shared__ __align__(16) float2 buf[];
+    __shared__ float2 red[16];
+    const int tid = threadIdx.x;
+    const int nfp = (p.n_frames + 1) >> 1;
+    const int c = blockIdx.x / nfp;
+    const int f0 = (blockIdx.x - c * nfp) * 2, f1 = f0 + 1;
+    const float* xc = p.x + (int64_t)c * p.ld;
+    FrameSrc a{xc, (int64_t)f0 * p.hop - p.pad_front};
+    FrameSrc b{f1 < p.n_frames ? xc : nullptr, (int64_t)f1 * p.hop - p.pad_front};
+    float2 v[C::BPT][4];
+    load_pair<N>(v, a, b, p.n_samples, p.W, p.window, p.detrend != 0, red, tid);
+    fft<N, false, true, false>(v, buf, p.tw, tid);
+    const int64_t F = p.n_frames, Cn = p.n_ch;
+    for (int k = tid; k <= N / 2; k += C::NT) {
+        float2 A, B;
+        unpack_bin<N>(buf, k, A, B);
+        float s = p.scale * ((k == 0 || k == N / 2) ? p.edge_scale : 1.0f);
+        if (p.power) {
+            // reference: |x/sqrt2|^2 * factor at the edges -> scale applied after squaring
+            float e = (k == 0 || k == N / 2) ? p.edge_scale * p.edge_scale : 1.0f;
+            A = make_float2((A.x * A.x + A.y * A.y) * e * p.scale, 0.f);
+            B = make_float2((B.x * B.x + B.y * B.y) * e * p.scale, 0.f);
+        } else {
+            A = make_float2(A.x * s, A.y * s);
+            B = make_float2(B.x * s, B.y * s);
+        }
+        p.out[((int64_t)k * F + f0) * Cn + c] = A;
+        if (f1 < p.n_frames) p.out[((int64_t)k * F + f1) * Cn + c] = B;
+    }
+}
+
+// ---------------------------------------------------------------- Welch: input spectra
+// grid = (n_chunks, n_cx).  Frames [q*fpc, min((q+1)*fpc, F)) of channel cx, two per
+// FFT.  Stores Xs[(cx*F + f)*NB + b] (if xs) and the chunk's sum |X|^2 in
+// pxx[(q*n_cx + cx)*NB + b].
+struct XspecArgs {
+    const float* x;
+    int64_t n_samples, ld;
+    int n_cx, W, hop, n_frames, detrend, fpc;  // fpc even
+    const float* window;
+    const float2* tw;
+    float2* xs;  // may be nullptr
+    float* pxx;
+};
+
+template <int N>
+__global__ __launch_bounds__(Cfg<N>::NT) void k_xspec(XspecArgs p) {
+    using C = Cfg<N>;
+    using BN = Bins<N>;
+    extern __shared__ __align__(16) float2 buf[];
+    __shared__ float2 red[16];
+    const int tid = threadIdx.x;
+    const int q = blockIdx.x, cx = blockIdx.y;
+    const float* xc = p.x + (int64_t)cx * p.ld;
+    const int fb = q * p.fpc, fe = min(fb + p.fpc, p.n_frames);
+    float acc[BN::BPB];
+#pragma unroll
+    for (int s = 0; s < BN::BPB; ++s) acc[s] = 0.f;
+    for (int f0 = fb; f0 < fe; f0 += 2) {
+        const int f1 = f0 + 1;
+        const bool v1 = f1 < fe;
+        FrameSrc a{xc, (int64_t)f0 * p.hop};
+        FrameSrc b{v1 ? xc : nullptr, (int64_t)f1 * p.hop};
+        float2 v[C::BPT][4];
+        __syncthreads();  // previous iteration's unpack reads are done
+        load_pair<N>(v, a, b, p.n_samples, p.W, p.window, p.detrend != 0, red, tid);
+        fft<N, false, true, false>(v, buf, p.tw, tid);
+#pragma unroll
+        for (int s = 0; s < BN::BPB; ++s) {
+            int k = tid + s * C::NT;
+            if (k <= N / 2) {
+                float2 A, B;
+                unpack_bin<N>(buf, k, A, B);
+                acc[s] += A.x * A.x + A.y * A.y;
+                if (v1) acc[s] += B.x * B.x + B.y * B.y;
+                if (p.xs) {
+                    p.xs[((int64_t)cx * p.n_frames + f0) * BN::NBINS + k] = A;
+                    if (v1) p.xs[((int64_t)cx * p.n_frames + f1) * BN::NBINS + k] = B;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < BN::BPB; ++s) {
+        int k = tid + s * C::NT;
+        if (k <= N / 2) p.pxx[((int64_t)q * p.n_cx + cx) * BN::NBINS + k] = acc[s];
+    }
+}
+
+// ---------------------------------------------------------------- Welch: output channels
+// grid = (n_chunks, ceil(n_cy/2)).  Channels (2p, 2p+1) ride one complex FFT per
+// frame; cross power against the stored input spectra.
+//   pxy[(q*n_cy + c)*NB + b] = sum_f conj(X_f[b]) Y_cf[b],  pyy[...] = sum_f |Y_cf[b]|^2
+struct YaccArgs {
+    const float* y;
+    int64_t n_samples, ld;
+    int n_cy, n_cx, W, hop, n_frames, detrend, fpc;
+    const float* window;
+    const float2* tw;
+    const float2* xs;
+    float2* pxy;
+    float* pyy;
+};
+
+template <int N>
+__global__ __launch_bounds__(Cfg<N>::NT) void k_yacc(YaccArgs p) {
+    using C = Cfg<N>;
+    using BN = Bins<N>;
+    extern __shared__ __align__(16) float2 buf[];
+    __shared__ float2 red[16];
+    const int tid = threadIdx.x;
+    const int q = blockIdx.x;
+    const int ca = 2 * blockIdx.y, cb = ca + 1;
+    const bool vb = cb < p.n_cy;
+    const float* ya = p.y + (int64_t)ca * p.ld;
+    const float* yb = vb ? p.y + (int64_t)cb * p.ld : nullptr;
+    const int xa = p.n_cx == 1 ? 0 : ca, xb = p.n_cx == 1 ? 0 : (vb ? cb : ca);
+    const int fb = q * p.fpc, fe = min(fb + p.fpc, p.n_frames);
+    float2 sxa[BN::BPB], sxb[BN::BPB];
+    float sya[BN::BPB], syb[BN::BPB];
+#pragma unroll
+    for (int s = 0; s < BN::BPB; ++s) {
+        sxa[s] = sxb[s] = make_float2(0.f, 0.f);
+        sya[s] = syb[s] = 0.f;
+    }
+    for (int f = fb; f < fe; ++f) {
+        FrameSrc a{ya, (int64_t)f * p.hop};
+        FrameSrc b{yb, (int64_t)f * p.hop};
+        float2 v[C::BPT][4];
+        __syncthreads();
+        load_pair<N>(v, a, b, p.n_samples, p.W, p.window, p.detrend != 0, red, tid);
+        fft<N, false, true, false>(v, buf, p.tw, tid);
+        const float2* Xa = p.xs + ((int64_t)xa * p.n_frames + f) * BN::NBINS;
+        const float2* Xb = p.xs + ((int64_t)xb * p.n_frames + f) * BN::NBINS;
+#pragma unroll
+        for (int s = 0; s < BN::BPB; ++s) {
+            int k = tid + s * C::NT;
+            if (k <= N / 2) {
+                float2 A, B;
+                unpack_bin<N>(buf, k, A, B);
+                float2 X = Xa[k];
+                float2 t = cmul_conj(A, X);  // A * conj(X) = conj(X) * A
+                sxa[s].x += t.x;
+                sxa[s].y += t.y;
+                sya[s] += A.x * A.x + A.y * A.y;
+                if (vb) {
+                    float2 X2 = (xb == xa) ? X : Xb[k];
+                    float2 u = cmul_conj(B, X2);
+                    sxb[s].x += u.x;
+                    sxb[s].y += u.y;
+                    syb[s] += B.x * B.x + B.y * B.y;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < BN::BPB; ++s) {
+        int k = tid + s * C::NT;
+        if (k <= N / 2) {
+            int64_t ia = ((int64_t)q * p.n_cy + ca) * BN::NBINS + k;
+            p.pxy[ia] = sxa[s];
+            p.pyy[ia] = sya[s];
+            if (vb) {
+                int64_t ib = ((int64_t)q * p.n_cy + cb) * BN::NBINS + k;
+                p.pxy[ib] = sxb[s];
+                p.pyy[ib] = syb[s];
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------- whole-signal rFFT
+// grid.x = ceil(n_ch/2); spec[b*n_ch + c] = rfft(x_c, N)[b] * scale
+struct RfftArgs {
+    const float* x;
+    int64_t n_samples, ld;
+    int n_ch;
+    const float2* tw;
+    float scale;
+    float2* spec;
+};
+
+template <int N>
+__global__ __launch_bounds__(Cfg<N>::NT) void k_rfft(RfftArgs p) {
+    using C = Cfg<N>;
+    extern __shared__ __align__(16) float2 buf[];
+    __shared__ float2 red[16];
+    const int tid = threadIdx.x;
+    const int ca = 2 * blockIdx.x, cb = ca + 1;
+    FrameSrc a{p.x + (int64_t)ca * p.ld, 0};
+    FrameSrc b{cb < p.n_ch ? p.x + (int64_t)cb * p.ld : nullptr, 0};
+    float2 v[C::BPT][4];
+    load_pair<N>(v, a, b, p.n_samples, N, nullptr, false, red, tid);
+    fft<N, false, true, false>(v, buf, p.tw, tid);
+    for (int k = tid; k <= N / 2; k += C::NT) {
+        float2 A, B;
+        unpack_bin<N>(buf, k, A, B);
+        p.spec[(int64_t)k * p.n_ch + ca] = make_float2(A.x * p.scale, A.y * p.scale);
+        if (cb < p.n_ch) p.spec[(int64_t)k * p.n_ch + cb] = make_float2(B.x * p.scale, B.y * p.scale);
+    }
+}
+
+// ---------------------------------------------------------------- spectral division
+// grid = (ceil(n_ch/2), n_items): ir = irfft(rfft(y, N) * r, N)[:n_out]
+struct DeconvArgs {
+    const float* y;
+    int64_t n_samples, ld, n_out, ld_out;
+    int n_ch, r_per_channel;
+    const float2* tw;
+    const float2* r;  // [n_ch or 1][N/2+1]
+    float* ir;
+};
+
+template <int N>
+__global__ __launch_bounds__(Cfg<N>::NT) void k_deconv(DeconvArgs p) {
+    using C = Cfg<N>;
+    constexpr int NB = N / 2 + 1;
+    extern __shared__ __align__(16) float2 buf[];
+    __shared__ float2 red[16];
+    const int tid = threadIdx.x;
+    const int ca = 2 * blockIdx.x, cb = ca + 1;
+    const bool vb = cb < p.n_ch;
+    const int64_t item = blockIdx.y;
+    const float* ya = p.y + (item * p.n_ch + ca) * p.ld;
+    FrameSrc a{ya, 0};
+    FrameSrc b{vb ? ya + p.ld : nullptr, 0};
+    float2 v[C::BPT][4];
+    load_pair<N>(v, a, b, p.n_samples, N, nullptr, false, red, tid);
+    fft<N, false, true, false>(v, buf, p.tw, tid);
+    const float2* Ra = p.r + (p.r_per_channel ? (int64_t)ca * NB : 0);
+    const float2* Rb = p.r + (p.r_per_channel ? (int64_t)(vb ? cb : ca) * NB : 0);
+    for (int k = tid; k <= N / 2; k += C::NT) {
+        float2 A, B;
+        unpack_bin<N>(buf, k, A, B);
+        float2 VA = cmul(A, Ra[k]), VB = cmul(B, Rb[k]);
+        if (k == 0 || k == N / 2) {  // irfft ignores the imaginary part there
+            buf[k] = make_float2(VA.x, VB.x);
+        } else {
+            buf[k] = make_float2(VA.x - VB.y, VA.y + VB.x);      // VA + i VB
+            buf[N - k] = make_float2(VA.x + VB.y, VB.x - VA.y);  // conj(VA) + i conj(VB)
+        }
+    }
+    __syncthreads();
+    fft<N, true, false, false>(v, buf, p.tw, tid);
+    const float inv = 1.0f / (float)N;
+    float* oa = p.ir + (item * p.n_ch + ca) * p.ld_out;
+    float* ob = oa + p.ld_out;
+    for (int n = tid; n < N && n < p.n_out; n += C::NT) {
+        float2 z = buf[n];
+        oa[n] = z.x * inv;
+        if (vb) ob[n] = z.y * inv;
+    }
+}
+
+// ---------------------------------------------------------------- FIR block convolution
+// tap spectra: grid.x = ceil(n_filt/2); hs[k*N + m] = fft(taps_k zero padded)[m] / N
+struct FirTapsArgs {
+    const float* taps;
+    int n_filt, n_taps;
+    const float2* tw;
+    float2* hs;
+};
+
+template <int N>
+__global__ __launch_bounds__(Cfg<N>::NT) void k_fir_taps(FirTapsArgs p) {
+    using C = Cfg<N>;
+    extern __shared__ __align__(16) float2 buf[];
+    __shared__ float2 red[16];
+    const int tid = threadIdx.x;
+    const int ka = 2 * blockIdx.x, kb = ka + 1;
+    FrameSrc a{p.taps + (int64_t)ka * p.n_taps, 0};
+    FrameSrc b{kb < p.n_filt ? p.taps + (int64_t)kb * p.n_taps : nullptr, 0};
+    float2 v[C::BPT][4];
+    load_pair<N>(v, a, b, p.n_taps, N, nullptr, false, red, tid);
+    fft<N, false, true, false>(v, buf, p.tw, tid);
+    const float inv = 1.0f / (float)N;
+    for (int k = tid; k <= N / 2; k += C::NT) {
+        float2 A, B;
+        unpack_bin<N>(buf, k, A, B);
+        A = make_float2(A.x * inv, A.y * inv);
+        B = make_float2(B.x * inv, B.y * inv);
+        float2* ha = p.hs + (int64_t)ka * N;
+        ha[k] = A;
+        if (k != 0 && k != N / 2) ha[N - k] = make_float2(A.x, -A.y);
+        if (kb < p.n_filt) {
+            float2* hb = ha + N;
+            hb[k] = B;
+            if (k != 0 && k != N / 2) hb[N - k] = make_float2(B.x, -B.y);
+        }
+    }
+}
+
+// grid = (n_blocks, ceil(n_ch/2)).  Overlap-save form of the overlap-add
+// convolution: block j transforms input samples [j*L - (T-1), j*L - (T-1) + N),
+// L = N - T + 1, multiplies by every filter spectrum and keeps the last L
+// outputs of each inverse transform = y[j*L .. j*L+L).  Every output sample is
+// produced once and stored once (no read-modify-write add-back pass); two
+// channels ride one complex transform, so no Hermitian separation is needed:
+// ifft(fft(xa + i xb) H) = ya + i yb.
+struct FirArgs {
+    const float* x;
+    int64_t n_samples, ldx, ld_y;
+    int n_ch, n_filt, n_taps;
+    const float2* tw;
+    const float2* hs;  // [n_filt][N], 1/N folded in
+    float* y;          // [(k*n_ch + c)*ld_y + n]
+};
+
+template <int N>
+__global__ __launch_bounds__(Cfg<N>::NT) void k_fir(FirArgs p) {
+    using C = Cfg<N>;
+    extern __shared__ __align__(16) float2 buf[];
+    __shared__ float2 red[16];
+    const int tid = threadIdx.x;
+    const int T1 = p.n_taps - 1;
+    const int L = N - T1;
+    const int64_t out0 = (int64_t)blockIdx.x * L;
+    const int ca = 2 * blockIdx.y, cb = ca + 1;
+    const bool vb = cb < p.n_ch;
+    FrameSrc a{p.x + (int64_t)ca * p.ldx, out0 - T1};
+    FrameSrc b{vb ? p.x + (int64_t)cb * p.ldx : nullptr, out0 - T1};
+    float2 z[C::BPT][4], v[C::BPT][4];
+    load_pair<N>(z, a, b, p.n_samples, N, nullptr, false, red, tid);
+    constexpr bool REG = !C::ODD;
+    fft<N, false, true, REG>(z, buf, p.tw, tid);
+    if (!REG) {
+#pragma unroll
+        for (int i = 0; i < C::BPT; ++i) {
+            int j = tid + i * C::NT;
+            if (C::NB4 >= C::NT || j < C::NB4) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) z[i][t] = buf[j + t * C::NB4];
+            }
+        }
+    }
+    for (int k = 0; k < p.n_filt; ++k) {
+        const float2* H = p.hs + (int64_t)k * N;
+#pragma unroll
+        for (int i = 0; i < C::BPT; ++i) {
+            int j = tid + i * C::NT;
+            if (C::NB4 >= C::NT || j < C::NB4) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) v[i][t] = cmul(z[i][t], H[j + t * C::NB4]);
+            }
+        }
+        __syncthreads();  // LDS free (previous filter's outputs were read)
+        fft<N, true, true, REG>(v, buf, p.tw, tid);
+        float* oa = p.y + ((int64_t)k * p.n_ch + ca) * p.ld_y;
+        float* ob = oa + p.ld_y;
+#pragma unroll
+        for (int i = 0; i < C::BPT; ++i) {
+            int j = tid + i * C::NT;
+            if (C::NB4 >= C::NT || j < C::NB4) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    int n = j + t * C::NB4;
+                    float2 o = REG ? v[i][t] : buf[n];
+                    int64_t g = out0 + (n - T1);
+                    if (n >= T1 && g < p.n_samples) {
+                        oa[g] = o.x;
+                        if (vb) ob[g] = o.y;
+                    }
+                }
+            }
+        }
+    }
+}
+
+}  // namespace dsk

@@ -1,0 +1,119 @@
+"""compute_transfer_function and spectral_deconvolve
+(API mirror of dsptoolbox/transfer_functions/transfer_functions.py:419-539 and
+:61-184; regularisation window helpers/windows.py:8-76, band detection
+helpers/other.py:9-41)."""
+
+import numpy as np
+from scipy.fft import next_fast_len
+from scipy.signal.windows import get_window
+
+from .. import backend
+from ..classes import ImpulseResponse, Signal, Spectrum
+from ..standard.enums import SpectrumMethod
+from .enums import TransferFunctionType
+
+__all__ = ["compute_transfer_function", "spectral_deconvolve", "TransferFunctionType"]
+
+
+def compute_transfer_function(output: Signal, input: Signal, window_length_samples: int,
+                              mode: TransferFunctionType = TransferFunctionType.H2) -> Spectrum:
+    """Welch H1 / H2 / H3 transfer functions with coherence.  A one-channel
+    input is the input of every output channel.  Window, overlap, detrend,
+    average and scaling are taken from the INPUT signal's spectrum parameters."""
+    assert input.sampling_rate_hz == output.sampling_rate_hz, "Sampling rates do not match"
+    assert input.time_data.shape[0] == output.time_data.shape[0], "Signal lengths do not match"
+    if input.number_of_channels != 1:
+        assert input.number_of_channels == output.number_of_channels, \
+            "Channel number does not match between signals"
+    par = input._spectrum_parameters.copy()
+    assert type(par) is dict, "Spectrum parameters should be passed as a dictionary"
+    for k in ("window_length_samples", "method", "smoothing", "pad_to_fast_length"):
+        par.pop(k)
+    if not isinstance(mode, TransferFunctionType):
+        raise ValueError("Unsupported transfer function type")
+    tf, coherence = backend.welch_transfer_function(
+        output.time_data, input.time_data, input.sampling_rate_hz, window_length_samples,
+        mode.name, **par)
+    spec = Spectrum(np.fft.rfftfreq(window_length_samples, 1 / input.sampling_rate_hz), tf)
+    spec.set_coherence(coherence)
+    return spec
+
+
+# ---- spectral deconvolution --------------------------------------------------
+def _to_db_amplitude(x):
+    tiny = float(np.finfo(np.float64).smallest_normal)
+    return 20.0 * np.log10(np.clip(np.abs(x), a_min=tiny, a_max=None))
+
+
+def find_frequencies_above_threshold(spec, f, threshold_db, normalize=True):
+    d = _to_db_amplitude(spec)
+    if normalize:
+        d = d - np.max(d)
+    fr = f[d > threshold_db]
+    return [fr[0], fr[-1]]
+
+
+def find_nearest_points_index_in_vector(points, vector):
+    points = np.atleast_1d(np.array(points))
+    return np.array([np.argmin(np.abs(p - vector)) for p in points], dtype=np.int_)
+
+
+def _inverse_hann_band(ids, length: int):
+    """1 - (0 .. Hann rise .. 1 .. Hann fall .. 0) over the four bin indices."""
+    i0, i1, i2, i3 = [int(i) for i in ids]
+    nl, nh = i1 - i0, i3 - i2
+    low = get_window("hann", nl * 2, fftbins=True)[:nl] if nl > 0 else np.ones(nl)
+    high = get_window("hann", nh * 2, fftbins=True)[nh:] if nh > 1 else np.ones(nh)
+    w = np.concatenate((np.zeros(i0), low, np.ones(i2 - i1), high, np.zeros(length - i3)))
+    return 1 - w
+
+
+def spectral_deconvolve(output: Signal, input: Signal, apply_regularization: bool = True,
+                        start_stop_hz=None, threshold_db: float = -30.0, padding: bool = False,
+                        keep_original_length: bool = False) -> ImpulseResponse:
+    """Impulse response by (regularised) spectral division output / input."""
+    assert output.time_data.shape[0] == input.time_data.shape[0], \
+        "Lengths do not match for spectral deconvolution"
+    multichannel = input.number_of_channels == 1
+    if not multichannel:
+        assert output.number_of_channels == input.number_of_channels, \
+            "The number of channels do not match."
+    assert output.sampling_rate_hz == input.sampling_rate_hz, "Sampling rates do not match"
+    if not apply_regularization:
+        assert start_stop_hz is None, \
+            "No start_stop_hz vector can be passed when using standard mode"
+    for s in (output, input):
+        par = s._spectrum_parameters
+        if (par["scaling"].fft_norm() != "backward" or par["scaling"].has_physical_units()
+                or par["smoothing"] != 0):
+            raise NotImplementedError(
+                "spectral_deconvolve on the GPU path expects unscaled spectra "
+                "(FFTBackward, no smoothing)")
+    fs_hz = output.sampling_rate_hz
+    original_length = output.time_data.shape[0]
+    n_time = original_length * 2 if padding else original_length
+    n_fft = (next_fast_len(n_time, True)
+             if input._spectrum_parameters["pad_to_fast_length"] else n_time)
+    # rfft(n=n_fft) zero pads, so the optional x2 padding needs no copy
+    denum_fft = backend.rfft_spectrum(input.time_data, n_fft)
+    freqs_hz = np.fft.rfftfreq(n_fft, 1 / fs_hz)
+    eps = None
+    if apply_regularization:
+        if start_stop_hz is None:  # band from the FIRST denominator channel only
+            start_stop_hz = find_frequencies_above_threshold(denum_fft[:, 0], freqs_hz,
+                                                             threshold_db)
+        if len(start_stop_hz) == 2:
+            start_stop_hz = np.array([start_stop_hz[0] / np.sqrt(2), start_stop_hz[0],
+                                      start_stop_hz[1],
+                                      np.min([start_stop_hz[1] * np.sqrt(2), fs_hz / 2])])
+        elif len(start_stop_hz) != 4:
+            raise ValueError("start_stop_hz vector should have 2 or 4 values")
+        ids = find_nearest_points_index_in_vector(start_stop_hz, freqs_hz)
+        eps = _inverse_hann_band(ids, len(freqs_hz)) * 10 ** (30 / 20)
+    inverse = backend.regularized_inverse(denum_fft, eps)  # (B, Cx)
+    new_time_data = backend.spectral_division(
+        output.time_data, n_fft, inverse[:, 0] if multichannel else inverse, n_time)
+    new_sig = ImpulseResponse(None, new_time_data, fs_hz, constrain_amplitude=False)
+    if padding and keep_original_length:
+        new_sig.time_data = new_sig.time_data[:original_length].copy()
+    return new_sig

@@ -1,0 +1,182 @@
+/*
+ * dsptoolbox_amd -- C-ABI of the MI355X (gfx950) spectral hot path.
+ *
+ * The reference (dsptoolbox 0.8) is pure Python and has no FFI; its "plugin
+ * boundary" for this path is the ndarray-in / ndarray-out private backend layer
+ * (SURVEY.md section 1, L2).  Each entry point below replaces one of those backend
+ * functions; the Python host shim (dsptoolbox_amd/backend.py) binds them with
+ * ctypes exactly as INTEGRATION.md shows.
+ *
+ * Conventions
+ *   - every function returns 0 on success, <0 on error; the message is
+ *     available through ds_last_error().  Nothing throws across the ABI.
+ *   - signals are PLANAR fp32: channel c, sample n at x[c*ld + n]
+ *     (the reference stores (samples, channels) float64; the shim transposes).
+ *   - outputs are written in the reference's axis order so the host only
+ *     casts: (bins, channels), (bins, frames, channels), (bins, ch, ch).
+ *   - `_dev` variants take DEVICE pointers (inputs already resident in HBM,
+ *     nothing is copied, everything is enqueued on the context's stream and
+ *     NOT synchronised).  The plain variants take HOST pointers, stage through
+ *     the context's workspace and return after the result is in host memory.
+ *   - a ds_ctx is bound to one device and one HIP stream; not re-entrant.
+ */
+#ifndef DSPTOOLBOX_AMD_H
+#define DSPTOOLBOX_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ds_ctx ds_ctx;
+typedef struct { float re, im; } ds_c32;
+
+/* error codes */
+#define DS_OK            0
+#define DS_ERR_ARG      -1   /* invalid argument (shape, size, null pointer)   */
+#define DS_ERR_UNSUP    -2   /* valid in the reference, not built yet on GPU   */
+#define DS_ERR_HIP      -3   /* HIP runtime error                              */
+#define DS_ERR_NOMEM    -4
+#define DS_ERR_COMM     -5   /* RCCL error                                     */
+
+/* transfer-function modes: transfer_functions/enums.py:4-16 */
+#define DS_TF_H1 1
+#define DS_TF_H2 2
+#define DS_TF_H3 3
+
+/* filter-bank modes: standard/enums.py:279-292 */
+#define DS_FB_PARALLEL   1
+#define DS_FB_SEQUENTIAL 2
+#define DS_FB_SUMMED     3
+
+/* ---- context, memory, timing ------------------------------------------- */
+int         ds_version(void);
+int         ds_device_count(void);
+int         ds_init(int device, ds_ctx** out);
+void        ds_destroy(ds_ctx* ctx);
+const char* ds_last_error(ds_ctx* ctx);            /* ctx may be NULL          */
+int         ds_malloc(ds_ctx* ctx, void** dptr, size_t bytes);
+int         ds_free(ds_ctx* ctx, void* dptr);
+int         ds_upload(ds_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);
+int         ds_download(ds_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes);
+int         ds_memset(ds_ctx* ctx, void* dst_dev, int value, size_t bytes);
+int         ds_sync(ds_ctx* ctx);
+/* hipEvent pair recorded on the context's stream (bench.py's live kernel time) */
+int         ds_timer_start(ds_ctx* ctx);
+int         ds_timer_stop(ds_ctx* ctx, float* elapsed_ms);
+/* max FFT length one workgroup transforms inside LDS (complex points)       */
+int         ds_max_fft_len(void);
+
+/* ---- STFT: replaces _stft, standard/_spectral_methods.py:176-282 --------
+ * frame k of channel c = samples [k*hop - pad_front, k*hop - pad_front + W)
+ * (out-of-range samples read as 0, which is the reference's zero padding:
+ * helpers/other.py:181-213), times window[W]; optional detrend (mean of the
+ * windowed frame, :264-265); rFFT of length nfft (crop / zero-pad, :268);
+ * out[b][k][c] *= scale, bins 0 and nfft/2 additionally *= edge_scale;
+ * power != 0 stores |.|^2 in .re (:271-278).  B = nfft/2 + 1.               */
+int ds_stft_r2c_dev(ds_ctx* ctx, const float* x_dev, int64_t n_samples, int n_ch,
+                    int64_t ld, int W, int hop, int nfft, int64_t pad_front,
+                    int n_frames, const float* window_dev, int detrend,
+                    float scale, float edge_scale, int power, ds_c32* out_dev);
+int ds_stft_r2c(ds_ctx* ctx, const float* x, int64_t n_samples, int n_ch,
+                int W, int hop, int nfft, int64_t pad_front, int n_frames,
+                const float* window, int detrend, float scale, float edge_scale,
+                int power, ds_c32* out);
+
+/* ---- Welch spectra: replaces _welch, _spectral_methods.py:10-173 ---------
+ * Raw frame averages Sxx=mean|X|^2, Syy=mean|Y|^2, Sxy=mean conj(X)Y over
+ * n_frames frames (frame k = samples [k*hop, k*hop+W), zero padded), then the
+ * reference's finish(): S *= norm_scale (1, 1/W^2, 1/W for the three FFT
+ * norms, enums.py:53-75); if halve_edges: S *= factor and bins 0, W/2 halved
+ * (:165-168); if amp_sqrt: principal sqrt (:170-171).
+ *
+ * ds_welch_tf: replaces compute_transfer_function,
+ * transfer_functions/transfer_functions.py:419-539.  n_cx is 1 (one input for
+ * every output channel) or n_cy (pairwise).  tf[b][c] (B x n_cy), coh[b][c].
+ *
+ * ds_welch_psd: auto spectra of every channel of x (psd[b][c], B x n_cx) --
+ * Signal.get_spectrum with the Welch method, classes/signal.py:881-897.      */
+int ds_welch_tf_dev(ds_ctx* ctx, const float* x_dev, int n_cx, int64_t ldx,
+                    const float* y_dev, int n_cy, int64_t ldy, int64_t n_samples,
+                    int W, int hop, int n_frames, const float* window_dev,
+                    int detrend, int mode, int amp_sqrt, double norm_scale,
+                    double factor, int halve_edges, ds_c32* tf_dev, float* coh_dev);
+int ds_welch_tf(ds_ctx* ctx, const float* x, int n_cx, const float* y, int n_cy,
+                int64_t n_samples, int W, int hop, int n_frames, const float* window,
+                int detrend, int mode, int amp_sqrt, double norm_scale, double factor,
+                int halve_edges, ds_c32* tf, float* coh);
+int ds_welch_psd_dev(ds_ctx* ctx, const float* x_dev, int n_cx, int64_t ldx,
+                     int64_t n_samples, int W, int hop, int n_frames,
+                     const float* window_dev, int detrend, int amp_sqrt,
+                     double norm_scale, double factor, int halve_edges, float* psd_dev);
+int ds_welch_psd(ds_ctx* ctx, const float* x, int n_cx, int64_t n_samples, int W,
+                 int hop, int n_frames, const float* window, int detrend,
+                 int amp_sqrt, double norm_scale, double factor, int halve_edges,
+                 float* psd);
+/* cross spectrum of channel pairs (x[c], y[c]) -- _welch(x, y): csd[b][c]     */
+int ds_welch_csd(ds_ctx* ctx, const float* x, const float* y, int n_ch,
+                 int64_t n_samples, int W, int hop, int n_frames, const float* window,
+                 int detrend, int amp_sqrt, double norm_scale, double factor,
+                 int halve_edges, ds_c32* csd);
+
+/* ---- cross-spectral matrix: replaces _csm_welch, _spectral_methods.py:285-371
+ * csm[b][i][j], B x C x C; lower triangle csm[b][i2][i1] (i2>=i1) =
+ * finish(mean conj(X_i1) X_i2), upper = its conjugate (:351-369).            */
+int ds_csm_dev(ds_ctx* ctx, const float* x_dev, int n_ch, int64_t ld, int64_t n_samples,
+               int W, int hop, int n_frames, const float* window_dev, int detrend,
+               int amp_sqrt, double norm_scale, double factor, int halve_edges,
+               ds_c32* csm_dev);
+int ds_csm(ds_ctx* ctx, const float* x, int n_ch, int64_t n_samples, int W, int hop,
+           int n_frames, const float* window, int detrend, int amp_sqrt,
+           double norm_scale, double factor, int halve_edges, ds_c32* csm);
+
+/* ---- whole-signal rFFT / regularised spectral division -------------------
+ * ds_rfft: Signal.get_spectrum with SpectrumMethod.FFT, classes/signal.py:899-911
+ * (n_fft power of two <= 2*ds_max_fft_len(); input zero padded to n_fft).
+ * spec[b][c], (n_fft/2+1) x n_ch, multiplied by scale.
+ *
+ * ds_deconv: replaces _spectral_deconvolve,
+ * transfer_functions/_transfer_functions.py:19-42, for a batch of n_items
+ * signals of n_ch channels each (planar: y[(item*n_ch + c)*ld + n]).
+ * r[(B) or (n_ch x B)] is the regularised inverse conj(X)/(|X|^2+eps) (or
+ * 1/X) built by ds_deconv_inverse; ir = irfft(rfft(y, n_fft) * r, n_fft),
+ * first n_out samples stored.                                                */
+int ds_rfft_dev(ds_ctx* ctx, const float* x_dev, int n_ch, int64_t ld, int64_t n_samples,
+                int n_fft, float scale, ds_c32* spec_dev);
+int ds_rfft(ds_ctx* ctx, const float* x, int n_ch, int64_t n_samples, int n_fft,
+            float scale, ds_c32* spec);
+/* r[c][b] = eps ? conj(X)/(|X|^2+eps[b]) : 1/X   (eps_dev may be NULL)        */
+int ds_deconv_inverse_dev(ds_ctx* ctx, const ds_c32* xspec_dev /*B x n_ch*/, int n_ch,
+                          int n_bins, const float* eps_dev, ds_c32* r_dev /*n_ch x B*/);
+int ds_deconv_dev(ds_ctx* ctx, const float* y_dev, int n_items, int n_ch, int64_t ld,
+                  int64_t n_samples, int n_fft, const ds_c32* r_dev, int r_per_channel,
+                  int64_t n_out, int64_t ld_out, float* ir_dev);
+int ds_deconv(ds_ctx* ctx, const float* y, int n_items, int n_ch, int64_t n_samples,
+              int n_fft, const ds_c32* r, int r_per_channel, int64_t n_out, float* ir);
+
+/* ---- FIR filtering by FFT block convolution: replaces _lfilter_fir,
+ * classes/filter_helpers.py:454-503 (scipy.signal.oaconvolve(...)[:N]) and the
+ * filter loop of _filterbank_on_signal, :385-451.
+ * y = (x * taps_k)[0:N] for each of n_filt filters of n_taps taps
+ * (taps[k*n_taps + t]); DS_FB_PARALLEL: y[(k*n_ch + c)*ld_y + n];
+ * DS_FB_SUMMED / DS_FB_SEQUENTIAL: y[c*ld_y + n].                             */
+int ds_fir_ola_dev(ds_ctx* ctx, const float* x_dev, int n_ch, int64_t ldx,
+                   int64_t n_samples, const float* taps_dev, int n_filt, int n_taps,
+                   int mode, float* y_dev, int64_t ld_y);
+int ds_fir_ola(ds_ctx* ctx, const float* x, int n_ch, int64_t n_samples,
+               const float* taps, int n_filt, int n_taps, int mode, float* y);
+
+/* ---- multi-GPU: RCCL broadcast of shared inputs (sweep / taps / inverse) --
+ * one process per GPU; rank 0 creates the id, the launcher (torch.distributed
+ * store, file, MPI ...) hands the 128 bytes to every rank.                   */
+int ds_comm_unique_id(char id_out[128]);
+int ds_comm_init(ds_ctx* ctx, int n_ranks, int rank, const char id[128]);
+int ds_bcast(ds_ctx* ctx, void* buf_dev, size_t bytes, int root);
+int ds_comm_destroy(ds_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DSPTOOLBOX_AMD_H */

@@ -1,0 +1,125 @@
+"""CPU-side checks: the C-ABI library builds/loads and exports every symbol the
+header declares; host-side logic (framing rules, parameter mapping, API
+validation) behaves like the reference.  No compute call is made here."""
+
+import os
+import re
+
+import numpy as np
+import pytest
+
+import dsptoolbox_amd as dsp
+from dsptoolbox_amd import backend
+from dsptoolbox_amd._lib import SIGNATURES, load_library
+from dsptoolbox_amd.standard.enums import SpectrumScaling, Window
+from oracle import dsp_oracle as orc
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    from dsptoolbox_amd._build import build_library
+    lib = load_library(build_library())
+    header = open(os.path.join(ROOT, "include", "dsptoolbox_amd.h")).read()
+    declared = set(re.findall(r"\b(ds_[a-z0-9_]+)\s*\(", header))
+    assert declared, "no declarations parsed"
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in the header but not exported"
+    assert declared == set(SIGNATURES), declared ^ set(SIGNATURES)
+    assert lib.ds_version() >= 100 and lib.ds_max_fft_len() == 16384
+
+
+def test_scaling_factors_match_oracle():
+    w = np.hanning(64) + 0.1
+    for sc in SpectrumScaling:
+        for win in (None, w):
+            a = np.asarray(sc.get_scaling_factor(64, 48000, win)).ravel()
+            b = np.asarray(orc.get_scaling_factor(sc.name, 64, 48000, win)).ravel()
+            assert np.allclose(a, b, rtol=1e-15)
+        assert sc.fft_norm() == orc.fft_norm(sc.name)
+        assert sc.is_amplitude_scaling() == orc.is_amplitude_scaling(sc.name)
+        assert sc.has_physical_units() == orc.has_physical_units(sc.name)
+        for dst in SpectrumScaling:
+            assert np.allclose(sc.conversion_factor(dst, 64, 48000, None),
+                               orc.conversion_factor(sc.name, dst.name, 64, 48000, None))
+
+
+def test_welch_framing_rule():
+    win = Window.Hann(256, False)
+    hop, f = backend._welch_framing(1000, 256, 50, win)
+    assert (hop, f) == (128, orc.compute_number_frames(256, 128, 1000, True)[0])
+    with pytest.warns(UserWarning):  # 33 % Hann overlap is not COLA
+        hop, f = backend._welch_framing(1024, 256, 33, win)  # overlap truncated: int(84.48) = 84
+    assert hop == 256 - 84 and f == int(np.ceil(1024 / hop))
+
+
+def test_finish_params():
+    w = Window.Hann(128, False)
+    assert backend._finish_params(SpectrumScaling.FFTBackward, 128, 48000, w) == (1, 1.0, 1.0, 0)
+    amp, ns, fac, phys = backend._finish_params(SpectrumScaling.PowerSpectralDensity, 128, 48000, w)
+    assert (amp, ns, phys) == (0, 1.0, 1) and np.isclose(fac, 2 / np.sum(w**2) / 48000)
+    amp, ns, fac, phys = backend._finish_params(SpectrumScaling.FFTForward, 128, 48000, w)
+    assert (amp, phys) == (1, 0) and np.isclose(ns, 1 / 128**2)
+
+
+def test_signal_container_semantics():
+    x = np.arange(12.0).reshape(3, 4)  # more columns than rows -> transposed
+    s = dsp.Signal(None, x, 48000)
+    assert s.time_data.shape == (4, 3) and s.number_of_channels == 3
+    with pytest.raises(AssertionError):
+        dsp.Signal(None, x, 48000.0)
+    with pytest.warns(UserWarning):
+        s2 = dsp.Signal.from_time_data(np.array([0.5, -2.0, 1.0]), 100)
+    assert np.isclose(np.max(np.abs(s2.time_data)), 1.0) and np.isclose(s2.amplitude_scale_factor, 0.5)
+    ir = dsp.ImpulseResponse(None, np.ones(8), 100)
+    assert ir.spectrum_method == dsp.SpectrumMethod.FFT and ir.constrain_amplitude
+    c = s.copy_with_new_time_data(np.zeros((10, 2)))
+    assert c._spectrum_parameters == s._spectrum_parameters and c.time_data.shape == (10, 2)
+    assert s._spectrum_parameters["scaling"] == SpectrumScaling.FFTBackward
+    assert s._spectrum_parameters["detrend"] is True and s._spectrogram_parameters["padding"] is True
+
+
+def test_filter_and_bank_validation():
+    f1 = dsp.Filter.fir_filter(20, 1000.0, dsp.FilterPassType.Lowpass, 48000)
+    assert f1.is_fir and f1.order == 20 and len(f1) == 21
+    f2 = dsp.Filter.from_ba([2.0, 1.0], [2.0], 48000)
+    assert np.allclose(f2.ba[0], [1.0, 0.5]) and np.allclose(f2.ba[1], [1.0])
+    with pytest.raises(NotImplementedError):
+        dsp.Filter({dsp.FilterCoefficientsType.Sos: np.ones((1, 6))}, 48000)
+    fb = dsp.FilterBank([f1, f2])
+    s = dsp.Signal(None, np.zeros((100, 2)), 44100)
+    with pytest.raises(AssertionError):
+        fb.filter_signal(s, dsp.FilterBankMode.Parallel)
+    with pytest.raises(AssertionError):
+        f1.filter_signal(s)
+
+
+def test_compute_transfer_function_validation():
+    a = dsp.Signal(None, np.zeros((100, 2)), 48000)
+    b = dsp.Signal(None, np.zeros((100, 3)), 48000)
+    with pytest.raises(AssertionError):
+        dsp.transfer_functions.compute_transfer_function(a, b, 64)
+    c = dsp.Signal(None, np.zeros((90, 1)), 48000)
+    with pytest.raises(AssertionError):
+        dsp.transfer_functions.compute_transfer_function(a, c, 64)
+    with pytest.raises(AssertionError):
+        dsp.transfer_functions.spectral_deconvolve(a, c)
+
+
+def test_no_gpu_means_loud_failure():
+    lib = load_library()
+    if lib.ds_device_count() > 0:
+        pytest.skip("GPU present")
+    from dsptoolbox_amd._lib import DeviceError
+    s = dsp.Signal(None, np.random.default_rng(0).standard_normal((1000, 2)), 48000)
+    with pytest.raises(DeviceError):
+        s.get_spectrum()
+
+
+def test_product_does_not_import_oracle():
+    pkg = os.path.join(ROOT, "dsptoolbox_amd")
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dp, f)).read()
+                assert "oracle" not in src.replace("# oracle", ""), f"{f} mentions the oracle"

@@ -1,0 +1,303 @@
+"""GPU parity: the HIP path (through the C-ABI, via the reference-shaped Python
+API) against (a) the golden vectors produced by the real reference and (b) the
+pinned CPU oracle on seeded inputs.  Tolerance: north_star's 1e-6 relative
+(max-norm per output array); the DC bin is excluded when
+detrend=True because it is 0/0 rounding noise in the reference itself."""
+
+import numpy as np
+import pytest
+
+import dsptoolbox_amd as dsp
+from dsptoolbox_amd import backend
+from dsptoolbox_amd.standard.enums import (FilterBankMode, FilterPassType, SpectrumMethod,
+                                           SpectrumScaling, Window)
+from dsptoolbox_amd.transfer_functions import TransferFunctionType
+from oracle import dsp_oracle as orc
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-6
+WIN = {"hann": Window.Hann, "hamming": Window.Hamming, "blackman": Window.Blackman,
+       "boxcar": Window.Boxcar}
+
+
+def relmax(a, b, skip_dc=False):
+    a, b = np.asarray(a), np.asarray(b)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    if skip_dc:
+        a, b = a[1:], b[1:]
+    return float(np.max(np.abs(a - b)) / np.max(np.abs(b)))
+
+
+def test_library_is_loaded_and_device_present():
+    from dsptoolbox_amd._lib import get_context
+    ctx = get_context()
+    assert ctx.lib.ds_device_count() >= 1
+
+
+def test_welch_golden():
+    meta, z = load_golden("welch")
+    x = z["x"]
+    worst = 0.0
+    for i, c in enumerate(meta["cases"]):
+        d = x if c["data"] == "full" else x[: meta["ragged_len"]]
+        sc = SpectrumScaling[c["scaling"]]
+        if c["average"] == "median":
+            with pytest.raises(NotImplementedError):
+                backend._welch(d, None, meta["fs"], WIN[c["window"]], c["W"], c["overlap"],
+                               c["detrend"], c["average"], sc)
+            continue
+        a = backend._welch(d, None, meta["fs"], WIN[c["window"]], c["W"], c["overlap"],
+                           c["detrend"], c["average"], sc)
+        k = backend._welch(d[:, 0], d[:, 2], meta["fs"], WIN[c["window"]], c["W"], c["overlap"],
+                           c["detrend"], c["average"], sc)
+        ea = relmax(a, z[f"auto_{i}"], c["detrend"])
+        ek = relmax(k, z[f"cross_{i}"], c["detrend"])
+        worst = max(worst, ea, ek)
+        assert ea < TOL and ek < TOL, (c, ea, ek)
+        assert a.dtype == np.float64 and k.dtype == np.complex128
+    print("welch worst rel-max", worst)
+
+
+def test_transfer_function_golden():
+    meta, z = load_golden("transfer_function")
+    worst = 0.0
+    for i, c in enumerate(meta["cases"]):
+        xin = z["x"][:, :1] if c["single_input"] else z["x"]
+        y = z["y_single"] if c["single_input"] else z["y_multi"]
+        inp = dsp.Signal(None, xin.copy(), meta["fs"])
+        out = dsp.Signal(None, y.copy(), meta["fs"])
+        inp.set_spectrum_parameters(window_length_samples=1024, window_type=Window.Hann,
+                                    overlap_percent=c["overlap"], detrend=c["detrend"],
+                                    average="mean", scaling=SpectrumScaling[c["scaling"]])
+        sp = dsp.transfer_functions.compute_transfer_function(out, inp, c["W"],
+                                                              TransferFunctionType[c["mode"]])
+        assert isinstance(sp, dsp.Spectrum) and sp.has_coherence
+        e1 = relmax(sp.spectral_data, z[f"tf_{i}"], c["detrend"])
+        e2 = relmax(sp.coherence, z[f"coh_{i}"], c["detrend"])
+        worst = max(worst, e1, e2)
+        assert e1 < TOL and e2 < TOL, (c, e1, e2)
+        assert np.array_equal(sp.frequency_vector_hz, z[f"f_{i}"])
+    print("tf worst rel-max", worst)
+
+
+def test_stft_golden():
+    meta, z = load_golden("stft")
+    worst = 0.0
+    for i, c in enumerate(meta["cases"]):
+        s = dsp.Signal(None, z["x"].copy(), meta["fs"])
+        s.set_spectrogram_parameters(window_length_samples=c["W"], window_type=Window.Hann,
+                                     overlap_percent=c["overlap"],
+                                     fft_length_samples=c["fft_length"], detrend=c["detrend"],
+                                     padding=c["padding"], scaling=SpectrumScaling[c["scaling"]])
+        t, f, st = s.get_spectrogram()
+        assert np.allclose(t, z[f"t_{i}"], rtol=1e-14, atol=0)
+        assert np.array_equal(f, z[f"f_{i}"])
+        assert st.dtype == z[f"stft_{i}"].dtype
+        e = relmax(st, z[f"stft_{i}"])
+        worst = max(worst, e)
+        assert e < TOL, (c, e)
+    print("stft worst rel-max", worst)
+
+
+def test_csm_golden():
+    meta, z = load_golden("csm")
+    worst = 0.0
+    for i, c in enumerate(meta["cases"]):
+        if c["method"] != "welch":
+            continue
+        s = dsp.Signal(None, z["x"].copy(), meta["fs"])
+        s.set_spectrum_parameters(method=SpectrumMethod.WelchPeriodogram,
+                                  window_length_samples=c["W"], overlap_percent=c["overlap"],
+                                  detrend=c["detrend"], scaling=SpectrumScaling[c["scaling"]])
+        f, csm = s.get_csm()
+        assert np.array_equal(f, z[f"f_{i}"])
+        e = relmax(csm, z[f"csm_{i}"], c["detrend"])
+        worst = max(worst, e)
+        assert e < TOL, (c, e)
+        # Hermitian by construction
+        assert np.array_equal(csm, np.conj(np.swapaxes(csm, 1, 2)))
+    print("csm worst rel-max", worst)
+
+
+def test_deconvolve_golden():
+    meta, z = load_golden("deconvolve")
+    worst = 0.0
+    for i, c in enumerate(meta["cases"]):
+        tag = c["data"]
+        x = z[f"x_{tag}"] if c["den"] == "mono" else z[f"x2_{tag}"]
+        inp = dsp.Signal(None, x.copy(), meta["fs"])
+        out = dsp.Signal(None, z[f"y_{tag}"].copy(), meta["fs"])
+        kw = dict(apply_regularization=c["reg"], start_stop_hz=c["ss"], threshold_db=c["thr"],
+                  padding=c["pad"], keep_original_length=c["keep"])
+        if tag == "np2":
+            with pytest.raises(NotImplementedError):
+                dsp.transfer_functions.spectral_deconvolve(out, inp, **kw)
+            continue
+        ir = dsp.transfer_functions.spectral_deconvolve(out, inp, **kw)
+        assert isinstance(ir, dsp.ImpulseResponse) and ir.constrain_amplitude is False
+        e = relmax(ir.time_data, z[f"ir_{i}"])
+        worst = max(worst, e)
+        assert e < TOL, (c, e)
+    print("deconvolve worst rel-max", worst)
+
+
+def test_fir_golden():
+    meta, z = load_golden("fir")
+    worst = 0.0
+    fs = meta["fs"]
+    for i, c in enumerate(meta["cases"]):
+        x = z["x_" + c["data"]]
+        sig = dsp.Signal(None, x.copy(), fs)
+        if c["kind"] == "filter":
+            flt = dsp.Filter.from_ba(z[c["taps_key"]], [1.0], fs)
+            o = flt.filter_signal(sig, channels=c["channels"])
+            assert np.array_equal(sig.time_data, x)  # input untouched
+            e = relmax(o.time_data, z[f"y_{i}"])
+        else:
+            fb = dsp.FilterBank([dsp.Filter.from_ba(b, [1.0], fs) for b in z["bank_taps"]])
+            o = fb.filter_signal(sig, FilterBankMode[c["mode"]])
+            if c["mode"] == "Parallel":
+                assert isinstance(o, dsp.MultiBandSignal)
+                e = relmax(o.get_all_time_data()[0], z[f"y_{i}"])
+            else:
+                assert type(o) is dsp.Signal
+                e = relmax(o.time_data, z[f"y_{i}"])
+        worst = max(worst, e)
+        assert e < TOL, (c, e)
+    print("fir worst rel-max", worst)
+
+
+def test_fir_design_matches_lfilter():
+    """reference tests/test_classes.py:495-512: FIR filter_signal == scipy.signal.lfilter."""
+    import scipy.signal as sig
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((20000, 3)) * 0.2
+    flt = dsp.Filter.fir_filter(150, 1000.0, FilterPassType.Lowpass, 48000)
+    s = dsp.Signal(None, x.copy(), 48000)
+    o = flt.filter_signal(s)
+    ref = sig.lfilter(flt.ba[0], [1.0], x, axis=0)
+    assert relmax(o.time_data, ref) < TOL
+
+
+@pytest.mark.parametrize("W", [8, 64, 512, 2048, 4096, 8192, 16384])
+def test_welch_all_lengths_vs_oracle(W):
+    rng = np.random.default_rng(W)
+    n = max(6 * W + 123, 5000)
+    x = rng.standard_normal((n, 3)) * 0.3
+    x[:, 2] = np.convolve(x[:, 0], [0.5, 0.3, -0.2, 0.1])[:n] + 0.05 * x[:, 2]
+    for det in (True, False):
+        a = backend._welch(x, None, 48000, Window.Hann, W, 50, det, "mean",
+                           SpectrumScaling.PowerSpectralDensity)
+        r = orc.welch(x, None, 48000, "hann", W, 50, det, "mean", "PowerSpectralDensity")
+        assert relmax(a, r, det) < TOL
+        k = backend._welch(x[:, 0], x[:, 2], 48000, Window.Hann, W, 50, det, "mean",
+                           SpectrumScaling.FFTBackward)
+        r = orc.welch(x[:, 0], x[:, 2], 48000, "hann", W, 50, det, "mean", "FFTBackward")
+        assert relmax(k, r, det) < TOL
+
+
+def test_welch_too_long_window_raises():
+    x = np.zeros((100000, 1))
+    with pytest.raises(NotImplementedError):
+        backend._welch(x, None, 48000, Window.Hann, 32768, 50, True, "mean",
+                       SpectrumScaling.FFTBackward)
+    with pytest.raises(AssertionError):
+        backend._welch(x, None, 48000, Window.Hann, 1000, 50, True, "mean",
+                       SpectrumScaling.FFTBackward)
+
+
+def test_headline_shape_reduced_vs_oracle():
+    """config 2 at reduced channel count / length: 1-channel sweep input, H1, nfft 4096."""
+    from dsptoolbox_amd.generators import sweep_and_responses
+    x, y = sweep_and_responses(n_samples=2**16, n_channels=6, fs_hz=48000)
+    for mode in ("H1", "H2", "H3"):
+        for det in (True, False):
+            tf, coh = backend.welch_transfer_function(y, x, 48000, 4096, mode, detrend=det)
+            rt, rc = orc.compute_transfer_function(y, x, 48000, 4096, mode, detrend=det)
+            assert relmax(tf, rt, det) < TOL, (mode, det, relmax(tf, rt, det))
+            assert relmax(coh, rc, det) < TOL, (mode, det, relmax(coh, rc, det))
+
+
+def test_headline_full_size_properties():
+    """config 2 at full size (64 ch x 2^20): size-independent checks -- channel
+    permutation invariance, linearity in the output gain, coherence in [0, 1]."""
+    from dsptoolbox_amd.generators import sweep_and_responses
+    x, y = sweep_and_responses(n_samples=2**20, n_channels=64, fs_hz=48000)
+    kw = dict(scaling=SpectrumScaling.PowerSpectralDensity, detrend=False)
+    tf, coh = backend.welch_transfer_function(y, x, 48000, 4096, "H1", **kw)
+    assert tf.shape == (2049, 64) and coh.shape == (2049, 64)
+    assert np.all(np.isfinite(tf)) and np.all(coh <= 1 + 1e-5) and np.all(coh >= 0)
+    perm = np.random.default_rng(0).permutation(64)
+    tf2, coh2 = backend.welch_transfer_function(3.0 * y[:, perm], x, 48000, 4096, "H1", **kw)
+    assert relmax(tf2, 3.0 * tf[:, perm]) < TOL
+    assert relmax(coh2, coh[:, perm]) < TOL
+    # a subset of channels against the oracle (oracle cost: seconds)
+    rt, rc = orc.compute_transfer_function_batched(y[:, :3], x, 48000, 4096, "H1",
+                                                   scaling="PowerSpectralDensity", detrend=False)
+    assert relmax(tf[:, :3], rt) < TOL
+    assert relmax(coh[:, :3], rc) < TOL
+
+
+def test_csm_64ch_vs_oracle():
+    rng = np.random.default_rng(4)
+    n = 40000
+    x = 0.1 * rng.standard_normal((n, 64)) + 0.2 * rng.standard_normal(n)[:, None]
+    f, csm = backend._csm_welch(x, 48000, 1024, Window.Hann, 50, True, "mean",
+                                SpectrumScaling.FFTBackward)
+    fr, ref = orc.csm_welch_batched(x, 48000, 1024, "hann", 50, True, "FFTBackward")
+    assert relmax(csm, ref, True) < TOL
+
+
+def test_deconvolve_batch_8192():
+    """config 5 shape: stereo responses against one shared sweep, n = 8192."""
+    from dsptoolbox_amd.generators import exponential_sweep
+    rng = np.random.default_rng(7)
+    n = 8192
+    x = exponential_sweep(n, 48000)[:, None]
+    items = []
+    for i in range(6):
+        h = rng.standard_normal((2, 64)) * np.exp(-np.arange(64) / 10.0)
+        items.append(np.stack([np.convolve(x[:, 0], h[c])[:n] for c in range(2)], axis=1)
+                     + 1e-3 * rng.standard_normal((n, 2)))
+    inp = dsp.Signal(None, x, 48000)
+    for y in items[:2]:
+        ir = dsp.transfer_functions.spectral_deconvolve(dsp.Signal(None, y, 48000), inp)
+        assert relmax(ir.time_data, orc.spectral_deconvolve(y, x, 48000)) < TOL
+    # batched entry point: all items in one call
+    den = backend.rfft_spectrum(x, n)
+    eps, _ = orc.regularization_eps(den[:, 0], np.fft.rfftfreq(n, 1 / 48000), 48000, None, -30.0)
+    inv = backend.regularized_inverse(den, eps)[:, 0]
+    out = backend.spectral_division(np.stack(items), n, inv, n)
+    for y, o in zip(items, out):
+        assert relmax(o, orc.spectral_deconvolve(y, x, 48000)) < TOL
+
+
+def test_fir_bank_4097_taps():
+    """config 3 at reduced length: 4097-tap linear-phase band filters, parallel + summed."""
+    from dsptoolbox_amd.generators import fir_bank_taps
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal((60000, 3)) * 0.1
+    taps = fir_bank_taps(4, 4097, 48000)
+    y = backend.fir_filter_bank(x, list(taps), backend.DS_FB_PARALLEL)
+    ref = orc.filterbank_fir(list(taps), x, "Parallel")  # (N, C, K)
+    assert relmax(np.transpose(y, (1, 2, 0)), ref) < TOL
+    ys = backend.fir_filter_bank(x, list(taps), backend.DS_FB_SUMMED)
+    assert relmax(ys, orc.filterbank_fir(list(taps), x, "Summed")) < TOL
+    yq = backend.fir_filter_bank(x, list(taps[:2]), backend.DS_FB_SEQUENTIAL)
+    assert relmax(yq, orc.filterbank_fir(list(taps[:2]), x, "Sequential")) < TOL
+
+
+def test_edge_cases():
+    # signal shorter than one window, single channel, odd channel counts
+    x = np.random.default_rng(1).standard_normal((100, 1))
+    a = backend._welch(x, None, 48000, Window.Hann, 256, 50, False, "mean",
+                       SpectrumScaling.PowerSpectrum)
+    assert relmax(a, orc.welch(x, None, 48000, "hann", 256, 50, False, "mean", "PowerSpectrum")) < TOL
+    x5 = np.random.default_rng(2).standard_normal((3000, 5))
+    t, f, s = backend._stft(x5, 48000, 128, Window.Hann, 50, None, False, True,
+                            SpectrumScaling.FFTBackward)
+    rt, rf, rs = orc.stft(x5, 48000, 128, "hann", 50, None, False, True, "FFTBackward")
+    assert relmax(s, rs) < TOL
+    with pytest.raises(AssertionError):
+        dsp.Signal(None, x5, 48000.0)
