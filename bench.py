@@ -1,0 +1,352 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X spectral hot path.
+
+    python bench.py --gpus N --steps K --warmup W [--workload welch_h1|fir_bank|csm|deconv]
+
+Default workload (BASELINE.json configs[1], the one the metric is quoted on):
+64-channel Welch H1 transfer-function estimation, one sweep input channel,
+2^20 samples per channel, nfft 4096, Hann, 50 % overlap.  One step = one
+ds_welch_tf_dev call over inputs that are already resident in HBM.
+N > 1: one process per GPU (torch.distributed.run), every rank owns an
+independent 64-channel batch (weak scaling, no data-path collective); the
+shared sweep channel is broadcast once over RCCL/xGMI before the timed region.
+
+Prints ONE JSON line on rank 0.
+"""
+
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+MFMA_F32_PEAK_TFLOPS = 157.3
+
+FS = 48000
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="welch_h1",
+                    choices=["welch_h1", "fir_bank", "csm", "deconv"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-channels", type=int, default=16,
+                    help="output channels of the bounded CPU-baseline sample")
+    ap.add_argument("--detrend", type=int, default=1)
+    return ap.parse_args()
+
+
+# ---------------------------------------------------------------------------
+class Dist:
+    """torch.distributed only as plumbing: rendezvous, barrier, max over ranks."""
+
+    def __init__(self, n_gpus: int):
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.torch = None
+        try:
+            import torch
+            self.torch = torch
+        except Exception:  # pragma: no cover
+            pass
+        if self.world > 1:
+            import torch.distributed as dist
+            self.torch.cuda.set_device(self.local_rank)
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group(backend="nccl")
+            self.dist = dist
+        assert self.world == n_gpus or self.world == 1, (self.world, n_gpus)
+
+    def barrier_sync(self, ctx):
+        ctx.sync()
+        if self.torch is not None and self.torch.cuda.is_available():
+            self.torch.cuda.synchronize()
+        if self.world > 1:
+            self.dist.barrier()
+
+    def max_over_ranks(self, v: float) -> float:
+        if self.world == 1:
+            return v
+        t = self.torch.tensor([v], dtype=self.torch.float64, device="cuda")
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def bcast_bytes(self, b: bytes, n: int) -> bytes:
+        if self.world == 1:
+            return b
+        t = self.torch.zeros(n, dtype=self.torch.uint8, device="cuda")
+        if self.rank == 0:
+            t.copy_(self.torch.frombuffer(bytearray(b), dtype=self.torch.uint8))
+        self.dist.broadcast(t, src=0)
+        return bytes(t.cpu().numpy().tobytes())
+
+
+def setup_rccl(ctx, dist: Dist):
+    """Library-level RCCL communicator (ds_comm_*) used for the sweep broadcast."""
+    if dist.world == 1:
+        return False
+    ident = C.create_string_buffer(128)
+    if dist.rank == 0:
+        ctx.check(ctx.lib.ds_comm_unique_id(ident), "ds_comm_unique_id")
+    raw = dist.bcast_bytes(ident.raw, 128)
+    ctx.check(ctx.lib.ds_comm_init(ctx.handle, dist.world, dist.rank, raw), "ds_comm_init")
+    return True
+
+
+# ---------------------------------------------------------------------------
+def welch_h1(args, ctx, dist):
+    from dsptoolbox_amd import backend
+    from dsptoolbox_amd._lib import DeviceBuffer
+    from dsptoolbox_amd.generators import exponential_sweep, sweep_and_responses
+    from dsptoolbox_amd.standard.enums import SpectrumScaling, Window
+
+    n, n_cy, W = 2**20, 64, 4096
+    # per-rank independent batch (different response / noise seeds), shared sweep
+    x, y = sweep_and_responses(n, n_cy, FS)
+    if dist.rank > 0:
+        rng = np.random.default_rng(9000 + dist.rank)
+        y = y[:, rng.permutation(n_cy)] * (1.0 + 0.01 * dist.rank)
+    window = backend._window_array(Window.Hann, W)
+    hop, n_frames = backend._welch_framing(n, W, 50, window)
+    amp, norm_scale, factor, phys = backend._finish_params(SpectrumScaling.FFTBackward, W, FS, window)
+    d_y = DeviceBuffer.from_array(ctx, backend._planar_f32(y))
+    d_w = DeviceBuffer.from_array(ctx, window.astype(np.float32))
+    xp = backend._planar_f32(x)
+    d_x = DeviceBuffer(ctx, xp.nbytes)
+    bcast_ms = None
+    if setup_rccl(ctx, dist):
+        if dist.rank == 0:
+            ctx.upload(d_x.ptr, xp)
+        dist.barrier_sync(ctx)
+        t0 = time.perf_counter()
+        ctx.check(ctx.lib.ds_bcast(ctx.handle, C.c_void_p(d_x.ptr), xp.nbytes, 0), "ds_bcast")
+        ctx.sync()
+        bcast_ms = (time.perf_counter() - t0) * 1e3
+    else:
+        ctx.upload(d_x.ptr, xp)
+    B = W // 2 + 1
+    d_tf = DeviceBuffer(ctx, B * n_cy * 8)
+    d_coh = DeviceBuffer(ctx, B * n_cy * 4)
+
+    def step():
+        ctx.check(ctx.lib.ds_welch_tf_dev(
+            ctx.handle, C.c_void_p(d_x.ptr), 1, n, C.c_void_p(d_y.ptr), n_cy, n, n, W, hop, n_frames,
+            C.c_void_p(d_w.ptr), int(args.detrend), 1, amp, norm_scale, factor, phys,
+            C.c_void_p(d_tf.ptr), C.c_void_p(d_coh.ptr)), "ds_welch_tf_dev")
+
+    samples_per_step = (n_cy + 1) * n
+    alg_bytes = (n_cy + 1) * n * 4 + B * n_cy * 8 + B * n_cy * 4
+    info = dict(
+        workload="welch_h1: 64 output ch + 1 sweep input ch x 2^20 samples, nfft 4096, Hann, 50% overlap"
+                 + (", detrend" if args.detrend else ""),
+        channels=n_cy, samples_per_channel=n, nfft=W, overlap_percent=50, frames=n_frames,
+        parallelism=f"channel-batch x{dist.world}")
+
+    def verify():
+        tf = d_tf.to_array((B, n_cy), np.complex64)
+        assert np.all(np.isfinite(tf[1:]))
+        return tf, d_coh.to_array((B, n_cy), np.float32)
+
+    def cpu_baseline():
+        from oracle import dsp_oracle as orc
+        cc = min(args.cpu_channels, n_cy)
+        t0 = time.perf_counter()
+        rt, rc = orc.compute_transfer_function(y[:, :cc], x, FS, W, "H1", detrend=bool(args.detrend))
+        dt = time.perf_counter() - t0
+        tf, coh = verify()
+        fr = np.fft.rfftfreq(W, 1 / FS)
+        sl = (fr >= 30.0) & (fr <= 19000.0)  # bins the 20 Hz - 20 kHz sweep excites
+        err = max(orc.rel_max(tf[sl, :cc], rt[sl]), orc.rel_max(coh[sl, :cc], rc[sl]))
+        # the reference loop re-frames/re-FFTs x per output channel: samples consumed = (cc + 1) n
+        return dict(value=(cc + 1) * n / dt / 1e6, unit="Msamples/s", cores=1, kind="port",
+                    sample=f"oracle.compute_transfer_function (reference loop structure) on {cc} of "
+                           f"{n_cy} output channels x 2^20, {dt:.1f} s",
+                    parity_rel_max_vs_gpu=err)
+
+    return step, samples_per_step, alg_bytes, "hbm", info, cpu_baseline, bcast_ms, \
+        ("welch4096_main", "welch_yacc")
+
+
+def fir_bank(args, ctx, dist):
+    from dsptoolbox_amd import backend
+    from dsptoolbox_amd._lib import DeviceBuffer
+    from dsptoolbox_amd.generators import fir_bank_taps
+
+    n, n_ch, K, T = 2**22, 8, 32, 4097
+    x = np.random.default_rng(3 + dist.rank).standard_normal((n, n_ch)) * 0.1
+    taps = fir_bank_taps(K, T, FS).astype(np.float32)
+    d_x = DeviceBuffer.from_array(ctx, backend._planar_f32(x))
+    d_t = DeviceBuffer.from_array(ctx, taps)
+    d_y = DeviceBuffer(ctx, K * n_ch * n * 4)
+
+    def step():
+        ctx.check(ctx.lib.ds_fir_ola_dev(ctx.handle, C.c_void_p(d_x.ptr), n_ch, n, n,
+                                         C.c_void_p(d_t.ptr), K, T, backend.DS_FB_PARALLEL,
+                                         C.c_void_p(d_y.ptr), n), "ds_fir_ola_dev")
+
+    alg_bytes = n_ch * n * 4 + K * T * 4 + K * n_ch * n * 4
+    info = dict(workload="fir_bank: FilterBank Parallel, 32 x 4097-tap FIR over 8 ch x 2^22",
+                channels=n_ch, samples_per_channel=n, bands=K, taps=T,
+                parallelism=f"signal-batch x{dist.world}")
+
+    def cpu_baseline():
+        from oracle import dsp_oracle as orc
+        nb = 1
+        t0 = time.perf_counter()
+        ref = orc.lfilter_fir(taps[0].astype(np.float64), x)
+        dt = time.perf_counter() - t0
+        got = d_y.to_array((K, n_ch, n), np.float32)[0].T
+        return dict(value=nb * n_ch * n / dt / 1e6 / K, unit="Msamples/s", cores=1, kind="port",
+                    sample=f"oracle.lfilter_fir (scipy oaconvolve) 1 of {K} bands, {dt:.1f} s; value "
+                           "scaled to all bands", parity_rel_max_vs_gpu=orc.rel_max(got, ref))
+
+    return step, n_ch * n, alg_bytes, "hbm", info, cpu_baseline, None, ("fir",)
+
+
+def csm(args, ctx, dist):
+    from dsptoolbox_amd import backend
+    from dsptoolbox_amd._lib import DeviceBuffer
+    from dsptoolbox_amd.generators import mic_array_noise
+    from dsptoolbox_amd.standard.enums import SpectrumScaling, Window
+
+    n, n_ch, W = 512000, 64, 1024
+    x = mic_array_noise(n, n_ch, 4 + dist.rank)
+    window = backend._window_array(Window.Hann, W)
+    hop, n_frames = backend._welch_framing(n, W, 50, window)
+    amp, norm_scale, factor, phys = backend._finish_params(SpectrumScaling.FFTBackward, W, FS, window)
+    d_x = DeviceBuffer.from_array(ctx, backend._planar_f32(x))
+    d_w = DeviceBuffer.from_array(ctx, window.astype(np.float32))
+    B = W // 2 + 1
+    d_c = DeviceBuffer(ctx, B * n_ch * n_ch * 8)
+
+    def step():
+        ctx.check(ctx.lib.ds_csm_dev(ctx.handle, C.c_void_p(d_x.ptr), n_ch, n, n, W, hop, n_frames,
+                                     C.c_void_p(d_w.ptr), 1, amp, norm_scale, factor, phys,
+                                     C.c_void_p(d_c.ptr)), "ds_csm_dev")
+
+    flops = B * n_ch * n_ch * n_frames * 8.0
+    info = dict(workload="csm: 64-mic Welch cross-spectral matrix, nfft 1024, 1000 frames",
+                channels=n_ch, samples_per_channel=n, nfft=W, frames=n_frames,
+                gemm_flops="513*64*64*1000*8 (full Hermitian count)",
+                parallelism=f"signal-batch x{dist.world}")
+
+    def cpu_baseline():
+        from oracle import dsp_oracle as orc
+        t0 = time.perf_counter()
+        f, ref = orc.csm_welch_batched(x[:, :16], FS, W, "hann", 50, True, "FFTBackward", workers=-1)
+        dt = time.perf_counter() - t0
+        got = d_c.to_array((B, n_ch, n_ch), np.complex64)[:, :16, :16]
+        return dict(value=16 * n / dt / 1e6, unit="Msamples/s", cores=os.cpu_count(), kind="port",
+                    sample=f"oracle.csm_welch_batched, 16 of 64 mics, {dt:.1f} s",
+                    parity_rel_max_vs_gpu=orc.rel_max(got[1:], ref[1:]))
+
+    return step, n_ch * n, flops, "mfma", info, cpu_baseline, None, ("csm_gemm",)
+
+
+def deconv(args, ctx, dist):
+    from dsptoolbox_amd import backend
+    from dsptoolbox_amd._lib import DeviceBuffer
+    from dsptoolbox_amd.generators import exponential_sweep
+
+    n, items, n_ch = 8192, 1024 // max(dist.world, 1) * 1, 2
+    x = exponential_sweep(n, FS)
+    rng = np.random.default_rng(5000 + dist.rank)
+    y = rng.standard_normal((items, n_ch, n)).astype(np.float32) * 0.1
+    r = (rng.standard_normal(n // 2 + 1) + 1j * rng.standard_normal(n // 2 + 1)).astype(np.complex64)
+    d_y = DeviceBuffer.from_array(ctx, y)
+    d_r = DeviceBuffer.from_array(ctx, r)
+    d_o = DeviceBuffer(ctx, y.nbytes)
+
+    def step():
+        ctx.check(ctx.lib.ds_deconv_dev(ctx.handle, C.c_void_p(d_y.ptr), items, n_ch, n, n, n,
+                                        C.c_void_p(d_r.ptr), 0, n, n, C.c_void_p(d_o.ptr)),
+                  "ds_deconv_dev")
+
+    alg_bytes = 2 * y.nbytes + r.nbytes
+    info = dict(workload="deconv: stereo spectral deconvolutions n=8192 against a shared inverse sweep",
+                items=items, channels=n_ch, samples_per_channel=n,
+                parallelism=f"item-shard x{dist.world}")
+    return step, items * n_ch * n, alg_bytes, "hbm", info, None, None, ("deconv",)
+
+
+# ---------------------------------------------------------------------------
+def main():
+    args = parse_args()
+    from dsptoolbox_amd._build import build_library
+    from dsptoolbox_amd._lib import Context
+
+    build_library()
+    dist = Dist(args.gpus)
+    ctx = Context(dist.local_rank)
+    maker = dict(welch_h1=welch_h1, fir_bank=fir_bank, csm=csm, deconv=deconv)[args.workload]
+    step, units, alg, bound, info, cpu_baseline, bcast_ms, dominant = maker(args, ctx, dist)
+
+    for _ in range(args.warmup):
+        step()
+    dist.barrier_sync(ctx)
+    ctx.profile_enable(True)
+    ctx.profile_report()
+    t0 = time.perf_counter()
+    ctx.timer_start()
+    for _ in range(args.steps):
+        step()
+    ev_ms = ctx.timer_stop()
+    dist.barrier_sync(ctx)
+    wall = time.perf_counter() - t0
+    prof = ctx.profile_report()
+    ctx.profile_enable(False)
+    wall = dist.max_over_ranks(wall)
+
+    if dist.rank != 0:
+        return
+    ms_per_step = wall * 1e3 / args.steps
+    value = units * dist.world / (wall / args.steps) / 1e6
+    dom = next((k for k in dominant if k in prof), max(prof, key=lambda k: prof[k][0]))
+    dom_ms = prof[dom][0] / prof[dom][1]
+    launches_per_step = prof[dom][1] / args.steps
+    if bound == "hbm":
+        achieved = alg / launches_per_step / (dom_ms * 1e-3) / 1e9
+        roof = dict(bound="hbm", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
+                    frac=achieved / HBM_PEAK_GBS, traffic=None)
+    else:
+        achieved = alg / launches_per_step / (dom_ms * 1e-3) / 1e12
+        roof = dict(bound="mfma", achieved=achieved, peak=MFMA_F32_PEAK_TFLOPS, unit="TFLOP/s",
+                    frac=achieved / MFMA_F32_PEAK_TFLOPS, traffic=None)
+    roof["kernel"] = dom
+    roof["kernel_avg_ms"] = dom_ms
+    roof["algorithmic_per_launch"] = alg / launches_per_step
+    out = {
+        "metric": "Msamples/s + GB/s vs HBM roofline, 64ch Welch H1 nfft=4096"
+                  if args.workload == "welch_h1" else f"Msamples/s ({args.workload})",
+        "value": value, "unit": "Msamples/s", "n_gpus": dist.world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": info, "roofline": roof,
+        "step_event_ms": ev_ms / args.steps,
+        "kernels_ms_per_step": {k: v[0] / args.steps for k, v in prof.items()},
+        "whole_step_gbs": (alg / (ev_ms / args.steps * 1e-3) / 1e9) if bound == "hbm" else None,
+    }
+    if bcast_ms is not None:
+        out["rccl_bcast_ms"] = bcast_ms
+    if cpu_baseline is not None and not args.no_cpu_baseline and dist.world == 1:
+        out["cpu_baseline"] = cpu_baseline()
+        out["cpu_baseline"]["host_cpus"] = os.cpu_count()
+    print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -32,6 +32,8 @@ SIGNATURES = {
     "ds_timer_start": (C.c_int, [ctx_p]),
     "ds_timer_stop": (C.c_int, [ctx_p, C.POINTER(C.c_float)]),
     "ds_max_fft_len": (C.c_int, []),
+    "ds_profile_enable": (C.c_int, [ctx_p, C.c_int]),
+    "ds_profile_report": (C.c_char_p, [ctx_p]),
     "ds_stft_r2c_dev": (C.c_int, [ctx_p, f32_p, i64, C.c_int, i64, C.c_int, C.c_int, C.c_int, i64,
                                   C.c_int, f32_p, C.c_int, C.c_float, C.c_float, C.c_int, c32_p]),
     "ds_stft_r2c": (C.c_int, [ctx_p, f32_p, i64, C.c_int, C.c_int, C.c_int, C.c_int, i64, C.c_int,
@@ -160,6 +162,18 @@ class Context:
         ms = C.c_float()
         self.check(self.lib.ds_timer_stop(self.handle, C.byref(ms)), "ds_timer_stop")
         return float(ms.value)
+
+    def profile_enable(self, on: bool = True):
+        self.check(self.lib.ds_profile_enable(self.handle, int(on)), "ds_profile_enable")
+
+    def profile_report(self) -> dict:
+        """{kernel: (total_ms, launches)} since the previous report."""
+        text = self.lib.ds_profile_report(self.handle).decode()
+        out = {}
+        for line in text.splitlines():
+            name, ms, cnt = line.split()
+            out[name] = (float(ms), int(cnt))
+        return out
 
     def close(self):
         if getattr(self, "handle", None):

@@ -25,6 +25,7 @@ struct ds_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::string err;
     std::map<int, float2*> tw;  // twiddle tables by length
+    float2* w4_tables = nullptr;  // welch4096::host_tables()
     void* ws = nullptr;         // kernel workspace (spectra, partials)
     size_t ws_bytes = 0;
     void* io = nullptr;  // staging for the host-pointer entry points
@@ -32,6 +33,15 @@ struct ds_ctx {
     // RCCL (dlopen'ed lazily)
     void* rccl = nullptr;
     void* comm = nullptr;
+    // per-kernel HIP-event timing (ds_profile_*)
+    bool prof = false;
+    struct ProfRec {
+        const char* name;
+        hipEvent_t a, b;
+    };
+    std::vector<ProfRec> prof_recs;
+    std::vector<hipEvent_t> prof_pool;
+    std::string prof_text;
 };
 
 static int fail(ds_ctx* c, int code, const std::string& msg) {
@@ -87,6 +97,12 @@ extern "C" void ds_destroy(ds_ctx* c) {
     ds_comm_destroy(c);
     (void)hipStreamSynchronize(c->stream);
     for (auto& kv : c->tw) (void)hipFree(kv.second);
+    if (c->w4_tables) (void)hipFree(c->w4_tables);
+    for (auto& r : c->prof_recs) {
+        (void)hipEventDestroy(r.a);
+        (void)hipEventDestroy(r.b);
+    }
+    for (auto& e : c->prof_pool) (void)hipEventDestroy(e);
     if (c->ws) (void)hipFree(c->ws);
     if (c->io) (void)hipFree(c->io);
     (void)hipEventDestroy(c->ev0);
@@ -145,6 +161,37 @@ extern "C" int ds_timer_stop(ds_ctx* c, float* ms) {
     return DS_OK;
 }
 
+extern "C" int ds_profile_enable(ds_ctx* c, int on) {
+    if (!c) return fail(c, DS_ERR_ARG, "ds_profile_enable: null ctx");
+    c->prof = on != 0;
+    return DS_OK;
+}
+
+// "name total_ms count\n" per kernel since the last call; synchronises the stream
+extern "C" const char* ds_profile_report(ds_ctx* c) {
+    if (!c) return "";
+    (void)hipStreamSynchronize(c->stream);
+    std::map<std::string, std::pair<double, long>> acc;
+    for (auto& r : c->prof_recs) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
+            auto& e = acc[r.name];
+            e.first += ms;
+            e.second += 1;
+        }
+        c->prof_pool.push_back(r.a);
+        c->prof_pool.push_back(r.b);
+    }
+    c->prof_recs.clear();
+    c->prof_text.clear();
+    char line[256];
+    for (auto& kv : acc) {
+        snprintf(line, sizeof line, "%s %.6f %ld\n", kv.first.c_str(), kv.second.first, kv.second.second);
+        c->prof_text += line;
+    }
+    return c->prof_text.c_str();
+}
+
 // ---- internal helpers ------------------------------------------------------
 static int get_twiddles(ds_ctx* c, int n, const float2** out) {
     auto it = c->tw.find(n);
@@ -192,12 +239,33 @@ struct Carver {  // 256-byte aligned sub-allocations out of one buffer
     static size_t pad(size_t bytes) { return (bytes + 255) & ~size_t(255); }
 };
 
+static int prof_event(ds_ctx* c, hipEvent_t* ev) {
+    if (!c->prof_pool.empty()) {
+        *ev = c->prof_pool.back();
+        c->prof_pool.pop_back();
+        return DS_OK;
+    }
+    HIPCHK(c, hipEventCreate(ev));
+    return DS_OK;
+}
+
 template <typename K, typename A>
-static int launch(ds_ctx* c, K kernel, dim3 grid, int threads, size_t lds, const A& args) {
+static int launch(ds_ctx* c, const char* name, K kernel, dim3 grid, int threads, size_t lds,
+                  const A& args) {
     if (lds > 64 * 1024)
         HIPCHK(c, hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    ds_ctx::ProfRec rec{name, nullptr, nullptr};
+    if (c->prof) {
+        CHK(prof_event(c, &rec.a));
+        CHK(prof_event(c, &rec.b));
+        HIPCHK(c, hipEventRecord(rec.a, c->stream));
+    }
     hipLaunchKernelGGL(kernel, grid, dim3(threads), lds, c->stream, args);
     HIPCHK(c, hipGetLastError());
+    if (c->prof) {
+        HIPCHK(c, hipEventRecord(rec.b, c->stream));
+        c->prof_recs.push_back(rec);
+    }
     return DS_OK;
 }
 
@@ -240,7 +308,7 @@ extern "C" int ds_stft_r2c_dev(ds_ctx* c, const float* x, int64_t n_samples, int
     StftArgs a{x, n_samples, ld, pad_front, n_ch, W, hop, n_frames, detrend, power, window, tw,
                scale, edge_scale, (float2*)out};
     dim3 grid((unsigned)((int64_t)n_ch * ((n_frames + 1) / 2)));
-    DISPATCH_N(nfft, CHK(launch(c, k_stft<NN>, grid, Cfg<NN>::NT, Cfg<NN>::LDS_BYTES, a)));
+    DISPATCH_N(nfft, CHK(launch(c, "stft", k_stft<NN>, grid, Cfg<NN>::NT, Cfg<NN>::LDS_BYTES, a)));
     return DS_OK;
 }
 
@@ -301,18 +369,80 @@ static int welch_common(ds_ctx* c, int kind, const float* x, int n_cx, int64_t l
     {
         XspecArgs a{x, n_samples, ldx, n_cx, W, hop, n_frames, detrend, pl.fpc, window, tw, xs, pxx};
         dim3 grid(pl.n_chunks, n_cx);
-        DISPATCH_N(W, CHK(launch(c, k_xspec<NN>, grid, Cfg<NN>::NT, Cfg<NN>::LDS_BYTES, a)));
+        DISPATCH_N(W, CHK(launch(c, "welch_xspec", k_xspec<NN>, grid, Cfg<NN>::NT, Cfg<NN>::LDS_BYTES, a)));
     }
     if (need_xs) {
         YaccArgs a{y, n_samples, ldy, n_cy, n_cx, W, hop, n_frames, detrend, pl.fpc, window, tw, xs, pxy, pyy};
         dim3 grid(pl.n_chunks, (n_cy + 1) / 2);
-        DISPATCH_N(W, CHK(launch(c, k_yacc<NN>, grid, Cfg<NN>::NT, Cfg<NN>::LDS_BYTES, a)));
+        DISPATCH_N(W, CHK(launch(c, "welch_yacc", k_yacc<NN>, grid, Cfg<NN>::NT, Cfg<NN>::LDS_BYTES, a)));
     }
-    WelchFinArgs f{pxx, pxy, pyy, pl.n_chunks, n_cx, n_cy, kind, mode,
+    WelchFinArgs f{pxx, pxy, pyy, pl.n_chunks, pl.n_chunks, n_cx, n_cy, kind, mode,
                    FinishPar{norm_scale / (double)n_frames, factor, halve_edges, amp_sqrt, nb},
                    out_c, out_r};
     int64_t total = (int64_t)nb * (kind == 1 ? n_cx : n_cy);
-    CHK(launch(c, k_welch_finish, dim3((unsigned)((total + 255) / 256)), 256, 0, f));
+    CHK(launch(c, "welch_finish", k_welch_finish, dim3((unsigned)((total + 255) / 256)), 256, 0, f));
+    return DS_OK;
+}
+
+// nfft 4096, one input channel: register-resident radix-16 FFT path (kernels_welch4096.hpp)
+static int welch4096_run(ds_ctx* c, const float* x, int64_t ldx, const float* y, int n_cy, int64_t ldy,
+                         int64_t n_samples, int hop, int n_frames, const float* window, int detrend,
+                         int mode, int amp_sqrt, double norm_scale, double factor, int halve_edges,
+                         float2* tf, float* coh) {
+    namespace w4 = welch4096;
+    if (!x || !y || !window) return fail(c, DS_ERR_ARG, "ds_welch_tf: null argument");
+    if (n_cy <= 0 || n_samples <= 0 || hop <= 0 || hop > 4096 || n_frames <= 0 || ldx < n_samples ||
+        ldy < n_samples)
+        return fail(c, DS_ERR_ARG, "ds_welch_tf: bad shape");
+    if (mode < DS_TF_H1 || mode > DS_TF_H3) return fail(c, DS_ERR_ARG, "welch: unsupported transfer function type");
+    if (!c->w4_tables) {
+        std::vector<float2> h;
+        w4::host_tables(h);
+        HIPCHK(c, hipMalloc((void**)&c->w4_tables, sizeof(float2) * h.size()));
+        HIPCHK(c, hipMemcpyAsync(c->w4_tables, h.data(), sizeof(float2) * h.size(), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    w4::Plan pl = w4::plan(n_frames, n_cy);
+    CHK(reserve(c, &c->ws, &c->ws_bytes, pl.bytes));
+    Carver cv(c->ws);
+    float2* xs = cv.take<float2>((size_t)pl.n_pairs * w4::N);
+    float* px = cv.take<float>((size_t)pl.n_pairs * w4::NB);
+    float* sxx = cv.take<float>(w4::NB);
+    float2* pxy = cv.take<float2>((size_t)pl.n_chunks * n_cy * w4::NB);
+    float* pyy = cv.take<float>((size_t)pl.n_chunks * n_cy * w4::NB);
+    const bool half = hop == 2048;
+    w4::Args ax{x, n_samples, ldx, 1, hop, n_frames, pl.n_pairs, detrend, pl.n_chunks, pl.ppc, window,
+                c->w4_tables, xs, px, pxy, pyy};
+    if (half)
+        CHK(launch(c, "welch4096_x", w4::k_x<true>, dim3(pl.n_pairs), w4::NT, w4::LDS_BYTES, ax));
+    else
+        CHK(launch(c, "welch4096_x", w4::k_x<false>, dim3(pl.n_pairs), w4::NT, w4::LDS_BYTES, ax));
+    {
+        struct A3 { const float* px; int n; float* sxx; };
+        hipLaunchKernelGGL(w4::k_sxx, dim3((w4::NB + 7) / 8), dim3(256), 0, c->stream, (const float*)px,
+                           pl.n_pairs, sxx);
+        HIPCHK(c, hipGetLastError());
+    }
+    w4::Args ay = ax;
+    ay.sig = y;
+    ay.ld = ldy;
+    ay.n_ch = n_cy;
+    {
+        dim3 grid(pl.n_chunks * n_cy);
+        const int occ = w4::occupancy_target();
+#define W4_LAUNCH(H, O) CHK(launch(c, "welch4096_main", w4::k_y<H, O>, grid, w4::NT, w4::LDS_BYTES, ay))
+        if (half) {
+            if (occ == 2) W4_LAUNCH(true, 2); else if (occ == 3) W4_LAUNCH(true, 3); else W4_LAUNCH(true, 4);
+        } else {
+            if (occ == 2) W4_LAUNCH(false, 2); else if (occ == 3) W4_LAUNCH(false, 3); else W4_LAUNCH(false, 4);
+        }
+#undef W4_LAUNCH
+    }
+    WelchFinArgs f{sxx, pxy, pyy, pl.n_chunks, 1, 1, n_cy, 0, mode,
+                   FinishPar{norm_scale / (double)n_frames, factor, halve_edges, amp_sqrt, w4::NB},
+                   tf, coh};
+    int64_t total = (int64_t)w4::NB * n_cy;
+    CHK(launch(c, "welch_finish", k_welch_finish, dim3((unsigned)((total + 255) / 256)), 256, 0, f));
     return DS_OK;
 }
 
@@ -322,9 +452,9 @@ extern "C" int ds_welch_tf_dev(ds_ctx* c, const float* x, int n_cx, int64_t ldx,
                                double norm_scale, double factor, int halve_edges, ds_c32* tf,
                                float* coh) {
     if (!tf || !coh) return fail(c, DS_ERR_ARG, "ds_welch_tf: null output");
-    if (c && W == 4096 && n_cx == 1 && hop == 2048 && welch4096::enabled())
-        return welch4096::run(c->stream, x, ldx, y, n_cy, ldy, n_samples, n_frames, window, detrend,
-                              mode, amp_sqrt, norm_scale, factor, halve_edges, (float2*)tf, coh);
+    if (c && W == 4096 && n_cx == 1 && welch4096::enabled())
+        return welch4096_run(c, x, ldx, y, n_cy, ldy, n_samples, hop, n_frames, window, detrend, mode,
+                             amp_sqrt, norm_scale, factor, halve_edges, (float2*)tf, coh);
     return welch_common(c, 0, x, n_cx, ldx, y, n_cy, ldy, n_samples, W, hop, n_frames, window, detrend,
                         mode, amp_sqrt, norm_scale, factor, halve_edges, (float2*)tf, coh);
 }
@@ -363,7 +493,7 @@ extern "C" int ds_csm_dev(ds_ctx* c, const float* x, int n_ch, int64_t ld, int64
     CsmArgs a{X, n_ch, n_frames,
               FinishPar{norm_scale / (double)n_frames, factor, halve_edges, amp_sqrt, nb},
               (float2*)csm};
-    CHK(launch(c, k_csm_gemm, dim3(nb, nt * (nt + 1) / 2), 256, 0, a));
+    CHK(launch(c, "csm_gemm", k_csm_gemm, dim3(nb, nt * (nt + 1) / 2), 256, 0, a));
     return DS_OK;
 }
 
@@ -377,7 +507,7 @@ extern "C" int ds_rfft_dev(ds_ctx* c, const float* x, int n_ch, int64_t ld, int6
     const float2* tw;
     CHK(get_twiddles(c, n_fft, &tw));
     RfftArgs a{x, n_samples, ld, n_ch, tw, scale, (float2*)spec};
-    DISPATCH_N(n_fft, CHK(launch(c, k_rfft<NN>, dim3((n_ch + 1) / 2), Cfg<NN>::NT, Cfg<NN>::LDS_BYTES, a)));
+    DISPATCH_N(n_fft, CHK(launch(c, "rfft", k_rfft<NN>, dim3((n_ch + 1) / 2), Cfg<NN>::NT, Cfg<NN>::LDS_BYTES, a)));
     return DS_OK;
 }
 
@@ -404,7 +534,7 @@ extern "C" int ds_deconv_dev(ds_ctx* c, const float* y, int n_items, int n_ch, i
     CHK(get_twiddles(c, n_fft, &tw));
     DeconvArgs a{y, n_samples, ld, n_out, ld_out, n_ch, r_per_channel, tw, (const float2*)r, ir};
     dim3 grid((n_ch + 1) / 2, n_items);
-    DISPATCH_N(n_fft, CHK(launch(c, k_deconv<NN>, grid, Cfg<NN>::NT, Cfg<NN>::LDS_BYTES, a)));
+    DISPATCH_N(n_fft, CHK(launch(c, "deconv", k_deconv<NN>, grid, Cfg<NN>::NT, Cfg<NN>::LDS_BYTES, a)));
     return DS_OK;
 }
 
@@ -426,13 +556,13 @@ static int fir_once(ds_ctx* c, const float* x, int n_ch, int64_t ldx, int64_t n_
     float2* hs = (float2*)c->ws;
     {
         FirTapsArgs a{taps, n_filt, n_taps, tw, hs};
-        DISPATCH_N(N, CHK(launch(c, k_fir_taps<NN>, dim3((n_filt + 1) / 2), Cfg<NN>::NT, Cfg<NN>::LDS_BYTES, a)));
+        DISPATCH_N(N, CHK(launch(c, "fir_taps", k_fir_taps<NN>, dim3((n_filt + 1) / 2), Cfg<NN>::NT, Cfg<NN>::LDS_BYTES, a)));
     }
     const int L = N - (n_taps - 1);
     const int64_t n_blocks = (n_samples + L - 1) / L;
     FirArgs a{x, n_samples, ldx, ld_y, n_ch, n_filt, n_taps, tw, hs, y};
     dim3 grid((unsigned)n_blocks, (n_ch + 1) / 2);
-    DISPATCH_N(N, CHK(launch(c, k_fir<NN>, grid, Cfg<NN>::NT, Cfg<NN>::LDS_BYTES, a)));
+    DISPATCH_N(N, CHK(launch(c, "fir", k_fir<NN>, grid, Cfg<NN>::NT, Cfg<NN>::LDS_BYTES, a)));
     return DS_OK;
 }
 
@@ -442,6 +572,24 @@ __global__ void k_sum_taps(const float* taps, int n_filt, int n_taps, float* out
     double s = 0.0;
     for (int k = 0; k < n_filt; ++k) s += (double)taps[(int64_t)k * n_taps + t];
     out[t] = (float)s;
+}
+
+__global__ void k_taps_to_f64(const float* a, int n, double* out) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (double)a[i];
+}
+__global__ void k_f64_to_taps(const double* a, int n, float* out) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (float)a[i];
+}
+// out[n] = sum_k a[k] b[n-k], fp64 accumulate
+__global__ void k_conv_taps(const double* a, int na, const float* b, int nb, double* out) {
+    int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= na + nb - 1) return;
+    int k0 = max(0, n - (nb - 1)), k1 = min(na - 1, n);
+    double s = 0.0;
+    for (int k = k0; k <= k1; ++k) s += a[k] * (double)b[n - k];
+    out[n] = s;
 }
 
 extern "C" int ds_fir_ola_dev(ds_ctx* c, const float* x, int n_ch, int64_t ldx, int64_t n_samples,
@@ -462,21 +610,45 @@ extern "C" int ds_fir_ola_dev(ds_ctx* c, const float* x, int n_ch, int64_t ldx, 
         return r;
     }
     if (mode == DS_FB_SEQUENTIAL) {
-        // cascade, each stage truncated to n_samples (causal, so identical to the reference loop)
+        // ((x*b1)[:N]*b2)[:N]... = (x*(b1*b2*...))[:N] for causal filters: when the combined
+        // response fits one block transform, convolve the taps (fp64, on the device) and
+        // filter once -- no fp32 round trip of the intermediate signals through HBM.
+        const int64_t n_comb = (int64_t)n_filt * (n_taps - 1) + 1;
+        if (n_filt > 1 && n_comb - 1 <= kMaxFft / 2) {
+            double *pa = nullptr, *pb = nullptr;
+            float* bf = nullptr;
+            HIPCHK(c, hipMalloc((void**)&pa, sizeof(double) * n_comb));
+            HIPCHK(c, hipMalloc((void**)&pb, sizeof(double) * n_comb));
+            HIPCHK(c, hipMalloc((void**)&bf, sizeof(float) * n_comb));
+            hipLaunchKernelGGL(k_taps_to_f64, dim3((n_taps + 255) / 256), dim3(256), 0, c->stream, taps, n_taps, pa);
+            int len = n_taps;
+            for (int k = 1; k < n_filt; ++k) {
+                int nl = len + n_taps - 1;
+                hipLaunchKernelGGL(k_conv_taps, dim3((nl + 255) / 256), dim3(256), 0, c->stream, pa, len,
+                                   taps + (int64_t)k * n_taps, n_taps, pb);
+                std::swap(pa, pb);
+                len = nl;
+            }
+            hipLaunchKernelGGL(k_f64_to_taps, dim3((len + 255) / 256), dim3(256), 0, c->stream, pa, len, bf);
+            int r = fir_once(c, x, n_ch, ldx, n_samples, bf, 1, len, y, ld_y);
+            (void)hipStreamSynchronize(c->stream);
+            (void)hipFree(pa);
+            (void)hipFree(pb);
+            (void)hipFree(bf);
+            return r;
+        }
+        // long cascades: stage by stage, each truncated to n_samples like the reference loop
         float* tmp = nullptr;
         if (n_filt > 1) HIPCHK(c, hipMalloc((void**)&tmp, sizeof(float) * (size_t)n_ch * n_samples));
         const float* src = x;
         int64_t lds = ldx;
         int r = DS_OK;
         for (int k = 0; k < n_filt && r == DS_OK; ++k) {
-            bool last = (k == n_filt - 1);
-            // ping-pong so the last stage lands in y
-            float* dst = ((n_filt - 1 - k) % 2 == 0) ? y : tmp;
+            float* dst = ((n_filt - 1 - k) % 2 == 0) ? y : tmp;  // ping-pong, last stage lands in y
             int64_t ldd = (dst == y) ? ld_y : n_samples;
             r = fir_once(c, src, n_ch, lds, n_samples, taps + (int64_t)k * n_taps, 1, n_taps, dst, ldd);
             src = dst;
             lds = ldd;
-            (void)last;
         }
         (void)hipStreamSynchronize(c->stream);
         if (tmp) (void)hipFree(tmp);

@@ -54,7 +54,7 @@ struct WelchFinArgs {
     const float* pxx;   // [q][n_cx][nb]
     const float2* pxy;  // [q][n_cy][nb]
     const float* pyy;   // [q][n_cy][nb]
-    int n_chunks, n_cx, n_cy, kind, mode;
+    int n_chunks, n_chunks_x, n_cx, n_cy, kind, mode;
     FinishPar fin;
     float2* tf;  // [nb][n_cy]   (kind 0: tf, kind 2: csd)
     float* coh;  // [nb][n_cy]   (kind 0: coherence, kind 1: psd [nb][n_cx])
@@ -63,19 +63,23 @@ struct WelchFinArgs {
 __global__ void k_welch_finish(WelchFinArgs p) {
     const int nb = p.fin.nb;
     const int nc = p.kind == 1 ? p.n_cx : p.n_cy;
-    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (int64_t)nb * nc) return;
-    const int b = (int)(idx / nc), c = (int)(idx % nc);
+    // bins vary fastest across threads: the partial slabs [q][c][b] are read coalesced
+    // (the (b, c)-ordered outputs are 64x smaller than the slabs)
+    int64_t tix = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (tix >= (int64_t)nb * nc) return;
+    const int c = (int)(tix / nb), b = (int)(tix % nb);
+    const int64_t idx = (int64_t)b * nc + c;
     const int cx = p.n_cx == 1 ? 0 : c;
     double sxx = 0.0, syy = 0.0;
     cd sxy{0.0, 0.0};
+    if (p.kind != 2)
+        for (int q = 0; q < p.n_chunks_x; ++q) sxx += (double)p.pxx[((int64_t)q * p.n_cx + cx) * nb + b];
     for (int q = 0; q < p.n_chunks; ++q) {
-        if (p.kind != 2) sxx += (double)p.pxx[((int64_t)q * p.n_cx + cx) * nb + b];
         if (p.kind != 1) {
             int64_t i = ((int64_t)q * p.n_cy + c) * nb + b;
             float2 t = p.pxy[i];
             sxy.x += (double)t.x;
-            sxy.y += (double)t.y;
+            sxy.y += (double)t.y + 0.0;  // -0 -> accumulates to +0 like the reference's mean
             if (p.kind == 0) syy += (double)p.pyy[i];
         }
     }
@@ -93,8 +97,11 @@ __global__ void k_welch_finish(WelchFinArgs p) {
     cd h;
     if (p.mode == 1) {  // H1 = Gxy / Gxx
         h = cd{gxy.x / gxx, gxy.y / gxx};
-    } else if (p.mode == 2) {  // H2 = Gyy / Gyx, Gyx = conj(Gxy)  ->  Gyy * Gxy / |Gxy|^2
-        h = cd{gyy * gxy.x / axy2, gyy * gxy.y / axy2};
+    } else if (p.mode == 2) {  // H2 = Gyy / Gyx, Gyx = finish(conj(Sxy)) = conj(Gxy) ...
+        // ... except where Sxy is exactly real and negative (DC / Nyquist bins): the
+        // reference takes the principal root of (-a + 0j) for Gxy AND for Gyx.
+        cd gyx = (sxy.y == 0.0) ? gxy : cd{gxy.x, -gxy.y};
+        h = cd{gyy * gyx.x / axy2, -gyy * gyx.y / axy2};  // Gyy / Gyx = Gyy conj(Gyx)/|Gyx|^2
     } else {  // H3 = Gxy/|Gxy| * sqrt(Gyy/Gxx)
         double s = sqrt(gyy / gxx) / sqrt(axy2);
         h = cd{gxy.x * s, gxy.y * s};

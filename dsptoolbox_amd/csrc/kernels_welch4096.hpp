@@ -1,14 +1,387 @@
-// Specialised Welch H1/H2/H3 path for the headline shape (nfft 4096, 50 % overlap,
-// one input channel).  Placeholder: the generic kernels serve it until the tuned
-// kernel lands.
+// Welch H1/H2/H3 for the headline shape: nfft 4096, ONE input channel, any hop
+// (50 % overlap has a shorter load path).  gfx950.
+//
+// Data flow (all fp32, finish() in fp64):
+//   k_x   : one workgroup per PAIR of input frames (2p, 2p+1):
+//             Wp = FFT4096( x_2p w + i x_2p+1 w )      -> xs[p][0..4095]  (L2 resident)
+//             (|Wp[k]|^2 + |Wp[N-k]|^2)/2              -> px[p][0..2048]
+//   k_y   : workgroup = (output channel c, chunk q of frame pairs); per pair
+//             Zp = FFT4096( y_2p w + i y_2p+1 w )
+//             T[k] += conj(Wp[k]) Zp[k] ,  P[k] += |Zp[k]|^2      (k = all 4096 bins,
+//             16 per thread, in registers -- NO Hermitian separation per frame)
+//           at the end of the chunk, once:
+//             Sxy[k] = (T[k] + conj T[N-k])/2 ,  Syy[k] = (P[k] + P[N-k])/2 ,  k <= 2048
+//           which is exact because both halves of a pair belong to the same channel:
+//             conj(W[k]) Z[k] + conj( conj(W[N-k]) Z[N-k] ) = 2 (conj(X_a) Y_a + conj(X_b) Y_b).
+//   k_sxx : sum of px over pairs (fp64) -> one "chunk" for k_welch_finish
+//   k_welch_finish (kernels_finish.hpp): chunks -> H, coherence.
+//
+// FFT: 4096 = 16 x 16 x 16, 256 threads, 16 complex values per thread,
+//   n = 256 n1 + 16 n2 + n3 ,  k = k1 + 16 k2 + 256 k3
+//   pass 1  thread t = 16 n2 + n3 : DFT16 over n1 of z[t + 256 n1]  (straight from HBM),
+//           times W4096^(t k1) (15 per-thread constants kept in registers)
+//           -> LDS image [k1][t], row stride 272 complex (bank-conflict-free b64 reads)
+//   pass 2  thread u = 16 k1 + n3 : DFT16 over n2, times W256^(n3 k2) (2 KB LDS table)
+//           -> LDS image rows v = 16 k2 + k1 of 16 complex (n3), row stride 18 complex
+//           (conflict-free ds_read_b128)
+//   pass 3  thread v = k1 + 16 k2 : DFT16 over n3 -> Z[v + 256 k3] in registers
+// Detrend: subtracting the mean of the windowed frame changes only bin 0 of its
+// DFT (to 0), so it is applied as "skip bin 0" -- bin 0 is 0/0 rounding noise in
+// the reference too.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <cmath>
+#include <vector>
+
+#include "kernels_finish.hpp"
+
 namespace welch4096 {
-inline bool enabled() { return false; }
-inline int run(hipStream_t, const float*, int64_t, const float*, int, int64_t, int64_t, int,
-               const float*, int, int, int, double, double, int, float2*, float*) {
-    return -2;
+
+constexpr int N = 4096, NT = 256, NB = N / 2 + 1;
+constexpr int L1S = 272, L2S = 18;
+constexpr int BUF_C = 256 * L2S;  // 4608 complex >= 16 * 272
+constexpr int LDS_BYTES = BUF_C * 8 + 256 * 8;
+
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) {
+    return make_float2(fmaf(a.x, b.x, -a.y * b.y), fmaf(a.x, b.y, a.y * b.x));
 }
+
+// in-place radix-4 butterfly on (a,b,c,d), forward
+__device__ __forceinline__ void r4(float2& a, float2& b, float2& c, float2& d) {
+    float2 s0 = make_float2(a.x + c.x, a.y + c.y), d0 = make_float2(a.x - c.x, a.y - c.y);
+    float2 s1 = make_float2(b.x + d.x, b.y + d.y), d1 = make_float2(b.x - d.x, b.y - d.y);
+    a = make_float2(s0.x + s1.x, s0.y + s1.y);
+    c = make_float2(s0.x - s1.x, s0.y - s1.y);
+    b = make_float2(d0.x + d1.y, d0.y - d1.x);  // d0 - i d1
+    d = make_float2(d0.x - d1.y, d0.y + d1.x);  // d0 + i d1
+}
+
+// 16-point DFT in registers.  Input v[n], n = n0 + 4 n1.  Output X[k] in v[4*(k&3) + (k>>2)].
+__device__ __forceinline__ void dft16(float2 (&v)[16]) {
+    constexpr float C8 = 0.92387953251128673848f, S8 = 0.38268343236508978178f;
+    constexpr float R2 = 0.70710678118654752440f;
+#pragma unroll
+    for (int n0 = 0; n0 < 4; ++n0) r4(v[n0], v[n0 + 4], v[n0 + 8], v[n0 + 12]);
+    // position n0 + 4 k1 holds Y[n0][k1]; multiply by W16^(n0 k1)
+    auto mulw = [](float2 z, float c, float s) {  // z * (c - i s)
+        return make_float2(fmaf(z.x, c, z.y * s), fmaf(z.y, c, -z.x * s));
+    };
+    v[1 + 4] = mulw(v[1 + 4], C8, S8);                                  // W16^1
+    v[1 + 8] = make_float2((v[9].x + v[9].y) * R2, (v[9].y - v[9].x) * R2);  // W16^2
+    v[1 + 12] = mulw(v[1 + 12], S8, C8);                                // W16^3
+    v[2 + 4] = make_float2((v[6].x + v[6].y) * R2, (v[6].y - v[6].x) * R2);  // W16^2
+    v[2 + 8] = make_float2(v[10].y, -v[10].x);                          // W16^4 = -i
+    v[2 + 12] = make_float2((v[14].y - v[14].x) * R2, -(v[14].x + v[14].y) * R2);  // W16^6
+    v[3 + 4] = mulw(v[3 + 4], S8, C8);                                  // W16^3
+    v[3 + 8] = make_float2((v[11].y - v[11].x) * R2, -(v[11].x + v[11].y) * R2);  // W16^6
+    v[3 + 12] = mulw(v[3 + 12], -C8, -S8);                              // W16^9 = -W16^1
+#pragma unroll
+    for (int k1 = 0; k1 < 4; ++k1) r4(v[4 * k1], v[4 * k1 + 1], v[4 * k1 + 2], v[4 * k1 + 3]);
+}
+__device__ __forceinline__ constexpr int pos16(int k) { return 4 * (k & 3) + (k >> 2); }
+
+struct Tw {
+    float2 w[15];  // W4096^(t k1), k1 = 1..15
+};
+
+// Transform the 16 register values (pass-1 inputs z[t + 256 n1]) into Z[t + 256 k3] (in
+// v[pos16(k3)]).  `buf` is the workgroup's LDS exchange buffer, `tw2` the W256 table.
+// The caller guarantees nobody still reads buf (one barrier before the first write here).
+__device__ __forceinline__ void fft4096(float2 (&v)[16], const Tw& tw, float2* __restrict__ buf,
+                                        const float2* __restrict__ tw2, int tid) {
+    dft16(v);
+#pragma unroll
+    for (int k1 = 1; k1 < 16; ++k1) v[pos16(k1)] = cmul(v[pos16(k1)], tw.w[k1 - 1]);
+    __syncthreads();  // previous readers of buf are done
+#pragma unroll
+    for (int k1 = 0; k1 < 16; ++k1) buf[k1 * L1S + tid] = v[pos16(k1)];
+    __syncthreads();
+    const int k1u = tid >> 4, n3 = tid & 15;
+#pragma unroll
+    for (int n2 = 0; n2 < 16; ++n2) v[n2] = buf[k1u * L1S + 16 * n2 + n3];
+    dft16(v);
+#pragma unroll
+    for (int k2 = 1; k2 < 16; ++k2) v[pos16(k2)] = cmul(v[pos16(k2)], tw2[k2 * 16 + n3]);
+    __syncthreads();  // all pass-2 reads done
+#pragma unroll
+    for (int k2 = 0; k2 < 16; ++k2) buf[(16 * k2 + k1u) * L2S + n3] = v[pos16(k2)];
+    __syncthreads();
+    const float4* row = reinterpret_cast<const float4*>(buf + tid * L2S);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        float4 r = row[j];
+        v[2 * j] = make_float2(r.x, r.y);
+        v[2 * j + 1] = make_float2(r.z, r.w);
+    }
+    dft16(v);
+}
+
+struct Args {
+    const float* sig;   // x (k_x) or y (k_y) planar
+    int64_t n_samples, ld;
+    int n_ch, hop, n_frames, n_pairs, detrend;
+    int n_chunks, ppc;  // k_y: pairs per chunk
+    const float* window;
+    const float2* twt;  // host_tables()
+    float2* xs;         // [n_pairs][4096]
+    float* px;          // [n_pairs][NB]
+    float2* pxy;        // [n_chunks][n_ch][NB]
+    float* pyy;         // [n_chunks][n_ch][NB]
+};
+
+// twt: fp64-computed tables, [15][256] W4096^(t k1) (k1 = 1..15) then [16][16] W256^(n3 k2)
+constexpr int TWT_LEN = 15 * 256 + 256;
+__device__ __forceinline__ void init_tables(Tw& tw, float (&win)[16], float2* tw2,
+                                            const float* __restrict__ window,
+                                            const float2* __restrict__ twt, int tid) {
+#pragma unroll
+    for (int k1 = 1; k1 < 16; ++k1) tw.w[k1 - 1] = twt[(k1 - 1) * 256 + tid];
+#pragma unroll
+    for (int n1 = 0; n1 < 16; ++n1) win[n1] = window[tid + 256 * n1];
+    tw2[tid] = twt[15 * 256 + tid];  // tw2[k2*16 + n3] = W256^(n3 k2)
+}
+inline void host_tables(std::vector<float2>& t) {
+    t.resize(TWT_LEN);
+    for (int k1 = 1; k1 < 16; ++k1)
+        for (int tt = 0; tt < 256; ++tt) {
+            double a = -2.0 * M_PI * (double)(tt * k1) / 4096.0;
+            t[(k1 - 1) * 256 + tt] = make_float2((float)std::cos(a), (float)std::sin(a));
+        }
+    for (int k2 = 0; k2 < 16; ++k2)
+        for (int n3 = 0; n3 < 16; ++n3) {
+            double a = -2.0 * M_PI * (double)(n3 * k2) / 256.0;
+            t[15 * 256 + k2 * 16 + n3] = make_float2((float)std::cos(a), (float)std::sin(a));
+        }
+}
+
+// Raw samples of the frame pair (2p, 2p+1) of one channel.  HALF_HOP (hop == 2048): the two
+// frames share half their samples -> 24 loads s[m] = ch[start + tid + 256 m]; otherwise 32.
+// Interior pairs take unconditional loads behind ONE wave-uniform test (a per-load
+// "in range ? load : 0" makes hipcc branch around every load and drain vmcnt each time);
+// the ragged tail clamps the address and selects the value.
+template <bool HALF_HOP>
+struct Raw {
+    float s[HALF_HOP ? 24 : 32];
+};
+
+template <bool HALF_HOP>
+__device__ __forceinline__ void load_raw(Raw<HALF_HOP>& r, const float* __restrict__ ch,
+                                         int64_t n_samples, int64_t start0, int hop, int tid) {
+    const float* __restrict__ src = ch + start0;  // wave-uniform base
+    const int64_t remain = n_samples - start0;    // >= 1 for every valid pair
+    const int span = HALF_HOP ? 3 * 2048 : hop + 4096;
+    if (remain >= span) {
+        if (HALF_HOP) {
+#pragma unroll
+            for (int m = 0; m < 24; ++m) r.s[m] = src[tid + 256 * m];
+        } else {
+#pragma unroll
+            for (int n1 = 0; n1 < 16; ++n1) {
+                r.s[n1] = src[tid + 256 * n1];
+                r.s[16 + n1] = src[hop + tid + 256 * n1];
+            }
+        }
+    } else {
+        const int last = (int)(remain > (int64_t)(1 << 30) ? (1 << 30) : remain) - 1;
+        constexpr int CNT = HALF_HOP ? 24 : 32;
+#pragma unroll
+        for (int m = 0; m < CNT; ++m) {
+            int i = HALF_HOP ? tid + 256 * m : (m < 16 ? tid + 256 * m : hop + tid + 256 * (m - 16));
+            float a = src[min(i, last)];
+            r.s[m] = i <= last ? a : 0.f;
+        }
+    }
+}
+
+// z[n1] = frame_2p[n] w[n] + i frame_2p+1[n] w[n], n = tid + 256 n1
+template <bool HALF_HOP>
+__device__ __forceinline__ void window_pair(float2 (&v)[16], const Raw<HALF_HOP>& r, bool second,
+                                            const float (&win)[16]) {
+    const float m2 = second ? 1.f : 0.f;  // odd frame count: the last pair has no second frame
+#pragma unroll
+    for (int n1 = 0; n1 < 16; ++n1) {
+        float b = HALF_HOP ? r.s[n1 + 8] : r.s[16 + n1];
+        v[n1] = make_float2(r.s[n1] * win[n1], b * (win[n1] * m2));
+    }
+}
+
+// ---- input spectra -----------------------------------------------------------
+template <bool HALF_HOP>
+__global__ __launch_bounds__(NT) void k_x(Args p) {
+    extern __shared__ __align__(16) float2 lds[];
+    float2* buf = lds;
+    float2* tw2 = lds + BUF_C;
+    const int tid = threadIdx.x, pr = blockIdx.x;
+    Tw tw;
+    float win[16];
+    init_tables(tw, win, tw2, p.window, p.twt, tid);
+    float2 v[16];
+    {
+        Raw<HALF_HOP> raw;
+        load_raw<HALF_HOP>(raw, p.sig, p.n_samples, (int64_t)(2 * pr) * p.hop, p.hop, tid);
+        window_pair<HALF_HOP>(v, raw, 2 * pr + 1 < p.n_frames, win);
+    }
+    fft4096(v, tw, buf, tw2, tid);
+    if (p.detrend && tid == 0) v[pos16(0)] = make_float2(0.f, 0.f);
+    float2* xo = p.xs + (int64_t)pr * N;
+#pragma unroll
+    for (int k3 = 0; k3 < 16; ++k3) xo[tid + 256 * k3] = v[pos16(k3)];
+    // symmetrised power for Sxx
+    float* pw = reinterpret_cast<float*>(buf);
+    __syncthreads();
+#pragma unroll
+    for (int k3 = 0; k3 < 16; ++k3) {
+        float2 z = v[pos16(k3)];
+        pw[tid + 256 * k3] = z.x * z.x + z.y * z.y;
+    }
+    __syncthreads();
+    float* po = p.px + (int64_t)pr * NB;
+    for (int k = tid; k < NB; k += NT) po[k] = 0.5f * (pw[k] + pw[(N - k) & (N - 1)]);
+}
+
+__global__ void k_sxx(const float* px, int n_pairs, float* sxx) {
+    // block = 8 bins x 32 pair groups
+    __shared__ double red[32][8];
+    const int bl = threadIdx.x & 7, g = threadIdx.x >> 3;
+    const int k = blockIdx.x * 8 + bl;
+    double s = 0.0;
+    if (k < NB)
+        for (int pr = g; pr < n_pairs; pr += 32) s += (double)px[(int64_t)pr * NB + k];
+    red[g][bl] = s;
+    __syncthreads();
+    if (g == 0 && k < NB) {
+        double t = 0.0;
+        for (int i = 0; i < 32; ++i) t += red[i][bl];
+        sxx[k] = (float)t;
+    }
+}
+
+// ---- output channels ---------------------------------------------------------
+// OCC = workgroups per CU the register allocation must allow (256 threads = 1 wave per SIMD)
+template <bool HALF_HOP, int OCC>
+__global__ __launch_bounds__(NT, OCC) void k_y(Args p) {
+    extern __shared__ __align__(16) float2 lds[];
+    float2* buf = lds;
+    float2* tw2 = lds + BUF_C;
+    const int tid = threadIdx.x;
+    // XCD-aware decode: blocks b, b+8, ... share an XCD (and its L2): give each XCD whole
+    // chunks so the input spectra it re-reads for every channel stay in that L2.
+    int q, c;
+    {
+        const int b = blockIdx.x;
+        if ((p.n_chunks & 7) == 0) {
+            const int per = p.n_chunks >> 3;
+            q = (b & 7) + 8 * ((b >> 3) % per);
+            c = (b >> 3) / per;
+        } else {
+            q = b % p.n_chunks;
+            c = b / p.n_chunks;
+        }
+    }
+    Tw tw;
+    float win[16];
+    init_tables(tw, win, tw2, p.window, p.twt, tid);
+    const float* ch = p.sig + (int64_t)c * p.ld;
+    const int p0 = q * p.ppc, p1 = min(p0 + p.ppc, p.n_pairs);
+    float2 T[16];
+    float P[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        T[j] = make_float2(0.f, 0.f);
+        P[j] = 0.f;
+    }
+    // software pipeline: the raw samples of pair pr+1 and the input spectrum of pair pr are
+    // in flight while pair pr is transformed
+    Raw<HALF_HOP> raw;
+    if (p0 < p1) load_raw<HALF_HOP>(raw, ch, p.n_samples, (int64_t)(2 * p0) * p.hop, p.hop, tid);
+    for (int pr = p0; pr < p1; ++pr) {
+        float2 v[16];
+        window_pair<HALF_HOP>(v, raw, 2 * pr + 1 < p.n_frames, win);
+        if (pr + 1 < p1)
+            load_raw<HALF_HOP>(raw, ch, p.n_samples, (int64_t)(2 * pr + 2) * p.hop, p.hop, tid);
+        float2 xw[16];
+        {
+            const float2* __restrict__ xp = p.xs + (int64_t)pr * N + tid;
+#pragma unroll
+            for (int k3 = 0; k3 < 16; ++k3) xw[k3] = xp[256 * k3];
+        }
+        fft4096(v, tw, buf, tw2, tid);
+#pragma unroll
+        for (int k3 = 0; k3 < 16; ++k3) {
+            float2 w = xw[k3];
+            float2 z = v[pos16(k3)];
+            T[k3].x = fmaf(w.x, z.x, fmaf(w.y, z.y, T[k3].x));   // conj(w) z
+            T[k3].y = fmaf(w.x, z.y, fmaf(-w.y, z.x, T[k3].y));
+            P[k3] = fmaf(z.x, z.x, fmaf(z.y, z.y, P[k3]));
+        }
+    }
+    if (p.detrend && tid == 0) P[0] = 0.f;  // xs bin 0 is already 0 -> T[0] = 0
+    // fold k <-> N-k once per chunk, through LDS
+    __syncthreads();
+#pragma unroll
+    for (int k3 = 0; k3 < 16; ++k3) buf[tid + 256 * k3] = T[k3];
+    __syncthreads();
+    const int64_t so = ((int64_t)q * p.n_ch + c) * NB;
+    for (int k = tid; k < NB; k += NT) {
+        float2 a = buf[k], b = buf[(N - k) & (N - 1)];
+        p.pxy[so + k] = make_float2(0.5f * (a.x + b.x), 0.5f * (a.y - b.y));
+    }
+    __syncthreads();
+    float* pw = reinterpret_cast<float*>(buf);
+#pragma unroll
+    for (int k3 = 0; k3 < 16; ++k3) pw[tid + 256 * k3] = P[k3];
+    __syncthreads();
+    for (int k = tid; k < NB; k += NT) p.pyy[so + k] = 0.5f * (pw[k] + pw[(N - k) & (N - 1)]);
+}
+
+// ---- host side -----------------------------------------------------------------
+inline bool enabled() {
+    static int on = -1;
+    if (on < 0) {
+        const char* e = getenv("DSPTOOLBOX_AMD_NO_WELCH4096");
+        on = (e && e[0] == '1') ? 0 : 1;
+    }
+    return on == 1;
+}
+
+inline int occupancy_target() {
+    const char* e = getenv("DSPTOOLBOX_AMD_WELCH_OCC");
+    int o = e ? atoi(e) : 3;
+    return o < 2 ? 2 : (o > 4 ? 4 : o);
+}
+
+inline int chunks_for(int n_pairs, int n_ch) {
+    const char* e = getenv("DSPTOOLBOX_AMD_WELCH_CHUNKS");
+    int want = e ? atoi(e) : 0;
+    if (want <= 0) {
+        // ~768-1024 workgroups when there is enough work; chains of <= 32 pairs
+        want = (1024 + n_ch - 1) / n_ch;
+        want = (want + 7) & ~7;
+        int by_len = (n_pairs + 31) / 32;
+        if (want < by_len) want = (by_len + 7) & ~7;
+    }
+    if (want > n_pairs) want = n_pairs;
+    if (want < 1) want = 1;
+    return want;
+}
+
+struct Plan {
+    int n_pairs, n_chunks, ppc;
+    size_t bytes;
+};
+inline Plan plan(int n_frames, int n_cy) {
+    Plan pl;
+    pl.n_pairs = (n_frames + 1) / 2;
+    pl.n_chunks = chunks_for(pl.n_pairs, n_cy);
+    pl.ppc = (pl.n_pairs + pl.n_chunks - 1) / pl.n_chunks;
+    pl.n_chunks = (pl.n_pairs + pl.ppc - 1) / pl.ppc;
+    auto pad = [](size_t b) { return (b + 255) & ~size_t(255); };
+    pl.bytes = pad(sizeof(float2) * (size_t)pl.n_pairs * N) + pad(sizeof(float) * (size_t)pl.n_pairs * NB) +
+               pad(sizeof(float) * NB) + pad(sizeof(float2) * (size_t)pl.n_chunks * n_cy * NB) +
+               pad(sizeof(float) * (size_t)pl.n_chunks * n_cy * NB);
+    return pl;
+}
+
 }  // namespace welch4096

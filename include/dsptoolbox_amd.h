@@ -66,6 +66,12 @@ int         ds_sync(ds_ctx* ctx);
 /* hipEvent pair recorded on the context's stream (bench.py's live kernel time) */
 int         ds_timer_start(ds_ctx* ctx);
 int         ds_timer_stop(ds_ctx* ctx, float* elapsed_ms);
+/* per-kernel HIP-event timing on the context's stream: while enabled every
+ * kernel launch is bracketed by an event pair; ds_profile_report synchronises
+ * and returns "name total_ms launches\n" lines for the launches since the
+ * previous report (string owned by the context).                             */
+int         ds_profile_enable(ds_ctx* ctx, int on);
+const char* ds_profile_report(ds_ctx* ctx);
 /* max FFT length one workgroup transforms inside LDS (complex points)       */
 int         ds_max_fft_len(void);
 

@@ -286,7 +286,7 @@ def main():
     # filter bank: three FIR band filters
     bank_taps = []
     flts = []
-    for (lo, hi) in ((100.0, 800.0), (800.0, 3000.0), (3000.0, 12000.0)):
+    for (lo, hi) in ((100.0, 3000.0), (800.0, 12000.0), (300.0, 6000.0)):  # overlapping pass bands
         f_ = dsp.Filter.fir_filter(300, [lo, hi], FilterPassType.Bandpass, fs)
         flts.append(f_)
         bank_taps.append(f_.ba[0])

@@ -21,6 +21,13 @@ WIN = {"hann": Window.Hann, "hamming": Window.Hamming, "blackman": Window.Blackm
        "boxcar": Window.Boxcar}
 
 
+def inband(w, fs=48000, lo=30.0, hi=19000.0):
+    """Bins where the 20 Hz - 20 kHz sweep input has energy.  Outside, H = Gxy/Gxx is
+    noise divided by leakage: ill-conditioned in the float64 reference itself."""
+    f = np.fft.rfftfreq(w, 1 / fs)
+    return (f >= lo) & (f <= hi)
+
+
 def relmax(a, b, skip_dc=False):
     a, b = np.asarray(a), np.asarray(b)
     assert a.shape == b.shape, (a.shape, b.shape)
@@ -76,6 +83,8 @@ def test_transfer_function_golden():
         e1 = relmax(sp.spectral_data, z[f"tf_{i}"], c["detrend"])
         e2 = relmax(sp.coherence, z[f"coh_{i}"], c["detrend"])
         worst = max(worst, e1, e2)
+        if max(e1, e2) > 4e-7:
+            print("  tf case", c, e1, e2)
         assert e1 < TOL and e2 < TOL, (c, e1, e2)
         assert np.array_equal(sp.frequency_vector_hz, z[f"f_{i}"])
     print("tf worst rel-max", worst)
@@ -208,15 +217,19 @@ def test_welch_too_long_window_raises():
 
 
 def test_headline_shape_reduced_vs_oracle():
-    """config 2 at reduced channel count / length: 1-channel sweep input, H1, nfft 4096."""
+    """config 2 at reduced channel count / length: 1-channel sweep input, H1, nfft 4096.
+    128 frames: a sweep puts each frame's energy into a few bins, so the fp32 FFT error
+    floor (1e-7 of the frame peak) is what every other bin sees; it averages down with the
+    frame count (coherence error 1.0e-6 at 32 frames, 2.9e-7 at the full 512)."""
     from dsptoolbox_amd.generators import sweep_and_responses
-    x, y = sweep_and_responses(n_samples=2**16, n_channels=6, fs_hz=48000)
+    x, y = sweep_and_responses(n_samples=2**18, n_channels=6, fs_hz=48000)
     for mode in ("H1", "H2", "H3"):
         for det in (True, False):
             tf, coh = backend.welch_transfer_function(y, x, 48000, 4096, mode, detrend=det)
             rt, rc = orc.compute_transfer_function(y, x, 48000, 4096, mode, detrend=det)
-            assert relmax(tf, rt, det) < TOL, (mode, det, relmax(tf, rt, det))
-            assert relmax(coh, rc, det) < TOL, (mode, det, relmax(coh, rc, det))
+            m = inband(4096)
+            assert relmax(tf[m], rt[m]) < TOL, (mode, det, relmax(tf[m], rt[m]))
+            assert relmax(coh[m], rc[m]) < TOL, (mode, det, relmax(coh[m], rc[m]))
 
 
 def test_headline_full_size_properties():
@@ -228,15 +241,16 @@ def test_headline_full_size_properties():
     tf, coh = backend.welch_transfer_function(y, x, 48000, 4096, "H1", **kw)
     assert tf.shape == (2049, 64) and coh.shape == (2049, 64)
     assert np.all(np.isfinite(tf)) and np.all(coh <= 1 + 1e-5) and np.all(coh >= 0)
+    m = inband(4096)
     perm = np.random.default_rng(0).permutation(64)
     tf2, coh2 = backend.welch_transfer_function(3.0 * y[:, perm], x, 48000, 4096, "H1", **kw)
-    assert relmax(tf2, 3.0 * tf[:, perm]) < TOL
-    assert relmax(coh2, coh[:, perm]) < TOL
+    assert relmax(tf2[m], 3.0 * tf[m][:, perm]) < TOL
+    assert relmax(coh2[m], coh[m][:, perm]) < TOL
     # a subset of channels against the oracle (oracle cost: seconds)
     rt, rc = orc.compute_transfer_function_batched(y[:, :3], x, 48000, 4096, "H1",
                                                    scaling="PowerSpectralDensity", detrend=False)
-    assert relmax(tf[:, :3], rt) < TOL
-    assert relmax(coh[:, :3], rc) < TOL
+    assert relmax(tf[m, :3], rt[m]) < TOL
+    assert relmax(coh[m, :3], rc[m]) < TOL
 
 
 def test_csm_64ch_vs_oracle():
@@ -301,3 +315,27 @@ def test_edge_cases():
     assert relmax(s, rs) < TOL
     with pytest.raises(AssertionError):
         dsp.Signal(None, x5, 48000.0)
+
+
+@pytest.mark.parametrize("overlap,n,n_cy", [(50, 70000, 3), (75, 50000, 5), (0, 36000, 1),
+                                            (50, 4096 * 10 + 17, 2), (33, 30000, 2)])
+def test_welch4096_fast_path_vs_oracle(overlap, n, n_cy):
+    """nfft 4096 + one input channel takes the register-FFT path (frame pairs as
+    real/imaginary part); broadband noise so every bin is well conditioned; odd
+    frame counts, ragged tails and non-50 % hops included."""
+    import warnings
+    rng = np.random.default_rng(n)
+    x = rng.standard_normal((n, 1)) * 0.3
+    h = rng.standard_normal((n_cy, 40)) * np.exp(-np.arange(40) / 8.0)
+    y = np.stack([np.convolve(x[:, 0], h[c])[:n] for c in range(n_cy)], axis=1)
+    y += 0.05 * rng.standard_normal(y.shape)
+    for mode in ("H1", "H2", "H3"):
+        for det, sc in ((True, SpectrumScaling.FFTBackward), (False, SpectrumScaling.PowerSpectralDensity)):
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                tf, coh = backend.welch_transfer_function(y, x, 48000, 4096, mode, detrend=det,
+                                                          overlap_percent=overlap, scaling=sc)
+                rt, rc = orc.compute_transfer_function(y, x, 48000, 4096, mode, detrend=det,
+                                                       overlap_percent=overlap, scaling=sc.name)
+            e1, e2 = relmax(tf, rt, det), relmax(coh, rc, det)
+            assert e1 < TOL and e2 < TOL, (mode, det, e1, e2)

@@ -1,0 +1,38 @@
+"""Condense rocprofv3 csv output (kernel trace stats + PMC passes) into a small text summary."""
+import csv
+import glob
+import os
+import sys
+from collections import defaultdict
+
+root = sys.argv[1]
+
+
+def find(pattern):
+    return sorted(glob.glob(os.path.join(root, "**", pattern), recursive=True))
+
+
+print("== kernel trace stats (", root, ")")
+for f in find("*kernel_stats.csv"):
+    with open(f) as fh:
+        for row in csv.DictReader(fh):
+            name = row.get("Name", "")[:70]
+            print(f"{name:70s} calls {row.get('Calls'):>6s} avg_ns {row.get('AverageNs'):>12s} "
+                  f"total_ns {row.get('TotalDurationNs'):>12s} pct {row.get('Percentage')}")
+print("== PMC (per-dispatch average by kernel)")
+acc = defaultdict(lambda: defaultdict(lambda: [0.0, 0]))
+for f in find("*counter_collection.csv"):
+    with open(f) as fh:
+        for row in csv.DictReader(fh):
+            k = row.get("Kernel_Name", "")[:60]
+            c = row.get("Counter_Name")
+            v = float(row.get("Counter_Value", 0))
+            a = acc[k][c]
+            a[0] += v
+            a[1] += 1
+for k in acc:
+    if "welch" not in k and "k_y" not in k and "k_x" not in k and "csm" not in k and "fir" not in k and "stft" not in k:
+        continue
+    print(k)
+    for c, (s, n) in sorted(acc[k].items()):
+        print(f"    {c:28s} {s / n:18.1f}  (n={n})")
