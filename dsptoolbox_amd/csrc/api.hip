@@ -430,7 +430,8 @@ static int welch4096_run(ds_ctx* c, const float* x, int64_t ldx, const float* y,
     {
         dim3 grid(pl.n_chunks * n_cy);
         const int occ = w4::occupancy_target();
-#define W4_LAUNCH(H, O) CHK(launch(c, "welch4096_main", w4::k_y<H, O>, grid, w4::NT, w4::LDS_BYTES, ay))
+#define W4_LAUNCH(H, O) \
+    CHK(launch(c, "welch4096_main", w4::k_y<H, O>, grid, w4::NT, (O) <= 2 ? w4::LDS_BYTES_2 : w4::LDS_BYTES, ay))
         if (half) {
             if (occ == 2) W4_LAUNCH(true, 2); else if (occ == 3) W4_LAUNCH(true, 3); else W4_LAUNCH(true, 4);
         } else {

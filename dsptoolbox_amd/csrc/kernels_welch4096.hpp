@@ -42,7 +42,8 @@ namespace welch4096 {
 constexpr int N = 4096, NT = 256, NB = N / 2 + 1;
 constexpr int L1S = 272, L2S = 18;
 constexpr int BUF_C = 256 * L2S;  // 4608 complex >= 16 * 272
-constexpr int LDS_BYTES = BUF_C * 8 + 256 * 8;
+constexpr int LDS_BYTES = BUF_C * 8 + 256 * 8;        // one exchange buffer + W256 table
+constexpr int LDS_BYTES_2 = 2 * BUF_C * 8 + 256 * 8;  // two exchange buffers: 2 barriers per FFT
 
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) {
     return make_float2(fmaf(a.x, b.x, -a.y * b.y), fmaf(a.x, b.y, a.y * b.x));
@@ -89,12 +90,16 @@ struct Tw {
 // Transform the 16 register values (pass-1 inputs z[t + 256 n1]) into Z[t + 256 k3] (in
 // v[pos16(k3)]).  `buf` is the workgroup's LDS exchange buffer, `tw2` the W256 table.
 // The caller guarantees nobody still reads buf (one barrier before the first write here).
+// TWO_BUF: pass-1 and pass-2 images live in different buffers (bufA, bufB); then the only
+// hazards are write-after-read across iterations, which the two barriers already order.
+template <bool TWO_BUF>
 __device__ __forceinline__ void fft4096(float2 (&v)[16], const Tw& tw, float2* __restrict__ buf,
                                         const float2* __restrict__ tw2, int tid) {
+    float2* __restrict__ bufB = TWO_BUF ? buf + BUF_C : buf;
     dft16(v);
 #pragma unroll
     for (int k1 = 1; k1 < 16; ++k1) v[pos16(k1)] = cmul(v[pos16(k1)], tw.w[k1 - 1]);
-    __syncthreads();  // previous readers of buf are done
+    if (!TWO_BUF) __syncthreads();  // previous readers of buf are done
 #pragma unroll
     for (int k1 = 0; k1 < 16; ++k1) buf[k1 * L1S + tid] = v[pos16(k1)];
     __syncthreads();
@@ -104,11 +109,11 @@ __device__ __forceinline__ void fft4096(float2 (&v)[16], const Tw& tw, float2* _
     dft16(v);
 #pragma unroll
     for (int k2 = 1; k2 < 16; ++k2) v[pos16(k2)] = cmul(v[pos16(k2)], tw2[k2 * 16 + n3]);
-    __syncthreads();  // all pass-2 reads done
+    if (!TWO_BUF) __syncthreads();  // all pass-2 reads done
 #pragma unroll
-    for (int k2 = 0; k2 < 16; ++k2) buf[(16 * k2 + k1u) * L2S + n3] = v[pos16(k2)];
+    for (int k2 = 0; k2 < 16; ++k2) bufB[(16 * k2 + k1u) * L2S + n3] = v[pos16(k2)];
     __syncthreads();
-    const float4* row = reinterpret_cast<const float4*>(buf + tid * L2S);
+    const float4* row = reinterpret_cast<const float4*>(bufB + tid * L2S);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         float4 r = row[j];
@@ -223,7 +228,7 @@ __global__ __launch_bounds__(NT) void k_x(Args p) {
         load_raw<HALF_HOP>(raw, p.sig, p.n_samples, (int64_t)(2 * pr) * p.hop, p.hop, tid);
         window_pair<HALF_HOP>(v, raw, 2 * pr + 1 < p.n_frames, win);
     }
-    fft4096(v, tw, buf, tw2, tid);
+    fft4096<false>(v, tw, buf, tw2, tid);
     if (p.detrend && tid == 0) v[pos16(0)] = make_float2(0.f, 0.f);
     float2* xo = p.xs + (int64_t)pr * N;
 #pragma unroll
@@ -262,9 +267,10 @@ __global__ void k_sxx(const float* px, int n_pairs, float* sxx) {
 // OCC = workgroups per CU the register allocation must allow (256 threads = 1 wave per SIMD)
 template <bool HALF_HOP, int OCC>
 __global__ __launch_bounds__(NT, OCC) void k_y(Args p) {
+    constexpr bool TWO_BUF = OCC <= 2;  // 2 x 36 KB fit twice per CU
     extern __shared__ __align__(16) float2 lds[];
     float2* buf = lds;
-    float2* tw2 = lds + BUF_C;
+    float2* tw2 = lds + (TWO_BUF ? 2 : 1) * BUF_C;
     const int tid = threadIdx.x;
     // XCD-aware decode: blocks b, b+8, ... share an XCD (and its L2): give each XCD whole
     // chunks so the input spectra it re-reads for every channel stay in that L2.
@@ -307,7 +313,7 @@ __global__ __launch_bounds__(NT, OCC) void k_y(Args p) {
 #pragma unroll
             for (int k3 = 0; k3 < 16; ++k3) xw[k3] = xp[256 * k3];
         }
-        fft4096(v, tw, buf, tw2, tid);
+        fft4096<TWO_BUF>(v, tw, buf, tw2, tid);
 #pragma unroll
         for (int k3 = 0; k3 < 16; ++k3) {
             float2 w = xw[k3];
@@ -348,7 +354,7 @@ inline bool enabled() {
 
 inline int occupancy_target() {
     const char* e = getenv("DSPTOOLBOX_AMD_WELCH_OCC");
-    int o = e ? atoi(e) : 3;
+    int o = e ? atoi(e) : 2;
     return o < 2 ? 2 : (o > 4 ? 4 : o);
 }
 

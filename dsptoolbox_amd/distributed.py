@@ -1,0 +1,124 @@
+"""Multi-GPU layer: one process per GPU, independent units sharded across ranks.
+
+The hot path has no exchange step: output channels
+(Welch / H1, FIR), items (deconvolution batch) or frequency bins are independent,
+so every rank runs the single-GPU path on its contiguous shard.  The only
+collective is a broadcast of the shared input (sweep channel, FIR taps, inverse
+spectrum) -- RCCL over xGMI through the library's ds_bcast on device buffers, or
+torch.distributed (gloo) for host arrays -- plus an optional gather of the
+small results to every rank.  torch.distributed is plumbing only (rendezvous,
+barrier, host-side gather); it never touches the signal data path on the GPU.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+
+def shard_range(n_units: int, world_size: int, rank: int) -> tuple[int, int]:
+    """Contiguous balanced split of n_units: the first (n_units % world) ranks get one
+    more.  Empty shards are allowed (start == stop)."""
+    assert world_size >= 1 and 0 <= rank < world_size
+    base, extra = divmod(n_units, world_size)
+    start = rank * base + min(rank, extra)
+    return start, start + base + (1 if rank < extra else 0)
+
+
+def _dist():
+    import torch.distributed as dist
+    return dist
+
+
+def world() -> tuple[int, int]:
+    """(rank, world_size) from torch.distributed if initialised, else the launcher's env."""
+    try:
+        dist = _dist()
+        if dist.is_available() and dist.is_initialized():
+            return dist.get_rank(), dist.get_world_size()
+    except Exception:
+        pass
+    return int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+
+
+def broadcast_array(arr: np.ndarray | None, src: int = 0) -> np.ndarray:
+    """Host-array broadcast through torch.distributed (gloo or nccl)."""
+    import torch
+    dist = _dist()
+    rank, ws = world()
+    if ws == 1:
+        return arr
+    meta = [None]
+    if rank == src:
+        meta = [(arr.shape, str(arr.dtype))]
+    dist.broadcast_object_list(meta, src=src)
+    shape, dtype = meta[0]
+    t = torch.from_numpy(np.ascontiguousarray(arr)) if rank == src else torch.empty(shape, dtype=getattr(torch, str(np.dtype(dtype))))
+    if dist.get_backend() == "nccl":
+        t = t.cuda()
+    dist.broadcast(t, src=src)
+    return t.cpu().numpy()
+
+
+def gather_channel_shards(local: np.ndarray, n_total: int, axis: int = -1) -> np.ndarray:
+    """All-gather per-rank result slices (split by shard_range along `axis`) into the full
+    array on every rank."""
+    rank, ws = world()
+    if ws == 1:
+        return local
+    dist = _dist()
+    parts = [None] * ws
+    dist.all_gather_object(parts, np.ascontiguousarray(local))
+    out = np.concatenate([p for p in parts if p.shape[axis] > 0], axis=axis)
+    assert out.shape[axis] == n_total, (out.shape, n_total)
+    return out
+
+
+def welch_transfer_function_sharded(output_td, input_td, fs_hz: int, window_length_samples: int,
+                                    mode: str, compute=None, gather: bool = True, **params):
+    """compute_transfer_function with the output channels sharded across ranks.
+    `compute(output_shard, input, fs, W, mode, **params) -> (tf, coh)` defaults to the
+    HIP path; a one-channel input is used by every rank (broadcast it first if only rank 0
+    holds it), a per-channel input is sharded together with the output."""
+    if compute is None:
+        from . import backend
+        compute = backend.welch_transfer_function
+    rank, ws = world()
+    n_cy = output_td.shape[1]
+    a, b = shard_range(n_cy, ws, rank)
+    x = input_td if input_td.shape[1] == 1 else input_td[:, a:b]
+    nb = window_length_samples // 2 + 1
+    if b > a:
+        tf, coh = compute(output_td[:, a:b], x, fs_hz, window_length_samples, mode, **params)
+    else:
+        tf, coh = np.zeros((nb, 0), dtype=np.complex128), np.zeros((nb, 0))
+    if not gather:
+        return tf, coh
+    return gather_channel_shards(tf, n_cy, 1), gather_channel_shards(coh, n_cy, 1)
+
+
+def init_library_comm(ctx, exchange=None) -> bool:
+    """Create the library's RCCL communicator (ds_comm_*): rank 0 makes the 128-byte id,
+    `exchange(bytes) -> bytes` hands it to every rank (default: torch.distributed
+    broadcast_object_list).  Returns False for a single-rank world."""
+    rank, ws = world()
+    if ws == 1:
+        return False
+    ident = C.create_string_buffer(128)
+    if rank == 0:
+        ctx.check(ctx.lib.ds_comm_unique_id(ident), "ds_comm_unique_id")
+    if exchange is None:
+        box = [ident.raw if rank == 0 else None]
+        _dist().broadcast_object_list(box, src=0)
+        raw = box[0]
+    else:
+        raw = exchange(ident.raw)
+    ctx.check(ctx.lib.ds_comm_init(ctx.handle, ws, rank, raw), "ds_comm_init")
+    return True
+
+
+def broadcast_device(ctx, dptr: int, nbytes: int, root: int = 0):
+    """RCCL broadcast of a device buffer on the context's stream (xGMI)."""
+    ctx.check(ctx.lib.ds_bcast(ctx.handle, C.c_void_p(dptr), nbytes, root), "ds_bcast")

@@ -1,0 +1,89 @@
+"""world_size-2 gloo tests (CPU): the sharding / broadcast / gather logic of the N > 1
+path.  The per-shard compute is injected (the oracle stands in for the device call, which
+needs a GPU); equality with the unsharded result proves the decomposition is exact."""
+
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    from dsptoolbox_amd import distributed as dd
+    from oracle import dsp_oracle as orc
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        rng = np.random.default_rng(42)
+        n, n_cy = 6000, 5  # 5 channels over 2 ranks: 3 + 2
+        x = rng.standard_normal((n, 1)) * 0.3
+        y = np.stack([np.convolve(x[:, 0], rng.standard_normal(8))[:n] for _ in range(n_cy)], axis=1)
+        y += 0.01 * rng.standard_normal(y.shape)
+        # only rank 0 "owns" the sweep: broadcast it
+        xb = dd.broadcast_array(x if rank == 0 else None, src=0)
+        assert np.array_equal(xb, x)
+
+        def compute(ys, xs, fs, W, mode, **kw):
+            return orc.compute_transfer_function(ys, xs, fs, W, mode, **kw)
+
+        tf, coh = dd.welch_transfer_function_sharded(y, xb, 48000, 256, "H1", compute=compute,
+                                                     detrend=True)
+        rt, rc = orc.compute_transfer_function(y, x, 48000, 256, "H1", detrend=True)
+        ok = (np.array_equal(tf[1:], rt[1:]) and np.array_equal(coh[1:], rc[1:])
+              and tf.shape == (129, n_cy))
+        # per-channel input is sharded with the output
+        x5 = np.repeat(x, n_cy, axis=1) * np.arange(1, n_cy + 1)
+        tf2, _ = dd.welch_transfer_function_sharded(y, x5, 48000, 256, "H2", compute=compute)
+        rt2, _ = orc.compute_transfer_function(y, x5, 48000, 256, "H2")
+        ok = ok and np.array_equal(tf2[1:], rt2[1:])
+        # more ranks than units: empty shards
+        tf3, _ = dd.welch_transfer_function_sharded(y[:, :1], xb, 48000, 256, "H1", compute=compute)
+        ok = ok and tf3.shape == (129, 1)
+        q.put((rank, bool(ok), dd.shard_range(n_cy, world, rank)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_shard_range_properties():
+    from dsptoolbox_amd.distributed import shard_range
+    for n in (0, 1, 7, 64, 1024, 1025):
+        for ws in (1, 2, 3, 8):
+            spans = [shard_range(n, ws, r) for r in range(ws)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(ws - 1))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
+    assert shard_range(64, 8, 3) == (24, 32) and shard_range(1024, 8, 7) == (896, 1024)
+
+
+@pytest.mark.timeout(120)
+def test_sharded_transfer_function_gloo_world2():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=100) for _ in procs]
+    for p in procs:
+        p.join(timeout=30)
+        assert p.exitcode == 0
+    assert sorted(r[0] for r in res) == [0, 1]
+    assert all(r[1] for r in res), res
+    assert {r[0]: r[2] for r in res} == {0: (0, 3), 1: (3, 5)}

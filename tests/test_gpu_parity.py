@@ -244,8 +244,9 @@ def test_headline_full_size_properties():
     m = inband(4096)
     perm = np.random.default_rng(0).permutation(64)
     tf2, coh2 = backend.welch_transfer_function(3.0 * y[:, perm], x, 48000, 4096, "H1", **kw)
-    assert relmax(tf2[m], 3.0 * tf[m][:, perm]) < TOL
-    assert relmax(coh2[m], coh[m][:, perm]) < TOL
+    # two fp32 runs on differently rounded inputs: each within TOL of the float64 truth
+    assert relmax(tf2[m], 3.0 * tf[m][:, perm]) < 2 * TOL
+    assert relmax(coh2[m], coh[m][:, perm]) < 2 * TOL
     # a subset of channels against the oracle (oracle cost: seconds)
     rt, rc = orc.compute_transfer_function_batched(y[:, :3], x, 48000, 4096, "H1",
                                                    scaling="PowerSpectralDensity", detrend=False)
