@@ -63,11 +63,13 @@ class Dist:
             self.torch = torch
         except Exception:  # pragma: no cover
             pass
+        self.backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")  # gloo: rehearsal on one GPU
         if self.world > 1:
             import torch.distributed as dist
-            self.torch.cuda.set_device(self.local_rank)
+            if self.backend == "nccl":
+                self.torch.cuda.set_device(self.local_rank)
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            dist.init_process_group(backend="nccl")
+            dist.init_process_group(backend=self.backend)
             self.dist = dist
         assert self.world == n_gpus or self.world == 1, (self.world, n_gpus)
 
@@ -81,30 +83,44 @@ class Dist:
     def max_over_ranks(self, v: float) -> float:
         if self.world == 1:
             return v
-        t = self.torch.tensor([v], dtype=self.torch.float64, device="cuda")
+        t = self.torch.tensor([v], dtype=self.torch.float64,
+                              device="cuda" if self.backend == "nccl" else "cpu")
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
         return float(t.item())
 
     def bcast_bytes(self, b: bytes, n: int) -> bytes:
         if self.world == 1:
             return b
-        t = self.torch.zeros(n, dtype=self.torch.uint8, device="cuda")
-        if self.rank == 0:
-            t.copy_(self.torch.frombuffer(bytearray(b), dtype=self.torch.uint8))
-        self.dist.broadcast(t, src=0)
-        return bytes(t.cpu().numpy().tobytes())
+        box = [b if self.rank == 0 else None]
+        self.dist.broadcast_object_list(box, src=0)
+        return box[0]
+
+    def all_ok(self, ok: bool) -> bool:
+        if self.world == 1:
+            return ok
+        t = self.torch.tensor([1.0 if ok else 0.0], dtype=self.torch.float64,
+                              device="cuda" if self.backend == "nccl" else "cpu")
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN)
+        return bool(t.item() > 0.5)
 
 
 def setup_rccl(ctx, dist: Dist):
-    """Library-level RCCL communicator (ds_comm_*) used for the sweep broadcast."""
+    """Library-level RCCL communicator (ds_comm_*) used for the sweep broadcast.  Returns
+    False (-> host broadcast + upload) for one rank, or if RCCL cannot be set up, e.g. a
+    gloo rehearsal with several ranks on one GPU."""
     if dist.world == 1:
         return False
+    if dist.backend != "nccl":
+        return False
     ident = C.create_string_buffer(128)
+    ok = True
     if dist.rank == 0:
-        ctx.check(ctx.lib.ds_comm_unique_id(ident), "ds_comm_unique_id")
+        ok = ctx.lib.ds_comm_unique_id(ident) == 0
     raw = dist.bcast_bytes(ident.raw, 128)
-    ctx.check(ctx.lib.ds_comm_init(ctx.handle, dist.world, dist.rank, raw), "ds_comm_init")
-    return True
+    if not dist.all_ok(ok):
+        return False
+    rc = ctx.lib.ds_comm_init(ctx.handle, dist.world, dist.rank, raw)
+    return dist.all_ok(rc == 0)
 
 
 # ---------------------------------------------------------------------------
@@ -137,6 +153,9 @@ def welch_h1(args, ctx, dist):
         ctx.sync()
         bcast_ms = (time.perf_counter() - t0) * 1e3
     else:
+        if dist.world > 1:  # no RCCL: broadcast on the host, then upload
+            from dsptoolbox_amd.distributed import broadcast_array
+            xp = broadcast_array(xp if dist.rank == 0 else None, src=0)
         ctx.upload(d_x.ptr, xp)
     B = W // 2 + 1
     d_tf = DeviceBuffer(ctx, B * n_cy * 8)
@@ -291,7 +310,7 @@ def main():
 
     build_library()
     dist = Dist(args.gpus)
-    ctx = Context(dist.local_rank)
+    ctx = Context(None)  # device = LOCAL_RANK (modulo the visible device count)
     maker = dict(welch_h1=welch_h1, fir_bank=fir_bank, csm=csm, deconv=deconv)[args.workload]
     step, units, alg, bound, info, cpu_baseline, bcast_ms, dominant = maker(args, ctx, dist)
 

@@ -411,8 +411,8 @@ static int welch4096_run(ds_ctx* c, const float* x, int64_t ldx, const float* y,
     float2* pxy = cv.take<float2>((size_t)pl.n_chunks * n_cy * w4::NB);
     float* pyy = cv.take<float>((size_t)pl.n_chunks * n_cy * w4::NB);
     const bool half = hop == 2048;
-    w4::Args ax{x, n_samples, ldx, 1, hop, n_frames, pl.n_pairs, detrend, pl.n_chunks, pl.ppc, window,
-                c->w4_tables, xs, px, pxy, pyy};
+    w4::Args ax{x, n_samples, ldx, 1, hop, n_frames, pl.n_pairs, detrend, pl.n_chunks, pl.ppc,
+                w4::stagger_units(), window, c->w4_tables, xs, px, pxy, pyy};
     if (half)
         CHK(launch(c, "welch4096_x", w4::k_x<true>, dim3(pl.n_pairs), w4::NT, w4::LDS_BYTES, ax));
     else

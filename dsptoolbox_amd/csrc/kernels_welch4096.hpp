@@ -39,6 +39,10 @@
 
 namespace welch4096 {
 
+#ifndef W4_ABLATE
+#define W4_ABLATE 0  // timing-only diagnostics (wrong results): 1 no xs loads, 2 no sample loads, 4 no LDS
+#endif
+
 constexpr int N = 4096, NT = 256, NB = N / 2 + 1;
 constexpr int L1S = 272, L2S = 18;
 constexpr int BUF_C = 256 * L2S;  // 4608 complex >= 16 * 272
@@ -99,26 +103,30 @@ __device__ __forceinline__ void fft4096(float2 (&v)[16], const Tw& tw, float2* _
     dft16(v);
 #pragma unroll
     for (int k1 = 1; k1 < 16; ++k1) v[pos16(k1)] = cmul(v[pos16(k1)], tw.w[k1 - 1]);
-    if (!TWO_BUF) __syncthreads();  // previous readers of buf are done
-#pragma unroll
-    for (int k1 = 0; k1 < 16; ++k1) buf[k1 * L1S + tid] = v[pos16(k1)];
-    __syncthreads();
     const int k1u = tid >> 4, n3 = tid & 15;
+    if (!(W4_ABLATE & 4)) {
+        if (!TWO_BUF) __syncthreads();  // previous readers of buf are done
 #pragma unroll
-    for (int n2 = 0; n2 < 16; ++n2) v[n2] = buf[k1u * L1S + 16 * n2 + n3];
+        for (int k1 = 0; k1 < 16; ++k1) buf[k1 * L1S + tid] = v[pos16(k1)];
+        __syncthreads();
+#pragma unroll
+        for (int n2 = 0; n2 < 16; ++n2) v[n2] = buf[k1u * L1S + 16 * n2 + n3];
+    }
     dft16(v);
 #pragma unroll
     for (int k2 = 1; k2 < 16; ++k2) v[pos16(k2)] = cmul(v[pos16(k2)], tw2[k2 * 16 + n3]);
-    if (!TWO_BUF) __syncthreads();  // all pass-2 reads done
+    if (!(W4_ABLATE & 4)) {
+        if (!TWO_BUF) __syncthreads();  // all pass-2 reads done
 #pragma unroll
-    for (int k2 = 0; k2 < 16; ++k2) bufB[(16 * k2 + k1u) * L2S + n3] = v[pos16(k2)];
-    __syncthreads();
-    const float4* row = reinterpret_cast<const float4*>(bufB + tid * L2S);
+        for (int k2 = 0; k2 < 16; ++k2) bufB[(16 * k2 + k1u) * L2S + n3] = v[pos16(k2)];
+        __syncthreads();
+        const float4* row = reinterpret_cast<const float4*>(bufB + tid * L2S);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        float4 r = row[j];
-        v[2 * j] = make_float2(r.x, r.y);
-        v[2 * j + 1] = make_float2(r.z, r.w);
+        for (int j = 0; j < 8; ++j) {
+            float4 r = row[j];
+            v[2 * j] = make_float2(r.x, r.y);
+            v[2 * j + 1] = make_float2(r.z, r.w);
+        }
     }
     dft16(v);
 }
@@ -128,6 +136,7 @@ struct Args {
     int64_t n_samples, ld;
     int n_ch, hop, n_frames, n_pairs, detrend;
     int n_chunks, ppc;  // k_y: pairs per chunk
+    int stagger;        // k_y: s_sleep units for the second half of the grid (de-lockstep co-resident WGs)
     const float* window;
     const float2* twt;  // host_tables()
     float2* xs;         // [n_pairs][4096]
@@ -289,6 +298,13 @@ __global__ __launch_bounds__(NT, OCC) void k_y(Args p) {
     Tw tw;
     float win[16];
     init_tables(tw, win, tw2, p.window, p.twt, tid);
+    // Two workgroups share a CU and run the same program: left alone they stay in lockstep
+    // (both in the butterflies, then both in the LDS exchange, then both waiting on loads)
+    // and VALU, LDS and the vector-memory pipe take turns instead of overlapping.  Delay
+    // the second half of the grid by about half an iteration.
+    if (p.stagger > 0 && (int)blockIdx.x >= (int)(gridDim.x >> 1)) {
+        for (int i = 0; i < p.stagger; ++i) __builtin_amdgcn_s_sleep(16);
+    }
     const float* ch = p.sig + (int64_t)c * p.ld;
     const int p0 = q * p.ppc, p1 = min(p0 + p.ppc, p.n_pairs);
     float2 T[16];
@@ -298,29 +314,55 @@ __global__ __launch_bounds__(NT, OCC) void k_y(Args p) {
         T[j] = make_float2(0.f, 0.f);
         P[j] = 0.f;
     }
-    // software pipeline: the raw samples of pair pr+1 and the input spectrum of pair pr are
-    // in flight while pair pr is transformed
-    Raw<HALF_HOP> raw;
-    if (p0 < p1) load_raw<HALF_HOP>(raw, ch, p.n_samples, (int64_t)(2 * p0) * p.hop, p.hop, tid);
-    for (int pr = p0; pr < p1; ++pr) {
-        float2 v[16];
-        window_pair<HALF_HOP>(v, raw, 2 * pr + 1 < p.n_frames, win);
-        if (pr + 1 < p1)
-            load_raw<HALF_HOP>(raw, ch, p.n_samples, (int64_t)(2 * pr + 2) * p.hop, p.hop, tid);
-        float2 xw[16];
-        {
+    if constexpr (TWO_BUF) {
+        // occupancy 2: registers to spare -> software pipeline: the raw samples of pair pr+1
+        // and the input spectrum of pair pr are in flight while pair pr is transformed
+        Raw<HALF_HOP> raw;
+        if (p0 < p1) load_raw<HALF_HOP>(raw, ch, p.n_samples, (int64_t)(2 * p0) * p.hop, p.hop, tid);
+        for (int pr = p0; pr < p1; ++pr) {
+            float2 v[16];
+            window_pair<HALF_HOP>(v, raw, 2 * pr + 1 < p.n_frames, win);
+            if (!(W4_ABLATE & 2) && pr + 1 < p1)
+                load_raw<HALF_HOP>(raw, ch, p.n_samples, (int64_t)(2 * pr + 2) * p.hop, p.hop, tid);
+            float2 xw[16];
+            if (W4_ABLATE & 1) {
+#pragma unroll
+                for (int k3 = 0; k3 < 16; ++k3) xw[k3] = tw.w[k3 % 15];
+            } else {
+                const float2* __restrict__ xp = p.xs + (int64_t)pr * N + tid;
+#pragma unroll
+                for (int k3 = 0; k3 < 16; ++k3) xw[k3] = xp[256 * k3];
+            }
+            fft4096<TWO_BUF>(v, tw, buf, tw2, tid);
+#pragma unroll
+            for (int k3 = 0; k3 < 16; ++k3) {
+                float2 w = xw[k3];
+                float2 z = v[pos16(k3)];
+                T[k3].x = fmaf(w.x, z.x, fmaf(w.y, z.y, T[k3].x));   // conj(w) z
+                T[k3].y = fmaf(w.x, z.y, fmaf(-w.y, z.x, T[k3].y));
+                P[k3] = fmaf(z.x, z.x, fmaf(z.y, z.y, P[k3]));
+            }
+        }
+    } else {
+        // occupancy 3+: <= 168 VGPRs, no prefetch registers -- the third workgroup on the CU
+        // hides the load latency instead
+        for (int pr = p0; pr < p1; ++pr) {
+            float2 v[16];
+            {
+                Raw<HALF_HOP> raw;
+                load_raw<HALF_HOP>(raw, ch, p.n_samples, (int64_t)(2 * pr) * p.hop, p.hop, tid);
+                window_pair<HALF_HOP>(v, raw, 2 * pr + 1 < p.n_frames, win);
+            }
+            fft4096<TWO_BUF>(v, tw, buf, tw2, tid);
             const float2* __restrict__ xp = p.xs + (int64_t)pr * N + tid;
 #pragma unroll
-            for (int k3 = 0; k3 < 16; ++k3) xw[k3] = xp[256 * k3];
-        }
-        fft4096<TWO_BUF>(v, tw, buf, tw2, tid);
-#pragma unroll
-        for (int k3 = 0; k3 < 16; ++k3) {
-            float2 w = xw[k3];
-            float2 z = v[pos16(k3)];
-            T[k3].x = fmaf(w.x, z.x, fmaf(w.y, z.y, T[k3].x));   // conj(w) z
-            T[k3].y = fmaf(w.x, z.y, fmaf(-w.y, z.x, T[k3].y));
-            P[k3] = fmaf(z.x, z.x, fmaf(z.y, z.y, P[k3]));
+            for (int k3 = 0; k3 < 16; ++k3) {
+                float2 w = xp[256 * k3];
+                float2 z = v[pos16(k3)];
+                T[k3].x = fmaf(w.x, z.x, fmaf(w.y, z.y, T[k3].x));   // conj(w) z
+                T[k3].y = fmaf(w.x, z.y, fmaf(-w.y, z.x, T[k3].y));
+                P[k3] = fmaf(z.x, z.x, fmaf(z.y, z.y, P[k3]));
+            }
         }
     }
     if (p.detrend && tid == 0) P[0] = 0.f;  // xs bin 0 is already 0 -> T[0] = 0
@@ -356,6 +398,11 @@ inline int occupancy_target() {
     const char* e = getenv("DSPTOOLBOX_AMD_WELCH_OCC");
     int o = e ? atoi(e) : 2;
     return o < 2 ? 2 : (o > 4 ? 4 : o);
+}
+
+inline int stagger_units() {
+    const char* e = getenv("DSPTOOLBOX_AMD_WELCH_STAGGER");
+    return e ? atoi(e) : 0;
 }
 
 inline int chunks_for(int n_pairs, int n_ch) {
