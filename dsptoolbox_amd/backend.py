@@ -207,6 +207,27 @@ def _csm_welch(time_data, sampling_rate_hz: int, window_length_samples: int, win
     return np.fft.rfftfreq(W, 1 / sampling_rate_hz), out.astype(np.complex128)
 
 
+def _csm_fft(spectrum, scaling: SpectrumScaling, window, sampling_rate_hz: int):
+    """Cross-spectral matrix of ONE whole-signal spectrum (B, C) (FFTBackward-normalised),
+    dsptoolbox/standard/_spectral_methods.py:374-443.  -> (B, C, C) complex128."""
+    if window is not None:
+        raise NotImplementedError("time-windowed signals are outside the GPU hot path")
+    xs = np.ascontiguousarray(spectrum, dtype=np.complex64)
+    nb, n_ch = xs.shape
+    if scaling == SpectrumScaling.FFTBackward:
+        amp, factor, halve = 0, 1.0, 0
+    else:
+        # the reference passes `spectrum.shape[0] // 2 + 1` as the length (:436)
+        factor = float(np.asarray(SpectrumScaling.FFTBackward.conversion_factor(
+            scaling, nb // 2 + 1, sampling_rate_hz, None)).ravel()[0])
+        amp, halve = int(scaling.is_amplitude_scaling()), 1
+    out = np.empty((nb, n_ch, n_ch), dtype=np.complex64)
+    ctx = get_context()
+    ctx.check(ctx.lib.ds_csm_spec(ctx.handle, _ptr(xs), nb, 1, n_ch, amp, 1.0, factor, halve,
+                                  _ptr(out)), "ds_csm_spec")
+    return out.astype(np.complex128)
+
+
 def rfft_spectrum(time_data, n_fft: int, scale: float = 1.0):
     """rfft(time_data, n=n_fft, axis=0) * scale -> (n_fft/2+1, C) complex128."""
     xp = _planar_f32(time_data)

@@ -293,9 +293,14 @@ class Signal(MultichannelData):
                                         par["overlap_percent"], par["detrend"], par["average"],
                                         par["scaling"])
         else:
-            raise NotImplementedError(
-                "get_csm with SpectrumMethod.FFT (single-frame outer product) is not built on "
-                "the GPU path yet")
+            # the spectrum is taken with FFTBackward scaling, the scaling is applied to the CSM
+            old_scaling = self.spectrum_scaling
+            self.spectrum_scaling = SpectrumScaling.FFTBackward
+            try:
+                f, sp = self.get_spectrum()
+            finally:
+                self.spectrum_scaling = old_scaling
+            csm = backend._csm_fft(sp, old_scaling, None, self.sampling_rate_hz)
         if self.activate_cache:
             self.csm = [f.copy(), csm.copy()]
             self.__csm_state_update = False

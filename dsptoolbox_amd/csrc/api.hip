@@ -305,10 +305,21 @@ extern "C" int ds_stft_r2c_dev(ds_ctx* c, const float* x, int64_t n_samples, int
     CHK(check_fft_len(c, nfft, "ds_stft_r2c nfft"));
     const float2* tw;
     CHK(get_twiddles(c, nfft, &tw));
-    StftArgs a{x, n_samples, ld, pad_front, n_ch, W, hop, n_frames, detrend, power, window, tw,
+    // channel tile: ct teams of NT threads (<= 1024 threads, <= ~70 KB of LDS so two
+    // workgroups share a CU)
+    int ct = 1;
+    size_t lds = 0;
+    int threads = 0;
+    DISPATCH_N(nfft, {
+        const size_t per = (size_t)stft_ch_stride<NN>() * sizeof(float2);
+        ct = std::min<int>({16, 1024 / Cfg<NN>::NT, std::max<int>(1, (int)((70 * 1024) / per)), n_ch});
+        lds = per * ct;
+        threads = ct * Cfg<NN>::NT;
+    });
+    StftArgs a{x, n_samples, ld, pad_front, n_ch, W, hop, n_frames, detrend, power, ct, window, tw,
                scale, edge_scale, (float2*)out};
-    dim3 grid((unsigned)((int64_t)n_ch * ((n_frames + 1) / 2)));
-    DISPATCH_N(nfft, CHK(launch(c, "stft", k_stft<NN>, grid, Cfg<NN>::NT, Cfg<NN>::LDS_BYTES, a)));
+    dim3 grid((unsigned)((n_frames + 1) / 2), (unsigned)((n_ch + ct - 1) / ct));
+    DISPATCH_N(nfft, CHK(launch(c, "stft", k_stft<NN>, grid, threads, lds, a)));
     return DS_OK;
 }
 
@@ -496,6 +507,34 @@ extern "C" int ds_csm_dev(ds_ctx* c, const float* x, int n_ch, int64_t ld, int64
               (float2*)csm};
     CHK(launch(c, "csm_gemm", k_csm_gemm, dim3(nb, nt * (nt + 1) / 2), 256, 0, a));
     return DS_OK;
+}
+
+extern "C" int ds_csm_spec_dev(ds_ctx* c, const ds_c32* X, int n_bins, int n_frames, int n_ch,
+                               int amp_sqrt, double norm_scale, double factor, int halve_edges,
+                               ds_c32* csm) {
+    if (!c || !X || !csm) return fail(c, DS_ERR_ARG, "ds_csm_spec: null argument");
+    if (n_bins <= 0 || n_frames <= 0 || n_ch <= 0) return fail(c, DS_ERR_ARG, "ds_csm_spec: bad shape");
+    const int nt = (n_ch + 31) / 32;
+    CsmArgs a{(const float2*)X, n_ch, n_frames,
+              FinishPar{norm_scale / (double)n_frames, factor, halve_edges, amp_sqrt, n_bins},
+              (float2*)csm};
+    CHK(launch(c, "csm_gemm", k_csm_gemm, dim3(n_bins, nt * (nt + 1) / 2), 256, 0, a));
+    return DS_OK;
+}
+
+extern "C" int ds_csm_spec(ds_ctx* c, const ds_c32* X, int n_bins, int n_frames, int n_ch, int amp_sqrt,
+                           double norm_scale, double factor, int halve_edges, ds_c32* csm) {
+    if (!c || !X || !csm) return fail(c, DS_ERR_ARG, "ds_csm_spec: null argument");
+    if (n_bins <= 0 || n_frames <= 0 || n_ch <= 0) return fail(c, DS_ERR_ARG, "ds_csm_spec: bad shape");
+    size_t nx = (size_t)n_bins * n_frames * n_ch, no = (size_t)n_bins * n_ch * n_ch;
+    CHK(reserve(c, &c->io, &c->io_bytes, Carver::pad(nx * 8) + Carver::pad(no * 8) + 4096));
+    Carver cv(c->io);
+    float2* dx = cv.take<float2>(nx);
+    float2* dc = cv.take<float2>(no);
+    CHK(ds_upload(c, dx, X, nx * 8));
+    CHK(ds_csm_spec_dev(c, (const ds_c32*)dx, n_bins, n_frames, n_ch, amp_sqrt, norm_scale, factor,
+                        halve_edges, (ds_c32*)dc));
+    return ds_download(c, csm, dc, no * 8);
 }
 
 // ---- whole-signal rFFT, deconvolution ---------------------------------------

@@ -188,9 +188,24 @@ __global__ __launch_bounds__(256) void k_csm_gemm(CsmArgs p) {
                     double d = finish_real(g.x, b, p.fin);
                     out[(int64_t)gi * C + gj] = make_float2((float)d, 0.f);
                 } else {
+                    bool real_bin = false;
+                    if (F == 1 && g.y == 0.0) {
+                        // one frame (_csm_fft) at a purely real bin: numpy's signed zeros decide the
+                        // branch of sqrt(-a +- 0j).  Lower element conj(X_j) X_i has imaginary part
+                        // -0 exactly when Re X_j < 0 < Re X_i; the mirrored upper element is
+                        // 0 + conj(lower), whose imaginary part is always +0.
+                        float xi = Xb[gi].x, xj = Xb[gj].x;
+                        g.y = (xj < 0.f && xi > 0.f) ? -0.0 : 0.0;
+                        real_bin = true;
+                    }
                     cd v = finish_cplx(g, b, p.fin);
                     out[(int64_t)gi * C + gj] = make_float2((float)v.x, (float)v.y);
-                    out[(int64_t)gj * C + gi] = make_float2((float)v.x, (float)-v.y);
+                    if (real_bin) {
+                        cd u = finish_cplx(cd{g.x, 0.0}, b, p.fin);
+                        out[(int64_t)gj * C + gi] = make_float2((float)u.x, (float)u.y);
+                    } else {
+                        out[(int64_t)gj * C + gi] = make_float2((float)v.x, (float)-v.y);
+                    }
                 }
             }
         }

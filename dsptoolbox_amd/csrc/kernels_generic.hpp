@@ -117,11 +117,18 @@ struct Bins {
 };
 
 // ---------------------------------------------------------------- STFT
-// grid.x = n_ch * ceil(n_frames/2); out[(b*F + f)*C + c]
+// grid = (ceil(n_frames/2), ceil(n_ch/ct)); block = ct teams of Cfg<N>::NT threads;
+// out[(b*F + f)*C + c].
+// Team j transforms the frame pair (f0, f0+1) of channel c0 + j in its own LDS buffer and
+// separates the two half spectra IN PLACE (frame f0 bins at [k], frame f0+1 bins at [N-k],
+// its bins 0 and N/2 in two spare slots).  Then the whole workgroup streams the images
+// out with the channel index fastest: the reference's (bins, frames, channels) order is
+// written in ct*8-byte contiguous runs.  Channel stride N + 33 complex keeps the
+// channel-fastest LDS reads bank-conflict free.
 struct StftArgs {
     const float* x;
     int64_t n_samples, ld, pad_front;
-    int n_ch, W, hop, n_frames, detrend, power;
+    int n_ch, W, hop, n_frames, detrend, power, ct;
     const float* window;
     const float2* tw;
     float scale, edge_scale;
@@ -129,36 +136,56 @@ struct StftArgs {
 };
 
 template <int N>
-__global__ __launch_bounds__(Cfg<N>::NT) void k_stft(StftArgs p) {
+__host__ __device__ constexpr int stft_ch_stride() { return N + 33; }
+
+template <int N>
+__global__ __launch_bounds__(1024) void k_stft(StftArgs p) {
     using C = Cfg<N>;
-    extern __shared__ __align__(16) float2 buf[];
-    __shared__ float2 red[16];
-    const int tid = threadIdx.x;
-    const int nfp = (p.n_frames + 1) >> 1;
-    const int c = blockIdx.x / nfp;
-    const int f0 = (blockIdx.x - c * nfp) * 2, f1 = f0 + 1;
-    const float* xc = p.x + (int64_t)c * p.ld;
-    FrameSrc a{xc, (int64_t)f0 * p.hop - p.pad_front};
-    FrameSrc b{f1 < p.n_frames ? xc : nullptr, (int64_t)f1 * p.hop - p.pad_front};
-    float2 v[C::BPT][4];
-    load_pair<N>(v, a, b, p.n_samples, p.W, p.window, p.detrend != 0, red, tid);
-    fft<N, false, true, false>(v, buf, p.tw, tid);
-    const int64_t F = p.n_frames, Cn = p.n_ch;
-    for (int k = tid; k <= N / 2; k += C::NT) {
-        float2 A, B;
-        unpack_bin<N>(buf, k, A, B);
-        float s = p.scale * ((k == 0 || k == N / 2) ? p.edge_scale : 1.0f);
-        if (p.power) {
-            // reference: |x/sqrt2|^2 * factor at the edges -> scale applied after squaring
-            float e = (k == 0 || k == N / 2) ? p.edge_scale * p.edge_scale : 1.0f;
-            A = make_float2((A.x * A.x + A.y * A.y) * e * p.scale, 0.f);
-            B = make_float2((B.x * B.x + B.y * B.y) * e * p.scale, 0.f);
-        } else {
-            A = make_float2(A.x * s, A.y * s);
-            B = make_float2(B.x * s, B.y * s);
+    constexpr int NB = N / 2 + 1, CHS = stft_ch_stride<N>();
+    extern __shared__ __align__(16) float2 lds[];
+    __shared__ float2 red_all[16][16];
+    const int team = threadIdx.x / C::NT, tid = threadIdx.x % C::NT;
+    float2* buf = lds + (int64_t)team * CHS;
+    const int f0 = blockIdx.x * 2, f1 = f0 + 1;
+    const int c0 = blockIdx.y * p.ct;
+    const int ctv = min(p.ct, p.n_ch - c0);  // valid channels in this tile
+    const bool v1 = f1 < p.n_frames;
+    {
+        const int c = c0 + team;
+        const float* xc = c < p.n_ch ? p.x + (int64_t)c * p.ld : nullptr;  // idle teams transform zeros
+        FrameSrc a{xc, (int64_t)f0 * p.hop - p.pad_front};
+        FrameSrc b{v1 ? xc : nullptr, (int64_t)f1 * p.hop - p.pad_front};
+        float2 v[C::BPT][4];
+        load_pair<N>(v, a, b, p.n_samples, p.W, p.window, p.detrend != 0, red_all[team], tid);
+        fft<N, false, true, false>(v, buf, p.tw, tid);
+        for (int k = tid; k <= N / 2; k += C::NT) {
+            float2 A, B;
+            unpack_bin<N>(buf, k, A, B);
+            const bool edge = (k == 0 || k == N / 2);
+            if (p.power) {
+                // reference: |x/sqrt2|^2 * factor at the edges -> scale applied after squaring
+                float e = (edge ? p.edge_scale * p.edge_scale : 1.0f) * p.scale;
+                A = make_float2((A.x * A.x + A.y * A.y) * e, 0.f);
+                B = make_float2((B.x * B.x + B.y * B.y) * e, 0.f);
+            } else {
+                float s = p.scale * (edge ? p.edge_scale : 1.0f);
+                A = make_float2(A.x * s, A.y * s);
+                B = make_float2(B.x * s, B.y * s);
+            }
+            buf[k] = A;  // this thread owns the pair (k, N-k): in place
+            buf[k == 0 ? N : (k == N / 2 ? N + 1 : N - k)] = B;
         }
-        p.out[((int64_t)k * F + f0) * Cn + c] = A;
-        if (f1 < p.n_frames) p.out[((int64_t)k * F + f1) * Cn + c] = B;
+    }
+    __syncthreads();
+    const int64_t F = p.n_frames, Cn = p.n_ch;
+    const int nf = v1 ? 2 : 1;
+    const int total = nf * NB * ctv;
+    for (int i = threadIdx.x; i < total; i += blockDim.x) {
+        int cl = i % ctv;
+        int r = i / ctv;
+        int fl = r % nf, k = r / nf;
+        int src = fl == 0 ? k : (k == 0 ? N : (k == N / 2 ? N + 1 : N - k));
+        p.out[((int64_t)k * F + f0 + fl) * Cn + c0 + cl] = lds[(int64_t)cl * CHS + src];
     }
 }
 

@@ -138,6 +138,16 @@ int ds_csm(ds_ctx* ctx, const float* x, int n_ch, int64_t n_samples, int W, int 
            int n_frames, const float* window, int detrend, int amp_sqrt,
            double norm_scale, double factor, int halve_edges, ds_c32* csm);
 
+/* CSM from spectra that are already on hand: X[b][f][c] (n_bins x n_frames x n_ch, the
+ * STFT layout) -> csm[b][i][j] = finish(norm_scale/n_frames * sum_f X_i conj X_j).
+ * n_frames = 1 replaces _csm_fft, _spectral_methods.py:374-443 (outer product of one
+ * whole-signal spectrum; FFTBackward: no finish, others: edges halved, factor, sqrt).     */
+int ds_csm_spec_dev(ds_ctx* ctx, const ds_c32* X_dev, int n_bins, int n_frames, int n_ch,
+                    int amp_sqrt, double norm_scale, double factor, int halve_edges,
+                    ds_c32* csm_dev);
+int ds_csm_spec(ds_ctx* ctx, const ds_c32* X, int n_bins, int n_frames, int n_ch, int amp_sqrt,
+                double norm_scale, double factor, int halve_edges, ds_c32* csm);
+
 /* ---- whole-signal rFFT / regularised spectral division -------------------
  * ds_rfft: Signal.get_spectrum with SpectrumMethod.FFT, classes/signal.py:899-911
  * (n_fft power of two <= 2*ds_max_fft_len(); input zero padded to n_fft).

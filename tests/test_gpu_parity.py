@@ -129,6 +129,26 @@ def test_csm_golden():
     print("csm worst rel-max", worst)
 
 
+def test_csm_fft_vs_oracle():
+    """Signal.get_csm with SpectrumMethod.FFT (_csm_fft): power-of-two length so the
+    whole-signal rFFT runs on the device; golden case (n = 1000) needs a non-pow2 FFT."""
+    rng = np.random.default_rng(21)
+    x = 0.1 * rng.standard_normal((2048, 5)) + 0.2 * rng.standard_normal(2048)[:, None]
+    for sc in SpectrumScaling:
+        s = dsp.Signal(None, x.copy(), 48000)
+        s.set_spectrum_parameters(method=SpectrumMethod.FFT, scaling=sc)
+        f, csm = s.get_csm()
+        fr, sp = orc.spectrum_fft(x, 48000, "FFTBackward", True)
+        ref = orc.csm_fft(sp, sc.name, None, 48000)
+        assert np.array_equal(f, fr)
+        assert relmax(csm, ref) < TOL, (sc, relmax(csm, ref))
+    meta, z = load_golden("csm")
+    s = dsp.Signal(None, z["x"][:1000, :3].copy(), meta["fs"])
+    s.set_spectrum_parameters(method=SpectrumMethod.FFT)
+    with pytest.raises(NotImplementedError):
+        s.get_csm()
+
+
 def test_deconvolve_golden():
     meta, z = load_golden("deconvolve")
     worst = 0.0
