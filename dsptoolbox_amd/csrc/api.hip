@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "../../include/dsptoolbox_amd.h"
+#include "kernels_bigfft.hpp"
 #include "kernels_finish.hpp"
 #include "kernels_generic.hpp"
 #include "kernels_welch4096.hpp"
@@ -63,6 +64,7 @@ static int fail(ds_ctx* c, int code, const std::string& msg) {
 
 static bool is_pow2(int64_t n) { return n > 0 && (n & (n - 1)) == 0; }
 static const int kMaxFft = 16384, kMinFft = 8;
+static const int64_t kMaxBigFft = (int64_t)1 << 24;  // four-step path (kernels_bigfft.hpp)
 
 extern "C" int ds_version(void) { return 100; }
 extern "C" int ds_max_fft_len(void) { return kMaxFft; }
@@ -193,25 +195,7 @@ extern "C" const char* ds_profile_report(ds_ctx* c) {
 }
 
 // ---- internal helpers ------------------------------------------------------
-static int get_twiddles(ds_ctx* c, int n, const float2** out) {
-    auto it = c->tw.find(n);
-    if (it != c->tw.end()) {
-        *out = it->second;
-        return DS_OK;
-    }
-    std::vector<float2> h(n);
-    for (int m = 0; m < n; ++m) {
-        double a = -2.0 * M_PI * (double)m / (double)n;
-        h[m] = make_float2((float)std::cos(a), (float)std::sin(a));
-    }
-    float2* d = nullptr;
-    HIPCHK(c, hipMalloc((void**)&d, sizeof(float2) * n));
-    HIPCHK(c, hipMemcpyAsync(d, h.data(), sizeof(float2) * n, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    c->tw[n] = d;
-    *out = d;
-    return DS_OK;
-}
+static int get_twiddles(ds_ctx* c, int n, const float2** out);
 
 static int reserve(ds_ctx* c, void** buf, size_t* cap, size_t bytes) {
     if (bytes <= *cap) return DS_OK;
@@ -286,6 +270,27 @@ static int launch(ds_ctx* c, const char* name, K kernel, dim3 grid, int threads,
         default: return fail(c, DS_ERR_UNSUP, "FFT length must be a power of two in [8, 16384]"); \
     }
 
+// per-length twiddle blob (fft_lds.hpp: one [k][t] table per pass, forward + reversed sequence)
+static int get_twiddles(ds_ctx* c, int n, const float2** out) {
+    auto it = c->tw.find(n);
+    if (it != c->tw.end()) {
+        *out = it->second;
+        return DS_OK;
+    }
+    std::vector<float2> h;
+    DISPATCH_N(n, {
+        h.resize(std::max(1, tw_table_len<NN>()));
+        fill_tw_table<NN>(h.data());
+    });
+    float2* d = nullptr;
+    HIPCHK(c, hipMalloc((void**)&d, sizeof(float2) * h.size()));
+    HIPCHK(c, hipMemcpyAsync(d, h.data(), sizeof(float2) * h.size(), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->tw[n] = d;
+    *out = d;
+    return DS_OK;
+}
+
 static int check_fft_len(ds_ctx* c, int n, const char* what) {
     if (!is_pow2(n) || n < kMinFft)
         return fail(c, DS_ERR_ARG, std::string(what) + ": length must be a power of two >= 8");
@@ -313,6 +318,7 @@ extern "C" int ds_stft_r2c_dev(ds_ctx* c, const float* x, int64_t n_samples, int
     DISPATCH_N(nfft, {
         const size_t per = (size_t)stft_ch_stride<NN>() * sizeof(float2);
         ct = std::min<int>({16, 1024 / Cfg<NN>::NT, std::max<int>(1, (int)((70 * 1024) / per)), n_ch});
+        while (ct & (ct - 1)) ct &= ct - 1;  // power of two (shift-only index math in the kernel)
         lds = per * ct;
         threads = ct * Cfg<NN>::NT;
     });
@@ -537,12 +543,89 @@ extern "C" int ds_csm_spec(ds_ctx* c, const ds_c32* X, int n_bins, int n_frames,
     return ds_download(c, csm, dc, no * 8);
 }
 
+// ---- four-step FFT for 2^15 .. 2^24 points (kernels_bigfft.hpp) -------------------
+static int big_rows_ct(int n2) {
+    int nt = dsfft::threads_for(n2);
+    size_t per = (size_t)(n2 + 33) * sizeof(float2);
+    int ct = std::min<int>({16, 1024 / nt, std::max<int>(1, (int)((70 * 1024) / per))});
+    return ct;
+}
+
+// cols stage: source = complex `zin` (may equal `zout`) or real channel pairs
+static int big_cols(ds_ctx* c, const float2* zin, const float* xreal, int n_ch, int64_t ld_real,
+                    int64_t n_samples, float2* zout, int64_t N, int batch) {
+    constexpr int N1 = 1024;
+    const int n2 = (int)(N / N1);
+    const float2* tw;
+    CHK(get_twiddles(c, N1, &tw));
+    const int ct = std::min(8, n2);
+    dsbig::ColsArgs a{zin, xreal, nullptr, n_samples, 0, zout, N, n2, ct, 0, ld_real, n_ch, tw};
+    size_t lds = (size_t)ct * dsbig::ch_stride<N1>() * sizeof(float2);
+    CHK(launch(c, "bigfft_cols", dsbig::k_big_cols<N1>, dim3(n2 / ct, batch), ct * Cfg<N1>::NT, lds, a));
+    return DS_OK;
+}
+
+static int big_rows(ds_ctx* c, const float2* zin, float2* zout, int64_t N, int batch) {
+    constexpr int N1 = 1024;
+    const int n2 = (int)(N / N1);
+    const float2* tw;
+    CHK(get_twiddles(c, n2, &tw));
+    const int ct = big_rows_ct(n2);
+    dsbig::RowsArgs a{zin, zout, N, N1, ct, tw};
+    size_t lds = (size_t)ct * (n2 + 33) * sizeof(float2);
+    DISPATCH_N(n2, CHK(launch(c, "bigfft_rows", dsbig::k_big_rows<NN>, dim3(N1 / ct, batch), ct * Cfg<NN>::NT, lds, a)));
+    return DS_OK;
+}
+
+static int check_big_len(ds_ctx* c, int64_t n, const char* what) {
+    if (!is_pow2(n)) return fail(c, DS_ERR_UNSUP, std::string(what) + ": length is not a power of two (Bluestein not built yet)");
+    if (n > kMaxBigFft) return fail(c, DS_ERR_UNSUP, std::string(what) + ": lengths above 2^24 are not built yet");
+    return DS_OK;
+}
+
+static int rfft_big(ds_ctx* c, const float* x, int n_ch, int64_t ld, int64_t n_samples, int64_t N,
+                    float scale, float2* spec) {
+    const int npair = (n_ch + 1) / 2;
+    CHK(reserve(c, &c->ws, &c->ws_bytes, 2 * Carver::pad(sizeof(float2) * (size_t)npair * N)));
+    Carver cv(c->ws);
+    float2* P = cv.take<float2>((size_t)npair * N);
+    float2* Q = cv.take<float2>((size_t)npair * N);
+    CHK(big_cols(c, nullptr, x, n_ch, ld, n_samples, P, N, npair));
+    CHK(big_rows(c, P, Q, N, npair));
+    dsbig::UnpackArgs u{Q, N, n_ch, scale, spec};
+    CHK(launch(c, "bigfft_unpack", dsbig::k_big_unpack, dim3(1024, npair), 256, 0, u));
+    return DS_OK;
+}
+
+static int deconv_big(ds_ctx* c, const float* y, int n_items, int n_ch, int64_t ld, int64_t n_samples,
+                      int64_t N, const float2* r, int r_per_channel, int64_t n_out, int64_t ld_out,
+                      float* ir) {
+    const int npair = (n_ch + 1) / 2, batch = n_items * npair;
+    CHK(reserve(c, &c->ws, &c->ws_bytes, 2 * Carver::pad(sizeof(float2) * (size_t)batch * N)));
+    Carver cv(c->ws);
+    float2* P = cv.take<float2>((size_t)batch * N);
+    float2* Q = cv.take<float2>((size_t)batch * N);
+    CHK(big_cols(c, nullptr, y, n_ch, ld, n_samples, P, N, batch));
+    CHK(big_rows(c, P, Q, N, batch));
+    dsbig::MulArgs m{Q, N, n_ch, r_per_channel, r};
+    CHK(launch(c, "bigfft_mul", dsbig::k_big_mul, dim3(1024, batch), 256, 0, m));
+    CHK(big_cols(c, Q, nullptr, n_ch, 0, 0, Q, N, batch));
+    CHK(big_rows(c, Q, P, N, batch));
+    dsbig::StoreArgs st{P, N, n_out, ld_out, n_ch, ir};
+    CHK(launch(c, "bigfft_store", dsbig::k_big_store, dim3(1024, batch), 256, 0, st));
+    return DS_OK;
+}
+
 // ---- whole-signal rFFT, deconvolution ---------------------------------------
 extern "C" int ds_rfft_dev(ds_ctx* c, const float* x, int n_ch, int64_t ld, int64_t n_samples,
                            int n_fft, float scale, ds_c32* spec) {
     if (!c || !x || !spec) return fail(c, DS_ERR_ARG, "ds_rfft: null argument");
     if (n_ch <= 0 || n_samples <= 0 || ld < n_samples || n_samples > n_fft)
         return fail(c, DS_ERR_ARG, "ds_rfft: bad shape (n_samples must be <= n_fft)");
+    if (n_fft > kMaxFft) {
+        CHK(check_big_len(c, n_fft, "ds_rfft n_fft"));
+        return rfft_big(c, x, n_ch, ld, n_samples, n_fft, scale, (float2*)spec);
+    }
     CHK(check_fft_len(c, n_fft, "ds_rfft n_fft"));
     const float2* tw;
     CHK(get_twiddles(c, n_fft, &tw));
@@ -569,6 +652,11 @@ extern "C" int ds_deconv_dev(ds_ctx* c, const float* y, int n_items, int n_ch, i
     if (n_items <= 0 || n_ch <= 0 || n_samples <= 0 || ld < n_samples || n_samples > n_fft ||
         n_out <= 0 || n_out > n_fft || ld_out < n_out)
         return fail(c, DS_ERR_ARG, "ds_deconv: bad shape");
+    if (n_fft > kMaxFft) {
+        CHK(check_big_len(c, n_fft, "ds_deconv n_fft"));
+        return deconv_big(c, y, n_items, n_ch, ld, n_samples, n_fft, (const float2*)r, r_per_channel,
+                          n_out, ld_out, ir);
+    }
     CHK(check_fft_len(c, n_fft, "ds_deconv n_fft"));
     const float2* tw;
     CHK(get_twiddles(c, n_fft, &tw));

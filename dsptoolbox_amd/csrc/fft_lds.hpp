@@ -1,40 +1,76 @@
-// Generic power-of-two complex FFT held in LDS by one workgroup (gfx950).
+// Generic power-of-two complex FFT held in LDS by one team of threads (gfx950).
 //
-// Stockham autosort, radix-4 passes (+ one radix-2 pass when log2 N is odd),
-// in place in ONE LDS buffer of N float2: every thread first reads all the
-// butterfly inputs it owns into registers, the workgroup barriers, then the
-// outputs go back to the (different) autosort positions.  The first pass can
-// take its inputs straight from registers (the caller loads x[j + t*N/4] from
-// global memory, coalesced over j), and the last pass can leave its outputs in
-// registers: thread j then owns X[j + t*N/4], which is again the input set of
-// a following first pass (used by the FIR kernel: forward -> multiply ->
-// inverse without touching LDS in between).
+// Stockham autosort with radix-16 passes (then one radix-4 and/or radix-2 pass for the
+// leftover bits), in place in ONE LDS buffer of N float2: every thread first reads all the
+// butterfly inputs it owns into registers, the team barriers, then the outputs go back to
+// the (different) autosort positions.  N = 16384 takes 4 passes (16,16,16,4) instead of
+// the 7 of a radix-4 scheme: 4/7 of the LDS traffic and barriers.
 //
-// Twiddles come from a table tw[m] = exp(-2 pi i m / N), m < N, computed in
-// fp64 on the host (one per length, cached in the context).
+// Register interfaces.  A pass of radix R owns, per thread, the butterflies
+// j = tid + i*NT (j < N/R) with inputs x[j + t*N/R], t < R, kept in v[i*R + t]:
+//   * FIRST_FROM_REG: the caller has loaded those values (coalesced over j) for the first
+//     pass -- radix first_radix<N, REVERSED>();
+//   * LAST_TO_REG: the last pass (radix last_radix<N, REVERSED>(), sub-transform length
+//     N/R) leaves X[j + t*N/R] in v[i*R + t].
+// REVERSED runs the radix sequence backwards (4,16,16,16): the output layout of a forward
+// transform (last radix 4) is then the input layout of the following reversed transform,
+// which lets the FIR kernel go forward -> multiply -> inverse without touching LDS.
+//
+// Twiddles: one table per pass, rows [k][t] = exp(-2 pi i t k / (NS R)) (k < NS, t < R), so a
+// thread reads its R-1 twiddles as one contiguous row and a wave reads consecutive rows --
+// no scattered gathers.  tw_offset<N, REVERSED>(pass) locates a pass's table inside the
+// per-length blob built in fp64 on the host (tw_table_len<N>() entries, forward sequence
+// first, then the reversed one), cached in the context.
 #pragma once
 #include <hip/hip_runtime.h>
+
+#include <cmath>
 
 namespace dsfft {
 
 __host__ __device__ constexpr int ilog2(int n) { return n <= 1 ? 0 : 1 + ilog2(n >> 1); }
+__host__ __device__ constexpr int cmax(int a, int b) { return a > b ? a : b; }
+__host__ __device__ constexpr int cmin(int a, int b) { return a < b ? a : b; }
 
 // threads cooperating on one length-N complex FFT
-__host__ __device__ constexpr int threads_for(int n) {
-    return n >= 4096 ? 512 : (n >= 2048 ? 256 : (n >= 1024 ? 128 : 64));
+__host__ __device__ constexpr int threads_for(int n) { return cmax(64, cmin(512, n / 16)); }
+
+// radix sequence: as many 16s as fit, then 4 and/or 2
+template <int N>
+struct Plan {
+    static constexpr int LOGN = ilog2(N);
+    static constexpr int N16 = LOGN / 4;
+    static constexpr int REM = LOGN % 4;  // 0, 1 (->2), 2 (->4), 3 (->4,2)
+    static constexpr int NPASS = N16 + (REM == 0 ? 0 : (REM == 3 ? 2 : 1));
+    static constexpr int NT = threads_for(N);
+    __host__ __device__ static constexpr int radix(int p) {  // forward order
+        return p < N16 ? 16 : ((REM == 1) ? 2 : ((REM == 2) ? 4 : (p == N16 ? 4 : 2)));
+    }
+    __host__ __device__ static constexpr int bpt(int r) { return (N / r + NT - 1) / NT; }
+    // registers per thread: the widest pass
+    static constexpr int VMAX = cmax(cmax(N16 > 0 ? bpt(16) * 16 : 0, (REM >= 2) ? bpt(4) * 4 : 0),
+                                     (REM == 1 || REM == 3) ? bpt(2) * 2 : 0);
+    static constexpr int LDS_BYTES = N * 8;
+};
+
+template <int N, bool REVERSED>
+__host__ __device__ constexpr int first_radix() {
+    return REVERSED ? Plan<N>::radix(Plan<N>::NPASS - 1) : Plan<N>::radix(0);
+}
+template <int N, bool REVERSED>
+__host__ __device__ constexpr int last_radix() {
+    return REVERSED ? Plan<N>::radix(0) : Plan<N>::radix(Plan<N>::NPASS - 1);
 }
 
+// Backwards-compatible names used by the kernels
 template <int N>
 struct Cfg {
-    static constexpr int LOGN = ilog2(N);
-    static constexpr int NT = threads_for(N);
-    static constexpr int NB4 = N / 4;                              // radix-4 butterflies per pass
-    static constexpr int BPT = (NB4 + NT - 1) / NT;                // per thread
-    static constexpr int NPASS4 = LOGN / 2;
-    static constexpr bool ODD = (LOGN & 1) != 0;
-    static constexpr int NB2 = N / 2;
-    static constexpr int BPT2 = (NB2 + NT - 1) / NT;
-    static constexpr int LDS_BYTES = N * 8;
+    static constexpr int NT = Plan<N>::NT;
+    static constexpr int LDS_BYTES = Plan<N>::LDS_BYTES;
+    static constexpr int VMAX = Plan<N>::VMAX;
+    static constexpr int R1 = first_radix<N, false>();      // radix of the register-fed first pass
+    static constexpr int BPT1 = Plan<N>::bpt(R1);           // butterflies per thread in it
+    static constexpr int NB1 = N / R1;                      // butterflies in it (= input stride)
 };
 
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) {
@@ -46,7 +82,14 @@ __device__ __forceinline__ float2 cmul_conj(float2 a, float2 b) {  // a * conj(b
 __device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
 __device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
 
-// radix-4 butterfly in registers; INV selects exp(+i...) kernels
+template <bool INV>
+__device__ __forceinline__ void bfly2(float2& a, float2& b) {
+    float2 s = cadd(a, b), d = csub(a, b);
+    a = s;
+    b = d;
+}
+
+// radix-4 butterfly in registers, natural output order; INV selects exp(+i...) kernels
 template <bool INV>
 __device__ __forceinline__ void bfly4(float2& x0, float2& x1, float2& x2, float2& x3) {
     float2 a = cadd(x0, x2), b = csub(x0, x2), c = cadd(x1, x3), d = csub(x1, x3);
@@ -57,6 +100,32 @@ __device__ __forceinline__ void bfly4(float2& x0, float2& x1, float2& x2, float2
     x3 = csub(b, jd);
 }
 
+// 16-point DFT in registers: input v[n] (n = n0 + 4 n1), output X[k] in v[pos16(k)]
+__host__ __device__ constexpr int pos16(int k) { return 4 * (k & 3) + (k >> 2); }
+template <bool INV>
+__device__ __forceinline__ void dft16(float2* v) {
+    constexpr float C8 = 0.92387953251128673848f, S8 = 0.38268343236508978178f;
+    constexpr float R2 = 0.70710678118654752440f;
+    constexpr float SG = INV ? -1.f : 1.f;  // sign of the sine terms
+#pragma unroll
+    for (int n0 = 0; n0 < 4; ++n0) bfly4<INV>(v[n0], v[n0 + 4], v[n0 + 8], v[n0 + 12]);
+    // position n0 + 4 k1 holds Y[n0][k1]; multiply by W16^(+- n0 k1) = c -+ i s
+    auto mulw = [](float2 z, float c, float s) {  // z * (c - i s)
+        return make_float2(fmaf(z.x, c, z.y * s), fmaf(z.y, c, -z.x * s));
+    };
+    v[5] = mulw(v[5], C8, SG * S8);
+    v[9] = mulw(v[9], R2, SG * R2);
+    v[13] = mulw(v[13], S8, SG * C8);
+    v[6] = mulw(v[6], R2, SG * R2);
+    v[10] = INV ? make_float2(-v[10].y, v[10].x) : make_float2(v[10].y, -v[10].x);
+    v[14] = mulw(v[14], -R2, SG * R2);
+    v[7] = mulw(v[7], S8, SG * C8);
+    v[11] = mulw(v[11], -R2, SG * R2);
+    v[15] = mulw(v[15], -C8, -SG * S8);
+#pragma unroll
+    for (int k1 = 0; k1 < 4; ++k1) bfly4<INV>(v[4 * k1], v[4 * k1 + 1], v[4 * k1 + 2], v[4 * k1 + 3]);
+}
+
 template <bool INV>
 __device__ __forceinline__ float2 twid(const float2* __restrict__ tw, int idx) {
     float2 w = tw[idx];
@@ -64,104 +133,155 @@ __device__ __forceinline__ float2 twid(const float2* __restrict__ tw, int idx) {
     return w;
 }
 
-// One radix-4 Stockham pass with sub-transform length NS (compile time).
-//   v[i][t]: in = x[j + t*N/4], j = tid + i*NT; out -> position (j-k)*4 + k + t*NS, k = j % NS
-// FROM_REG: inputs already in v (first pass);  TO_REG: keep outputs in v (last pass)
-template <int N, int NS, bool INV, bool FROM_REG, bool TO_REG>
-__device__ __forceinline__ void pass4(float2 (&v)[Cfg<N>::BPT][4], float2* __restrict__ buf,
-                                      const float2* __restrict__ tw, int tid) {
-    using C = Cfg<N>;
+template <int N, bool REVERSED>
+__host__ __device__ constexpr int pass_radix(int p) {
+    return REVERSED ? Plan<N>::radix(Plan<N>::NPASS - 1 - p) : Plan<N>::radix(p);
+}
+template <int N, bool REVERSED>
+__host__ __device__ constexpr int pass_ns(int p) {  // product of the radices before pass p
+    int ns = 1;
+    for (int q = 0; q < p; ++q) ns *= pass_radix<N, REVERSED>(q);
+    return ns;
+}
+// entries of the table of pass p (NS * R; the NS == 1 pass has no twiddles)
+template <int N, bool REVERSED>
+__host__ __device__ constexpr int tw_pass_len(int p) {
+    return pass_ns<N, REVERSED>(p) == 1 ? 0 : pass_ns<N, REVERSED>(p) * pass_radix<N, REVERSED>(p);
+}
+template <int N, bool REVERSED>
+__host__ __device__ constexpr int tw_seq_len() {
+    int n = 0;
+    for (int p = 0; p < Plan<N>::NPASS; ++p) n += tw_pass_len<N, REVERSED>(p);
+    return n;
+}
+template <int N, bool REVERSED>
+__host__ __device__ constexpr int tw_offset(int p) {
+    int n = REVERSED ? tw_seq_len<N, false>() : 0;
+    for (int q = 0; q < p; ++q) n += tw_pass_len<N, REVERSED>(q);
+    return n;
+}
+template <int N>
+__host__ __device__ constexpr int tw_table_len() { return tw_seq_len<N, false>() + tw_seq_len<N, true>(); }
+
+// One Stockham pass of radix R with sub-transform length NS (both compile time).
+template <int N, int R, int NS, int TWOFF, bool INV, bool FROM_REG, bool TO_REG>
+__device__ __forceinline__ void pass(float2 (&v)[Plan<N>::VMAX], float2* __restrict__ buf,
+                                     const float2* __restrict__ tw, int tid) {
+    using P = Plan<N>;
+    constexpr int NBF = N / R, BPT = P::bpt(R);
+    constexpr bool FULL = (NBF % P::NT) == 0;  // every thread owns BPT butterflies
     if (!FROM_REG) {
 #pragma unroll
-        for (int i = 0; i < C::BPT; ++i) {
-            int j = tid + i * C::NT;
-            if (C::NB4 >= C::NT || j < C::NB4) {
+        for (int i = 0; i < BPT; ++i) {
+            int j = tid + i * P::NT;
+            if (FULL || j < NBF) {
 #pragma unroll
-                for (int t = 0; t < 4; ++t) v[i][t] = buf[j + t * C::NB4];
+                for (int t = 0; t < R; ++t) v[i * R + t] = buf[j + t * NBF];
             }
         }
     }
 #pragma unroll
-    for (int i = 0; i < C::BPT; ++i) {
-        int j = tid + i * C::NT;
-        if (C::NB4 >= C::NT || j < C::NB4) {
+    for (int i = 0; i < BPT; ++i) {
+        int j = tid + i * P::NT;
+        if (FULL || j < NBF) {
+            float2* x = &v[i * R];
             if (NS > 1) {
-                int k = j & (NS - 1);
-                constexpr int STEP = N / (NS * 4);
-                v[i][1] = cmul(v[i][1], twid<INV>(tw, k * STEP));
-                v[i][2] = cmul(v[i][2], twid<INV>(tw, 2 * k * STEP));
-                v[i][3] = cmul(v[i][3], twid<INV>(tw, 3 * k * STEP));
+                const float2* __restrict__ row = tw + TWOFF + (j & (NS - 1)) * R;
+#pragma unroll
+                for (int t = 1; t < R; ++t) x[t] = cmul(x[t], twid<INV>(row, t));
             }
-            bfly4<INV>(v[i][0], v[i][1], v[i][2], v[i][3]);
+            if (R == 16) {
+                dft16<INV>(x);
+                float2 o[16];
+#pragma unroll
+                for (int t = 0; t < 16; ++t) o[t] = x[pos16(t)];
+#pragma unroll
+                for (int t = 0; t < 16; ++t) x[t] = o[t];
+            } else if (R == 4) {
+                bfly4<INV>(x[0], x[1], x[2], x[3]);
+            } else {
+                bfly2<INV>(x[0], x[1]);
+            }
         }
     }
     if (!TO_REG) {
         if (!FROM_REG) __syncthreads();  // every read of this pass done before any write
 #pragma unroll
-        for (int i = 0; i < C::BPT; ++i) {
-            int j = tid + i * C::NT;
-            if (C::NB4 >= C::NT || j < C::NB4) {
+        for (int i = 0; i < BPT; ++i) {
+            int j = tid + i * P::NT;
+            if (FULL || j < NBF) {
                 int k = j & (NS - 1);
-                int o = ((j - k) << 2) + k;
+                int o = (j - k) * R + k;
 #pragma unroll
-                for (int t = 0; t < 4; ++t) buf[o + t * NS] = v[i][t];
+                for (int t = 0; t < R; ++t) buf[o + t * NS] = v[i * R + t];
             }
         }
         __syncthreads();
     }
 }
 
-// final radix-2 pass (log2 N odd), NS = N/2: in x[j], x[j+N/2]; out j, j+N/2
-template <int N, bool INV>
-__device__ __forceinline__ void pass2_last(float2* __restrict__ buf, const float2* __restrict__ tw,
-                                           int tid) {
-    using C = Cfg<N>;
-    float2 a[C::BPT2], b[C::BPT2];
-#pragma unroll
-    for (int i = 0; i < C::BPT2; ++i) {
-        int j = tid + i * C::NT;
-        if (C::NB2 >= C::NT || j < C::NB2) {
-            a[i] = buf[j];
-            b[i] = cmul(buf[j + C::NB2], twid<INV>(tw, j));  // k = j, STEP = 1
-        }
-    }
-    // in == out positions per thread: no barrier needed between read and write
-#pragma unroll
-    for (int i = 0; i < C::BPT2; ++i) {
-        int j = tid + i * C::NT;
-        if (C::NB2 >= C::NT || j < C::NB2) {
-            buf[j] = cadd(a[i], b[i]);
-            buf[j + C::NB2] = csub(a[i], b[i]);
-        }
-    }
-    __syncthreads();
-}
-
-template <int N, int P, bool INV, bool FIRST_FROM_REG, bool LAST_TO_REG>
+template <int N, int PI, bool INV, bool REVERSED, bool FIRST_FROM_REG, bool LAST_TO_REG>
 struct Passes {
-    static __device__ __forceinline__ void run(float2 (&v)[Cfg<N>::BPT][4], float2* buf,
+    static __device__ __forceinline__ void run(float2 (&v)[Plan<N>::VMAX], float2* buf,
                                                const float2* tw, int tid) {
-        using C = Cfg<N>;
-        constexpr int NS = 1 << (2 * P);
-        constexpr bool last = (P == C::NPASS4 - 1) && !C::ODD;
-        if constexpr (P < C::NPASS4) {
-            pass4<N, NS, INV, (P == 0) && FIRST_FROM_REG, last && LAST_TO_REG>(v, buf, tw, tid);
-            Passes<N, P + 1, INV, FIRST_FROM_REG, LAST_TO_REG>::run(v, buf, tw, tid);
+        using P = Plan<N>;
+        if constexpr (PI < P::NPASS) {
+            constexpr int R = pass_radix<N, REVERSED>(PI);
+            constexpr int NS = pass_ns<N, REVERSED>(PI);
+            constexpr int OFF = tw_offset<N, REVERSED>(PI);
+            pass<N, R, NS, OFF, INV, (PI == 0) && FIRST_FROM_REG, (PI == P::NPASS - 1) && LAST_TO_REG>(
+                v, buf, tw, tid);
+            Passes<N, PI + 1, INV, REVERSED, FIRST_FROM_REG, LAST_TO_REG>::run(v, buf, tw, tid);
         }
     }
 };
 
-// Full transform.  If FIRST_FROM_REG the caller has filled v[i][t] = x[tid + i*NT + t*N/4].
-// Otherwise the data is taken from buf (caller barriers after filling it).
-// Result: natural order in buf (after a barrier), or -- LAST_TO_REG, even log2 N
-// only -- X[tid + i*NT + t*N/4] in v[i][t] with buf left undefined.
-template <int N, bool INV, bool FIRST_FROM_REG, bool LAST_TO_REG>
-__device__ __forceinline__ void fft(float2 (&v)[Cfg<N>::BPT][4], float2* buf, const float2* tw,
+// Full transform of one team (blockDim may hold several teams: every barrier is a
+// __syncthreads of the whole workgroup, so all teams must call this together).
+// FIRST_FROM_REG: the caller filled v for the first pass (see header); otherwise the data
+// is taken from buf (caller barriers after filling it).  Result: natural order in buf
+// (after a barrier), or -- LAST_TO_REG -- X[j + t*N/R] in v[i*R + t], buf undefined.
+// When FIRST_FROM_REG the caller guarantees nobody still reads buf.
+template <int N, bool INV, bool FIRST_FROM_REG, bool LAST_TO_REG, bool REVERSED = false>
+__device__ __forceinline__ void fft(float2 (&v)[Plan<N>::VMAX], float2* buf, const float2* tw,
                                     int tid) {
-    using C = Cfg<N>;
-    static_assert(!(LAST_TO_REG && C::ODD), "register output needs an even log2 N");
-    Passes<N, 0, INV, FIRST_FROM_REG, LAST_TO_REG>::run(v, buf, tw, tid);
-    if constexpr (C::ODD) pass2_last<N, INV>(buf, tw, tid);
+    Passes<N, 0, INV, REVERSED, FIRST_FROM_REG, LAST_TO_REG>::run(v, buf, tw, tid);
+}
+
+// iterate the register set of a radix-R pass: f(i*R + t, n) with n = (tid + i*NT) + t*N/R
+template <int N, int R, typename F>
+__device__ __forceinline__ void for_each_reg(int tid, F f) {
+    using P = Plan<N>;
+    constexpr int NBF = N / R, BPT = P::bpt(R);
+#pragma unroll
+    for (int i = 0; i < BPT; ++i) {
+        int j = tid + i * P::NT;
+        if ((NBF % P::NT) == 0 || j < NBF) {
+#pragma unroll
+            for (int t = 0; t < R; ++t) f(i * R + t, j + t * NBF);
+        }
+    }
+}
+
+// host: fill the per-length twiddle blob (tw_table_len<N>() entries)
+template <int N, bool REVERSED, typename F2>
+inline void fill_tw_seq(F2* out) {
+    for (int p = 0; p < Plan<N>::NPASS; ++p) {
+        const int ns = pass_ns<N, REVERSED>(p), r = pass_radix<N, REVERSED>(p);
+        if (ns == 1) continue;
+        F2* t = out + tw_offset<N, REVERSED>(p);
+        for (int k = 0; k < ns; ++k)
+            for (int q = 0; q < r; ++q) {
+                double a = -2.0 * 3.14159265358979323846 * (double)q * (double)k / ((double)ns * r);
+                t[k * r + q].x = (float)cos(a);
+                t[k * r + q].y = (float)sin(a);
+            }
+    }
+}
+template <int N, typename F2>
+inline void fill_tw_table(F2* out) {
+    fill_tw_seq<N, false>(out);
+    fill_tw_seq<N, true>(out);
 }
 
 }  // namespace dsfft

@@ -1,0 +1,196 @@
+// Four-step FFT for power-of-two lengths beyond one workgroup's LDS (N = N1 * N2,
+// 2^15 .. 2^24), used by the whole-signal paths (ds_rfft, ds_deconv).
+//   view z[n1*N2 + j2]:
+//   columns  (k_big_cols): for each column j2, FFT over n1 (length N1, stride N2), times
+//            W_N^(j2 k1), in place -> t[k1*N2 + j2]
+//   rows     (k_big_rows): for each row k1, FFT over j2 (length N2, contiguous)
+//            -> X[k1 + N1 k2] stored at out[k2*N1 + k1] (natural order)
+// Both kernels work on CT columns / rows per workgroup (CT teams of Cfg<N>::NT threads,
+// each with its own LDS buffer, channel stride N+33 complex) so that every global access
+// is a CT*8-byte contiguous run.  Twiddles W_N^m come from sincospi in fp64 (exact to
+// fp32 rounding for any N).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "fft_lds.hpp"
+
+namespace dsbig {
+using namespace dsfft;
+
+template <int N>
+__host__ __device__ constexpr int ch_stride() { return N + 33; }
+
+struct ColsArgs {
+    // source: complex buffer `zin` (in place allowed) or, if xa != nullptr, two real
+    // signals xa + i xb (xb may be nullptr) zero padded beyond n_samples
+    const float2* zin;
+    const float* xa;
+    const float* xb;
+    int64_t n_samples;
+    int64_t batch_stride_real;  // between consecutive batch entries of xa / xb (floats)
+    float2* zout;               // [batch][N]
+    int64_t n_total;            // N
+    int n2, ct, pairs;          // pairs: real-source batch = channel pairs (xb = xa + ld)
+    int64_t ld_real;
+    int n_ch;
+    const float2* tw;  // length-N1 table
+};
+
+template <int N1>
+__global__ __launch_bounds__(1024) void k_big_cols(ColsArgs p) {
+    using C = Cfg<N1>;
+    constexpr int CHS = ch_stride<N1>();
+    extern __shared__ __align__(16) float2 lds[];
+    const int team = threadIdx.x / C::NT, tid = threadIdx.x % C::NT;
+    const int j20 = blockIdx.x * p.ct;
+    const int64_t bt = blockIdx.y;
+    const int64_t N = p.n_total;
+    float2* zo = p.zout + bt * N;
+    // cooperative coalesced load: rows n1, ct consecutive columns
+    const int total = N1 * p.ct;
+    if (p.xa) {
+        const int ca = 2 * (int)(bt % ((p.n_ch + 1) / 2)), item = (int)(bt / ((p.n_ch + 1) / 2));
+        const float* a = p.xa + ((int64_t)item * p.n_ch + ca) * p.ld_real;
+        const float* b = (ca + 1 < p.n_ch) ? a + p.ld_real : nullptr;
+        for (int i = threadIdx.x; i < total; i += blockDim.x) {
+            int j = i % p.ct, n1 = i / p.ct;
+            int64_t n = (int64_t)n1 * p.n2 + j20 + j;
+            float2 z = make_float2(0.f, 0.f);
+            if (n < p.n_samples) {
+                z.x = a[n];
+                if (b) z.y = b[n];
+            }
+            lds[j * CHS + n1] = z;
+        }
+    } else {
+        const float2* zi = p.zin + bt * N;
+        for (int i = threadIdx.x; i < total; i += blockDim.x) {
+            int j = i % p.ct, n1 = i / p.ct;
+            lds[j * CHS + n1] = zi[(int64_t)n1 * p.n2 + j20 + j];
+        }
+    }
+    __syncthreads();
+    float2* buf = lds + team * CHS;
+    float2 v[C::VMAX];
+    fft<N1, false, false, false>(v, buf, p.tw, tid);
+    // twiddle W_N^(j2 k1)
+    const int j2 = j20 + team;
+    for (int k1 = tid; k1 < N1; k1 += C::NT) {
+        double s, c;
+        sincospi(-2.0 * (double)((int64_t)j2 * k1) / (double)N, &s, &c);
+        buf[k1] = cmul(buf[k1], make_float2((float)c, (float)s));
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < total; i += blockDim.x) {
+        int j = i % p.ct, k1 = i / p.ct;
+        zo[(int64_t)k1 * p.n2 + j20 + j] = lds[j * CHS + k1];
+    }
+}
+
+struct RowsArgs {
+    const float2* zin;  // [batch][N1][N2]
+    float2* zout;       // [batch][N] natural order
+    int64_t n_total;
+    int n1, ct;
+    const float2* tw;  // length-N2 table
+};
+
+template <int N2>
+__global__ __launch_bounds__(1024) void k_big_rows(RowsArgs p) {
+    using C = Cfg<N2>;
+    constexpr int CHS = ch_stride<N2>();
+    extern __shared__ __align__(16) float2 lds[];
+    const int team = threadIdx.x / C::NT, tid = threadIdx.x % C::NT;
+    const int k10 = blockIdx.x * p.ct;
+    const int64_t bt = blockIdx.y;
+    const float2* zi = p.zin + bt * p.n_total + (int64_t)(k10 + team) * N2;
+    float2* zo = p.zout + bt * p.n_total;
+    float2* buf = lds + team * CHS;
+    float2 v[C::VMAX];
+    for_each_reg<N2, C::R1>(tid, [&](int idx, int n) { v[idx] = zi[n]; });
+    fft<N2, false, true, false>(v, buf, p.tw, tid);
+    const int total = N2 * p.ct;
+    for (int i = threadIdx.x; i < total; i += blockDim.x) {
+        int j = i % p.ct, k2 = i / p.ct;
+        zo[(int64_t)k2 * p.n1 + k10 + j] = lds[j * CHS + k2];
+    }
+}
+
+// spec[k*n_ch + c] = scale * (spectrum of channel c), k <= N/2, from packed pair spectra
+struct UnpackArgs {
+    const float2* z;  // [batch = items * pairs][N]
+    int64_t n_total;
+    int n_ch;
+    float scale;
+    float2* spec;  // [N/2+1][n_ch]   (items == 1)
+};
+__global__ void k_big_unpack(UnpackArgs p) {
+    const int64_t N = p.n_total, nb = N / 2 + 1;
+    const int pair = blockIdx.y;
+    const float2* z = p.z + (int64_t)pair * N;
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < nb; k += (int64_t)gridDim.x * blockDim.x) {
+        float2 P = z[k], Qc = z[(N - k) & (N - 1)];
+        float2 A = make_float2(0.5f * (P.x + Qc.x) * p.scale, 0.5f * (P.y - Qc.y) * p.scale);
+        float2 B = make_float2(0.5f * (P.y + Qc.y) * p.scale, -0.5f * (P.x - Qc.x) * p.scale);
+        const int ca = 2 * pair;
+        p.spec[k * p.n_ch + ca] = A;
+        if (ca + 1 < p.n_ch) p.spec[k * p.n_ch + ca + 1] = B;
+    }
+}
+
+// in place: z <- conj( A Ra + i B Rb ) with Hermitian completion, ready for a FORWARD
+// transform that realises the inverse one (ifft(V) = conj(fft(conj V)) / N)
+struct MulArgs {
+    float2* z;  // [batch][N]
+    int64_t n_total;
+    int n_ch, r_per_channel;
+    const float2* r;  // [n_ch or 1][N/2+1]
+};
+__global__ void k_big_mul(MulArgs p) {
+    const int64_t N = p.n_total, nb = N / 2 + 1;
+    const int64_t bt = blockIdx.y;
+    const int npair = (p.n_ch + 1) / 2;
+    const int ca = 2 * (int)(bt % npair), cb = (ca + 1 < p.n_ch) ? ca + 1 : ca;
+    float2* z = p.z + bt * N;
+    const float2* Ra = p.r + (p.r_per_channel ? (int64_t)ca * nb : 0);
+    const float2* Rb = p.r + (p.r_per_channel ? (int64_t)cb * nb : 0);
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < nb; k += (int64_t)gridDim.x * blockDim.x) {
+        float2 P = z[k], Qc = z[(N - k) & (N - 1)];
+        float2 A = make_float2(0.5f * (P.x + Qc.x), 0.5f * (P.y - Qc.y));
+        float2 B = make_float2(0.5f * (P.y + Qc.y), -0.5f * (P.x - Qc.x));
+        float2 VA = cmul(A, Ra[k]), VB = cmul(B, Rb[k]);
+        if (k == 0 || k == N / 2) {
+            z[k] = make_float2(VA.x, -VB.x);  // conj(VA.x + i VB.x)
+        } else {
+            // V[k] = VA + i VB, V[N-k] = conj(VA) + i conj(VB); store the conjugates
+            z[k] = make_float2(VA.x - VB.y, -(VA.y + VB.x));
+            z[N - k] = make_float2(VA.x + VB.y, -(VB.x - VA.y));
+        }
+    }
+}
+
+// ir_a[n] = Re F[n] / N, ir_b[n] = -Im F[n] / N
+struct StoreArgs {
+    const float2* z;
+    int64_t n_total, n_out, ld_out;
+    int n_ch;
+    float* ir;  // [(item*n_ch + c)*ld_out + n]
+};
+__global__ void k_big_store(StoreArgs p) {
+    const int64_t bt = blockIdx.y;
+    const int npair = (p.n_ch + 1) / 2;
+    const int ca = 2 * (int)(bt % npair);
+    const int64_t item = bt / npair;
+    const float2* z = p.z + bt * p.n_total;
+    float* oa = p.ir + (item * p.n_ch + ca) * p.ld_out;
+    const bool vb = ca + 1 < p.n_ch;
+    const float inv = 1.0f / (float)p.n_total;
+    for (int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; n < p.n_out; n += (int64_t)gridDim.x * blockDim.x) {
+        float2 f = z[n];
+        oa[n] = f.x * inv;
+        if (vb) oa[p.ld_out + n] = -f.y * inv;
+    }
+}
+
+}  // namespace dsbig

@@ -190,12 +190,11 @@ __global__ __launch_bounds__(256) void k_csm_gemm(CsmArgs p) {
                 } else {
                     bool real_bin = false;
                     if (F == 1 && g.y == 0.0) {
-                        // one frame (_csm_fft) at a purely real bin: numpy's signed zeros decide the
-                        // branch of sqrt(-a +- 0j).  Lower element conj(X_j) X_i has imaginary part
-                        // -0 exactly when Re X_j < 0 < Re X_i; the mirrored upper element is
-                        // 0 + conj(lower), whose imaginary part is always +0.
-                        float xi = Xb[gi].x, xj = Xb[gj].x;
-                        g.y = (xj < 0.f && xi > 0.f) ? -0.0 : 0.0;
+                        // one frame (_csm_fft) at a purely real bin (DC / Nyquist): numpy's
+                        // `csm[[0, -1]] /= 2.0` (complex / real) turns every -0 imaginary part of
+                        // a negative real element into +0, so BOTH mirror elements take the +i
+                        // branch of the square root (the matrix is not Hermitian there).
+                        g.y = 0.0;
                         real_bin = true;
                     }
                     cd v = finish_cplx(g, b, p.fin);

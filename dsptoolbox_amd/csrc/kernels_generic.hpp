@@ -44,35 +44,29 @@ __device__ __forceinline__ float2 block_sum2(float2 s, float2* red, int tid) {
     return s;
 }
 
-// Load two real frames as the real / imaginary part of the first-pass register
-// set v[i][t] = z[tid + i*NT + t*N/4]:  z[n] = a[n] w[n] + i b[n] w[n] for n < W,
-// zero beyond W or outside [0, n_samples).  Optional detrend = subtract the mean
-// over the W windowed samples (also those cropped away when W > N).
+// Load two real frames as the real / imaginary part of the first-pass register set
+// (radix Cfg<N>::R1: v[i*R1 + t] = z[tid + i*NT + t*N/R1]):  z[n] = a[n] w[n] + i b[n] w[n]
+// for n < W, zero beyond W or outside [0, n_samples).  Optional detrend = subtract the
+// mean over the W windowed samples (also those cropped away when W > N).
 template <int N>
-__device__ __forceinline__ void load_pair(float2 (&v)[Cfg<N>::BPT][4], FrameSrc a, FrameSrc b,
+__device__ __forceinline__ void load_pair(float2 (&v)[Cfg<N>::VMAX], FrameSrc a, FrameSrc b,
                                           int64_t n_samples, int W,
                                           const float* __restrict__ window, bool detrend,
                                           float2* red, int tid) {
     using C = Cfg<N>;
     float2 sum = make_float2(0.f, 0.f);
-#pragma unroll
-    for (int i = 0; i < C::BPT; ++i) {
-        int j = tid + i * C::NT;
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            int n = j + t * C::NB4;
-            float2 z = make_float2(0.f, 0.f);
-            if ((C::NB4 >= C::NT || j < C::NB4) && n < W) {
-                float w = window ? window[n] : 1.0f;
-                int64_t ga = a.start + n, gb = b.start + n;
-                if (a.base && ga >= 0 && ga < n_samples) z.x = a.base[ga] * w;
-                if (b.base && gb >= 0 && gb < n_samples) z.y = b.base[gb] * w;
-            }
-            v[i][t] = z;
-            sum.x += z.x;
-            sum.y += z.y;
+    for_each_reg<N, C::R1>(tid, [&](int idx, int n) {
+        float2 z = make_float2(0.f, 0.f);
+        if (n < W) {
+            float w = window ? window[n] : 1.0f;
+            int64_t ga = a.start + n, gb = b.start + n;
+            if (a.base && ga >= 0 && ga < n_samples) z.x = a.base[ga] * w;
+            if (b.base && gb >= 0 && gb < n_samples) z.y = b.base[gb] * w;
         }
-    }
+        v[idx] = z;
+        sum.x += z.x;
+        sum.y += z.y;
+    });
     if (detrend) {
         for (int n = N + tid; n < W; n += C::NT) {  // samples cropped by nfft < W still count
             float w = window ? window[n] : 1.0f;
@@ -83,18 +77,12 @@ __device__ __forceinline__ void load_pair(float2 (&v)[Cfg<N>::BPT][4], FrameSrc 
         sum = block_sum2<C::NT>(sum, red, tid);
         float inv = 1.0f / (float)W;
         float2 m = make_float2(sum.x * inv, sum.y * inv);
-#pragma unroll
-        for (int i = 0; i < C::BPT; ++i) {
-            int j = tid + i * C::NT;
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                int n = j + t * C::NB4;
-                if (n < W) {
-                    v[i][t].x -= m.x;
-                    v[i][t].y -= m.y;
-                }
+        for_each_reg<N, C::R1>(tid, [&](int idx, int n) {
+            if (n < W) {
+                v[idx].x -= m.x;
+                v[idx].y -= m.y;
             }
-        }
+        });
     }
 }
 
@@ -155,7 +143,7 @@ __global__ __launch_bounds__(1024) void k_stft(StftArgs p) {
         const float* xc = c < p.n_ch ? p.x + (int64_t)c * p.ld : nullptr;  // idle teams transform zeros
         FrameSrc a{xc, (int64_t)f0 * p.hop - p.pad_front};
         FrameSrc b{v1 ? xc : nullptr, (int64_t)f1 * p.hop - p.pad_front};
-        float2 v[C::BPT][4];
+        float2 v[C::VMAX];
         load_pair<N>(v, a, b, p.n_samples, p.W, p.window, p.detrend != 0, red_all[team], tid);
         fft<N, false, true, false>(v, buf, p.tw, tid);
         for (int k = tid; k <= N / 2; k += C::NT) {
@@ -178,14 +166,17 @@ __global__ __launch_bounds__(1024) void k_stft(StftArgs p) {
     }
     __syncthreads();
     const int64_t F = p.n_frames, Cn = p.n_ch;
-    const int nf = v1 ? 2 : 1;
-    const int total = nf * NB * ctv;
-    for (int i = threadIdx.x; i < total; i += blockDim.x) {
-        int cl = i % ctv;
-        int r = i / ctv;
-        int fl = r % nf, k = r / nf;
-        int src = fl == 0 ? k : (k == 0 ? N : (k == N / 2 ? N + 1 : N - k));
-        p.out[((int64_t)k * F + f0 + fl) * Cn + c0 + cl] = lds[(int64_t)cl * CHS + src];
+    // ct is a power of two: (bin, frame, channel) from shifts, channel fastest
+    const int lct = __ffs(p.ct) - 1;
+    const int cl = threadIdx.x & (p.ct - 1);
+    const int rows = 2 * NB;  // row = 2*k + frame
+    if (cl < ctv) {
+        for (int r = threadIdx.x >> lct; r < rows; r += blockDim.x >> lct) {
+            const int fl = r & 1, k = r >> 1;
+            if (fl && !v1) continue;
+            const int src = fl == 0 ? k : (k == 0 ? N : (k == N / 2 ? N + 1 : N - k));
+            p.out[((int64_t)k * F + f0 + fl) * Cn + c0 + cl] = lds[(int64_t)cl * CHS + src];
+        }
     }
 }
 
@@ -221,7 +212,7 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_xspec(XspecArgs p) {
         const bool v1 = f1 < fe;
         FrameSrc a{xc, (int64_t)f0 * p.hop};
         FrameSrc b{v1 ? xc : nullptr, (int64_t)f1 * p.hop};
-        float2 v[C::BPT][4];
+        float2 v[C::VMAX];
         __syncthreads();  // previous iteration's unpack reads are done
         load_pair<N>(v, a, b, p.n_samples, p.W, p.window, p.detrend != 0, red, tid);
         fft<N, false, true, false>(v, buf, p.tw, tid);
@@ -286,7 +277,7 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_yacc(YaccArgs p) {
     for (int f = fb; f < fe; ++f) {
         FrameSrc a{ya, (int64_t)f * p.hop};
         FrameSrc b{yb, (int64_t)f * p.hop};
-        float2 v[C::BPT][4];
+        float2 v[C::VMAX];
         __syncthreads();
         load_pair<N>(v, a, b, p.n_samples, p.W, p.window, p.detrend != 0, red, tid);
         fft<N, false, true, false>(v, buf, p.tw, tid);
@@ -349,7 +340,7 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_rfft(RfftArgs p) {
     const int ca = 2 * blockIdx.x, cb = ca + 1;
     FrameSrc a{p.x + (int64_t)ca * p.ld, 0};
     FrameSrc b{cb < p.n_ch ? p.x + (int64_t)cb * p.ld : nullptr, 0};
-    float2 v[C::BPT][4];
+    float2 v[C::VMAX];
     load_pair<N>(v, a, b, p.n_samples, N, nullptr, false, red, tid);
     fft<N, false, true, false>(v, buf, p.tw, tid);
     for (int k = tid; k <= N / 2; k += C::NT) {
@@ -384,7 +375,7 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_deconv(DeconvArgs p) {
     const float* ya = p.y + (item * p.n_ch + ca) * p.ld;
     FrameSrc a{ya, 0};
     FrameSrc b{vb ? ya + p.ld : nullptr, 0};
-    float2 v[C::BPT][4];
+    float2 v[C::VMAX];
     load_pair<N>(v, a, b, p.n_samples, N, nullptr, false, red, tid);
     fft<N, false, true, false>(v, buf, p.tw, tid);
     const float2* Ra = p.r + (p.r_per_channel ? (int64_t)ca * NB : 0);
@@ -430,7 +421,7 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_fir_taps(FirTapsArgs p) {
     const int ka = 2 * blockIdx.x, kb = ka + 1;
     FrameSrc a{p.taps + (int64_t)ka * p.n_taps, 0};
     FrameSrc b{kb < p.n_filt ? p.taps + (int64_t)kb * p.n_taps : nullptr, 0};
-    float2 v[C::BPT][4];
+    float2 v[C::VMAX];
     load_pair<N>(v, a, b, p.n_taps, N, nullptr, false, red, tid);
     fft<N, false, true, false>(v, buf, p.tw, tid);
     const float inv = 1.0f / (float)N;
@@ -469,6 +460,9 @@ struct FirArgs {
 template <int N>
 __global__ __launch_bounds__(Cfg<N>::NT) void k_fir(FirArgs p) {
     using C = Cfg<N>;
+    constexpr int RZ = last_radix<N, false>();  // layout of the spectrum kept in registers
+    constexpr int RO = last_radix<N, true>();   // layout of the time-domain block
+    static_assert(RZ == first_radix<N, true>(), "forward output layout must feed the inverse");
     extern __shared__ __align__(16) float2 buf[];
     __shared__ float2 red[16];
     const int tid = threadIdx.x;
@@ -479,50 +473,23 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_fir(FirArgs p) {
     const bool vb = cb < p.n_ch;
     FrameSrc a{p.x + (int64_t)ca * p.ldx, out0 - T1};
     FrameSrc b{vb ? p.x + (int64_t)cb * p.ldx : nullptr, out0 - T1};
-    float2 z[C::BPT][4], v[C::BPT][4];
+    float2 z[C::VMAX], v[C::VMAX];
     load_pair<N>(z, a, b, p.n_samples, N, nullptr, false, red, tid);
-    constexpr bool REG = !C::ODD;
-    fft<N, false, true, REG>(z, buf, p.tw, tid);
-    if (!REG) {
-#pragma unroll
-        for (int i = 0; i < C::BPT; ++i) {
-            int j = tid + i * C::NT;
-            if (C::NB4 >= C::NT || j < C::NB4) {
-#pragma unroll
-                for (int t = 0; t < 4; ++t) z[i][t] = buf[j + t * C::NB4];
-            }
-        }
-    }
+    fft<N, false, true, true>(z, buf, p.tw, tid);  // spectrum stays in registers
     for (int k = 0; k < p.n_filt; ++k) {
         const float2* H = p.hs + (int64_t)k * N;
-#pragma unroll
-        for (int i = 0; i < C::BPT; ++i) {
-            int j = tid + i * C::NT;
-            if (C::NB4 >= C::NT || j < C::NB4) {
-#pragma unroll
-                for (int t = 0; t < 4; ++t) v[i][t] = cmul(z[i][t], H[j + t * C::NB4]);
-            }
-        }
-        __syncthreads();  // LDS free (previous filter's outputs were read)
-        fft<N, true, true, REG>(v, buf, p.tw, tid);
+        for_each_reg<N, RZ>(tid, [&](int idx, int n) { v[idx] = cmul(z[idx], H[n]); });
+        __syncthreads();  // LDS free: the previous transform's last pass has read it
+        fft<N, true, true, true, true>(v, buf, p.tw, tid);  // reversed radix order
         float* oa = p.y + ((int64_t)k * p.n_ch + ca) * p.ld_y;
         float* ob = oa + p.ld_y;
-#pragma unroll
-        for (int i = 0; i < C::BPT; ++i) {
-            int j = tid + i * C::NT;
-            if (C::NB4 >= C::NT || j < C::NB4) {
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    int n = j + t * C::NB4;
-                    float2 o = REG ? v[i][t] : buf[n];
-                    int64_t g = out0 + (n - T1);
-                    if (n >= T1 && g < p.n_samples) {
-                        oa[g] = o.x;
-                        if (vb) ob[g] = o.y;
-                    }
-                }
+        for_each_reg<N, RO>(tid, [&](int idx, int n) {
+            int64_t g = out0 + (n - T1);
+            if (n >= T1 && g < p.n_samples) {
+                oa[g] = v[idx].x;
+                if (vb) ob[g] = v[idx].y;
             }
-        }
+        });
     }
 }
 

@@ -360,3 +360,28 @@ def test_welch4096_fast_path_vs_oracle(overlap, n, n_cy):
                                                        overlap_percent=overlap, scaling=sc.name)
             e1, e2 = relmax(tf, rt, det), relmax(coh, rc, det)
             assert e1 < TOL and e2 < TOL, (mode, det, e1, e2)
+
+
+@pytest.mark.parametrize("n", [2**15, 2**17, 2**20])
+def test_big_fft_whole_signal(n):
+    """Lengths beyond one workgroup's LDS use the four-step path: whole-signal spectrum
+    (Signal.get_spectrum, FFT method) and regularised deconvolution of a long sweep."""
+    from dsptoolbox_amd.generators import exponential_sweep
+    rng = np.random.default_rng(n)
+    x3 = rng.standard_normal((n - 17, 3)) * 0.2  # zero padded to n by next_fast_len? use exact n below
+    x3 = np.vstack([x3, rng.standard_normal((17, 3)) * 0.2])
+    s = dsp.Signal(None, x3.copy(), 48000)
+    s.set_spectrum_parameters(method=SpectrumMethod.FFT, scaling=SpectrumScaling.FFTBackward)
+    f, sp = s.get_spectrum()
+    assert sp.shape == (n // 2 + 1, 3)
+    assert relmax(sp, np.fft.rfft(x3, axis=0)) < TOL
+    # deconvolution: 2 output channels, mono sweep
+    x = exponential_sweep(n, 48000)[:, None]
+    h = rng.standard_normal((2, 128)) * np.exp(-np.arange(128) / 20.0)
+    nf = 1 << int(np.ceil(np.log2(n + 128)))
+    X = np.fft.rfft(x[:, 0], nf)
+    y = np.stack([np.fft.irfft(X * np.fft.rfft(h[c], nf), nf)[:n] for c in range(2)], axis=1)
+    y += 1e-3 * rng.standard_normal(y.shape)
+    ir = dsp.transfer_functions.spectral_deconvolve(dsp.Signal(None, y, 48000), dsp.Signal(None, x, 48000))
+    ref = orc.spectral_deconvolve(y, x, 48000)
+    assert relmax(ir.time_data, ref) < TOL, relmax(ir.time_data, ref)
