@@ -232,10 +232,6 @@ def rfft_spectrum(time_data, n_fft: int, scale: float = 1.0):
     """rfft(time_data, n=n_fft, axis=0) * scale -> (n_fft/2+1, C) complex128."""
     xp = _planar_f32(time_data)
     n_ch, n = xp.shape
-    if n_fft & (n_fft - 1):
-        raise NotImplementedError(
-            f"whole-signal FFT length {n_fft} is not a power of two: not built on the GPU path yet "
-            "(Bluestein)")
     out = np.empty((n_fft // 2 + 1, n_ch), dtype=np.complex64)
     ctx = get_context()
     ctx.check(ctx.lib.ds_rfft(ctx.handle, _ptr(xp), n_ch, n, int(n_fft), float(scale), _ptr(out)),

@@ -12,6 +12,7 @@
 
 #include "../../include/dsptoolbox_amd.h"
 #include "kernels_bigfft.hpp"
+#include "kernels_bluestein.hpp"
 #include "kernels_finish.hpp"
 #include "kernels_generic.hpp"
 #include "kernels_welch4096.hpp"
@@ -26,6 +27,7 @@ struct ds_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::string err;
     std::map<int, float2*> tw;  // twiddle tables by length
+    std::map<std::pair<int64_t, int64_t>, float2*> blue;  // Bluestein chirp-filter spectra by (L, M)
     float2* w4_tables = nullptr;  // welch4096::host_tables()
     void* ws = nullptr;         // kernel workspace (spectra, partials)
     size_t ws_bytes = 0;
@@ -100,6 +102,7 @@ extern "C" void ds_destroy(ds_ctx* c) {
     (void)hipStreamSynchronize(c->stream);
     for (auto& kv : c->tw) (void)hipFree(kv.second);
     if (c->w4_tables) (void)hipFree(c->w4_tables);
+    for (auto& kv : c->blue) (void)hipFree(kv.second);
     for (auto& r : c->prof_recs) {
         (void)hipEventDestroy(r.a);
         (void)hipEventDestroy(r.b);
@@ -578,7 +581,7 @@ static int big_rows(ds_ctx* c, const float2* zin, float2* zout, int64_t N, int b
 }
 
 static int check_big_len(ds_ctx* c, int64_t n, const char* what) {
-    if (!is_pow2(n)) return fail(c, DS_ERR_UNSUP, std::string(what) + ": length is not a power of two (Bluestein not built yet)");
+    if (!is_pow2(n)) return fail(c, DS_ERR_ARG, std::string(what) + ": internal: not a power of two");
     if (n > kMaxBigFft) return fail(c, DS_ERR_UNSUP, std::string(what) + ": lengths above 2^24 are not built yet");
     return DS_OK;
 }
@@ -616,12 +619,107 @@ static int deconv_big(ds_ctx* c, const float* y, int n_items, int n_ch, int64_t 
     return DS_OK;
 }
 
+// ---- arbitrary lengths: Bluestein on top of the four-step FFT ------------------------
+static int64_t blue_len(int64_t L) {
+    int64_t m = (int64_t)1 << 15;  // smallest four-step length
+    while (m < 2 * L - 1) m <<= 1;
+    return m;
+}
+
+static int blue_filter(ds_ctx* c, int64_t L, int64_t M, const float2** out) {
+    auto key = std::make_pair(L, M);
+    auto it = c->blue.find(key);
+    if (it != c->blue.end()) {
+        *out = it->second;
+        return DS_OK;
+    }
+    float2 *bt = nullptr, *bf = nullptr;
+    HIPCHK(c, hipMalloc((void**)&bt, sizeof(float2) * M));
+    HIPCHK(c, hipMalloc((void**)&bf, sizeof(float2) * M));
+    hipLaunchKernelGGL(dsblue::k_filter, dim3(1024), dim3(256), 0, c->stream, bt, L, M);
+    HIPCHK(c, hipGetLastError());
+    CHK(big_cols(c, bt, nullptr, 0, 0, 0, bt, M, 1));
+    CHK(big_rows(c, bt, bf, M, 1));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipFree(bt));
+    c->blue[key] = bf;
+    *out = bf;
+    return DS_OK;
+}
+
+// X[batch][L] = DFT_L of (real channel pairs | complex zin[batch][L]); P, Q: [batch][M] scratch
+static int blue_dft(ds_ctx* c, const float* xreal, int n_ch, int64_t ld_real, int64_t n_samples,
+                    const float2* zin, int batch, int64_t L, int64_t M, float2* P, float2* Q, float2* X) {
+    const float2* bf;
+    CHK(blue_filter(c, L, M, &bf));
+    dsblue::PreArgs pa{xreal, ld_real, n_samples, n_ch, zin, P, L, M};
+    CHK(launch(c, "blue_pre", dsblue::k_pre, dim3(512, batch), 256, 0, pa));
+    CHK(big_cols(c, P, nullptr, 0, 0, 0, P, M, batch));
+    CHK(big_rows(c, P, Q, M, batch));
+    hipLaunchKernelGGL(dsblue::k_mul_filter, dim3(512, batch), dim3(256), 0, c->stream, Q, bf, M);
+    HIPCHK(c, hipGetLastError());
+    CHK(big_cols(c, Q, nullptr, 0, 0, 0, Q, M, batch));
+    CHK(big_rows(c, Q, P, M, batch));
+    hipLaunchKernelGGL(dsblue::k_post, dim3(512, batch), dim3(256), 0, c->stream, (const float2*)P, X, L, M);
+    HIPCHK(c, hipGetLastError());
+    return DS_OK;
+}
+
+static int check_blue_len(ds_ctx* c, int64_t L, const char* what) {
+    if (L < 2) return fail(c, DS_ERR_ARG, std::string(what) + ": length must be >= 2");
+    if (2 * L - 1 > kMaxBigFft) return fail(c, DS_ERR_UNSUP, std::string(what) + ": non-power-of-two lengths above 2^23 are not built yet");
+    return DS_OK;
+}
+
+static int rfft_blue(ds_ctx* c, const float* x, int n_ch, int64_t ld, int64_t n_samples, int64_t L,
+                     float scale, float2* spec) {
+    const int npair = (n_ch + 1) / 2;
+    const int64_t M = blue_len(L);
+    CHK(reserve(c, &c->ws, &c->ws_bytes, 2 * Carver::pad(sizeof(float2) * (size_t)npair * M) +
+                                             Carver::pad(sizeof(float2) * (size_t)npair * L)));
+    Carver cv(c->ws);
+    float2* P = cv.take<float2>((size_t)npair * M);
+    float2* Q = cv.take<float2>((size_t)npair * M);
+    float2* X = cv.take<float2>((size_t)npair * L);
+    CHK(blue_dft(c, x, n_ch, ld, n_samples, nullptr, npair, L, M, P, Q, X));
+    hipLaunchKernelGGL(dsblue::k_unpack, dim3(512, npair), dim3(256), 0, c->stream, (const float2*)X, L, n_ch,
+                       scale, spec);
+    HIPCHK(c, hipGetLastError());
+    return DS_OK;
+}
+
+static int deconv_blue(ds_ctx* c, const float* y, int n_items, int n_ch, int64_t ld, int64_t n_samples,
+                       int64_t L, const float2* r, int r_per_channel, int64_t n_out, int64_t ld_out,
+                       float* ir) {
+    const int npair = (n_ch + 1) / 2, batch = n_items * npair;
+    const int64_t M = blue_len(L);
+    CHK(reserve(c, &c->ws, &c->ws_bytes, 2 * Carver::pad(sizeof(float2) * (size_t)batch * M) +
+                                             2 * Carver::pad(sizeof(float2) * (size_t)batch * L)));
+    Carver cv(c->ws);
+    float2* P = cv.take<float2>((size_t)batch * M);
+    float2* Q = cv.take<float2>((size_t)batch * M);
+    float2* X = cv.take<float2>((size_t)batch * L);
+    float2* Y = cv.take<float2>((size_t)batch * L);
+    CHK(blue_dft(c, y, n_ch, ld, n_samples, nullptr, batch, L, M, P, Q, X));
+    hipLaunchKernelGGL(dsblue::k_mul_r, dim3(512, batch), dim3(256), 0, c->stream, X, L, n_ch, r_per_channel, r);
+    HIPCHK(c, hipGetLastError());
+    CHK(blue_dft(c, nullptr, n_ch, 0, 0, X, batch, L, M, P, Q, Y));
+    hipLaunchKernelGGL(dsblue::k_store, dim3(512, batch), dim3(256), 0, c->stream, (const float2*)Y, L, n_out,
+                       ld_out, n_ch, ir);
+    HIPCHK(c, hipGetLastError());
+    return DS_OK;
+}
+
 // ---- whole-signal rFFT, deconvolution ---------------------------------------
 extern "C" int ds_rfft_dev(ds_ctx* c, const float* x, int n_ch, int64_t ld, int64_t n_samples,
                            int n_fft, float scale, ds_c32* spec) {
     if (!c || !x || !spec) return fail(c, DS_ERR_ARG, "ds_rfft: null argument");
     if (n_ch <= 0 || n_samples <= 0 || ld < n_samples || n_samples > n_fft)
         return fail(c, DS_ERR_ARG, "ds_rfft: bad shape (n_samples must be <= n_fft)");
+    if (!is_pow2(n_fft)) {
+        CHK(check_blue_len(c, n_fft, "ds_rfft n_fft"));
+        return rfft_blue(c, x, n_ch, ld, n_samples, n_fft, scale, (float2*)spec);
+    }
     if (n_fft > kMaxFft) {
         CHK(check_big_len(c, n_fft, "ds_rfft n_fft"));
         return rfft_big(c, x, n_ch, ld, n_samples, n_fft, scale, (float2*)spec);
@@ -652,6 +750,11 @@ extern "C" int ds_deconv_dev(ds_ctx* c, const float* y, int n_items, int n_ch, i
     if (n_items <= 0 || n_ch <= 0 || n_samples <= 0 || ld < n_samples || n_samples > n_fft ||
         n_out <= 0 || n_out > n_fft || ld_out < n_out)
         return fail(c, DS_ERR_ARG, "ds_deconv: bad shape");
+    if (!is_pow2(n_fft)) {
+        CHK(check_blue_len(c, n_fft, "ds_deconv n_fft"));
+        return deconv_blue(c, y, n_items, n_ch, ld, n_samples, n_fft, (const float2*)r, r_per_channel, n_out,
+                           ld_out, ir);
+    }
     if (n_fft > kMaxFft) {
         CHK(check_big_len(c, n_fft, "ds_deconv n_fft"));
         return deconv_big(c, y, n_items, n_ch, ld, n_samples, n_fft, (const float2*)r, r_per_channel,

@@ -153,17 +153,29 @@ __global__ __launch_bounds__(256) void k_csm_gemm(CsmArgs p) {
         const int ci = 32 * I + (l & 31), cj = 32 * J + (l & 31);
         const float2* Xb = p.X + (int64_t)b * F * C;
         f32x16 re = {0}, im = {0};
-        for (int s = w; 2 * s < F; s += 4) {
-            int f = 2 * s + (l >> 5);
-            float2 a = make_float2(0.f, 0.f), bb = make_float2(0.f, 0.f);
-            if (f < F) {
-                if (ci < C) a = Xb[(int64_t)f * C + ci];
-                if (cj < C) bb = Xb[(int64_t)f * C + cj];
+        // k-steps (2 frames each) w, w+4, w+8, ... ; U of them are loaded before their 4*U MFMAs
+        // are issued, so the global-load latency hides behind the matrix pipe
+        constexpr int U = 4;
+        const int fo = l >> 5;
+        for (int s0 = w; 2 * s0 < F; s0 += 4 * U) {
+            float2 a[U], bb[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int f = 2 * (s0 + 4 * u) + fo;
+                a[u] = make_float2(0.f, 0.f);
+                bb[u] = make_float2(0.f, 0.f);
+                if (f < F) {
+                    if (ci < C) a[u] = Xb[(int64_t)f * C + ci];
+                    if (cj < C) bb[u] = Xb[(int64_t)f * C + cj];
+                }
             }
-            re = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bb.x, re, 0, 0, 0);
-            re = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bb.y, re, 0, 0, 0);
-            im = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bb.x, im, 0, 0, 0);
-            im = __builtin_amdgcn_mfma_f32_32x32x2f32(-a.x, bb.y, im, 0, 0, 0);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                re = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].x, bb[u].x, re, 0, 0, 0);
+                re = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].y, bb[u].y, re, 0, 0, 0);
+                im = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].y, bb[u].x, im, 0, 0, 0);
+                im = __builtin_amdgcn_mfma_f32_32x32x2f32(-a[u].x, bb[u].y, im, 0, 0, 0);
+            }
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {

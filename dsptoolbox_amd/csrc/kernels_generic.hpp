@@ -55,18 +55,45 @@ __device__ __forceinline__ void load_pair(float2 (&v)[Cfg<N>::VMAX], FrameSrc a,
                                           float2* red, int tid) {
     using C = Cfg<N>;
     float2 sum = make_float2(0.f, 0.f);
-    for_each_reg<N, C::R1>(tid, [&](int idx, int n) {
-        float2 z = make_float2(0.f, 0.f);
-        if (n < W) {
-            float w = window ? window[n] : 1.0f;
-            int64_t ga = a.start + n, gb = b.start + n;
-            if (a.base && ga >= 0 && ga < n_samples) z.x = a.base[ga] * w;
-            if (b.base && gb >= 0 && gb < n_samples) z.y = b.base[gb] * w;
-        }
-        v[idx] = z;
-        sum.x += z.x;
-        sum.y += z.y;
-    });
+    const int span = W < N ? W : N;
+    // interior frames: unconditional loads behind ONE team-uniform test (a per-load range
+    // test makes hipcc branch around every load and drain vmcnt each time)
+    const bool ia = a.base && a.start >= 0 && a.start + span <= n_samples;
+    const bool ib = b.base && b.start >= 0 && b.start + span <= n_samples;
+    if (ia && ib) {
+        const float* __restrict__ pa = a.base + a.start;
+        const float* __restrict__ pb = b.base + b.start;
+        for_each_reg<N, C::R1>(tid, [&](int idx, int n) {
+            float2 z = make_float2(0.f, 0.f);
+            if (n < W) {
+                float w = window ? window[n] : 1.0f;
+                z = make_float2(pa[n] * w, pb[n] * w);
+            }
+            v[idx] = z;
+            sum.x += z.x;
+            sum.y += z.y;
+        });
+    } else {
+        // edges / padding / missing partner: clamp the address, select the value
+        const float* __restrict__ pa = a.base ? a.base : window;  // any valid address
+        const float* __restrict__ pb = b.base ? b.base : pa;
+        const int64_t last = n_samples - 1;
+        for_each_reg<N, C::R1>(tid, [&](int idx, int n) {
+            float2 z = make_float2(0.f, 0.f);
+            if (n < W) {
+                float w = window ? window[n] : 1.0f;
+                int64_t ga = a.start + n, gb = b.start + n;
+                int64_t ca = ga < 0 ? 0 : (ga > last ? last : ga);
+                int64_t cb = gb < 0 ? 0 : (gb > last ? last : gb);
+                float xa = pa ? pa[a.base ? ca : 0] : 0.f, xb = pb ? pb[b.base ? cb : 0] : 0.f;
+                z.x = (a.base && ga == ca) ? xa * w : 0.f;
+                z.y = (b.base && gb == cb) ? xb * w : 0.f;
+            }
+            v[idx] = z;
+            sum.x += z.x;
+            sum.y += z.y;
+        });
+    }
     if (detrend) {
         for (int n = N + tid; n < W; n += C::NT) {  // samples cropped by nfft < W still count
             float w = window ? window[n] : 1.0f;

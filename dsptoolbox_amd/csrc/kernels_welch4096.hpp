@@ -3,7 +3,7 @@
 //
 // Data flow (all fp32, finish() in fp64):
 //   k_x   : one workgroup per PAIR of input frames (2p, 2p+1):
-//             Wp = FFT4096( x_2p w + i x_2p+1 w )      -> xs[p][0..4095]  (L2 resident)
+//             Wp = FFT4096( x_2p w + i x_2p+1 w )      -> xs[p][...] (L2 resident, thread-major)
 //             (|Wp[k]|^2 + |Wp[N-k]|^2)/2              -> px[p][0..2048]
 //   k_y   : workgroup = (output channel c, chunk q of frame pairs); per pair
 //             Zp = FFT4096( y_2p w + i y_2p+1 w )
@@ -139,7 +139,8 @@ struct Args {
     int stagger;        // k_y: s_sleep units for the second half of the grid (de-lockstep co-resident WGs)
     const float* window;
     const float2* twt;  // host_tables()
-    float2* xs;         // [n_pairs][4096]
+    float2* xs;         // [n_pairs][8][256][2]: bins (tid + 256*2g, tid + 256*(2g+1)) of thread tid
+                        // adjacent -> one coalesced 16-byte load per two bins
     float* px;          // [n_pairs][NB]
     float2* pxy;        // [n_chunks][n_ch][NB]
     float* pyy;         // [n_chunks][n_ch][NB]
@@ -239,9 +240,12 @@ __global__ __launch_bounds__(NT) void k_x(Args p) {
     }
     fft4096<false>(v, tw, buf, tw2, tid);
     if (p.detrend && tid == 0) v[pos16(0)] = make_float2(0.f, 0.f);
-    float2* xo = p.xs + (int64_t)pr * N;
+    float4* xo = reinterpret_cast<float4*>(p.xs + (int64_t)pr * N) + tid;
 #pragma unroll
-    for (int k3 = 0; k3 < 16; ++k3) xo[tid + 256 * k3] = v[pos16(k3)];
+    for (int g = 0; g < 8; ++g) {
+        float2 z0 = v[pos16(2 * g)], z1 = v[pos16(2 * g + 1)];
+        xo[256 * g] = make_float4(z0.x, z0.y, z1.x, z1.y);
+    }
     // symmetrised power for Sxx
     float* pw = reinterpret_cast<float*>(buf);
     __syncthreads();
@@ -329,9 +333,13 @@ __global__ __launch_bounds__(NT, OCC) void k_y(Args p) {
 #pragma unroll
                 for (int k3 = 0; k3 < 16; ++k3) xw[k3] = tw.w[k3 % 15];
             } else {
-                const float2* __restrict__ xp = p.xs + (int64_t)pr * N + tid;
+                const float4* __restrict__ xp = reinterpret_cast<const float4*>(p.xs + (int64_t)pr * N) + tid;
 #pragma unroll
-                for (int k3 = 0; k3 < 16; ++k3) xw[k3] = xp[256 * k3];
+                for (int g = 0; g < 8; ++g) {
+                    float4 q = xp[256 * g];
+                    xw[2 * g] = make_float2(q.x, q.y);
+                    xw[2 * g + 1] = make_float2(q.z, q.w);
+                }
             }
             fft4096<TWO_BUF>(v, tw, buf, tw2, tid);
 #pragma unroll
@@ -354,10 +362,11 @@ __global__ __launch_bounds__(NT, OCC) void k_y(Args p) {
                 window_pair<HALF_HOP>(v, raw, 2 * pr + 1 < p.n_frames, win);
             }
             fft4096<TWO_BUF>(v, tw, buf, tw2, tid);
-            const float2* __restrict__ xp = p.xs + (int64_t)pr * N + tid;
+            const float4* __restrict__ xp = reinterpret_cast<const float4*>(p.xs + (int64_t)pr * N) + tid;
 #pragma unroll
             for (int k3 = 0; k3 < 16; ++k3) {
-                float2 w = xp[256 * k3];
+                float4 q = xp[256 * (k3 >> 1)];
+                float2 w = (k3 & 1) ? make_float2(q.z, q.w) : make_float2(q.x, q.y);
                 float2 z = v[pos16(k3)];
                 T[k3].x = fmaf(w.x, z.x, fmaf(w.y, z.y, T[k3].x));   // conj(w) z
                 T[k3].y = fmaf(w.x, z.y, fmaf(-w.y, z.x, T[k3].y));

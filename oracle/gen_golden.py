@@ -307,6 +307,27 @@ def main():
         i += 1
     save("fir", dict(cases=cases, fs=fs), arrs)
 
+    # ------------------------------------------------------------ config 1: the example chirps
+    # BASELINE.json configs[0]: chirp_stereo.wav vs chirp.wav (16-bit PCM, 192 000 samples, 48 kHz):
+    # Welch H1 (nfft 4096, Hann, 50 %) and the regularised spectral deconvolution.
+    from scipy.io import wavfile
+    fsw, xi = wavfile.read(os.path.join(REF, "example_data", "chirp.wav"))
+    _, yi = wavfile.read(os.path.join(REF, "example_data", "chirp_stereo.wav"))
+    assert xi.dtype == np.int16 and yi.dtype == np.int16
+    xs_, ys_ = xi.astype(np.float64) / 32768, yi.astype(np.float64) / 32768
+    inp = dsp.Signal(None, xs_.copy(), int(fsw))
+    out = dsp.Signal(None, ys_.copy(), int(fsw))
+    inp.set_spectrum_parameters(window_length_samples=4096, window_type=Window.Hann,
+                                overlap_percent=50, detrend=True, scaling=S.FFTBackward)
+    sp = dsp.transfer_functions.compute_transfer_function(out, inp, 4096, TransferFunctionType.H1)
+    ir = dsp.transfer_functions.spectral_deconvolve(out, inp)
+    n = ir.time_data.shape[0]
+    save("chirp_pair", dict(cases=[dict(name="chirp_stereo vs chirp", n=int(n), fs=int(fsw),
+                                        ir_head=48000, ir_tail=4096)], fs=int(fsw)),
+         dict(x_int16=xi, y_int16=yi, tf=np.asarray(sp.spectral_data), coh=np.asarray(sp.coherence),
+              ir_head=ir.time_data[:48000], ir_tail=ir.time_data[-4096:],
+              ir_peak=np.array([np.max(np.abs(ir.time_data))])))
+
 
 if __name__ == "__main__":
     main()

@@ -130,6 +130,21 @@ def test_fir():
             close(y, ref, tol=1e-12)
 
 
+def test_chirp_pair_config1():
+    """BASELINE.json configs[0]: the reference's own example chirps (16-bit PCM fixtures)."""
+    meta, z = load_golden("chirp_pair")
+    c = meta["cases"][0]
+    x = z["x_int16"].astype(np.float64)[:, None] / 32768
+    y = z["y_int16"].astype(np.float64) / 32768
+    tf, coh = orc.compute_transfer_function(y, x, c["fs"], 4096, "H1", detrend=True)
+    close(tf, z["tf"], skip_dc=True, tol=1e-9)
+    close(coh, z["coh"], skip_dc=True, tol=1e-9)
+    ir = orc.spectral_deconvolve(y, x, c["fs"])
+    pk = float(z["ir_peak"][0])
+    assert np.max(np.abs(ir[: c["ir_head"]] - z["ir_head"])) < 1e-11 * pk
+    assert np.max(np.abs(ir[-c["ir_tail"]:] - z["ir_tail"])) < 1e-11 * pk
+
+
 @pytest.mark.parametrize("mode", ["H1", "H2", "H3"])
 def test_property_linearity_of_h1(mode):
     """Scaling the output by g scales H by g and leaves coherence unchanged."""
