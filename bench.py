@@ -164,7 +164,7 @@ def welch_h1(args, ctx, dist):
     def step():
         ctx.check(ctx.lib.ds_welch_tf_dev(
             ctx.handle, C.c_void_p(d_x.ptr), 1, n, C.c_void_p(d_y.ptr), n_cy, n, n, W, hop, n_frames,
-            C.c_void_p(d_w.ptr), int(args.detrend), 1, amp, norm_scale, factor, phys,
+            C.c_void_p(d_w.ptr), int(args.detrend), 0, 1, amp, norm_scale, factor, phys,
             C.c_void_p(d_tf.ptr), C.c_void_p(d_coh.ptr)), "ds_welch_tf_dev")
 
     samples_per_step = (n_cy + 1) * n

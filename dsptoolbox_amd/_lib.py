@@ -39,17 +39,17 @@ SIGNATURES = {
     "ds_stft_r2c": (C.c_int, [ctx_p, f32_p, i64, C.c_int, C.c_int, C.c_int, C.c_int, i64, C.c_int,
                               f32_p, C.c_int, C.c_float, C.c_float, C.c_int, c32_p]),
     "ds_welch_tf_dev": (C.c_int, [ctx_p, f32_p, C.c_int, i64, f32_p, C.c_int, i64, i64, C.c_int,
-                                  C.c_int, C.c_int, f32_p, C.c_int, C.c_int, C.c_int, C.c_double,
-                                  C.c_double, C.c_int, c32_p, f32_p]),
+                                  C.c_int, C.c_int, f32_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                  C.c_double, C.c_double, C.c_int, c32_p, f32_p]),
     "ds_welch_tf": (C.c_int, [ctx_p, f32_p, C.c_int, f32_p, C.c_int, i64, C.c_int, C.c_int, C.c_int,
-                              f32_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int,
-                              c32_p, f32_p]),
+                              f32_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double,
+                              C.c_int, c32_p, f32_p]),
     "ds_welch_psd_dev": (C.c_int, [ctx_p, f32_p, C.c_int, i64, i64, C.c_int, C.c_int, C.c_int, f32_p,
-                                   C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, f32_p]),
+                                   C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, f32_p]),
     "ds_welch_psd": (C.c_int, [ctx_p, f32_p, C.c_int, i64, C.c_int, C.c_int, C.c_int, f32_p, C.c_int,
-                               C.c_int, C.c_double, C.c_double, C.c_int, f32_p]),
+                               C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, f32_p]),
     "ds_welch_csd": (C.c_int, [ctx_p, f32_p, f32_p, C.c_int, i64, C.c_int, C.c_int, C.c_int, f32_p,
-                               C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, c32_p]),
+                               C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, c32_p]),
     "ds_csm_dev": (C.c_int, [ctx_p, f32_p, C.c_int, i64, i64, C.c_int, C.c_int, C.c_int, f32_p,
                              C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, c32_p]),
     "ds_csm": (C.c_int, [ctx_p, f32_p, C.c_int, i64, C.c_int, C.c_int, C.c_int, f32_p, C.c_int,

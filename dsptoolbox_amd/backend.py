@@ -30,6 +30,7 @@ from ._lib import DeviceBuffer, get_context
 from .standard.enums import SpectrumScaling, Window
 
 DS_TF = {"H1": 1, "H2": 2, "H3": 3}
+DS_AVG = {"mean": 0, "median": 1}
 DS_FB_PARALLEL, DS_FB_SEQUENTIAL, DS_FB_SUMMED = 1, 2, 3
 
 
@@ -65,9 +66,6 @@ def _welch_checks(window_length_samples, overlap_percent, average):
     assert overlap_percent >= 0 and overlap_percent < 100, \
         "overlap_percent should be between 0 and 100"
     assert average in ("mean", "median"), f"{average} is not valid. Use either mean or median"
-    if average == "median":
-        raise NotImplementedError(
-            "median averaging is not built on the GPU path yet (needs per-frame spectra)")
 
 
 def _welch_framing(n_samples: int, W: int, overlap_percent: float, window: np.ndarray):
@@ -95,6 +93,7 @@ def _welch(x, y, fs_hz: int, window_type, window_length_samples: int, overlap_pe
     window = _window_array(window_type, W)
     hop, n_frames = _welch_framing(x.shape[0], W, overlap_percent, window)
     amp, norm_scale, factor, phys = _finish_params(scaling, W, fs_hz, window)
+    avg = DS_AVG[average]
     ctx = get_context()
     xp = _planar_f32(x)
     n_ch, n = xp.shape
@@ -103,15 +102,16 @@ def _welch(x, y, fs_hz: int, window_type, window_length_samples: int, overlap_pe
     if auto:
         out = np.empty((B, n_ch), dtype=np.float32)
         ctx.check(ctx.lib.ds_welch_psd(ctx.handle, _ptr(xp), n_ch, n, W, hop, n_frames, _ptr(w32),
-                                       int(bool(detrend)), amp, norm_scale, factor, phys, _ptr(out)),
-                  "ds_welch_psd")
-        res = out.astype(np.float64)
+                                       int(bool(detrend)), avg, amp, norm_scale, factor, phys,
+                                       _ptr(out)), "ds_welch_psd")
+        # median averaging makes the reference's autospectrum complex128 (median_re + 1j*median_im)
+        res = out.astype(np.complex128 if avg else np.float64)
     else:
         yp = _planar_f32(y)
         out = np.empty((B, n_ch), dtype=np.complex64)
         ctx.check(ctx.lib.ds_welch_csd(ctx.handle, _ptr(xp), _ptr(yp), n_ch, n, W, hop, n_frames,
-                                       _ptr(w32), int(bool(detrend)), amp, norm_scale, factor, phys,
-                                       _ptr(out)), "ds_welch_csd")
+                                       _ptr(w32), int(bool(detrend)), avg, amp, norm_scale, factor,
+                                       phys, _ptr(out)), "ds_welch_csd")
         res = out.astype(np.complex128)
     return res if multi else res[:, 0]
 
@@ -140,8 +140,8 @@ def welch_transfer_function(output_td, input_td, fs_hz: int, window_length_sampl
     coh = np.empty((B, n_cy), dtype=np.float32)
     ctx = get_context()
     ctx.check(ctx.lib.ds_welch_tf(ctx.handle, _ptr(xp), n_cx, _ptr(yp), n_cy, n, W, hop, n_frames,
-                                  _ptr(w32), int(bool(detrend)), DS_TF[mode], amp, norm_scale, factor,
-                                  phys, _ptr(tf), _ptr(coh)), "ds_welch_tf")
+                                  _ptr(w32), int(bool(detrend)), DS_AVG[average], DS_TF[mode], amp,
+                                  norm_scale, factor, phys, _ptr(tf), _ptr(coh)), "ds_welch_tf")
     return tf.astype(np.complex128), coh.astype(np.float64)
 
 
@@ -192,6 +192,9 @@ def _csm_welch(time_data, sampling_rate_hz: int, window_length_samples: int, win
                overlap_percent, detrend: bool, average: str, scaling: SpectrumScaling):
     """-> (f (B,), csm (B, C, C) complex128)."""
     _welch_checks(window_length_samples, overlap_percent, average)
+    if average == "median":
+        raise NotImplementedError("median averaging of the cross-spectral matrix is not built on "
+                                  "the GPU path yet")
     W = int(window_length_samples)
     window = _window_array(window_type, W)
     xp = _planar_f32(time_data)

@@ -351,10 +351,12 @@ static WelchPlan plan_welch(int n_frames, int units) {
 // kind 0: tf+coh, 1: psd of x, 2: csd of (x[c], y[c])
 static int welch_common(ds_ctx* c, int kind, const float* x, int n_cx, int64_t ldx, const float* y,
                         int n_cy, int64_t ldy, int64_t n_samples, int W, int hop, int n_frames,
-                        const float* window, int detrend, int mode, int amp_sqrt,
+                        const float* window, int detrend, int average, int mode, int amp_sqrt,
                         double norm_scale, double factor, int halve_edges, float2* out_c,
                         float* out_r) {
     if (!c || !x || !window) return fail(c, DS_ERR_ARG, "welch: null argument");
+    if (average != DS_AVG_MEAN && average != DS_AVG_MEDIAN)
+        return fail(c, DS_ERR_ARG, "welch: average must be mean (0) or median (1)");
     if (kind != 1 && !y) return fail(c, DS_ERR_ARG, "welch: null output-signal pointer");
     if (n_cx <= 0 || n_samples <= 0 || hop <= 0 || hop > W || n_frames <= 0 || ldx < n_samples)
         return fail(c, DS_ERR_ARG, "welch: bad shape");
@@ -368,6 +370,44 @@ static int welch_common(ds_ctx* c, int kind, const float* x, int n_cx, int64_t l
     const int nb = W / 2 + 1;
     const int units = kind == 1 ? n_cx : (n_cy + 1) / 2;
     WelchPlan pl = plan_welch(n_frames, units);
+    if (average == DS_AVG_MEDIAN) {
+        // frame spectra of x (and y) -> per-bin medians -> the usual finish with bias n
+        // (n = F or F-1, odd; the reference's `csd /= sum((-1)**(n+1)/n)` multiplies by n)
+        const int nyc = kind == 1 ? 0 : n_cy;
+        const size_t lds = ((size_t)8 * 3 * n_frames + 48) * sizeof(float);
+        if (lds > 150 * 1024)
+            return fail(c, DS_ERR_UNSUP, "welch: median averaging over more than ~1590 frames is not built yet");
+        size_t mb = Carver::pad(sizeof(float2) * (size_t)n_cx * n_frames * nb) +
+                    Carver::pad(sizeof(float2) * (size_t)nyc * n_frames * nb) +
+                    Carver::pad(sizeof(float) * (size_t)pl.n_chunks * std::max(n_cx, nyc) * nb) +
+                    Carver::pad(sizeof(float) * (size_t)n_cx * nb) + Carver::pad(sizeof(float2) * (size_t)std::max(1, nyc) * nb) +
+                    Carver::pad(sizeof(float) * (size_t)std::max(1, nyc) * nb);
+        CHK(reserve(c, &c->ws, &c->ws_bytes, mb));
+        Carver cv(c->ws);
+        float2* xsp = cv.take<float2>((size_t)n_cx * n_frames * nb);
+        float2* ysp = nyc ? cv.take<float2>((size_t)nyc * n_frames * nb) : nullptr;
+        float* scratch = cv.take<float>((size_t)pl.n_chunks * std::max(n_cx, nyc) * nb);
+        float* mxx = cv.take<float>((size_t)n_cx * nb);
+        float2* mxy = cv.take<float2>((size_t)std::max(1, nyc) * nb);
+        float* myy = cv.take<float>((size_t)std::max(1, nyc) * nb);
+        {
+            XspecArgs ax{x, n_samples, ldx, n_cx, W, hop, n_frames, detrend, pl.fpc, window, tw, xsp, scratch};
+            DISPATCH_N(W, CHK(launch(c, "welch_xspec", k_xspec<NN>, dim3(pl.n_chunks, n_cx), Cfg<NN>::NT, Cfg<NN>::LDS_BYTES, ax)));
+        }
+        if (nyc) {
+            XspecArgs ay{y, n_samples, ldy, nyc, W, hop, n_frames, detrend, pl.fpc, window, tw, ysp, scratch};
+            DISPATCH_N(W, CHK(launch(c, "welch_xspec", k_xspec<NN>, dim3(pl.n_chunks, nyc), Cfg<NN>::NT, Cfg<NN>::LDS_BYTES, ay)));
+        }
+        MedianArgs m{xsp, ysp, n_cx, nyc, n_frames, nb, kind, mxx, mxy, myy};
+        CHK(launch(c, "welch_median", k_welch_median, dim3((nb + 7) / 8, kind == 1 ? n_cx : n_cy), 256, lds, m));
+        const int nbias = (n_frames & 1) ? n_frames : n_frames - 1;
+        WelchFinArgs f{mxx, mxy, myy, 1, 1, n_cx, n_cy, kind, mode,
+                       FinishPar{norm_scale * (double)std::max(1, nbias), factor, halve_edges, amp_sqrt, nb},
+                       out_c, out_r};
+        int64_t total = (int64_t)nb * (kind == 1 ? n_cx : n_cy);
+        CHK(launch(c, "welch_finish", k_welch_finish, dim3((unsigned)((total + 255) / 256)), 256, 0, f));
+        return DS_OK;
+    }
     const bool need_xs = kind != 1;
     size_t bytes = Carver::pad(sizeof(float) * (size_t)pl.n_chunks * n_cx * nb);
     if (need_xs) {
@@ -469,30 +509,30 @@ static int welch4096_run(ds_ctx* c, const float* x, int64_t ldx, const float* y,
 
 extern "C" int ds_welch_tf_dev(ds_ctx* c, const float* x, int n_cx, int64_t ldx, const float* y,
                                int n_cy, int64_t ldy, int64_t n_samples, int W, int hop, int n_frames,
-                               const float* window, int detrend, int mode, int amp_sqrt,
+                               const float* window, int detrend, int average, int mode, int amp_sqrt,
                                double norm_scale, double factor, int halve_edges, ds_c32* tf,
                                float* coh) {
     if (!tf || !coh) return fail(c, DS_ERR_ARG, "ds_welch_tf: null output");
-    if (c && W == 4096 && n_cx == 1 && welch4096::enabled())
+    if (c && W == 4096 && n_cx == 1 && average == DS_AVG_MEAN && welch4096::enabled())
         return welch4096_run(c, x, ldx, y, n_cy, ldy, n_samples, hop, n_frames, window, detrend, mode,
                              amp_sqrt, norm_scale, factor, halve_edges, (float2*)tf, coh);
     return welch_common(c, 0, x, n_cx, ldx, y, n_cy, ldy, n_samples, W, hop, n_frames, window, detrend,
-                        mode, amp_sqrt, norm_scale, factor, halve_edges, (float2*)tf, coh);
+                        average, mode, amp_sqrt, norm_scale, factor, halve_edges, (float2*)tf, coh);
 }
 extern "C" int ds_welch_psd_dev(ds_ctx* c, const float* x, int n_cx, int64_t ldx, int64_t n_samples,
                                 int W, int hop, int n_frames, const float* window, int detrend,
-                                int amp_sqrt, double norm_scale, double factor, int halve_edges,
-                                float* psd) {
+                                int average, int amp_sqrt, double norm_scale, double factor,
+                                int halve_edges, float* psd) {
     if (!psd) return fail(c, DS_ERR_ARG, "ds_welch_psd: null output");
     return welch_common(c, 1, x, n_cx, ldx, nullptr, 0, 0, n_samples, W, hop, n_frames, window, detrend,
-                        0, amp_sqrt, norm_scale, factor, halve_edges, nullptr, psd);
+                        average, 0, amp_sqrt, norm_scale, factor, halve_edges, nullptr, psd);
 }
 static int welch_csd_dev(ds_ctx* c, const float* x, const float* y, int n_ch, int64_t ld,
                          int64_t n_samples, int W, int hop, int n_frames, const float* window,
-                         int detrend, int amp_sqrt, double norm_scale, double factor,
+                         int detrend, int average, int amp_sqrt, double norm_scale, double factor,
                          int halve_edges, ds_c32* csd) {
-    return welch_common(c, 2, x, n_ch, ld, y, n_ch, ld, n_samples, W, hop, n_frames, window, detrend, 0,
-                        amp_sqrt, norm_scale, factor, halve_edges, (float2*)csd, nullptr);
+    return welch_common(c, 2, x, n_ch, ld, y, n_ch, ld, n_samples, W, hop, n_frames, window, detrend,
+                        average, 0, amp_sqrt, norm_scale, factor, halve_edges, (float2*)csd, nullptr);
 }
 
 // ---- CSM -------------------------------------------------------------------
@@ -916,8 +956,8 @@ extern "C" int ds_stft_r2c(ds_ctx* c, const float* x, int64_t n_samples, int n_c
 
 extern "C" int ds_welch_tf(ds_ctx* c, const float* x, int n_cx, const float* y, int n_cy,
                            int64_t n_samples, int W, int hop, int n_frames, const float* window,
-                           int detrend, int mode, int amp_sqrt, double norm_scale, double factor,
-                           int halve_edges, ds_c32* tf, float* coh) {
+                           int detrend, int average, int mode, int amp_sqrt, double norm_scale,
+                           double factor, int halve_edges, ds_c32* tf, float* coh) {
     if (!c || !x || !y || !window || !tf || !coh) return fail(c, DS_ERR_ARG, "ds_welch_tf: null argument");
     if (n_cx <= 0 || n_cy <= 0 || n_samples <= 0 || W <= 0) return fail(c, DS_ERR_ARG, "ds_welch_tf: bad shape");
     size_t nx = (size_t)n_cx * n_samples, ny = (size_t)n_cy * n_samples, no = (size_t)(W / 2 + 1) * n_cy;
@@ -933,13 +973,14 @@ extern "C" int ds_welch_tf(ds_ctx* c, const float* x, int n_cx, const float* y, 
     CHK(ds_upload(c, dy, y, ny * 4));
     CHK(ds_upload(c, dw, window, (size_t)W * 4));
     CHK(ds_welch_tf_dev(c, dx, n_cx, n_samples, dy, n_cy, n_samples, n_samples, W, hop, n_frames, dw,
-                        detrend, mode, amp_sqrt, norm_scale, factor, halve_edges, (ds_c32*)dtf, dcoh));
+                        detrend, average, mode, amp_sqrt, norm_scale, factor, halve_edges, (ds_c32*)dtf,
+                        dcoh));
     CHK(ds_download(c, tf, dtf, no * 8));
     return ds_download(c, coh, dcoh, no * 4);
 }
 
 extern "C" int ds_welch_psd(ds_ctx* c, const float* x, int n_cx, int64_t n_samples, int W, int hop,
-                            int n_frames, const float* window, int detrend, int amp_sqrt,
+                            int n_frames, const float* window, int detrend, int average, int amp_sqrt,
                             double norm_scale, double factor, int halve_edges, float* psd) {
     if (!c || !x || !window || !psd) return fail(c, DS_ERR_ARG, "ds_welch_psd: null argument");
     if (n_cx <= 0 || n_samples <= 0 || W <= 0) return fail(c, DS_ERR_ARG, "ds_welch_psd: bad shape");
@@ -951,15 +992,15 @@ extern "C" int ds_welch_psd(ds_ctx* c, const float* x, int n_cx, int64_t n_sampl
     float* dp = cv.take<float>(no);
     CHK(ds_upload(c, dx, x, nx * 4));
     CHK(ds_upload(c, dw, window, (size_t)W * 4));
-    CHK(ds_welch_psd_dev(c, dx, n_cx, n_samples, n_samples, W, hop, n_frames, dw, detrend, amp_sqrt,
-                         norm_scale, factor, halve_edges, dp));
+    CHK(ds_welch_psd_dev(c, dx, n_cx, n_samples, n_samples, W, hop, n_frames, dw, detrend, average,
+                         amp_sqrt, norm_scale, factor, halve_edges, dp));
     return ds_download(c, psd, dp, no * 4);
 }
 
 extern "C" int ds_welch_csd(ds_ctx* c, const float* x, const float* y, int n_ch, int64_t n_samples,
                             int W, int hop, int n_frames, const float* window, int detrend,
-                            int amp_sqrt, double norm_scale, double factor, int halve_edges,
-                            ds_c32* csd) {
+                            int average, int amp_sqrt, double norm_scale, double factor,
+                            int halve_edges, ds_c32* csd) {
     if (!c || !x || !y || !window || !csd) return fail(c, DS_ERR_ARG, "ds_welch_csd: null argument");
     if (n_ch <= 0 || n_samples <= 0 || W <= 0) return fail(c, DS_ERR_ARG, "ds_welch_csd: bad shape");
     size_t nx = (size_t)n_ch * n_samples, no = (size_t)(W / 2 + 1) * n_ch;
@@ -972,8 +1013,8 @@ extern "C" int ds_welch_csd(ds_ctx* c, const float* x, const float* y, int n_ch,
     CHK(ds_upload(c, dx, x, nx * 4));
     CHK(ds_upload(c, dy, y, nx * 4));
     CHK(ds_upload(c, dw, window, (size_t)W * 4));
-    CHK(welch_csd_dev(c, dx, dy, n_ch, n_samples, n_samples, W, hop, n_frames, dw, detrend, amp_sqrt,
-                      norm_scale, factor, halve_edges, (ds_c32*)dc));
+    CHK(welch_csd_dev(c, dx, dy, n_ch, n_samples, n_samples, W, hop, n_frames, dw, detrend, average,
+                      amp_sqrt, norm_scale, factor, halve_edges, (ds_c32*)dc));
     return ds_download(c, csd, dc, no * 8);
 }
 

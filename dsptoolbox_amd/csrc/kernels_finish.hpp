@@ -110,6 +110,90 @@ __global__ void k_welch_finish(WelchFinArgs p) {
     p.coh[idx] = (float)(axy2 / gxx / gyy);
 }
 
+// Median over frames (average="median", standard/_spectral_methods.py:153-162): per (channel, bin)
+// the median of the per-frame auto power |X_f|^2, or of the real and imaginary parts of the cross
+// power conj(X_f) Y_f, from the stored frame spectra xs[cx][f][b], ys[c][f][b].  One block = one
+// channel x 8 bins; the series sit in LDS and every element is ranked against all others (ties
+// by index), O(F^2) -- frame counts are a few hundred to a few thousand.  Results go into the
+// one-chunk partial layout k_welch_finish reads.
+struct MedianArgs {
+    const float2* xs;  // [n_cx][F][nb]
+    const float2* ys;  // [n_cy][F][nb] or nullptr (auto spectra of xs only)
+    int n_cx, n_cy, n_frames, nb, kind;  // kind as in WelchFinArgs
+    float* pxx;   // [n_cx][nb]
+    float2* pxy;  // [n_cy][nb]
+    float* pyy;   // [n_cy][nb]
+};
+
+__device__ __forceinline__ float median_of(const float* s, int F, int tid, int nt, float* out2) {
+    // rank every element; the elements of rank (F-1)/2 and F/2 are the two middle ones
+    const int r0 = (F - 1) / 2, r1 = F / 2;
+    for (int i = tid; i < F; i += nt) {
+        const float v = s[i];
+        int rank = 0;
+        for (int j = 0; j < F; ++j) {
+            const float u = s[j];
+            rank += (u < v || (u == v && j < i)) ? 1 : 0;
+        }
+        if (rank == r0) out2[0] = v;
+        if (rank == r1) out2[1] = v;
+    }
+    return 0.f;
+}
+
+__global__ __launch_bounds__(256) void k_welch_median(MedianArgs p) {
+    extern __shared__ float ser[];  // [8 bins][3 series][F]  (+ 8*3*2 results)
+    const int F = p.n_frames, nb = p.nb;
+    const int b0 = blockIdx.x * 8, c = blockIdx.y;
+    const int tid = threadIdx.x;
+    const bool have_y = p.ys != nullptr;
+    const int cx = p.n_cx == 1 ? 0 : c;
+    float* res = ser + (size_t)8 * 3 * F;  // [8][3][2]
+    // series 0: |X|^2 (kind 0: of xs[cx]; kind 1: of xs[c]); 1: Re conj(X) Y; 2: Im conj(X) Y; for kind 0
+    // |Y|^2 replaces series 0 in a second sweep below
+    const float2* X = p.xs + (size_t)(p.kind == 1 ? c : cx) * F * nb;
+    const float2* Y = have_y ? p.ys + (size_t)c * F * nb : nullptr;
+    for (int i = tid; i < 8 * F; i += 256) {
+        const int bl = i & 7, f = i >> 3, b = b0 + bl;
+        float2 xv = make_float2(0.f, 0.f), yv = make_float2(0.f, 0.f);
+        if (b < nb) {
+            xv = X[(size_t)f * nb + b];
+            if (have_y) yv = Y[(size_t)f * nb + b];
+        }
+        ser[(bl * 3 + 0) * F + f] = xv.x * xv.x + xv.y * xv.y;
+        ser[(bl * 3 + 1) * F + f] = xv.x * yv.x + xv.y * yv.y;  // Re conj(x) y
+        ser[(bl * 3 + 2) * F + f] = xv.x * yv.y - xv.y * yv.x;  // Im conj(x) y
+    }
+    __syncthreads();
+    const int ns = have_y ? 3 : 1;
+    for (int bl = 0; bl < 8; ++bl)
+        for (int q = 0; q < ns; ++q) median_of(ser + (bl * 3 + q) * F, F, tid, 256, res + (bl * 3 + q) * 2);
+    __syncthreads();
+    if (tid < 8 && b0 + tid < nb) {
+        const int b = b0 + tid;
+        const float* r = res + tid * 6;
+        const float mxx = 0.5f * (r[0] + r[1]);
+        if (p.kind == 1) {
+            p.pxx[(size_t)c * nb + b] = mxx;
+        } else {
+            if (p.n_cx == 1 ? c == 0 : true) p.pxx[(size_t)cx * nb + b] = mxx;
+            p.pxy[(size_t)c * nb + b] = make_float2(0.5f * (r[2] + r[3]), 0.5f * (r[4] + r[5]));
+        }
+    }
+    if (p.kind == 0) {  // |Y|^2 series
+        __syncthreads();
+        for (int i = tid; i < 8 * F; i += 256) {
+            const int bl = i & 7, f = i >> 3, b = b0 + bl;
+            float2 yv = b < nb ? Y[(size_t)f * nb + b] : make_float2(0.f, 0.f);
+            ser[(bl * 3 + 0) * F + f] = yv.x * yv.x + yv.y * yv.y;
+        }
+        __syncthreads();
+        for (int bl = 0; bl < 8; ++bl) median_of(ser + (bl * 3) * F, F, tid, 256, res + (bl * 3) * 2);
+        __syncthreads();
+        if (tid < 8 && b0 + tid < nb) p.pyy[(size_t)c * nb + b0 + tid] = 0.5f * (res[tid * 6] + res[tid * 6 + 1]);
+    }
+}
+
 // r[c][b] = eps ? conj(X)/(|X|^2 + eps[b]) : 1/X ; xspec is [b][c]
 __global__ void k_deconv_inverse(const float2* xspec, int n_ch, int nb, const float* eps,
                                  float2* r) {

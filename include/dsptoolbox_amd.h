@@ -46,6 +46,10 @@ typedef struct { float re, im; } ds_c32;
 #define DS_TF_H2 2
 #define DS_TF_H3 3
 
+/* Welch averaging over frames: _spectral_methods.py:151-162 */
+#define DS_AVG_MEAN   0
+#define DS_AVG_MEDIAN 1
+
 /* filter-bank modes: standard/enums.py:279-292 */
 #define DS_FB_PARALLEL   1
 #define DS_FB_SEQUENTIAL 2
@@ -96,7 +100,9 @@ int ds_stft_r2c(ds_ctx* ctx, const float* x, int64_t n_samples, int n_ch,
  * n_frames frames (frame k = samples [k*hop, k*hop+W), zero padded), then the
  * reference's finish(): S *= norm_scale (1, 1/W^2, 1/W for the three FFT
  * norms, enums.py:53-75); if halve_edges: S *= factor and bins 0, W/2 halved
- * (:165-168); if amp_sqrt: principal sqrt (:170-171).
+ * (:165-168); if amp_sqrt: principal sqrt (:170-171).  average = DS_AVG_MEDIAN takes the
+ * per-bin median over frames (real and imaginary parts separately) times the
+ * reference's bias n (:153-162) instead of the mean.
  *
  * ds_welch_tf: replaces compute_transfer_function,
  * transfer_functions/transfer_functions.py:419-539.  n_cx is 1 (one input for
@@ -107,24 +113,24 @@ int ds_stft_r2c(ds_ctx* ctx, const float* x, int64_t n_samples, int n_ch,
 int ds_welch_tf_dev(ds_ctx* ctx, const float* x_dev, int n_cx, int64_t ldx,
                     const float* y_dev, int n_cy, int64_t ldy, int64_t n_samples,
                     int W, int hop, int n_frames, const float* window_dev,
-                    int detrend, int mode, int amp_sqrt, double norm_scale,
+                    int detrend, int average, int mode, int amp_sqrt, double norm_scale,
                     double factor, int halve_edges, ds_c32* tf_dev, float* coh_dev);
 int ds_welch_tf(ds_ctx* ctx, const float* x, int n_cx, const float* y, int n_cy,
                 int64_t n_samples, int W, int hop, int n_frames, const float* window,
-                int detrend, int mode, int amp_sqrt, double norm_scale, double factor,
-                int halve_edges, ds_c32* tf, float* coh);
+                int detrend, int average, int mode, int amp_sqrt, double norm_scale,
+                double factor, int halve_edges, ds_c32* tf, float* coh);
 int ds_welch_psd_dev(ds_ctx* ctx, const float* x_dev, int n_cx, int64_t ldx,
                      int64_t n_samples, int W, int hop, int n_frames,
-                     const float* window_dev, int detrend, int amp_sqrt,
+                     const float* window_dev, int detrend, int average, int amp_sqrt,
                      double norm_scale, double factor, int halve_edges, float* psd_dev);
 int ds_welch_psd(ds_ctx* ctx, const float* x, int n_cx, int64_t n_samples, int W,
-                 int hop, int n_frames, const float* window, int detrend,
+                 int hop, int n_frames, const float* window, int detrend, int average,
                  int amp_sqrt, double norm_scale, double factor, int halve_edges,
                  float* psd);
 /* cross spectrum of channel pairs (x[c], y[c]) -- _welch(x, y): csd[b][c]     */
 int ds_welch_csd(ds_ctx* ctx, const float* x, const float* y, int n_ch,
                  int64_t n_samples, int W, int hop, int n_frames, const float* window,
-                 int detrend, int amp_sqrt, double norm_scale, double factor,
+                 int detrend, int average, int amp_sqrt, double norm_scale, double factor,
                  int halve_edges, ds_c32* csd);
 
 /* ---- cross-spectral matrix: replaces _csm_welch, _spectral_methods.py:285-371

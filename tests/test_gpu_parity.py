@@ -49,11 +49,6 @@ def test_welch_golden():
     for i, c in enumerate(meta["cases"]):
         d = x if c["data"] == "full" else x[: meta["ragged_len"]]
         sc = SpectrumScaling[c["scaling"]]
-        if c["average"] == "median":
-            with pytest.raises(NotImplementedError):
-                backend._welch(d, None, meta["fs"], WIN[c["window"]], c["W"], c["overlap"],
-                               c["detrend"], c["average"], sc)
-            continue
         a = backend._welch(d, None, meta["fs"], WIN[c["window"]], c["W"], c["overlap"],
                            c["detrend"], c["average"], sc)
         k = backend._welch(d[:, 0], d[:, 2], meta["fs"], WIN[c["window"]], c["W"], c["overlap"],
@@ -62,7 +57,8 @@ def test_welch_golden():
         ek = relmax(k, z[f"cross_{i}"], c["detrend"])
         worst = max(worst, ea, ek)
         assert ea < TOL and ek < TOL, (c, ea, ek)
-        assert a.dtype == np.float64 and k.dtype == np.complex128
+        # quirk 11: median averaging makes even the autospectrum complex128
+        assert a.dtype == z[f"auto_{i}"].dtype and k.dtype == np.complex128
     print("welch worst rel-max", worst)
 
 
@@ -292,6 +288,24 @@ def test_welch_all_lengths_vs_oracle(W):
                            SpectrumScaling.FFTBackward)
         r = orc.welch(x[:, 0], x[:, 2], 48000, "hann", W, 50, det, "mean", "FFTBackward")
         assert relmax(k, r, det) < TOL
+
+
+def test_transfer_function_median_vs_oracle():
+    rng = np.random.default_rng(77)
+    n = 30000
+    x = rng.standard_normal((n, 1)) * 0.3
+    y = np.stack([np.convolve(x[:, 0], rng.standard_normal(16))[:n] for _ in range(3)], axis=1)
+    y += 0.05 * rng.standard_normal(y.shape)
+    for mode in ("H1", "H2", "H3"):
+        for W, sc in ((512, SpectrumScaling.FFTBackward), (4096, SpectrumScaling.PowerSpectralDensity)):
+            tf, coh = backend.welch_transfer_function(y, x, 48000, W, mode, average="median", scaling=sc)
+            rt, rc = orc.compute_transfer_function(y, x, 48000, W, mode, average="median",
+                                                   scaling=sc.name)
+            # the median picks single-frame values: no averaging-down of the per-frame fp32 FFT
+            # error (~3e-7 per power quantity), and the coherence combines three of them
+            assert relmax(tf, rt, True) < TOL and relmax(coh, rc, True) < 3 * TOL, (mode, W)
+    with pytest.raises(NotImplementedError):
+        backend._csm_welch(y, 48000, 256, Window.Hann, 50, True, "median", SpectrumScaling.FFTBackward)
 
 
 def test_welch_too_long_window_raises():

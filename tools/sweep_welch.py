@@ -29,7 +29,7 @@ d_tf, d_coh = DeviceBuffer(ctx, B * n_cy * 8), DeviceBuffer(ctx, B * n_cy * 4)
 
 def step():
     ctx.check(ctx.lib.ds_welch_tf_dev(ctx.handle, C.c_void_p(d_x.ptr), 1, n, C.c_void_p(d_y.ptr), n_cy, n,
-                                      n, W, hop, n_frames, C.c_void_p(d_w.ptr), 1, 1, amp, norm_scale,
+                                      n, W, hop, n_frames, C.c_void_p(d_w.ptr), 1, 0, 1, amp, norm_scale,
                                       factor, phys, C.c_void_p(d_tf.ptr), C.c_void_p(d_coh.ptr)), "tf")
 
 
