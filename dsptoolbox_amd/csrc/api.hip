@@ -471,8 +471,8 @@ static int welch4096_run(ds_ctx* c, const float* x, int64_t ldx, const float* y,
     float2* pxy = cv.take<float2>((size_t)pl.n_chunks * n_cy * w4::NB);
     float* pyy = cv.take<float>((size_t)pl.n_chunks * n_cy * w4::NB);
     const bool half = hop == 2048;
-    w4::Args ax{x, n_samples, ldx, 1, hop, n_frames, pl.n_pairs, detrend, pl.n_chunks, pl.ppc,
-                w4::stagger_units(), window, c->w4_tables, xs, px, pxy, pyy};
+    w4::Args ax{x, n_samples, ldx, 1, hop, n_frames, pl.n_pairs, detrend, pl.n_chunks, pl.ppc, window,
+                c->w4_tables, xs, px, pxy, pyy};
     if (half)
         CHK(launch(c, "welch4096_x", w4::k_x<true>, dim3(pl.n_pairs), w4::NT, w4::LDS_BYTES, ax));
     else
@@ -489,15 +489,10 @@ static int welch4096_run(ds_ctx* c, const float* x, int64_t ldx, const float* y,
     ay.n_ch = n_cy;
     {
         dim3 grid(pl.n_chunks * n_cy);
-        const int occ = w4::occupancy_target();
-#define W4_LAUNCH(H, O) \
-    CHK(launch(c, "welch4096_main", w4::k_y<H, O>, grid, w4::NT, (O) <= 2 ? w4::LDS_BYTES_2 : w4::LDS_BYTES, ay))
-        if (half) {
-            if (occ == 2) W4_LAUNCH(true, 2); else if (occ == 3) W4_LAUNCH(true, 3); else W4_LAUNCH(true, 4);
-        } else {
-            if (occ == 2) W4_LAUNCH(false, 2); else if (occ == 3) W4_LAUNCH(false, 3); else W4_LAUNCH(false, 4);
-        }
-#undef W4_LAUNCH
+        if (half)
+            CHK(launch(c, "welch4096_main", w4::k_y<true>, grid, w4::NT, w4::LDS_BYTES_2, ay));
+        else
+            CHK(launch(c, "welch4096_main", w4::k_y<false>, grid, w4::NT, w4::LDS_BYTES_2, ay));
     }
     WelchFinArgs f{sxx, pxy, pyy, pl.n_chunks, 1, 1, n_cy, 0, mode,
                    FinishPar{norm_scale / (double)n_frames, factor, halve_edges, amp_sqrt, w4::NB},

@@ -136,7 +136,6 @@ struct Args {
     int64_t n_samples, ld;
     int n_ch, hop, n_frames, n_pairs, detrend;
     int n_chunks, ppc;  // k_y: pairs per chunk
-    int stagger;        // k_y: s_sleep units for the second half of the grid (de-lockstep co-resident WGs)
     const float* window;
     const float2* twt;  // host_tables()
     float2* xs;         // [n_pairs][8][256][2]: bins (tid + 256*2g, tid + 256*(2g+1)) of thread tid
@@ -277,10 +276,12 @@ __global__ void k_sxx(const float* px, int n_pairs, float* sxx) {
 }
 
 // ---- output channels ---------------------------------------------------------
-// OCC = workgroups per CU the register allocation must allow (256 threads = 1 wave per SIMD)
-template <bool HALF_HOP, int OCC>
-__global__ __launch_bounds__(NT, OCC) void k_y(Args p) {
-    constexpr bool TWO_BUF = OCC <= 2;  // 2 x 36 KB fit twice per CU
+// Two workgroups per CU (<= 256 VGPRs, 2 x 37 KB of LDS each).  Occupancy 3 (<= 168 VGPRs:
+// on-the-fly Hann window, input spectrum loaded where used) and 4 were built and measured:
+// the spills / exposed load latency cost more than the third workgroup hides (147 vs 108 us).
+template <bool HALF_HOP>
+__global__ __launch_bounds__(NT, 2) void k_y(Args p) {
+    constexpr bool TWO_BUF = true;
     extern __shared__ __align__(16) float2 lds[];
     float2* buf = lds;
     float2* tw2 = lds + (TWO_BUF ? 2 : 1) * BUF_C;
@@ -302,13 +303,6 @@ __global__ __launch_bounds__(NT, OCC) void k_y(Args p) {
     Tw tw;
     float win[16];
     init_tables(tw, win, tw2, p.window, p.twt, tid);
-    // Two workgroups share a CU and run the same program: left alone they stay in lockstep
-    // (both in the butterflies, then both in the LDS exchange, then both waiting on loads)
-    // and VALU, LDS and the vector-memory pipe take turns instead of overlapping.  Delay
-    // the second half of the grid by about half an iteration.
-    if (p.stagger > 0 && (int)blockIdx.x >= (int)(gridDim.x >> 1)) {
-        for (int i = 0; i < p.stagger; ++i) __builtin_amdgcn_s_sleep(16);
-    }
     const float* ch = p.sig + (int64_t)c * p.ld;
     const int p0 = q * p.ppc, p1 = min(p0 + p.ppc, p.n_pairs);
     float2 T[16];
@@ -351,28 +345,6 @@ __global__ __launch_bounds__(NT, OCC) void k_y(Args p) {
                 P[k3] = fmaf(z.x, z.x, fmaf(z.y, z.y, P[k3]));
             }
         }
-    } else {
-        // occupancy 3+: <= 168 VGPRs, no prefetch registers -- the third workgroup on the CU
-        // hides the load latency instead
-        for (int pr = p0; pr < p1; ++pr) {
-            float2 v[16];
-            {
-                Raw<HALF_HOP> raw;
-                load_raw<HALF_HOP>(raw, ch, p.n_samples, (int64_t)(2 * pr) * p.hop, p.hop, tid);
-                window_pair<HALF_HOP>(v, raw, 2 * pr + 1 < p.n_frames, win);
-            }
-            fft4096<TWO_BUF>(v, tw, buf, tw2, tid);
-            const float4* __restrict__ xp = reinterpret_cast<const float4*>(p.xs + (int64_t)pr * N) + tid;
-#pragma unroll
-            for (int k3 = 0; k3 < 16; ++k3) {
-                float4 q = xp[256 * (k3 >> 1)];
-                float2 w = (k3 & 1) ? make_float2(q.z, q.w) : make_float2(q.x, q.y);
-                float2 z = v[pos16(k3)];
-                T[k3].x = fmaf(w.x, z.x, fmaf(w.y, z.y, T[k3].x));   // conj(w) z
-                T[k3].y = fmaf(w.x, z.y, fmaf(-w.y, z.x, T[k3].y));
-                P[k3] = fmaf(z.x, z.x, fmaf(z.y, z.y, P[k3]));
-            }
-        }
     }
     if (p.detrend && tid == 0) P[0] = 0.f;  // xs bin 0 is already 0 -> T[0] = 0
     // fold k <-> N-k once per chunk, through LDS
@@ -403,25 +375,15 @@ inline bool enabled() {
     return on == 1;
 }
 
-inline int occupancy_target() {
-    const char* e = getenv("DSPTOOLBOX_AMD_WELCH_OCC");
-    int o = e ? atoi(e) : 2;
-    return o < 2 ? 2 : (o > 4 ? 4 : o);
-}
-
-inline int stagger_units() {
-    const char* e = getenv("DSPTOOLBOX_AMD_WELCH_STAGGER");
-    return e ? atoi(e) : 0;
-}
-
 inline int chunks_for(int n_pairs, int n_ch) {
     const char* e = getenv("DSPTOOLBOX_AMD_WELCH_CHUNKS");
     int want = e ? atoi(e) : 0;
     if (want <= 0) {
-        // ~768-1024 workgroups when there is enough work; chains of <= 32 pairs
-        want = (1024 + n_ch - 1) / n_ch;
+        // exactly two workgroups per CU (512 on the 256 CUs) when there is enough work: all of
+        // them are resident at once, no tail; fp32 accumulation chains stay <= 64 pairs
+        want = (512 + n_ch - 1) / n_ch;
         want = (want + 7) & ~7;
-        int by_len = (n_pairs + 31) / 32;
+        int by_len = (n_pairs + 63) / 64;
         if (want < by_len) want = (by_len + 7) & ~7;
     }
     if (want > n_pairs) want = n_pairs;

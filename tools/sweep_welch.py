@@ -33,16 +33,14 @@ def step():
                                       factor, phys, C.c_void_p(d_tf.ptr), C.c_void_p(d_coh.ptr)), "tf")
 
 
-variants = [(o, q) for o in (2, 3, 4) for q in (8, 16, 24, 32)]
+variants = [(2, q) for q in (4, 8, 16, 24, 32)]
 if os.environ.get("SWEEP_VARIANTS"):
     variants = [tuple(int(v) for v in s.split(":")) for s in os.environ["SWEEP_VARIANTS"].split(",")]
 res = {v: [] for v in variants}
 ctx.profile_enable(True)
 for r in range(rounds + 1):
     for v in variants:
-        os.environ["DSPTOOLBOX_AMD_WELCH_OCC"] = str(v[0])
         os.environ["DSPTOOLBOX_AMD_WELCH_CHUNKS"] = str(v[1])
-        os.environ["DSPTOOLBOX_AMD_WELCH_STAGGER"] = str(v[2]) if len(v) > 2 else "0"
         for _ in range(3):
             step()
         prof = ctx.profile_report()
@@ -51,6 +49,6 @@ for r in range(rounds + 1):
 for v in variants:
     main = sorted(d["welch4096_main"] for d in res[v])
     tot = sorted(sum(d.values()) for d in res[v])
-    print(f"occ={v[0]} chunks={v[1]:3d} stagger={v[2] if len(v) > 2 else 0:3d}  main med {main[len(main)//2]*1e3:7.1f} us  min {main[0]*1e3:7.1f} us   "
+    print(f"chunks={v[1]:3d}  main med {main[len(main)//2]*1e3:7.1f} us  min {main[0]*1e3:7.1f} us   "
           f"all kernels med {tot[len(tot)//2]*1e3:7.1f} us  "
           + " ".join(f"{k}={res[v][-1][k]*1e3:.1f}" for k in res[v][-1] if k != "welch4096_main"))
