@@ -584,8 +584,9 @@ extern "C" int ds_csm_spec(ds_ctx* c, const ds_c32* X, int n_bins, int n_frames,
 // ---- four-step FFT for 2^15 .. 2^24 points (kernels_bigfft.hpp) -------------------
 static int big_rows_ct(int n2) {
     int nt = dsfft::threads_for(n2);
-    size_t per = (size_t)(n2 + 33) * sizeof(float2);
+    size_t per = (size_t)(((n2 + n2 / 16 + 2 + 30) / 32) * 32 + 1) * sizeof(float2);
     int ct = std::min<int>({16, 1024 / nt, std::max<int>(1, (int)((70 * 1024) / per))});
+    while (ct & (ct - 1)) ct &= ct - 1;  // power of two: must divide N1
     return ct;
 }
 
@@ -610,7 +611,8 @@ static int big_rows(ds_ctx* c, const float2* zin, float2* zout, int64_t N, int b
     CHK(get_twiddles(c, n2, &tw));
     const int ct = big_rows_ct(n2);
     dsbig::RowsArgs a{zin, zout, N, N1, ct, tw};
-    size_t lds = (size_t)ct * (n2 + 33) * sizeof(float2);
+    size_t lds = 0;
+    DISPATCH_N(n2, lds = (size_t)ct * dsbig::ch_stride<NN>() * sizeof(float2));
     DISPATCH_N(n2, CHK(launch(c, "bigfft_rows", dsbig::k_big_rows<NN>, dim3(N1 / ct, batch), ct * Cfg<NN>::NT, lds, a)));
     return DS_OK;
 }

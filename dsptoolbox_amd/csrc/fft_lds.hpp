@@ -16,6 +16,13 @@
 // transform (last radix 4) is then the input layout of the following reversed transform,
 // which lets the FIR kernel go forward -> multiply -> inverse without touching LDS.
 //
+// LDS addressing: logical index i lives at lidx(i) = i + (i >> 4).  Without the extra slot per
+// 16 elements the first pass (sub-transform length 1) scatters its outputs with a stride of
+// 16 complex = 32 banks: every lane of a wave on the same two banks (rocprof: 67 % of the LDS
+// cycles of the 1024-point STFT kernel were bank conflicts).  Every access to a transform
+// buffer -- inside the passes and by the kernels that read the natural-order result -- goes
+// through lidx(); a buffer holds lds_len<N>() float2.
+//
 // Twiddles: one table per pass, rows [k][t] = exp(-2 pi i t k / (NS R)) (k < NS, t < R), so a
 // thread reads its R-1 twiddles as one contiguous row and a wave reads consecutive rows --
 // no scattered gathers.  tw_offset<N, REVERSED>(pass) locates a pass's table inside the
@@ -29,6 +36,9 @@
 namespace dsfft {
 
 __host__ __device__ constexpr int ilog2(int n) { return n <= 1 ? 0 : 1 + ilog2(n >> 1); }
+__host__ __device__ constexpr int lidx(int i) { return i + (i >> 4); }
+template <int N>
+__host__ __device__ constexpr int lds_len() { return N + N / 16 + 2; }
 __host__ __device__ constexpr int cmax(int a, int b) { return a > b ? a : b; }
 __host__ __device__ constexpr int cmin(int a, int b) { return a < b ? a : b; }
 
@@ -50,7 +60,7 @@ struct Plan {
     // registers per thread: the widest pass
     static constexpr int VMAX = cmax(cmax(N16 > 0 ? bpt(16) * 16 : 0, (REM >= 2) ? bpt(4) * 4 : 0),
                                      (REM == 1 || REM == 3) ? bpt(2) * 2 : 0);
-    static constexpr int LDS_BYTES = N * 8;
+    static constexpr int LDS_BYTES = lds_len<N>() * 8;
 };
 
 template <int N, bool REVERSED>
@@ -170,13 +180,21 @@ __device__ __forceinline__ void pass(float2 (&v)[Plan<N>::VMAX], float2* __restr
     using P = Plan<N>;
     constexpr int NBF = N / R, BPT = P::bpt(R);
     constexpr bool FULL = (NBF % P::NT) == 0;  // every thread owns BPT butterflies
+    // lidx(a + c) = lidx(a) + c + c/16 when c is a multiple of 16: one shift-add per butterfly,
+    // the rest are immediates
     if (!FROM_REG) {
 #pragma unroll
         for (int i = 0; i < BPT; ++i) {
             int j = tid + i * P::NT;
             if (FULL || j < NBF) {
+                if constexpr (NBF % 16 == 0) {
+                    const int b = lidx(j);
 #pragma unroll
-                for (int t = 0; t < R; ++t) v[i * R + t] = buf[j + t * NBF];
+                    for (int t = 0; t < R; ++t) v[i * R + t] = buf[b + t * (NBF + NBF / 16)];
+                } else {
+#pragma unroll
+                    for (int t = 0; t < R; ++t) v[i * R + t] = buf[lidx(j + t * NBF)];
+                }
             }
         }
     }
@@ -212,8 +230,18 @@ __device__ __forceinline__ void pass(float2 (&v)[Plan<N>::VMAX], float2* __restr
             if (FULL || j < NBF) {
                 int k = j & (NS - 1);
                 int o = (j - k) * R + k;
+                if constexpr (NS % 16 == 0) {
+                    const int b = lidx(o);
 #pragma unroll
-                for (int t = 0; t < R; ++t) buf[o + t * NS] = v[i * R + t];
+                    for (int t = 0; t < R; ++t) buf[b + t * (NS + NS / 16)] = v[i * R + t];
+                } else if constexpr (NS == 1 && R == 16) {
+                    const int b = 17 * j;  // lidx(16 j + t) = 17 j + t
+#pragma unroll
+                    for (int t = 0; t < R; ++t) buf[b + t] = v[i * R + t];
+                } else {
+#pragma unroll
+                    for (int t = 0; t < R; ++t) buf[lidx(o + t * NS)] = v[i * R + t];
+                }
             }
         }
         __syncthreads();

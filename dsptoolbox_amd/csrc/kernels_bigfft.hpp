@@ -19,7 +19,7 @@ namespace dsbig {
 using namespace dsfft;
 
 template <int N>
-__host__ __device__ constexpr int ch_stride() { return N + 33; }
+__host__ __device__ constexpr int ch_stride() { return ((lds_len<N>() + 30) / 32) * 32 + 1; }
 
 struct ColsArgs {
     // source: complex buffer `zin` (in place allowed) or, if xa != nullptr, two real
@@ -61,13 +61,13 @@ __global__ __launch_bounds__(1024) void k_big_cols(ColsArgs p) {
                 z.x = a[n];
                 if (b) z.y = b[n];
             }
-            lds[j * CHS + n1] = z;
+            lds[j * CHS + lidx(n1)] = z;
         }
     } else {
         const float2* zi = p.zin + bt * N;
         for (int i = threadIdx.x; i < total; i += blockDim.x) {
             int j = i % p.ct, n1 = i / p.ct;
-            lds[j * CHS + n1] = zi[(int64_t)n1 * p.n2 + j20 + j];
+            lds[j * CHS + lidx(n1)] = zi[(int64_t)n1 * p.n2 + j20 + j];
         }
     }
     __syncthreads();
@@ -79,12 +79,12 @@ __global__ __launch_bounds__(1024) void k_big_cols(ColsArgs p) {
     for (int k1 = tid; k1 < N1; k1 += C::NT) {
         double s, c;
         sincospi(-2.0 * (double)((int64_t)j2 * k1) / (double)N, &s, &c);
-        buf[k1] = cmul(buf[k1], make_float2((float)c, (float)s));
+        buf[lidx(k1)] = cmul(buf[lidx(k1)], make_float2((float)c, (float)s));
     }
     __syncthreads();
     for (int i = threadIdx.x; i < total; i += blockDim.x) {
         int j = i % p.ct, k1 = i / p.ct;
-        zo[(int64_t)k1 * p.n2 + j20 + j] = lds[j * CHS + k1];
+        zo[(int64_t)k1 * p.n2 + j20 + j] = lds[j * CHS + lidx(k1)];
     }
 }
 
@@ -113,7 +113,7 @@ __global__ __launch_bounds__(1024) void k_big_rows(RowsArgs p) {
     const int total = N2 * p.ct;
     for (int i = threadIdx.x; i < total; i += blockDim.x) {
         int j = i % p.ct, k2 = i / p.ct;
-        zo[(int64_t)k2 * p.n1 + k10 + j] = lds[j * CHS + k2];
+        zo[(int64_t)k2 * p.n1 + k10 + j] = lds[j * CHS + lidx(k2)];
     }
 }
 

@@ -118,8 +118,8 @@ __device__ __forceinline__ void load_pair(float2 (&v)[Cfg<N>::VMAX], FrameSrc a,
 template <int N>
 __device__ __forceinline__ void unpack_bin(const float2* __restrict__ buf, int k, float2& A,
                                            float2& B) {
-    float2 P = buf[k];
-    float2 Qc = buf[(N - k) & (N - 1)];  // Q = conj(Qc)
+    float2 P = buf[lidx(k)];
+    float2 Qc = buf[lidx((N - k) & (N - 1))];  // Q = conj(Qc)
     A = make_float2(0.5f * (P.x + Qc.x), 0.5f * (P.y - Qc.y));
     // B = -i (P - Q)/2,  P - Q = (P.x - Qc.x, P.y + Qc.y)
     B = make_float2(0.5f * (P.y + Qc.y), -0.5f * (P.x - Qc.x));
@@ -150,8 +150,10 @@ struct StftArgs {
     float2* out;
 };
 
+// per-channel image: padded transform buffer (+2 spare slots), rounded up to 1 (mod 32) complex
+// so the channel-fastest read-out hits distinct banks
 template <int N>
-__host__ __device__ constexpr int stft_ch_stride() { return N + 33; }
+__host__ __device__ constexpr int stft_ch_stride() { return ((lds_len<N>() + 2 + 30) / 32) * 32 + 1; }
 
 template <int N>
 __global__ __launch_bounds__(1024) void k_stft(StftArgs p) {
@@ -187,8 +189,8 @@ __global__ __launch_bounds__(1024) void k_stft(StftArgs p) {
                 A = make_float2(A.x * s, A.y * s);
                 B = make_float2(B.x * s, B.y * s);
             }
-            buf[k] = A;  // this thread owns the pair (k, N-k): in place
-            buf[k == 0 ? N : (k == N / 2 ? N + 1 : N - k)] = B;
+            buf[lidx(k)] = A;  // this thread owns the pair (k, N-k): in place
+            buf[k == 0 ? lidx(N) : (k == N / 2 ? lidx(N) + 1 : lidx(N - k))] = B;
         }
     }
     __syncthreads();
@@ -201,7 +203,7 @@ __global__ __launch_bounds__(1024) void k_stft(StftArgs p) {
         for (int r = threadIdx.x >> lct; r < rows; r += blockDim.x >> lct) {
             const int fl = r & 1, k = r >> 1;
             if (fl && !v1) continue;
-            const int src = fl == 0 ? k : (k == 0 ? N : (k == N / 2 ? N + 1 : N - k));
+            const int src = fl == 0 ? lidx(k) : (k == 0 ? lidx(N) : (k == N / 2 ? lidx(N) + 1 : lidx(N - k)));
             p.out[((int64_t)k * F + f0 + fl) * Cn + c0 + cl] = lds[(int64_t)cl * CHS + src];
         }
     }
@@ -412,10 +414,10 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_deconv(DeconvArgs p) {
         unpack_bin<N>(buf, k, A, B);
         float2 VA = cmul(A, Ra[k]), VB = cmul(B, Rb[k]);
         if (k == 0 || k == N / 2) {  // irfft ignores the imaginary part there
-            buf[k] = make_float2(VA.x, VB.x);
+            buf[lidx(k)] = make_float2(VA.x, VB.x);
         } else {
-            buf[k] = make_float2(VA.x - VB.y, VA.y + VB.x);      // VA + i VB
-            buf[N - k] = make_float2(VA.x + VB.y, VB.x - VA.y);  // conj(VA) + i conj(VB)
+            buf[lidx(k)] = make_float2(VA.x - VB.y, VA.y + VB.x);      // VA + i VB
+            buf[lidx(N - k)] = make_float2(VA.x + VB.y, VB.x - VA.y);  // conj(VA) + i conj(VB)
         }
     }
     __syncthreads();
@@ -424,7 +426,7 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_deconv(DeconvArgs p) {
     float* oa = p.ir + (item * p.n_ch + ca) * p.ld_out;
     float* ob = oa + p.ld_out;
     for (int n = tid; n < N && n < p.n_out; n += C::NT) {
-        float2 z = buf[n];
+        float2 z = buf[lidx(n)];
         oa[n] = z.x * inv;
         if (vb) ob[n] = z.y * inv;
     }

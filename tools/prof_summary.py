@@ -31,7 +31,7 @@ for f in find("*counter_collection.csv"):
             a[0] += v
             a[1] += 1
 for k in acc:
-    if "welch" not in k and "k_y" not in k and "k_x" not in k and "csm" not in k and "fir" not in k and "stft" not in k:
+    if not any(t in k for t in ("welch", "k_y", "k_x", "csm", "fir", "stft", "deconv", "big", "blue")):
         continue
     print(k)
     for c, (s, n) in sorted(acc[k].items()):
