@@ -156,7 +156,8 @@ int ds_csm_spec(ds_ctx* ctx, const ds_c32* X, int n_bins, int n_frames, int n_ch
 
 /* ---- whole-signal rFFT / regularised spectral division -------------------
  * ds_rfft: Signal.get_spectrum with SpectrumMethod.FFT, classes/signal.py:899-911
- * (n_fft power of two <= 2*ds_max_fft_len(); input zero padded to n_fft).
+ * (any n_fft >= 2: one-workgroup LDS FFT up to ds_max_fft_len(), four-step FFT for powers
+ * of two up to 2^24, Bluestein for every other length up to 2^23; input zero padded).
  * spec[b][c], (n_fft/2+1) x n_ch, multiplied by scale.
  *
  * ds_deconv: replaces _spectral_deconvolve,
