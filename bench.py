@@ -302,6 +302,30 @@ def deconv(args, ctx, dist):
     return step, items * n_ch * n, alg_bytes, "hbm", info, None, None, ("deconv",)
 
 
+def pmc_traffic(workload: str, kernel_hint: str):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary of
+    this same command (profiles/rNN_<workload>_rocprofv3_summary.txt; FETCH_SIZE and WRITE_SIZE
+    are KiB, collected in separate --pmc passes; on gfx950 FETCH_SIZE counts half of a coalesced
+    streaming read -- MI355X_MICROARCH.md, HBM section -- hence the factor 2).  None if absent."""
+    import glob
+    import re
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_{workload}_rocprofv3_summary.txt")))
+    if not files:
+        return None, None
+    text = open(files[-1]).read()
+    sect = text.split("== PMC", 1)[-1]
+    blocks = re.split(r"\n(?=\S)", sect)
+    for blk in blocks:
+        head = blk.splitlines()[0] if blk.strip() else ""
+        if kernel_hint not in head:
+            continue
+        f = re.search(r"FETCH_SIZE\s+([0-9.]+)", blk)
+        w = re.search(r"WRITE_SIZE\s+([0-9.]+)", blk)
+        if f and w:
+            return (2.0 * float(f.group(1)) + float(w.group(1))) * 1024.0, os.path.basename(files[-1])
+    return None, None
+
+
 # ---------------------------------------------------------------------------
 def main():
     args = parse_args()
@@ -345,6 +369,12 @@ def main():
         achieved = alg / launches_per_step / (dom_ms * 1e-3) / 1e12
         roof = dict(bound="mfma", achieved=achieved, peak=MFMA_F32_PEAK_TFLOPS, unit="TFLOP/s",
                     frac=achieved / MFMA_F32_PEAK_TFLOPS, traffic=None)
+    hint = {"welch4096_main": "k_y<", "welch_yacc": "k_yacc", "fir": "k_fir<", "csm_gemm": "k_csm_gemm",
+            "deconv": "k_deconv"}.get(dom, dom)
+    traffic, src = pmc_traffic(args.workload, hint)
+    roof["traffic"] = traffic
+    if src:
+        roof["traffic_source"] = src + " (2*FETCH_SIZE + WRITE_SIZE) KiB"
     roof["kernel"] = dom
     roof["kernel_avg_ms"] = dom_ms
     roof["algorithmic_per_launch"] = alg / launches_per_step
