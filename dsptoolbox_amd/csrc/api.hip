@@ -325,9 +325,13 @@ extern "C" int ds_stft_r2c_dev(ds_ctx* c, const float* x, int64_t n_samples, int
         lds = per * ct;
         threads = ct * Cfg<NN>::NT;
     });
-    StftArgs a{x, n_samples, ld, pad_front, n_ch, W, hop, n_frames, detrend, power, ct, window, tw,
+    // frame pairs per workgroup: enough workgroups to fill the chip several times over, then
+    // amortise the pipeline fill over a few pairs
+    const int n_fp = (n_frames + 1) / 2, n_ct = (n_ch + ct - 1) / ct;
+    int fpw = std::max(1, std::min(8, (int)(((int64_t)n_fp * n_ct) / 2048)));
+    StftArgs a{x, n_samples, ld, pad_front, n_ch, W, hop, n_frames, detrend, power, ct, fpw, window, tw,
                scale, edge_scale, (float2*)out};
-    dim3 grid((unsigned)((n_frames + 1) / 2), (unsigned)((n_ch + ct - 1) / ct));
+    dim3 grid((unsigned)((n_fp + fpw - 1) / fpw), (unsigned)n_ct);
     DISPATCH_N(nfft, CHK(launch(c, "stft", k_stft<NN>, grid, threads, lds, a)));
     return DS_OK;
 }

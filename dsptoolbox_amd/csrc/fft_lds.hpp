@@ -92,6 +92,15 @@ __device__ __forceinline__ float2 cmul_conj(float2 a, float2 b) {  // a * conj(b
 __device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
 __device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
 
+// Barrier between the threads of ONE transform.  A transform of <= 1024 points is owned by a
+// single wave (NT == 64): its LDS operations execute in program order, so no s_barrier is needed
+// (6 workgroup barriers per transform removed from the 1024-point STFT).  Kernels that let OTHER
+// teams touch a transform's buffer (cooperative loads / stores) place their own __syncthreads().
+template <int N>
+__device__ __forceinline__ void team_barrier() {
+    if constexpr (Plan<N>::NT > 64) __syncthreads();
+}
+
 template <bool INV>
 __device__ __forceinline__ void bfly2(float2& a, float2& b) {
     float2 s = cadd(a, b), d = csub(a, b);
@@ -223,7 +232,7 @@ __device__ __forceinline__ void pass(float2 (&v)[Plan<N>::VMAX], float2* __restr
         }
     }
     if (!TO_REG) {
-        if (!FROM_REG) __syncthreads();  // every read of this pass done before any write
+        if (!FROM_REG) team_barrier<N>();  // every read of this pass done before any write
 #pragma unroll
         for (int i = 0; i < BPT; ++i) {
             int j = tid + i * P::NT;
@@ -244,7 +253,7 @@ __device__ __forceinline__ void pass(float2 (&v)[Plan<N>::VMAX], float2* __restr
                 }
             }
         }
-        __syncthreads();
+        team_barrier<N>();
     }
 }
 

@@ -74,6 +74,7 @@ __global__ __launch_bounds__(1024) void k_big_cols(ColsArgs p) {
     float2* buf = lds + team * CHS;
     float2 v[C::VMAX];
     fft<N1, false, false, false>(v, buf, p.tw, tid);
+    team_barrier<N1>();
     // twiddle W_N^(j2 k1)
     const int j2 = j20 + team;
     for (int k1 = tid; k1 < N1; k1 += C::NT) {
@@ -110,6 +111,7 @@ __global__ __launch_bounds__(1024) void k_big_rows(RowsArgs p) {
     float2 v[C::VMAX];
     for_each_reg<N2, C::R1>(tid, [&](int idx, int n) { v[idx] = zi[n]; });
     fft<N2, false, true, false>(v, buf, p.tw, tid);
+    __syncthreads();  // all teams' spectra complete before the cooperative transposed store
     const int total = N2 * p.ct;
     for (int i = threadIdx.x; i < total; i += blockDim.x) {
         int j = i % p.ct, k2 = i / p.ct;

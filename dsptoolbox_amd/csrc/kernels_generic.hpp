@@ -44,17 +44,19 @@ __device__ __forceinline__ float2 block_sum2(float2 s, float2* red, int tid) {
     return s;
 }
 
-// Load two real frames as the real / imaginary part of the first-pass register set
-// (radix Cfg<N>::R1: v[i*R1 + t] = z[tid + i*NT + t*N/R1]):  z[n] = a[n] w[n] + i b[n] w[n]
-// for n < W, zero beyond W or outside [0, n_samples).  Optional detrend = subtract the
-// mean over the W windowed samples (also those cropped away when W > N).
+// Raw samples of two real frames in the first-pass register layout (radix Cfg<N>::R1:
+// slot i*R1 + t holds sample n = tid + i*NT + t*N/R1), zero for n >= W or outside
+// [0, n_samples).  Kept apart from the windowing so a kernel can issue the loads of the next
+// frame pair before it transforms the current one.
 template <int N>
-__device__ __forceinline__ void load_pair(float2 (&v)[Cfg<N>::VMAX], FrameSrc a, FrameSrc b,
-                                          int64_t n_samples, int W,
-                                          const float* __restrict__ window, bool detrend,
-                                          float2* red, int tid) {
+struct RawPair {
+    float a[Cfg<N>::VMAX], b[Cfg<N>::VMAX];
+};
+
+template <int N>
+__device__ __forceinline__ void load_raw_pair(RawPair<N>& r, FrameSrc a, FrameSrc b,
+                                              int64_t n_samples, int W, int tid) {
     using C = Cfg<N>;
-    float2 sum = make_float2(0.f, 0.f);
     const int span = W < N ? W : N;
     // interior frames: unconditional loads behind ONE team-uniform test (a per-load range
     // test makes hipcc branch around every load and drain vmcnt each time)
@@ -64,36 +66,46 @@ __device__ __forceinline__ void load_pair(float2 (&v)[Cfg<N>::VMAX], FrameSrc a,
         const float* __restrict__ pa = a.base + a.start;
         const float* __restrict__ pb = b.base + b.start;
         for_each_reg<N, C::R1>(tid, [&](int idx, int n) {
-            float2 z = make_float2(0.f, 0.f);
-            if (n < W) {
-                float w = window ? window[n] : 1.0f;
-                z = make_float2(pa[n] * w, pb[n] * w);
-            }
-            v[idx] = z;
-            sum.x += z.x;
-            sum.y += z.y;
+            r.a[idx] = n < W ? pa[n] : 0.f;
+            r.b[idx] = n < W ? pb[n] : 0.f;
         });
     } else {
         // edges / padding / missing partner: clamp the address, select the value
-        const float* __restrict__ pa = a.base ? a.base : window;  // any valid address
-        const float* __restrict__ pb = b.base ? b.base : pa;
+        const float* __restrict__ pa = a.base ? a.base : b.base;
+        const float* __restrict__ pb = b.base ? b.base : a.base;
         const int64_t last = n_samples - 1;
         for_each_reg<N, C::R1>(tid, [&](int idx, int n) {
-            float2 z = make_float2(0.f, 0.f);
-            if (n < W) {
-                float w = window ? window[n] : 1.0f;
+            float xa = 0.f, xb = 0.f;
+            if (n < W && pa) {
                 int64_t ga = a.start + n, gb = b.start + n;
                 int64_t ca = ga < 0 ? 0 : (ga > last ? last : ga);
                 int64_t cb = gb < 0 ? 0 : (gb > last ? last : gb);
-                float xa = pa ? pa[a.base ? ca : 0] : 0.f, xb = pb ? pb[b.base ? cb : 0] : 0.f;
-                z.x = (a.base && ga == ca) ? xa * w : 0.f;
-                z.y = (b.base && gb == cb) ? xb * w : 0.f;
+                float ta = pa[ca], tb = pb[cb];
+                xa = (a.base && ga == ca) ? ta : 0.f;
+                xb = (b.base && gb == cb) ? tb : 0.f;
             }
-            v[idx] = z;
-            sum.x += z.x;
-            sum.y += z.y;
+            r.a[idx] = xa;
+            r.b[idx] = xb;
         });
     }
+}
+
+// z[n] = a[n] w[n] + i b[n] w[n]; optional detrend = subtract the mean over the W windowed
+// samples (also those cropped away when W > N: they are read here).
+template <int N>
+__device__ __forceinline__ void window_pair(float2 (&v)[Cfg<N>::VMAX], const RawPair<N>& r, FrameSrc a,
+                                            FrameSrc b, int64_t n_samples, int W,
+                                            const float* __restrict__ window, bool detrend,
+                                            float2* red, int tid) {
+    using C = Cfg<N>;
+    float2 sum = make_float2(0.f, 0.f);
+    for_each_reg<N, C::R1>(tid, [&](int idx, int n) {
+        const float w = (window && n < W) ? window[n] : 1.0f;
+        float2 z = make_float2(r.a[idx] * w, r.b[idx] * w);
+        v[idx] = z;
+        sum.x += z.x;
+        sum.y += z.y;
+    });
     if (detrend) {
         for (int n = N + tid; n < W; n += C::NT) {  // samples cropped by nfft < W still count
             float w = window ? window[n] : 1.0f;
@@ -111,6 +123,16 @@ __device__ __forceinline__ void load_pair(float2 (&v)[Cfg<N>::VMAX], FrameSrc a,
             }
         });
     }
+}
+
+template <int N>
+__device__ __forceinline__ void load_pair(float2 (&v)[Cfg<N>::VMAX], FrameSrc a, FrameSrc b,
+                                          int64_t n_samples, int W,
+                                          const float* __restrict__ window, bool detrend,
+                                          float2* red, int tid) {
+    RawPair<N> r;
+    load_raw_pair<N>(r, a, b, n_samples, W, tid);
+    window_pair<N>(v, r, a, b, n_samples, W, window, detrend, red, tid);
 }
 
 // spectra of the two packed real sequences at bin k (0 <= k <= N/2), from the
@@ -132,7 +154,7 @@ struct Bins {
 };
 
 // ---------------------------------------------------------------- STFT
-// grid = (ceil(n_frames/2), ceil(n_ch/ct)); block = ct teams of Cfg<N>::NT threads;
+// grid = (ceil(ceil(n_frames/2)/fpw), ceil(n_ch/ct)); block = ct teams of Cfg<N>::NT threads;
 // out[(b*F + f)*C + c].
 // Team j transforms the frame pair (f0, f0+1) of channel c0 + j in its own LDS buffer and
 // separates the two half spectra IN PLACE (frame f0 bins at [k], frame f0+1 bins at [N-k],
@@ -143,7 +165,7 @@ struct Bins {
 struct StftArgs {
     const float* x;
     int64_t n_samples, ld, pad_front;
-    int n_ch, W, hop, n_frames, detrend, power, ct;
+    int n_ch, W, hop, n_frames, detrend, power, ct, fpw;  // fpw: frame pairs per workgroup
     const float* window;
     const float2* tw;
     float scale, edge_scale;
@@ -163,17 +185,40 @@ __global__ __launch_bounds__(1024) void k_stft(StftArgs p) {
     __shared__ float2 red_all[16][16];
     const int team = threadIdx.x / C::NT, tid = threadIdx.x % C::NT;
     float2* buf = lds + (int64_t)team * CHS;
-    const int f0 = blockIdx.x * 2, f1 = f0 + 1;
     const int c0 = blockIdx.y * p.ct;
     const int ctv = min(p.ct, p.n_ch - c0);  // valid channels in this tile
-    const bool v1 = f1 < p.n_frames;
-    {
-        const int c = c0 + team;
-        const float* xc = c < p.n_ch ? p.x + (int64_t)c * p.ld : nullptr;  // idle teams transform zeros
-        FrameSrc a{xc, (int64_t)f0 * p.hop - p.pad_front};
-        FrameSrc b{v1 ? xc : nullptr, (int64_t)f1 * p.hop - p.pad_front};
+    const int c = c0 + team;
+    const float* xc = c < p.n_ch ? p.x + (int64_t)c * p.ld : nullptr;  // idle teams transform zeros
+    const int64_t F = p.n_frames, Cn = p.n_ch;
+    const int lct = __ffs(p.ct) - 1;  // ct is a power of two
+    const int cl = threadIdx.x & (p.ct - 1);
+    // this workgroup's frame pairs: fp0, fp0 + 1, ... (fpw of them); the raw samples of the
+    // next pair are in flight while the current one is transformed and written out
+    const int n_fp = (p.n_frames + 1) >> 1;
+    const int fp0 = blockIdx.x * p.fpw, fp1 = min(fp0 + p.fpw, n_fp);
+    auto src = [&](int fp, FrameSrc& a, FrameSrc& b) {
+        const int f0 = 2 * fp, f1 = f0 + 1;
+        a = FrameSrc{xc, (int64_t)f0 * p.hop - p.pad_front};
+        b = FrameSrc{f1 < p.n_frames ? xc : nullptr, (int64_t)f1 * p.hop - p.pad_front};
+    };
+    RawPair<N> raw;
+    FrameSrc a, b;
+    if (fp0 < fp1) {
+        src(fp0, a, b);
+        load_raw_pair<N>(raw, a, b, p.n_samples, p.W, tid);
+    }
+    for (int fp = fp0; fp < fp1; ++fp) {
+        const int f0 = 2 * fp;
+        const bool v1 = f0 + 1 < p.n_frames;
         float2 v[C::VMAX];
-        load_pair<N>(v, a, b, p.n_samples, p.W, p.window, p.detrend != 0, red_all[team], tid);
+        src(fp, a, b);
+        __syncthreads();  // the previous pair has been streamed out of the LDS images
+        window_pair<N>(v, raw, a, b, p.n_samples, p.W, p.window, p.detrend != 0, red_all[team], tid);
+        if (fp + 1 < fp1) {
+            FrameSrc na, nb;
+            src(fp + 1, na, nb);
+            load_raw_pair<N>(raw, na, nb, p.n_samples, p.W, tid);
+        }
         fft<N, false, true, false>(v, buf, p.tw, tid);
         for (int k = tid; k <= N / 2; k += C::NT) {
             float2 A, B;
@@ -185,26 +230,22 @@ __global__ __launch_bounds__(1024) void k_stft(StftArgs p) {
                 A = make_float2((A.x * A.x + A.y * A.y) * e, 0.f);
                 B = make_float2((B.x * B.x + B.y * B.y) * e, 0.f);
             } else {
-                float s = p.scale * (edge ? p.edge_scale : 1.0f);
-                A = make_float2(A.x * s, A.y * s);
-                B = make_float2(B.x * s, B.y * s);
+                float sc = p.scale * (edge ? p.edge_scale : 1.0f);
+                A = make_float2(A.x * sc, A.y * sc);
+                B = make_float2(B.x * sc, B.y * sc);
             }
             buf[lidx(k)] = A;  // this thread owns the pair (k, N-k): in place
             buf[k == 0 ? lidx(N) : (k == N / 2 ? lidx(N) + 1 : lidx(N - k))] = B;
         }
-    }
-    __syncthreads();
-    const int64_t F = p.n_frames, Cn = p.n_ch;
-    // ct is a power of two: (bin, frame, channel) from shifts, channel fastest
-    const int lct = __ffs(p.ct) - 1;
-    const int cl = threadIdx.x & (p.ct - 1);
-    const int rows = 2 * NB;  // row = 2*k + frame
-    if (cl < ctv) {
-        for (int r = threadIdx.x >> lct; r < rows; r += blockDim.x >> lct) {
-            const int fl = r & 1, k = r >> 1;
-            if (fl && !v1) continue;
-            const int src = fl == 0 ? lidx(k) : (k == 0 ? lidx(N) : (k == N / 2 ? lidx(N) + 1 : lidx(N - k)));
-            p.out[((int64_t)k * F + f0 + fl) * Cn + c0 + cl] = lds[(int64_t)cl * CHS + src];
+        __syncthreads();
+        // (bin, frame, channel) from shifts, channel fastest; row = 2*k + frame
+        if (cl < ctv) {
+            for (int r = threadIdx.x >> lct; r < 2 * NB; r += blockDim.x >> lct) {
+                const int fl = r & 1, k = r >> 1;
+                if (fl && !v1) continue;
+                const int sidx = fl == 0 ? lidx(k) : (k == 0 ? lidx(N) : (k == N / 2 ? lidx(N) + 1 : lidx(N - k)));
+                p.out[((int64_t)k * F + f0 + fl) * Cn + c0 + cl] = lds[(int64_t)cl * CHS + sidx];
+            }
         }
     }
 }
