@@ -329,6 +329,7 @@ extern "C" int ds_stft_r2c_dev(ds_ctx* c, const float* x, int64_t n_samples, int
     // amortise the pipeline fill over a few pairs
     const int n_fp = (n_frames + 1) / 2, n_ct = (n_ch + ct - 1) / ct;
     int fpw = std::max(1, std::min(8, (int)(((int64_t)n_fp * n_ct) / 2048)));
+    if (const char* e = getenv("DSPTOOLBOX_AMD_STFT_FPW")) fpw = std::max(1, atoi(e));
     StftArgs a{x, n_samples, ld, pad_front, n_ch, W, hop, n_frames, detrend, power, ct, fpw, window, tw,
                scale, edge_scale, (float2*)out};
     dim3 grid((unsigned)((n_fp + fpw - 1) / fpw), (unsigned)n_ct);
@@ -814,6 +815,10 @@ extern "C" int ds_deconv_dev(ds_ctx* c, const float* y, int n_items, int n_ch, i
 static int fir_block_len(int n_taps) {
     int n = 1024;
     while (n < 4 * n_taps && n < kMaxFft) n <<= 1;
+    if (const char* e = getenv("DSPTOOLBOX_AMD_FIR_BLOCK")) {
+        int v = atoi(e);
+        if (v >= 1024 && v <= kMaxFft && is_pow2(v) && n_taps - 1 <= v / 2) n = v;
+    }
     return n;
 }
 
