@@ -95,6 +95,14 @@ class Dist:
         self.dist.broadcast_object_list(box, src=0)
         return box[0]
 
+    def finish(self):
+        if self.world > 1:
+            try:
+                self.dist.barrier()
+                self.dist.destroy_process_group()
+            except Exception:  # pragma: no cover - teardown only
+                pass
+
     def all_ok(self, ok: bool) -> bool:
         if self.world == 1:
             return ok
@@ -254,7 +262,7 @@ def csm(args, ctx, dist):
 
     def step():
         ctx.check(ctx.lib.ds_csm_dev(ctx.handle, C.c_void_p(d_x.ptr), n_ch, n, n, W, hop, n_frames,
-                                     C.c_void_p(d_w.ptr), 1, amp, norm_scale, factor, phys,
+                                     C.c_void_p(d_w.ptr), 1, 0, amp, norm_scale, factor, phys,
                                      C.c_void_p(d_c.ptr)), "ds_csm_dev")
 
     flops = B * n_ch * n_ch * n_frames * 8.0
@@ -355,6 +363,7 @@ def main():
     wall = dist.max_over_ranks(wall)
 
     if dist.rank != 0:
+        dist.finish()
         return
     ms_per_step = wall * 1e3 / args.steps
     value = units * dist.world / (wall / args.steps) / 1e6
@@ -379,7 +388,7 @@ def main():
     roof["kernel_avg_ms"] = dom_ms
     roof["algorithmic_per_launch"] = alg / launches_per_step
     out = {
-        "metric": "Msamples/s + GB/s vs HBM roofline, 64ch Welch H1 nfft=4096"
+        "metric": "Msamples/s + GB/s vs HBM roofline, 64ch Welch H1 nfft=4096 @1/2/4/8 GPU"
                   if args.workload == "welch_h1" else f"Msamples/s ({args.workload})",
         "value": value, "unit": "Msamples/s", "n_gpus": dist.world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
@@ -395,6 +404,7 @@ def main():
         out["cpu_baseline"] = cpu_baseline()
         out["cpu_baseline"]["host_cpus"] = os.cpu_count()
     print(json.dumps(out), flush=True)
+    dist.finish()
 
 
 if __name__ == "__main__":

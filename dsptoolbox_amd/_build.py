@@ -21,21 +21,41 @@ def _newest_source_mtime() -> float:
     return newest
 
 
+def _up_to_date() -> bool:
+    return os.path.exists(LIB_PATH) and os.path.getmtime(LIB_PATH) >= _newest_source_mtime()
+
+
 def build_library(force: bool = False, verbose: bool = True) -> str:
-    """hipcc --offload-arch=gfx950 -> dsptoolbox_amd/lib/libdsptoolbox_amd.so"""
+    """hipcc --offload-arch=gfx950 -> dsptoolbox_amd/lib/libdsptoolbox_amd.so
+
+    Safe to call from several ranks at once: one process compiles (file lock) into a
+    temporary name and renames it into place, the others wait and reuse the result."""
     os.makedirs(LIB_DIR, exist_ok=True)
-    if (not force and os.path.exists(LIB_PATH)
-            and os.path.getmtime(LIB_PATH) >= _newest_source_mtime()):
+    if not force and _up_to_date():
         return LIB_PATH
-    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    # -fno-slp-vectorize: hipcc's SLP pass turns the complex butterflies into v_pk_* pairs
-    # glued together with ~270 v_mov per FFT; scalar fp32 VALU code is 25 % faster here
-    # (measured on MI355X, profiles/).
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-shared",
-           "-fPIC", "-o", LIB_PATH] + SOURCES + ["-ldl"]
-    if verbose:
-        print(" ".join(cmd), flush=True)
-    subprocess.check_call(cmd)
+    import fcntl
+    with open(os.path.join(LIB_DIR, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and _up_to_date():  # another rank built it while we waited
+                return LIB_PATH
+            hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+            # -fno-slp-vectorize: hipcc's SLP pass turns the complex butterflies into v_pk_*
+            # pairs glued together with ~270 v_mov per FFT; scalar fp32 VALU code is 25 %
+            # faster here (measured on MI355X, profiles/).
+            tmp = LIB_PATH + f".tmp{os.getpid()}"
+            cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize",
+                   "-shared", "-fPIC", "-o", tmp] + SOURCES + ["-ldl"]
+            if verbose:
+                print(" ".join(cmd), file=sys.stderr, flush=True)
+            try:
+                subprocess.check_call(cmd, stdout=sys.stderr)
+                os.replace(tmp, LIB_PATH)
+            finally:
+                if os.path.exists(tmp):
+                    os.remove(tmp)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
     return LIB_PATH
 
 

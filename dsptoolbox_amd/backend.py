@@ -192,9 +192,6 @@ def _csm_welch(time_data, sampling_rate_hz: int, window_length_samples: int, win
                overlap_percent, detrend: bool, average: str, scaling: SpectrumScaling):
     """-> (f (B,), csm (B, C, C) complex128)."""
     _welch_checks(window_length_samples, overlap_percent, average)
-    if average == "median":
-        raise NotImplementedError("median averaging of the cross-spectral matrix is not built on "
-                                  "the GPU path yet")
     W = int(window_length_samples)
     window = _window_array(window_type, W)
     xp = _planar_f32(time_data)
@@ -206,7 +203,8 @@ def _csm_welch(time_data, sampling_rate_hz: int, window_length_samples: int, win
     w32 = window.astype(np.float32)
     ctx = get_context()
     ctx.check(ctx.lib.ds_csm(ctx.handle, _ptr(xp), n_ch, n, W, hop, n_frames, _ptr(w32),
-                             int(bool(detrend)), amp, norm_scale, factor, phys, _ptr(out)), "ds_csm")
+                             int(bool(detrend)), DS_AVG[average], amp, norm_scale, factor, phys,
+                             _ptr(out)), "ds_csm")
     return np.fft.rfftfreq(W, 1 / sampling_rate_hz), out.astype(np.complex128)
 
 

@@ -302,6 +302,15 @@ static int check_fft_len(ds_ctx* c, int n, const char* what) {
     return DS_OK;
 }
 
+static size_t stft_big_ws(int n_ch, int n_frames, int64_t nfft);
+static int stft_big(ds_ctx* c, Carver& cv, const float* x, int n_ch, int64_t ld, int64_t n_samples,
+                    int W, int hop, int64_t nfft, int64_t pad_front, int n_frames, const float* window,
+                    int detrend, float scale, float edge_scale, int power, int layout, float2* out);
+static int welch_big(ds_ctx* c, int kind, const float* x, int n_cx, int64_t ldx, const float* y,
+                     int n_cy, int64_t ldy, int64_t n_samples, int W, int hop, int n_frames,
+                     const float* window, int detrend, int average, int mode, int amp_sqrt,
+                     double norm_scale, double factor, int halve_edges, float2* out_c, float* out_r);
+
 // ---- STFT ------------------------------------------------------------------
 extern "C" int ds_stft_r2c_dev(ds_ctx* c, const float* x, int64_t n_samples, int n_ch, int64_t ld,
                                int W, int hop, int nfft, int64_t pad_front, int n_frames,
@@ -310,6 +319,12 @@ extern "C" int ds_stft_r2c_dev(ds_ctx* c, const float* x, int64_t n_samples, int
     if (!c || !x || !out || !window) return fail(c, DS_ERR_ARG, "ds_stft_r2c: null argument");
     if (n_ch <= 0 || n_samples <= 0 || W <= 0 || hop <= 0 || n_frames <= 0 || ld < n_samples)
         return fail(c, DS_ERR_ARG, "ds_stft_r2c: bad shape");
+    if (nfft > kMaxFft && is_pow2(nfft)) {  // four-step transform per frame pair
+        CHK(reserve(c, &c->ws, &c->ws_bytes, stft_big_ws(n_ch, n_frames, nfft)));
+        Carver cv(c->ws);
+        return stft_big(c, cv, x, n_ch, ld, n_samples, W, hop, nfft, pad_front, n_frames, window, detrend,
+                        scale, edge_scale, power, 1, (float2*)out);
+    }
     CHK(check_fft_len(c, nfft, "ds_stft_r2c nfft"));
     const float2* tw;
     CHK(get_twiddles(c, nfft, &tw));
@@ -369,6 +384,9 @@ static int welch_common(ds_ctx* c, int kind, const float* x, int n_cx, int64_t l
         return fail(c, DS_ERR_ARG, "welch: input must have 1 channel or as many as the output");
     if (kind == 0 && (mode < DS_TF_H1 || mode > DS_TF_H3))
         return fail(c, DS_ERR_ARG, "welch: unsupported transfer function type");
+    if (W > kMaxFft && is_pow2(W))
+        return welch_big(c, kind, x, n_cx, ldx, y, n_cy, ldy, n_samples, W, hop, n_frames, window, detrend,
+                         average, mode, amp_sqrt, norm_scale, factor, halve_edges, out_c, out_r);
     CHK(check_fft_len(c, W, "welch window length"));
     const float2* tw;
     CHK(get_twiddles(c, W, &tw));
@@ -537,19 +555,54 @@ static int welch_csd_dev(ds_ctx* c, const float* x, const float* y, int n_ch, in
 
 // ---- CSM -------------------------------------------------------------------
 extern "C" int ds_csm_dev(ds_ctx* c, const float* x, int n_ch, int64_t ld, int64_t n_samples, int W,
-                          int hop, int n_frames, const float* window, int detrend, int amp_sqrt,
-                          double norm_scale, double factor, int halve_edges, ds_c32* csm) {
+                          int hop, int n_frames, const float* window, int detrend, int average,
+                          int amp_sqrt, double norm_scale, double factor, int halve_edges, ds_c32* csm) {
     if (!c || !x || !window || !csm) return fail(c, DS_ERR_ARG, "ds_csm: null argument");
     if (n_ch < 1 || n_samples <= 0 || hop <= 0 || hop > W || n_frames <= 0 || ld < n_samples)
         return fail(c, DS_ERR_ARG, "ds_csm: bad shape");
-    CHK(check_fft_len(c, W, "ds_csm window length"));
+    if (average != DS_AVG_MEAN && average != DS_AVG_MEDIAN)
+        return fail(c, DS_ERR_ARG, "ds_csm: average must be mean (0) or median (1)");
+    const bool big = W > kMaxFft && is_pow2(W);
+    if (!big) CHK(check_fft_len(c, W, "ds_csm window length"));
     const int nb = W / 2 + 1;
-    // the STFT buffer X[b][f][c] lives in the io workspace tail? no: own workspace
-    size_t bytes = sizeof(float2) * (size_t)nb * n_frames * n_ch;
+    if (average == DS_AVG_MEDIAN) {
+        // spectra of every frame [c][F][nb] -> per-pair, per-bin medians
+        const size_t lds = ((size_t)8 * 2 * n_frames + 32) * sizeof(float);
+        if (lds > 150 * 1024)
+            return fail(c, DS_ERR_UNSUP, "ds_csm: median averaging over more than ~2390 frames is not built yet");
+        size_t bytes = Carver::pad(sizeof(float2) * (size_t)n_ch * n_frames * nb);
+        WelchPlan pl = plan_welch(n_frames, n_ch);
+        bytes += big ? stft_big_ws(n_ch, n_frames, W) : Carver::pad(sizeof(float) * (size_t)pl.n_chunks * n_ch * nb);
+        CHK(reserve(c, &c->ws, &c->ws_bytes, bytes));
+        Carver cv(c->ws);
+        float2* xsp = cv.take<float2>((size_t)n_ch * n_frames * nb);
+        if (big) {
+            CHK(stft_big(c, cv, x, n_ch, ld, n_samples, W, hop, W, 0, n_frames, window, detrend, 1.0f, 1.0f, 0, 0, xsp));
+        } else {
+            const float2* tw;
+            CHK(get_twiddles(c, W, &tw));
+            float* scratch = cv.take<float>((size_t)pl.n_chunks * n_ch * nb);
+            XspecArgs ax{x, n_samples, ld, n_ch, W, hop, n_frames, detrend, pl.fpc, window, tw, xsp, scratch};
+            DISPATCH_N(W, CHK(launch(c, "welch_xspec", k_xspec<NN>, dim3(pl.n_chunks, n_ch), Cfg<NN>::NT, Cfg<NN>::LDS_BYTES, ax)));
+        }
+        const int nbias = (n_frames & 1) ? n_frames : n_frames - 1;
+        CsmMedianArgs m{xsp, n_ch, n_frames,
+                        FinishPar{norm_scale * (double)std::max(1, nbias), factor, halve_edges, amp_sqrt, nb},
+                        (float2*)csm};
+        CHK(launch(c, "csm_median", k_csm_median, dim3((nb + 7) / 8, n_ch * (n_ch + 1) / 2), 256, lds, m));
+        return DS_OK;
+    }
+    // the STFT buffer X[b][f][c] (+ the four-step scratch for long windows) in the workspace
+    size_t bytes = Carver::pad(sizeof(float2) * (size_t)nb * n_frames * n_ch);
+    if (big) bytes += stft_big_ws(n_ch, n_frames, W);
     CHK(reserve(c, &c->ws, &c->ws_bytes, bytes));
-    float2* X = (float2*)c->ws;
-    CHK(ds_stft_r2c_dev(c, x, n_samples, n_ch, ld, W, hop, W, 0, n_frames, window, detrend, 1.0f, 1.0f,
-                        0, (ds_c32*)X));
+    Carver cv(c->ws);
+    float2* X = cv.take<float2>((size_t)nb * n_frames * n_ch);
+    if (big)
+        CHK(stft_big(c, cv, x, n_ch, ld, n_samples, W, hop, W, 0, n_frames, window, detrend, 1.0f, 1.0f, 0, 1, X));
+    else
+        CHK(ds_stft_r2c_dev(c, x, n_samples, n_ch, ld, W, hop, W, 0, n_frames, window, detrend, 1.0f, 1.0f,
+                            0, (ds_c32*)X));
     const int nt = (n_ch + 31) / 32;
     CsmArgs a{X, n_ch, n_frames,
               FinishPar{norm_scale / (double)n_frames, factor, halve_edges, amp_sqrt, nb},
@@ -658,6 +711,98 @@ static int deconv_big(ds_ctx* c, const float* y, int n_items, int n_ch, int64_t 
     CHK(big_rows(c, Q, P, N, batch));
     dsbig::StoreArgs st{P, N, n_out, ld_out, n_ch, ir};
     CHK(launch(c, "bigfft_store", dsbig::k_big_store, dim3(1024, batch), 256, 0, st));
+    return DS_OK;
+}
+
+// ---- framed transforms beyond the LDS-resident FFT (window / FFT length 2^15 .. 2^24) ------
+// Frame pairs of every channel are one batch of four-step complex FFTs, processed in groups
+// of <= 2^25 complex points per scratch buffer.
+static int64_t stft_big_group(int64_t nfft, int64_t batch) {
+    return std::max<int64_t>(1, std::min<int64_t>({batch, ((int64_t)1 << 25) / nfft, (int64_t)32768}));
+}
+static size_t stft_big_ws(int n_ch, int n_frames, int64_t nfft) {
+    const int64_t batch = (int64_t)n_ch * ((n_frames + 1) / 2);
+    const int64_t g = stft_big_group(nfft, batch);
+    return 2 * Carver::pad(sizeof(float2) * (size_t)g * nfft) + Carver::pad(sizeof(float) * (size_t)n_ch * n_frames);
+}
+// layout 0: out[(c*F + f)*nb + k] (unscaled spectra for the Welch sums), 1: out[(k*F + f)*C + c]
+static int stft_big(ds_ctx* c, Carver& cv, const float* x, int n_ch, int64_t ld, int64_t n_samples,
+                    int W, int hop, int64_t nfft, int64_t pad_front, int n_frames, const float* window,
+                    int detrend, float scale, float edge_scale, int power, int layout, float2* out) {
+    CHK(check_big_len(c, nfft, "framed transform length"));
+    constexpr int N1 = 1024;
+    const int n2 = (int)(nfft / N1);
+    const int64_t batch = (int64_t)n_ch * ((n_frames + 1) / 2);
+    const int64_t grp = stft_big_group(nfft, batch);
+    float2* P = cv.take<float2>((size_t)grp * nfft);
+    float2* Q = cv.take<float2>((size_t)grp * nfft);
+    float* means = cv.take<float>((size_t)n_ch * n_frames);
+    if (detrend) {
+        dsbig::FrameMeansArgs m{x, n_samples, ld, pad_front, n_ch, W, hop, n_frames, window, means};
+        CHK(launch(c, "bigfft_means", dsbig::k_frame_means, dim3(n_frames, n_ch), 256, 0, m));
+    }
+    const float2* tw;
+    CHK(get_twiddles(c, N1, &tw));
+    const int ct = std::min(8, n2);
+    const size_t lds = (size_t)ct * dsbig::ch_stride<N1>() * sizeof(float2);
+    for (int64_t b0 = 0; b0 < batch; b0 += grp) {
+        const int nb = (int)std::min<int64_t>(grp, batch - b0);
+        dsbig::ColsArgs a{nullptr, x, nullptr, n_samples, 0, P, nfft, n2, ct, 0, ld, n_ch, tw,
+                          window, detrend ? means : nullptr, W, hop, n_frames, pad_front, b0};
+        CHK(launch(c, "bigfft_cols", dsbig::k_big_cols<N1>, dim3(n2 / ct, nb), ct * Cfg<N1>::NT, lds, a));
+        CHK(big_rows(c, P, Q, nfft, nb));
+        dsbig::UnpackFramesArgs u{Q, nfft, b0, n_ch, n_frames, layout, power, scale, edge_scale, out};
+        CHK(launch(c, "bigfft_unpack", dsbig::k_big_unpack_frames, dim3(64, nb), 256, 0, u));
+    }
+    return DS_OK;
+}
+
+// Welch for window lengths beyond the LDS-resident FFT: spectra of every frame -> frame sums
+// (or per-bin medians) -> the usual finish
+static int welch_big(ds_ctx* c, int kind, const float* x, int n_cx, int64_t ldx, const float* y,
+                     int n_cy, int64_t ldy, int64_t n_samples, int W, int hop, int n_frames,
+                     const float* window, int detrend, int average, int mode, int amp_sqrt,
+                     double norm_scale, double factor, int halve_edges, float2* out_c, float* out_r) {
+    const int nb = W / 2 + 1;
+    const int nyc = kind == 1 ? 0 : n_cy;
+    const int nmax = std::max(n_cx, nyc);
+    const size_t med_lds = ((size_t)8 * 3 * n_frames + 48) * sizeof(float);
+    if (average == DS_AVG_MEDIAN && med_lds > 150 * 1024)
+        return fail(c, DS_ERR_UNSUP, "welch: median averaging over more than ~1590 frames is not built yet");
+    size_t bytes = stft_big_ws(nmax, n_frames, W) + Carver::pad(sizeof(float2) * (size_t)n_cx * n_frames * nb) +
+                   Carver::pad(sizeof(float2) * (size_t)std::max(1, nyc) * n_frames * nb) +
+                   Carver::pad(sizeof(float) * (size_t)n_cx * nb) +
+                   Carver::pad(sizeof(float2) * (size_t)std::max(1, nyc) * nb) +
+                   Carver::pad(sizeof(float) * (size_t)std::max(1, nyc) * nb);
+    CHK(reserve(c, &c->ws, &c->ws_bytes, bytes));
+    Carver cv(c->ws);
+    float2* xsp = cv.take<float2>((size_t)n_cx * n_frames * nb);
+    float2* ysp = cv.take<float2>((size_t)std::max(1, nyc) * n_frames * nb);
+    float* pxx = cv.take<float>((size_t)n_cx * nb);
+    float2* pxy = cv.take<float2>((size_t)std::max(1, nyc) * nb);
+    float* pyy = cv.take<float>((size_t)std::max(1, nyc) * nb);
+    Carver scratch = cv;  // the FFT scratch is reused by both signals
+    CHK(stft_big(c, scratch, x, n_cx, ldx, n_samples, W, hop, W, 0, n_frames, window, detrend, 1.0f, 1.0f, 0,
+                 0, xsp));
+    if (nyc) {
+        scratch = cv;
+        CHK(stft_big(c, scratch, y, nyc, ldy, n_samples, W, hop, W, 0, n_frames, window, detrend, 1.0f, 1.0f,
+                     0, 0, ysp));
+    }
+    double count = (double)n_frames;
+    if (average == DS_AVG_MEDIAN) {
+        MedianArgs m{xsp, nyc ? ysp : nullptr, n_cx, nyc, n_frames, nb, kind, pxx, pxy, pyy};
+        CHK(launch(c, "welch_median", k_welch_median, dim3((nb + 7) / 8, kind == 1 ? n_cx : n_cy), 256, med_lds, m));
+        const int nbias = (n_frames & 1) ? n_frames : n_frames - 1;
+        count = 1.0 / (double)std::max(1, nbias);
+    } else {
+        dsbig::SpecSumArgs sa{xsp, nyc ? ysp : nullptr, n_cx, nyc, n_frames, nb, kind, pxx, pxy, pyy};
+        CHK(launch(c, "welch_specsum", dsbig::k_spec_sum, dim3((nb + 255) / 256, kind == 1 ? n_cx : n_cy), 256, 0, sa));
+    }
+    WelchFinArgs f{pxx, pxy, pyy, 1, 1, n_cx, n_cy, kind, mode,
+                   FinishPar{norm_scale / count, factor, halve_edges, amp_sqrt, nb}, out_c, out_r};
+    int64_t total = (int64_t)nb * (kind == 1 ? n_cx : n_cy);
+    CHK(launch(c, "welch_finish", k_welch_finish, dim3((unsigned)((total + 255) / 256)), 256, 0, f));
     return DS_OK;
 }
 
@@ -1025,8 +1170,8 @@ extern "C" int ds_welch_csd(ds_ctx* c, const float* x, const float* y, int n_ch,
 }
 
 extern "C" int ds_csm(ds_ctx* c, const float* x, int n_ch, int64_t n_samples, int W, int hop,
-                      int n_frames, const float* window, int detrend, int amp_sqrt, double norm_scale,
-                      double factor, int halve_edges, ds_c32* csm) {
+                      int n_frames, const float* window, int detrend, int average, int amp_sqrt,
+                      double norm_scale, double factor, int halve_edges, ds_c32* csm) {
     if (!c || !x || !window || !csm) return fail(c, DS_ERR_ARG, "ds_csm: null argument");
     if (n_ch <= 0 || n_samples <= 0 || W <= 0) return fail(c, DS_ERR_ARG, "ds_csm: bad shape");
     size_t nx = (size_t)n_ch * n_samples, no = (size_t)(W / 2 + 1) * n_ch * n_ch;
@@ -1037,8 +1182,8 @@ extern "C" int ds_csm(ds_ctx* c, const float* x, int n_ch, int64_t n_samples, in
     float2* dc = cv.take<float2>(no);
     CHK(ds_upload(c, dx, x, nx * 4));
     CHK(ds_upload(c, dw, window, (size_t)W * 4));
-    CHK(ds_csm_dev(c, dx, n_ch, n_samples, n_samples, W, hop, n_frames, dw, detrend, amp_sqrt, norm_scale,
-                   factor, halve_edges, (ds_c32*)dc));
+    CHK(ds_csm_dev(c, dx, n_ch, n_samples, n_samples, W, hop, n_frames, dw, detrend, average, amp_sqrt,
+                   norm_scale, factor, halve_edges, (ds_c32*)dc));
     return ds_download(c, csm, dc, no * 8);
 }
 
@@ -1103,9 +1248,11 @@ typedef const char* (*nccl_errstr_t)(int);
 
 static void* rccl_handle() {
     static void* h = nullptr;
-    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
-    if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
-    if (!h) h = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    // reuse a copy the host process already mapped (e.g. the one PyTorch links) before loading one
+    if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);
+    if (!h) h = dlopen("librccl.so.1", RTLD_NOW);
+    if (!h) h = dlopen("librccl.so", RTLD_NOW);
+    if (!h) h = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW);
     return h;
 }
 

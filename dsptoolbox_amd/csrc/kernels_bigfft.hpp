@@ -35,6 +35,14 @@ struct ColsArgs {
     int64_t ld_real;
     int n_ch;
     const float2* tw;  // length-N1 table
+    // frame mode (win != nullptr): batch entry bt0 + blockIdx.y = (channel, frame pair) of the
+    // framed signal xa[channel]; frames 2p and 2p+1 travel as real / imaginary part, windowed,
+    // minus means[channel*n_frames + frame] if means != nullptr (detrend), zero beyond
+    // min(W, N) and outside [0, n_samples)
+    const float* win;
+    const float* means;
+    int W, hop, n_frames;
+    int64_t pad_front, bt0;
 };
 
 template <int N1>
@@ -49,7 +57,34 @@ __global__ __launch_bounds__(1024) void k_big_cols(ColsArgs p) {
     float2* zo = p.zout + bt * N;
     // cooperative coalesced load: rows n1, ct consecutive columns
     const int total = N1 * p.ct;
-    if (p.xa) {
+    if (p.win) {
+        const int64_t g = p.bt0 + bt;
+        const int nfp = (p.n_frames + 1) / 2;
+        const int ch = (int)(g / nfp), f0 = 2 * (int)(g % nfp);
+        const bool v1 = f0 + 1 < p.n_frames;
+        const float* xc = p.xa + (int64_t)ch * p.ld_real;
+        const int64_t sa = (int64_t)f0 * p.hop - p.pad_front, sb = sa + p.hop;
+        float ma = 0.f, mb = 0.f;
+        if (p.means) {
+            ma = p.means[(int64_t)ch * p.n_frames + f0];
+            if (v1) mb = p.means[(int64_t)ch * p.n_frames + f0 + 1];
+        }
+        const int64_t span = p.W < N ? p.W : N;
+        for (int i = threadIdx.x; i < total; i += blockDim.x) {
+            int j = i % p.ct, n1 = i / p.ct;
+            int64_t n = (int64_t)n1 * p.n2 + j20 + j;
+            float2 z = make_float2(0.f, 0.f);
+            if (n < span) {
+                const float w = p.win[n];
+                const int64_t ga = sa + n, gb = sb + n;
+                const float xa = (ga >= 0 && ga < p.n_samples) ? xc[ga] : 0.f;
+                const float xb = (v1 && gb >= 0 && gb < p.n_samples) ? xc[gb] : 0.f;
+                z.x = xa * w - ma;
+                z.y = v1 ? xb * w - mb : 0.f;
+            }
+            lds[j * CHS + lidx(n1)] = z;
+        }
+    } else if (p.xa) {
         const int ca = 2 * (int)(bt % ((p.n_ch + 1) / 2)), item = (int)(bt / ((p.n_ch + 1) / 2));
         const float* a = p.xa + ((int64_t)item * p.n_ch + ca) * p.ld_real;
         const float* b = (ca + 1 < p.n_ch) ? a + p.ld_real : nullptr;
@@ -193,6 +228,116 @@ __global__ void k_big_store(StoreArgs p) {
         oa[n] = f.x * inv;
         if (vb) oa[p.ld_out + n] = -f.y * inv;
     }
+}
+
+// ---- framed transforms (STFT / Welch with window or FFT lengths beyond the LDS-resident FFT) ----
+// mean of the windowed frame (the reference detrends AFTER windowing, over all W samples)
+struct FrameMeansArgs {
+    const float* x;
+    int64_t n_samples, ld, pad_front;
+    int n_ch, W, hop, n_frames;
+    const float* window;
+    float* means;  // [n_ch][n_frames]
+};
+__global__ __launch_bounds__(256) void k_frame_means(FrameMeansArgs p) {
+    __shared__ double red[4];
+    const int f = blockIdx.x, c = blockIdx.y;
+    const float* xc = p.x + (int64_t)c * p.ld;
+    const int64_t s0 = (int64_t)f * p.hop - p.pad_front;
+    double acc = 0.0;
+    for (int n = threadIdx.x; n < p.W; n += 256) {
+        const int64_t s = s0 + n;
+        if (s >= 0 && s < p.n_samples) acc += (double)(xc[s] * p.window[n]);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0)
+        p.means[(int64_t)c * p.n_frames + f] = (float)((red[0] + red[1] + red[2] + red[3]) / (double)p.W);
+}
+
+// packed frame-pair spectra z[bt][N] -> layout 0: spec[(c*F + f)*nb + k] (Welch accumulation /
+// median), layout 1: out[(k*F + f)*C + c] (the reference's STFT order) with the STFT scalings
+struct UnpackFramesArgs {
+    const float2* z;
+    int64_t n_total, bt0;
+    int n_ch, n_frames, layout, power;
+    float scale, edge_scale;
+    float2* out;
+};
+__global__ void k_big_unpack_frames(UnpackFramesArgs p) {
+    const int64_t N = p.n_total, nb = N / 2 + 1;
+    const int64_t g = p.bt0 + blockIdx.y;
+    const int nfp = (p.n_frames + 1) / 2;
+    const int ch = (int)(g / nfp), f0 = 2 * (int)(g % nfp);
+    const bool v1 = f0 + 1 < p.n_frames;
+    const float2* z = p.z + (int64_t)blockIdx.y * N;
+    const int64_t F = p.n_frames, C = p.n_ch;
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < nb; k += (int64_t)gridDim.x * blockDim.x) {
+        float2 P = z[k], Qc = z[(N - k) & (N - 1)];
+        float2 A = make_float2(0.5f * (P.x + Qc.x), 0.5f * (P.y - Qc.y));
+        float2 B = make_float2(0.5f * (P.y + Qc.y), -0.5f * (P.x - Qc.x));
+        const bool edge = (k == 0 || k == N / 2);
+        if (p.power) {
+            float e = (edge ? p.edge_scale * p.edge_scale : 1.0f) * p.scale;
+            A = make_float2((A.x * A.x + A.y * A.y) * e, 0.f);
+            B = make_float2((B.x * B.x + B.y * B.y) * e, 0.f);
+        } else {
+            float sc = p.scale * (edge ? p.edge_scale : 1.0f);
+            A = make_float2(A.x * sc, A.y * sc);
+            B = make_float2(B.x * sc, B.y * sc);
+        }
+        if (p.layout == 0) {
+            p.out[((int64_t)ch * F + f0) * nb + k] = A;
+            if (v1) p.out[((int64_t)ch * F + f0 + 1) * nb + k] = B;
+        } else {
+            p.out[(k * F + f0) * C + ch] = A;
+            if (v1) p.out[(k * F + f0 + 1) * C + ch] = B;
+        }
+    }
+}
+
+// frame sums of |X|^2, conj(X) Y, |Y|^2 from stored spectra [c][F][nb] (fp64 accumulation);
+// outputs in the one-chunk slab layout k_welch_finish reads.  kind as in WelchFinArgs.
+struct SpecSumArgs {
+    const float2* xs;
+    const float2* ys;
+    int n_cx, n_cy, n_frames, nb, kind;
+    float* pxx;   // [n_cx][nb]
+    float2* pxy;  // [n_cy][nb]
+    float* pyy;   // [n_cy][nb]
+};
+__global__ void k_spec_sum(SpecSumArgs p) {
+    const int nb = p.nb, F = p.n_frames;
+    const int c = blockIdx.y;
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nb) return;
+    const int cx = (p.kind == 1 || p.n_cx != 1) ? c : 0;
+    const float2* X = p.xs + (size_t)cx * F * nb + b;
+    double sxx = 0.0;
+    if (p.kind == 1) {
+        for (int f = 0; f < F; ++f) {
+            float2 x = X[(size_t)f * nb];
+            sxx += (double)x.x * x.x + (double)x.y * x.y;
+        }
+        p.pxx[(size_t)c * nb + b] = (float)sxx;
+        return;
+    }
+    const float2* Y = p.ys + (size_t)c * F * nb + b;
+    double syy = 0.0, sr = 0.0, si = 0.0;
+    for (int f = 0; f < F; ++f) {
+        float2 x = X[(size_t)f * nb], y = Y[(size_t)f * nb];
+        sxx += (double)x.x * x.x + (double)x.y * x.y;
+        syy += (double)y.x * y.x + (double)y.y * y.y;
+        sr += (double)x.x * y.x + (double)x.y * y.y;
+        si += (double)x.x * y.y - (double)x.y * y.x;
+    }
+    if (p.kind == 0) {
+        if (p.n_cx != 1 || c == 0) p.pxx[(size_t)cx * nb + b] = (float)sxx;
+        p.pyy[(size_t)c * nb + b] = (float)syy;
+    }
+    p.pxy[(size_t)c * nb + b] = make_float2((float)sr, (float)si);
 }
 
 }  // namespace dsbig

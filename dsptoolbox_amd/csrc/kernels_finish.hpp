@@ -194,6 +194,58 @@ __global__ __launch_bounds__(256) void k_welch_median(MedianArgs p) {
     }
 }
 
+// Median-averaged cross-spectral matrix (reference: _csm_welch's pair loop of _welch(...,
+// average="median"), _spectral_methods.py:153-162 + :351-369).  grid = (ceil(nb/8), C(C+1)/2);
+// pair (i1 <= i2): per-bin medians over the frames of Re / Im conj(X_i1) X_i2 from the stored
+// spectra xs[c][F][nb], then the Welch finish; csm[b][i2][i1] = g, csm[b][i1][i2] = conj(g).
+struct CsmMedianArgs {
+    const float2* xs;
+    int n_ch, n_frames;
+    FinishPar fin;  // fin.scale already holds norm_scale * n_bias
+    float2* csm;    // [nb][C][C]
+};
+__global__ __launch_bounds__(256) void k_csm_median(CsmMedianArgs p) {
+    extern __shared__ float ser[];  // [8 bins][2 series][F] (+ 8*2*2 results)
+    const int F = p.n_frames, nb = p.fin.nb, C = p.n_ch;
+    const int b0 = blockIdx.x * 8, tid = threadIdx.x;
+    // triangular decode: pair index -> (i1 <= i2), rows of length C, C-1, ...
+    int i1 = 0, rem = blockIdx.y;
+    while (rem >= C - i1) {
+        rem -= C - i1;
+        ++i1;
+    }
+    const int i2 = i1 + rem;
+    float* res = ser + (size_t)8 * 2 * F;
+    const float2* X = p.xs + (size_t)i1 * F * nb;
+    const float2* Y = p.xs + (size_t)i2 * F * nb;
+    for (int i = tid; i < 8 * F; i += 256) {
+        const int bl = i & 7, f = i >> 3, b = b0 + bl;
+        float2 xv = make_float2(0.f, 0.f), yv = make_float2(0.f, 0.f);
+        if (b < nb) {
+            xv = X[(size_t)f * nb + b];
+            yv = Y[(size_t)f * nb + b];
+        }
+        ser[(bl * 2 + 0) * F + f] = xv.x * yv.x + xv.y * yv.y;
+        ser[(bl * 2 + 1) * F + f] = xv.x * yv.y - xv.y * yv.x;
+    }
+    __syncthreads();
+    for (int q = 0; q < 16; ++q) median_of(ser + (size_t)q * F, F, tid, 256, res + q * 2);
+    __syncthreads();
+    if (tid < 8 && b0 + tid < nb) {
+        const int b = b0 + tid;
+        const float* r = res + tid * 4;
+        cd m{0.5 * ((double)r[0] + (double)r[1]), 0.5 * ((double)r[2] + (double)r[3]) + 0.0};
+        cd g = finish_cplx(m, b, p.fin);
+        float2* o = p.csm + (size_t)b * C * C;
+        if (i1 == i2) {
+            o[(size_t)i1 * C + i1] = make_float2((float)g.x, 0.f);
+        } else {
+            o[(size_t)i2 * C + i1] = make_float2((float)g.x, (float)g.y);
+            o[(size_t)i1 * C + i2] = make_float2((float)g.x, (float)-g.y);
+        }
+    }
+}
+
 // r[c][b] = eps ? conj(X)/(|X|^2 + eps[b]) : 1/X ; xspec is [b][c]
 __global__ void k_deconv_inverse(const float2* xspec, int n_ch, int nb, const float* eps,
                                  float2* r) {

@@ -135,13 +135,14 @@ int ds_welch_csd(ds_ctx* ctx, const float* x, const float* y, int n_ch,
 
 /* ---- cross-spectral matrix: replaces _csm_welch, _spectral_methods.py:285-371
  * csm[b][i][j], B x C x C; lower triangle csm[b][i2][i1] (i2>=i1) =
- * finish(mean conj(X_i1) X_i2), upper = its conjugate (:351-369).            */
+ * finish(mean or median over frames of conj(X_i1) X_i2), upper = its conjugate
+ * (:351-369).  average: DS_AVG_MEAN (MFMA rank-F update) / DS_AVG_MEDIAN.      */
 int ds_csm_dev(ds_ctx* ctx, const float* x_dev, int n_ch, int64_t ld, int64_t n_samples,
                int W, int hop, int n_frames, const float* window_dev, int detrend,
-               int amp_sqrt, double norm_scale, double factor, int halve_edges,
-               ds_c32* csm_dev);
+               int average, int amp_sqrt, double norm_scale, double factor,
+               int halve_edges, ds_c32* csm_dev);
 int ds_csm(ds_ctx* ctx, const float* x, int n_ch, int64_t n_samples, int W, int hop,
-           int n_frames, const float* window, int detrend, int amp_sqrt,
+           int n_frames, const float* window, int detrend, int average, int amp_sqrt,
            double norm_scale, double factor, int halve_edges, ds_c32* csm);
 
 /* CSM from spectra that are already on hand: X[b][f][c] (n_bins x n_frames x n_ch, the

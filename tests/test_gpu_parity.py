@@ -305,18 +305,79 @@ def test_transfer_function_median_vs_oracle():
             # error (~3e-7 per power quantity), the coherence combines three of them, and two
             # nearly equal frames can swap ranks: observed up to 3.2e-6 at 15 frames
             assert relmax(tf, rt, True) < TOL and relmax(coh, rc, True) < 10 * TOL, (mode, W)
-    with pytest.raises(NotImplementedError):
-        backend._csm_welch(y, 48000, 256, Window.Hann, 50, True, "median", SpectrumScaling.FFTBackward)
 
 
-def test_welch_too_long_window_raises():
+def test_csm_median_vs_oracle():
+    """get_csm with average="median": the reference's pair loop of median-averaged _welch calls."""
+    rng = np.random.default_rng(78)
+    n = 20000
+    common = rng.standard_normal(n)
+    x = np.stack([0.3 * rng.standard_normal(n) + 0.5 * np.roll(common, 3 * c) for c in range(5)], axis=1)
+    for W, det, sc in ((256, True, SpectrumScaling.FFTBackward), (1024, False, SpectrumScaling.PowerSpectralDensity),
+                       (512, True, SpectrumScaling.AmplitudeSpectrum)):
+        f, csm = backend._csm_welch(x, 48000, W, Window.Hann, 50, det, "median", sc)
+        rf, rcsm = orc.csm_welch(x, 48000, W, "hann", 50, det, "median", sc.name)
+        assert np.allclose(f, rf)
+        # single-frame (median) values carry the full per-frame fp32 error: see the tf test above
+        assert relmax(csm, rcsm) < 10 * TOL, (W, relmax(csm, rcsm))
+        assert orc.rel_l2(csm, rcsm) < TOL
+
+
+def test_welch_window_length_limits():
     x = np.zeros((100000, 1))
-    with pytest.raises(NotImplementedError):
-        backend._welch(x, None, 48000, Window.Hann, 32768, 50, True, "mean",
+    with pytest.raises(AssertionError):  # the reference's own limit: 2**3 .. 2**18
+        backend._welch(x, None, 48000, Window.Hann, 2**19, 50, True, "mean",
                        SpectrumScaling.FFTBackward)
     with pytest.raises(AssertionError):
         backend._welch(x, None, 48000, Window.Hann, 1000, 50, True, "mean",
                        SpectrumScaling.FFTBackward)
+
+
+@pytest.mark.parametrize("W", [2**15, 2**16, 2**18])
+def test_welch_long_windows_vs_oracle(W):
+    """Window lengths beyond the LDS-resident FFT (four-step transform per frame pair)."""
+    rng = np.random.default_rng(W)
+    n = 5 * W + 1234
+    x = rng.standard_normal((n, 3)) * 0.3
+    x[:, 2] = np.convolve(x[:, 0], [0.5, 0.3, -0.2, 0.1])[:n] + 0.05 * x[:, 2]
+    for det in (True, False):
+        a = backend._welch(x, None, 48000, Window.Hann, W, 50, det, "mean",
+                           SpectrumScaling.PowerSpectralDensity)
+        r = orc.welch(x, None, 48000, "hann", W, 50, det, "mean", "PowerSpectralDensity")
+        assert relmax(a, r, det) < TOL
+        k = backend._welch(x[:, 0], x[:, 2], 48000, Window.Hann, W, 50, det, "mean",
+                           SpectrumScaling.FFTBackward)
+        r = orc.welch(x[:, 0], x[:, 2], 48000, "hann", W, 50, det, "mean", "FFTBackward")
+        assert relmax(k, r, det) < TOL
+    if W == 2**15:
+        for mode in ("H1", "H2", "H3"):
+            for avg in ("mean", "median"):
+                tf, coh = backend.welch_transfer_function(x[:, 1:], x[:, :1], 48000, W, mode, average=avg,
+                                                          overlap_percent=75)
+                rt, rc = orc.compute_transfer_function(x[:, 1:], x[:, :1], 48000, W, mode, average=avg,
+                                                       overlap_percent=75)
+                lim = TOL if avg == "mean" else 10 * TOL  # see test_transfer_function_median_vs_oracle
+                # channel 1 is independent noise (coherence ~ 1/sqrt(F)): compare the correlated one tightly
+                assert relmax(tf[:, 1], rt[:, 1], True) < lim, (mode, avg)
+                assert relmax(coh[:, 1], rc[:, 1], True) < lim, (mode, avg)
+                if mode == "H1":  # the uncorrelated channel too where the estimator is well conditioned
+                    assert orc.rel_l2(tf[1:], rt[1:]) < lim, (mode, avg)  # DC is 0/0 after detrending
+
+
+def test_stft_and_csm_long_windows_vs_oracle():
+    rng = np.random.default_rng(5)
+    n = 200000
+    x = rng.standard_normal((n, 3)) * 0.3 + 0.1
+    for W, nfft, pad, det, sc in ((2**15, None, True, True, SpectrumScaling.FFTBackward),
+                                  (2**16, None, False, False, SpectrumScaling.AmplitudeSpectrum),
+                                  (2**13, 2**15, True, True, SpectrumScaling.PowerSpectralDensity)):
+        t, f, st = backend._stft(x, 48000, W, Window.Hann, 50, nfft, det, pad, sc)
+        rt, rf, rs = orc.stft(x, 48000, W, "hann", 50, nfft, det, pad, sc.name)
+        assert st.shape == rs.shape and np.allclose(t, rt) and np.allclose(f, rf)
+        assert relmax(st, rs) < TOL, (W, nfft)
+    f, csm = backend._csm_welch(x, 48000, 2**15, Window.Hann, 50, True, "mean", SpectrumScaling.FFTBackward)
+    rf, rcsm = orc.csm_welch(x, 48000, 2**15, "hann", 50, True, "mean", "FFTBackward")
+    assert relmax(csm, rcsm) < TOL
 
 
 def test_headline_shape_reduced_vs_oracle():
