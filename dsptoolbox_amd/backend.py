@@ -297,19 +297,60 @@ def fir_filter_bank(x, taps_list, mode: int):
 
 
 def _lfilter_fir(b, a, x, zi=None, axis: int = 0):
-    """Causal FIR filtering y = (x * b)[:N] along axis 0."""
+    """Causal FIR filtering y = (x * b)[:N] along axis 0 (dsptoolbox/classes/filter_helpers.py:
+    454-503).  With zi (T-1, C): the full convolution (N + T - 1 samples, device) gets zi added
+    to its head, the new state is its tail; returns (y, zf)."""
     a = np.atleast_1d(a)
     assert len(a) == 1, f"{a} is not valid. It has to be 1 in order to be a valid FIR filter"
     b = np.asarray(b)
     if b.ndim != 1:
         b = np.squeeze(b)
         assert b.ndim == 1, "FIR Filters for audio must be 1D-arrays"
-    if zi is not None:
-        raise NotImplementedError("filter state (zi) is not built on the GPU path yet")
     if np.iscomplexobj(b) or np.iscomplexobj(x):
         raise NotImplementedError("complex FIR filtering is not built on the GPU path yet")
     x = np.asarray(x)
+    if zi is not None:
+        zi = np.asarray(zi)
+        assert zi.ndim == x.ndim, \
+            "Vector to filter and initial values should have the same number of dimensions!"
     if x.ndim < 2:
         x = x[..., None]
+        if zi is not None:
+            zi = zi[..., None]
     assert x.ndim == 2, "Filtering only works on 2D-arrays"
-    return fir_filter_bank(x, [b], DS_FB_PARALLEL)[0]
+    if zi is None:
+        return fir_filter_bank(x, [b], DS_FB_PARALLEL)[0]
+    # mode="full": run the device convolution over the signal followed by T - 1 zeros
+    xfull = np.concatenate([x, np.zeros((len(b) - 1, x.shape[1]))], axis=0)
+    y = fir_filter_bank(xfull, [b], DS_FB_PARALLEL)[0]
+    y[: zi.shape[0], :] += zi
+    zf = y[-zi.shape[0]:, :]
+    return y[: x.shape[0], :], zf
+
+
+def _lfilter_zi_fir(b):
+    """scipy.signal.lfilter_zi(b, [1.0]) in closed form (the reference's Filter.initialize_zi,
+    classes/filter.py:331-353): steady-state step-response state of a transposed direct-form
+    FIR filter, zi[i] = sum_{j > i} b[j].  Host-side parameter preparation."""
+    b = np.asarray(b, dtype=np.float64)
+    return np.cumsum(b[::-1])[::-1][1:].copy()
+
+
+def _filtfilt_fir(b, x):
+    """Zero-phase FIR filtering = scipy.signal.filtfilt(b, [1.0], x, axis=0) with its defaults
+    (odd extension by 3*len(b) samples, steady-state initial conditions), the zero_phase branch
+    of the reference (filter_helpers.py:362-363).  Both convolutions run on the device; the
+    extension, the time reversals and the state terms are host-side array plumbing."""
+    b = np.asarray(b, dtype=np.float64)
+    x = np.asarray(x, dtype=np.float64)
+    if x.ndim < 2:
+        x = x[..., None]
+    edge = 3 * len(b)
+    if x.shape[0] <= edge:
+        raise ValueError(
+            "The length of the input vector x must be greater than padlen, which is %d." % edge)
+    ext = np.concatenate([2 * x[:1] - x[edge:0:-1], x, 2 * x[-1:] - x[-2:-(edge + 2):-1]], axis=0)
+    zi = _lfilter_zi_fir(b)[:, None]
+    y, _ = _lfilter_fir(b, [1.0], ext, zi * ext[:1])
+    y, _ = _lfilter_fir(b, [1.0], y[::-1], zi * y[-1:])
+    return y[::-1][edge:-edge]

@@ -1,9 +1,10 @@
 """Filter: FIR part of dsptoolbox/classes/filter.py (fir_filter :189-235,
 from_ba :237-260, ba setter :485-529, is_fir :460-470, filter_signal :648-743).
 FIR filtering runs on the device as FFT block convolution
-(dsptoolbox_amd.backend.fir_filter_bank).  IIR / SOS / zpk filters, filter state
-(zi) and zero-phase filtering are recursive or two-pass operations outside the
-FFT-batchable hot path; they raise NotImplementedError."""
+(dsptoolbox_amd.backend.fir_filter_bank), including filter state (zi, initialize_zi
+:331-353) and zero-phase filtering (two device convolutions).  IIR / SOS / zpk
+filters are recursive and outside the FFT-batchable hot path; they raise
+NotImplementedError."""
 
 from copy import deepcopy
 from warnings import warn
@@ -123,16 +124,42 @@ class Filter:
             assert all(channels < signal.number_of_channels), (
                 f"Selected channels ({channels}) are not valid for the signal with "
                 f"{signal.number_of_channels} channels")
-        if activate_zi or zero_phase:
-            raise NotImplementedError("zi / zero-phase filtering is not built on the GPU path yet")
         if not self.is_fir:
             raise NotImplementedError("IIR filtering is outside the FFT-batchable GPU hot path")
+        # zi: always created for all channels, the selected ones are updated (filter.py:693-707)
+        if activate_zi:
+            if not hasattr(self, "zi"):
+                self.initialize_zi(signal.number_of_channels)
+            if len(self.zi) != signal.number_of_channels:
+                warn("zi values of the filter have not been correctly intialized for the number "
+                     "of channels. They have now been corrected")
+                self.initialize_zi(signal.number_of_channels)
+            zi = np.asarray(self.zi).T  # (T-1, C), filter_helpers.py:344-345
+        else:
+            zi = None
         if self.order > signal.time_data.shape[0]:
             warn("Filter is longer than signal, results might be meaningless!")
         new_time_data = signal.time_data.copy()
-        new_time_data[:, channels] = backend._lfilter_fir(self.ba[0], self.ba[1],
-                                                          signal.time_data[:, channels])
+        if zi is not None:
+            y, zi[:, channels] = backend._lfilter_fir(self.ba[0], self.ba[1],
+                                                      signal.time_data[:, channels], zi=zi[:, channels])
+        elif zero_phase:
+            y = backend._filtfilt_fir(self.ba[0], signal.time_data[:, channels])
+        else:
+            y = backend._lfilter_fir(self.ba[0], self.ba[1], signal.time_data[:, channels])
+        new_time_data[:, channels] = y
+        if activate_zi:
+            # the reference hands back the (T-1, C) state array itself, not a per-channel list
+            # (filter_helpers.py:377-382 returns `zi`, not `zi_new`): kept as is, so the next
+            # call sees len(zi) == T-1 and re-initialises unless T-1 equals the channel count
+            self.zi = zi
         return signal.copy_with_new_time_data(new_time_data)
+
+    def initialize_zi(self, number_of_channels: int = 1):
+        """Steady-state initial filter state for every channel (scipy.signal.lfilter_zi)."""
+        assert number_of_channels > 0, "Zi's have to be initialized for at least one channel"
+        self.zi = [backend._lfilter_zi_fir(self.ba[0]) for _ in range(number_of_channels)]
+        return self
 
     def copy(self) -> "Filter":
         return deepcopy(self)

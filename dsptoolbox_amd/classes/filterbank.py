@@ -75,6 +75,12 @@ class FilterBank:
     def copy(self):
         return deepcopy(self)
 
+    def initialize_zi(self, number_of_channels: int = 1):
+        """Initial state of every filter for the given number of channels (filterbank.py:126-138)."""
+        for f in self.filters:
+            f.initialize_zi(number_of_channels)
+        return self
+
     def filter_signal(self, signal: Signal, mode: FilterBankMode, activate_zi: bool = False,
                       zero_phase: bool = False):
         """Parallel -> MultiBandSignal; Sequential / Summed -> Signal."""
@@ -88,13 +94,33 @@ class FilterBank:
             "Sampling rates do not match"
         if zero_phase:
             assert not activate_zi, "Zero-phase filtering and zi cannot be used at the same time"
-        if activate_zi or zero_phase:
-            raise NotImplementedError("zi / zero-phase filtering is not built on the GPU path yet")
+        if activate_zi:
+            if not hasattr(self.filters[0], "zi"):
+                self.initialize_zi(signal.number_of_channels)
+            if len(self.filters[0].zi) != signal.number_of_channels:
+                self.initialize_zi(signal.number_of_channels)
         if mode not in (FilterBankMode.Parallel, FilterBankMode.Sequential, FilterBankMode.Summed):
             raise ValueError("Invalid filter bank apply mode")
         for f in self.filters:
             if not f.is_fir:
                 raise NotImplementedError("IIR filters are outside the FFT-batchable GPU hot path")
+        if activate_zi or zero_phase:
+            # per-filter state / two-pass filtering: the reference's own loop
+            # (filter_helpers.py:385-451), one device convolution (or two) per filter
+            if mode == FilterBankMode.Parallel:
+                bands = [f.filter_signal(signal, activate_zi=activate_zi, zero_phase=zero_phase)
+                         for f in self.filters]
+                return MultiBandSignal(bands, same_sampling_rate=self.same_sampling_rate)
+            if mode == FilterBankMode.Sequential:
+                out = signal.copy()
+                for f in self.filters:
+                    out = f.filter_signal(out, activate_zi=activate_zi, zero_phase=zero_phase)
+                return out
+            acc = np.zeros((signal.time_data.shape[0], signal.number_of_channels, len(self.filters)))
+            for n, f in enumerate(self.filters):
+                acc[:, :, n] = f.filter_signal(signal, activate_zi=activate_zi,
+                                               zero_phase=zero_phase).time_data
+            return signal.copy_with_new_time_data(np.sum(acc, axis=-1))
         taps = [f.ba[0] for f in self.filters]
         n_taps = max(len(t) for t in taps)
         # zero-extending a FIR filter at the end does not change its output

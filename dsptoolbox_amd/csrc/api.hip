@@ -690,7 +690,7 @@ static int rfft_big(ds_ctx* c, const float* x, int n_ch, int64_t ld, int64_t n_s
     float2* Q = cv.take<float2>((size_t)npair * N);
     CHK(big_cols(c, nullptr, x, n_ch, ld, n_samples, P, N, npair));
     CHK(big_rows(c, P, Q, N, npair));
-    dsbig::UnpackArgs u{Q, N, n_ch, scale, spec};
+    dsbig::UnpackArgs u{Q, N, n_ch, scale, spec, n_ch, 1};
     CHK(launch(c, "bigfft_unpack", dsbig::k_big_unpack, dim3(1024, npair), 256, 0, u));
     return DS_OK;
 }
@@ -967,11 +967,65 @@ static int fir_block_len(int n_taps) {
     return n;
 }
 
+// Long filters (more taps than half the largest LDS-resident block): overlap-save on the
+// four-step FFT with blocks of 2^15 .. 2^24 points.  Per block: one forward transform of the
+// channel pairs, then groups of filters: multiply by the tap spectra, inverse, store.
+static int fir_long(ds_ctx* c, const float* x, int n_ch, int64_t ldx, int64_t n_samples,
+                    const float* taps, int n_filt, int n_taps, float* y, int64_t ld_y) {
+    if ((int64_t)n_taps - 1 > kMaxBigFft / 2)
+        return fail(c, DS_ERR_UNSUP, "ds_fir_ola: more than 2^23 + 1 taps is not built yet");
+    int64_t L = (int64_t)1 << 15;
+    while (L < 4 * (int64_t)n_taps && L < kMaxBigFft) L <<= 1;
+    while (L > ((int64_t)1 << 15) && L / 2 >= n_samples + n_taps - 1) L >>= 1;  // short signals: one block
+    const int64_t nb = L / 2 + 1, step = L - (n_taps - 1);
+    const int npair = (n_ch + 1) / 2;
+    const int G = (int)std::max<int64_t>(1, std::min<int64_t>(n_filt, ((int64_t)1 << 25) / (npair * L)));
+    const size_t scratch = (size_t)G * npair * L;
+    CHK(reserve(c, &c->ws, &c->ws_bytes,
+                Carver::pad(sizeof(float2) * (size_t)n_filt * nb) + Carver::pad(sizeof(float2) * (size_t)npair * L) +
+                    2 * Carver::pad(sizeof(float2) * scratch)));
+    Carver cv(c->ws);
+    float2* R = cv.take<float2>((size_t)n_filt * nb);
+    float2* Qs = cv.take<float2>((size_t)npair * L);
+    float2* P = cv.take<float2>(scratch);
+    float2* S = cv.take<float2>(scratch);
+    constexpr int N1 = 1024;
+    const int n2 = (int)(L / N1);
+    const float2* tw;
+    CHK(get_twiddles(c, N1, &tw));
+    const int ct = std::min(8, n2);
+    const size_t lds = (size_t)ct * dsbig::ch_stride<N1>() * sizeof(float2);
+    // tap spectra R[k][nb], 2*G*npair filters per pass through the scratch buffers
+    for (int k0 = 0; k0 < n_filt; k0 += 2 * G * npair) {
+        const int nf = std::min(2 * G * npair, n_filt - k0), bt = (nf + 1) / 2;
+        CHK(big_cols(c, nullptr, taps + (int64_t)k0 * n_taps, nf, n_taps, n_taps, P, L, bt));
+        CHK(big_rows(c, P, S, L, bt));
+        dsbig::UnpackArgs u{S, L, nf, 1.0f, R + (int64_t)k0 * nb, 1, nb};
+        CHK(launch(c, "bigfft_unpack", dsbig::k_big_unpack, dim3(1024, bt), 256, 0, u));
+    }
+    for (int64_t b0 = 0; b0 < n_samples; b0 += step) {
+        dsbig::ColsArgs a{nullptr, x, nullptr, n_samples, 0, P, L, n2, ct, 0, ldx, n_ch, tw,
+                          nullptr, nullptr, 0, 0, 0, 0, 0, b0 - (n_taps - 1)};
+        CHK(launch(c, "bigfft_cols", dsbig::k_big_cols<N1>, dim3(n2 / ct, npair), ct * Cfg<N1>::NT, lds, a));
+        CHK(big_rows(c, P, Qs, L, npair));  // spectrum of the block, kept while the filter groups reuse P / S
+        const int64_t n_out = std::min<int64_t>(step, n_samples - b0);
+        for (int k0 = 0; k0 < n_filt; k0 += G) {
+            const int g = std::min(G, n_filt - k0), bt = g * npair;
+            dsbig::MulBankArgs m{Qs, R + (int64_t)k0 * nb, P, L, npair};
+            CHK(launch(c, "bigfft_mul", dsbig::k_big_mul_bank, dim3(1024, bt), 256, 0, m));
+            CHK(big_cols(c, P, nullptr, n_ch, 0, 0, P, L, bt));
+            CHK(big_rows(c, P, S, L, bt));
+            dsbig::StoreArgs st{S, L, n_out, ld_y, n_ch, y + (int64_t)k0 * n_ch * ld_y + b0, (int64_t)n_taps - 1};
+            CHK(launch(c, "bigfft_store", dsbig::k_big_store, dim3(1024, bt), 256, 0, st));
+        }
+    }
+    return DS_OK;
+}
+
 static int fir_once(ds_ctx* c, const float* x, int n_ch, int64_t ldx, int64_t n_samples,
                     const float* taps, int n_filt, int n_taps, float* y, int64_t ld_y) {
     const int N = fir_block_len(n_taps);
-    if (n_taps - 1 > N / 2)
-        return fail(c, DS_ERR_UNSUP, "ds_fir_ola: more than 8193 taps needs partitioned convolution (not built yet)");
+    if (n_taps - 1 > N / 2) return fir_long(c, x, n_ch, ldx, n_samples, taps, n_filt, n_taps, y, ld_y);
     const float2* tw;
     CHK(get_twiddles(c, N, &tw));
     CHK(reserve(c, &c->ws, &c->ws_bytes, sizeof(float2) * (size_t)n_filt * N));
@@ -1036,7 +1090,7 @@ extern "C" int ds_fir_ola_dev(ds_ctx* c, const float* x, int n_ch, int64_t ldx, 
         // response fits one block transform, convolve the taps (fp64, on the device) and
         // filter once -- no fp32 round trip of the intermediate signals through HBM.
         const int64_t n_comb = (int64_t)n_filt * (n_taps - 1) + 1;
-        if (n_filt > 1 && n_comb - 1 <= kMaxFft / 2) {
+        if (n_filt > 1 && n_comb - 1 <= kMaxBigFft / 2 && (double)n_comb * n_taps <= 1.0e10) {
             double *pa = nullptr, *pb = nullptr;
             float* bf = nullptr;
             HIPCHK(c, hipMalloc((void**)&pa, sizeof(double) * n_comb));

@@ -43,6 +43,7 @@ struct ColsArgs {
     const float* means;
     int W, hop, n_frames;
     int64_t pad_front, bt0;
+    int64_t x_off;  // real channel-pair source: sample index of n = 0 (may be negative: zeros)
 };
 
 template <int N1>
@@ -92,9 +93,10 @@ __global__ __launch_bounds__(1024) void k_big_cols(ColsArgs p) {
             int j = i % p.ct, n1 = i / p.ct;
             int64_t n = (int64_t)n1 * p.n2 + j20 + j;
             float2 z = make_float2(0.f, 0.f);
-            if (n < p.n_samples) {
-                z.x = a[n];
-                if (b) z.y = b[n];
+            const int64_t g = n + p.x_off;
+            if (g >= 0 && g < p.n_samples) {
+                z.x = a[g];
+                if (b) z.y = b[g];
             }
             lds[j * CHS + lidx(n1)] = z;
         }
@@ -160,7 +162,8 @@ struct UnpackArgs {
     int64_t n_total;
     int n_ch;
     float scale;
-    float2* spec;  // [N/2+1][n_ch]   (items == 1)
+    float2* spec;  // spec[k*bin_stride + c*ch_stride]; [N/2+1][n_ch] = (n_ch, 1)
+    int64_t bin_stride, ch_stride;
 };
 __global__ void k_big_unpack(UnpackArgs p) {
     const int64_t N = p.n_total, nb = N / 2 + 1;
@@ -171,8 +174,8 @@ __global__ void k_big_unpack(UnpackArgs p) {
         float2 A = make_float2(0.5f * (P.x + Qc.x) * p.scale, 0.5f * (P.y - Qc.y) * p.scale);
         float2 B = make_float2(0.5f * (P.y + Qc.y) * p.scale, -0.5f * (P.x - Qc.x) * p.scale);
         const int ca = 2 * pair;
-        p.spec[k * p.n_ch + ca] = A;
-        if (ca + 1 < p.n_ch) p.spec[k * p.n_ch + ca + 1] = B;
+        p.spec[k * p.bin_stride + ca * p.ch_stride] = A;
+        if (ca + 1 < p.n_ch) p.spec[k * p.bin_stride + (ca + 1) * p.ch_stride] = B;
     }
 }
 
@@ -213,6 +216,7 @@ struct StoreArgs {
     int64_t n_total, n_out, ld_out;
     int n_ch;
     float* ir;  // [(item*n_ch + c)*ld_out + n]
+    int64_t z_off;  // first transform sample that is stored (overlap-save: n_taps - 1)
 };
 __global__ void k_big_store(StoreArgs p) {
     const int64_t bt = blockIdx.y;
@@ -224,7 +228,7 @@ __global__ void k_big_store(StoreArgs p) {
     const bool vb = ca + 1 < p.n_ch;
     const float inv = 1.0f / (float)p.n_total;
     for (int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; n < p.n_out; n += (int64_t)gridDim.x * blockDim.x) {
-        float2 f = z[n];
+        float2 f = z[n + p.z_off];
         oa[n] = f.x * inv;
         if (vb) oa[p.ld_out + n] = -f.y * inv;
     }
@@ -338,6 +342,35 @@ __global__ void k_spec_sum(SpecSumArgs p) {
         p.pyy[(size_t)c * nb + b] = (float)syy;
     }
     p.pxy[(size_t)c * nb + b] = make_float2((float)sr, (float)si);
+}
+
+// FIR bank on the four-step FFT: z[(kf*npair + pair)] <- conj( A R_kf + i B R_kf ) with A, B the
+// two channel spectra packed in spec[pair] and R_kf the (real-signal) tap spectrum of filter kf
+struct MulBankArgs {
+    const float2* spec;  // [npair][N]
+    const float2* r;     // [filters][N/2+1]
+    float2* z;           // [filters*npair][N]
+    int64_t n_total;
+    int npair;
+};
+__global__ void k_big_mul_bank(MulBankArgs p) {
+    const int64_t N = p.n_total, nb = N / 2 + 1;
+    const int64_t bt = blockIdx.y;
+    const float2* zi = p.spec + (bt % p.npair) * N;
+    const float2* R = p.r + (bt / p.npair) * nb;
+    float2* z = p.z + bt * N;
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < nb; k += (int64_t)gridDim.x * blockDim.x) {
+        float2 P = zi[k], Qc = zi[(N - k) & (N - 1)];
+        float2 A = make_float2(0.5f * (P.x + Qc.x), 0.5f * (P.y - Qc.y));
+        float2 B = make_float2(0.5f * (P.y + Qc.y), -0.5f * (P.x - Qc.x));
+        float2 VA = cmul(A, R[k]), VB = cmul(B, R[k]);
+        if (k == 0 || k == N / 2) {
+            z[k] = make_float2(VA.x, -VB.x);
+        } else {
+            z[k] = make_float2(VA.x - VB.y, -(VA.y + VB.x));
+            z[N - k] = make_float2(VA.x + VB.y, -(VB.x - VA.y));
+        }
+    }
 }
 
 }  // namespace dsbig

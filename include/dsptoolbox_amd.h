@@ -185,7 +185,11 @@ int ds_deconv(ds_ctx* ctx, const float* y, int n_items, int n_ch, int64_t n_samp
  * filter loop of _filterbank_on_signal, :385-451.
  * y = (x * taps_k)[0:N] for each of n_filt filters of n_taps taps
  * (taps[k*n_taps + t]); DS_FB_PARALLEL: y[(k*n_ch + c)*ld_y + n];
- * DS_FB_SUMMED / DS_FB_SEQUENTIAL: y[c*ld_y + n].                             */
+ * DS_FB_SUMMED / DS_FB_SEQUENTIAL: y[c*ld_y + n].
+ * Up to 8193 taps: LDS-resident blocks of <= 16384 points; longer filters (to
+ * 2^23 + 1 taps): overlap-save on the four-step FFT.  Filter state (zi) and
+ * zero-phase filtering are built on this call by the host shim: the full
+ * convolution is this call over the signal followed by n_taps - 1 zeros.      */
 int ds_fir_ola_dev(ds_ctx* ctx, const float* x_dev, int n_ch, int64_t ldx,
                    int64_t n_samples, const float* taps_dev, int n_filt, int n_taps,
                    int mode, float* y_dev, int64_t ld_y);

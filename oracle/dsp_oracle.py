@@ -480,13 +480,45 @@ def spectral_deconvolve(y, x, fs_hz: int, apply_regularization: bool = True,
 # --------------------------------------------------------------------------
 # FIR filtering (classes/filter_helpers.py:288-503)
 # --------------------------------------------------------------------------
-def lfilter_fir(b, x):
-    """filter_helpers.py:454-503 without zi: oaconvolve(...)[:N]."""
+def lfilter_fir(b, x, zi=None):
+    """filter_helpers.py:454-503: oaconvolve(...)[:N]; with zi (T-1, C) the state is added to
+    the head of the full convolution and the new state is its tail (:493-500)."""
     b = np.asarray(b, dtype=np.float64).squeeze()
     x = np.asarray(x, dtype=np.float64)
     if x.ndim < 2:
         x = x[:, None]
-    return oaconvolve(x, b[:, None], mode="full", axes=0)[: x.shape[0], :]
+        if zi is not None:
+            zi = np.asarray(zi)[:, None]
+    y = oaconvolve(x, b[:, None], mode="full", axes=0)
+    if zi is None:
+        return y[: x.shape[0], :]
+    y[: zi.shape[0], :] += zi
+    zf = y[-zi.shape[0]:, :]
+    return y[: x.shape[0], :], zf
+
+
+def lfilter_zi_fir(b):
+    """scipy.signal.lfilter_zi(b, [1.0]) (Filter.initialize_zi, filter.py:331-353) in closed
+    form: the step-response steady state of a transposed direct-form FIR filter is the tail
+    sum of the taps, zi[i] = sum_{j > i} b[j]."""
+    b = np.asarray(b, dtype=np.float64)
+    return np.cumsum(b[::-1])[::-1][1:].copy()
+
+
+def filtfilt_fir(b, x):
+    """scipy.signal.filtfilt(b, [1.0], x, axis=0) with its defaults (padtype="odd",
+    padlen = 3 * len(b), method="pad") -- the zero_phase branch of _filter_on_signal_ba
+    (filter_helpers.py:362-363) -- restated on top of lfilter_fir."""
+    b = np.asarray(b, dtype=np.float64)
+    x = np.asarray(x, dtype=np.float64)
+    edge = 3 * len(b)
+    if x.shape[0] <= edge:
+        raise ValueError("The length of the input vector x must be greater than padlen, which is %d." % edge)
+    ext = np.concatenate([2 * x[:1] - x[edge:0:-1], x, 2 * x[-1:] - x[-2:-(edge + 2):-1]], axis=0)
+    zi = lfilter_zi_fir(b)[:, None]
+    y, _ = lfilter_fir(b, ext, zi * ext[:1])
+    y, _ = lfilter_fir(b, y[::-1], zi * y[-1:])
+    return y[::-1][edge:-edge]
 
 
 def filter_fir_on_channels(b, td, channels=None):

@@ -57,8 +57,70 @@ def save(name, meta, arrays):
     print(f"{name}: {os.path.getsize(path) / 1024:.1f} KiB, {len(meta['cases'])} cases")
 
 
+def gen_fir_state(dsp):
+    """Filter state (zi), zero-phase and long FIR filters: Filter / FilterBank.filter_signal with
+    activate_zi / zero_phase (classes/filter.py:648-743, filter_helpers.py:288-382, 454-503)."""
+    from dsptoolbox.standard.enums import FilterBankMode, FilterPassType
+    fs = 48000
+    rng = np.random.default_rng(19)
+    cases, arrs = [], {}
+    x = rng.standard_normal((6000, 2)) * 0.1 + 0.05
+    arrs["x"] = x
+    # block-wise filtering with state: three consecutive blocks through one filter object
+    for order in (64, 700):
+        flt = dsp.Filter.fir_filter(order, 3000.0, FilterPassType.Lowpass, fs)
+        arrs[f"b_{order}"] = flt.ba[0]
+        flt.initialize_zi(2)
+        arrs[f"zi0_{order}"] = np.asarray(flt.zi)
+        outs = []
+        for k, (a, b) in enumerate(((0, 2500), (2500, 3000), (3000, 6000))):
+            o = flt.filter_signal(dsp.Signal(None, x[a:b].copy(), fs), activate_zi=True)
+            outs.append(o.time_data)
+            arrs[f"zi_{order}_{k}"] = np.asarray(flt.zi)
+        arrs[f"y_zi_{order}"] = np.concatenate(outs, axis=0)
+        cases.append(dict(kind="zi_blocks", order=order, blocks=[[0, 2500], [2500, 3000], [3000, 6000]]))
+        # only channel 1 with state
+        flt.initialize_zi(2)
+        o = flt.filter_signal(dsp.Signal(None, x[:2000].copy(), fs), channels=[1], activate_zi=True)
+        arrs[f"y_zi_ch1_{order}"] = o.time_data
+        arrs[f"zi_ch1_{order}"] = np.asarray(flt.zi)
+        cases.append(dict(kind="zi_channel", order=order, channels=[1], n=2000))
+        # zero phase
+        o = flt.filter_signal(dsp.Signal(None, x.copy(), fs), zero_phase=True)
+        arrs[f"y_zp_{order}"] = o.time_data
+        cases.append(dict(kind="zero_phase", order=order))
+    # filter bank, zero phase and state
+    flts = [dsp.Filter.fir_filter(200, [lo, hi], FilterPassType.Bandpass, fs)
+            for (lo, hi) in ((100.0, 3000.0), (800.0, 12000.0))]
+    arrs["bank_taps"] = np.stack([f.ba[0] for f in flts])
+    fb = dsp.FilterBank(flts)
+    for mode in FilterBankMode:
+        o = fb.filter_signal(dsp.Signal(None, x.copy(), fs), mode, zero_phase=True)
+        arrs[f"y_bank_zp_{mode.name}"] = (np.asarray(o.get_all_time_data()[0]) if mode == FilterBankMode.Parallel
+                                          else o.time_data)
+        cases.append(dict(kind="bank_zero_phase", mode=mode.name))
+    fb.initialize_zi(2)
+    o = fb.filter_signal(dsp.Signal(None, x[:3000].copy(), fs), FilterBankMode.Parallel, activate_zi=True)
+    o2 = fb.filter_signal(dsp.Signal(None, x[3000:].copy(), fs), FilterBankMode.Parallel, activate_zi=True)
+    arrs["y_bank_zi"] = np.concatenate([np.asarray(o.get_all_time_data()[0]),
+                                        np.asarray(o2.get_all_time_data()[0])], axis=0)
+    cases.append(dict(kind="bank_zi", mode="Parallel", blocks=[[0, 3000], [3000, 6000]]))
+    # long filter: more taps than the largest LDS-resident block can take (> 8193)
+    xl = rng.standard_normal((70000, 3)) * 0.1
+    bl = rng.standard_normal(20001) * np.exp(-np.arange(20001) / 3000.0) * 0.05
+    fl = dsp.Filter.from_ba(bl, [1.0], fs)
+    o = fl.filter_signal(dsp.Signal(None, xl.copy(), fs))
+    arrs["x_long"], arrs["b_long"], arrs["y_long"] = xl.astype(np.float32), bl, o.time_data.astype(np.float32)
+    cases.append(dict(kind="long", taps=20001, note="x_long / y_long stored as float32"))
+    save("fir_state", dict(cases=cases, fs=fs), arrs)
+
+
 def main():
     dsp = import_reference()
+    if "--only-fir-state" in sys.argv:
+        import warnings
+        warnings.simplefilter("ignore")
+        return gen_fir_state(dsp)
     from dsptoolbox.standard._spectral_methods import _welch
     from dsptoolbox.standard._framed_signal_representation import _get_framed_signal
     from dsptoolbox.helpers.other import _compute_number_frames
@@ -327,6 +389,7 @@ def main():
          dict(x_int16=xi, y_int16=yi, tf=np.asarray(sp.spectral_data), coh=np.asarray(sp.coherence),
               ir_head=ir.time_data[:48000], ir_tail=ir.time_data[-4096:],
               ir_peak=np.array([np.max(np.abs(ir.time_data))])))
+    gen_fir_state(dsp)
 
 
 if __name__ == "__main__":

@@ -261,6 +261,78 @@ def test_fir_golden():
     print("fir worst rel-max", worst)
 
 
+def test_fir_state_zero_phase_long_golden():
+    """activate_zi (incl. the reference's state hand-back quirk), zero_phase (filtfilt) and a
+    20001-tap filter (four-step FFT overlap-save) against the reference's outputs."""
+    import warnings
+    meta, z = load_golden("fir_state")
+    fs = meta["fs"]
+    x = z["x"]
+    for c in meta["cases"]:
+        if c["kind"] == "zi_blocks":
+            flt = dsp.Filter.from_ba(z[f"b_{c['order']}"], [1.0], fs)
+            flt.initialize_zi(2)
+            assert np.allclose(np.asarray(flt.zi), z[f"zi0_{c['order']}"], rtol=1e-12, atol=1e-15)
+            outs = []
+            for k, (a, e) in enumerate(c["blocks"]):
+                with warnings.catch_warnings():
+                    warnings.simplefilter("ignore")
+                    o = flt.filter_signal(dsp.Signal(None, x[a:e].copy(), fs), activate_zi=True)
+                outs.append(o.time_data)
+                assert np.asarray(flt.zi).shape == z[f"zi_{c['order']}_{k}"].shape
+                assert relmax(np.asarray(flt.zi), z[f"zi_{c['order']}_{k}"]) < TOL
+            assert relmax(np.concatenate(outs), z[f"y_zi_{c['order']}"]) < TOL
+        elif c["kind"] == "zi_channel":
+            flt = dsp.Filter.from_ba(z[f"b_{c['order']}"], [1.0], fs)
+            flt.initialize_zi(2)
+            o = flt.filter_signal(dsp.Signal(None, x[:c["n"]].copy(), fs), channels=c["channels"],
+                                  activate_zi=True)
+            assert relmax(o.time_data, z[f"y_zi_ch1_{c['order']}"]) < TOL
+            assert relmax(np.asarray(flt.zi), z[f"zi_ch1_{c['order']}"]) < TOL
+        elif c["kind"] == "zero_phase":
+            flt = dsp.Filter.from_ba(z[f"b_{c['order']}"], [1.0], fs)
+            o = flt.filter_signal(dsp.Signal(None, x.copy(), fs), zero_phase=True)
+            assert relmax(o.time_data, z[f"y_zp_{c['order']}"]) < TOL
+        elif c["kind"] == "bank_zero_phase":
+            fb = dsp.FilterBank([dsp.Filter.from_ba(b, [1.0], fs) for b in z["bank_taps"]])
+            o = fb.filter_signal(dsp.Signal(None, x.copy(), fs), FilterBankMode[c["mode"]], zero_phase=True)
+            got = o.get_all_time_data()[0] if c["mode"] == "Parallel" else o.time_data
+            assert relmax(got, z[f"y_bank_zp_{c['mode']}"]) < TOL, c
+        elif c["kind"] == "bank_zi":
+            fb = dsp.FilterBank([dsp.Filter.from_ba(b, [1.0], fs) for b in z["bank_taps"]])
+            fb.initialize_zi(2)
+            outs = []
+            for a, e in c["blocks"]:
+                with warnings.catch_warnings():
+                    warnings.simplefilter("ignore")
+                    o = fb.filter_signal(dsp.Signal(None, x[a:e].copy(), fs), FilterBankMode.Parallel,
+                                         activate_zi=True)
+                outs.append(o.get_all_time_data()[0])
+            assert relmax(np.concatenate(outs), z["y_bank_zi"]) < TOL
+        elif c["kind"] == "long":
+            flt = dsp.Filter.from_ba(z["b_long"], [1.0], fs)
+            o = flt.filter_signal(dsp.Signal(None, z["x_long"].astype(np.float64), fs))
+            assert relmax(o.time_data, z["y_long"]) < TOL
+    with pytest.raises(AssertionError):
+        dsp.Filter.from_ba(z["b_64"], [1.0], fs).filter_signal(dsp.Signal(None, x.copy(), fs),
+                                                              activate_zi=True, zero_phase=True)
+
+
+def test_fir_long_filters_vs_oracle():
+    """> 8193 taps: overlap-save on the four-step FFT, several blocks, bank modes."""
+    rng = np.random.default_rng(91)
+    n, t = 300000, 9000
+    x = rng.standard_normal((n, 3)) * 0.1
+    taps = [rng.standard_normal(t) * np.exp(-np.arange(t) / 1500.0) * 0.05 for _ in range(3)]
+    for mode, name in ((backend.DS_FB_PARALLEL, "Parallel"), (backend.DS_FB_SUMMED, "Summed"),
+                       (backend.DS_FB_SEQUENTIAL, "Sequential")):
+        y = backend.fir_filter_bank(x, taps, mode)
+        r = orc.filterbank_fir(taps, x, name)
+        if name == "Parallel":
+            r = np.transpose(r, (2, 0, 1))
+        assert relmax(y, r) < TOL, (name, relmax(y, r))
+
+
 def test_fir_design_matches_lfilter():
     """reference tests/test_classes.py:495-512: FIR filter_signal == scipy.signal.lfilter."""
     import scipy.signal as sig

@@ -130,6 +130,43 @@ def test_fir():
             close(y, ref, tol=1e-12)
 
 
+def test_fir_state_zero_phase_long():
+    """Filter state (zi), zero-phase and long FIR filters against the reference's outputs."""
+    import scipy.signal as sig
+    meta, z = load_golden("fir_state")
+    x = z["x"]
+    for c in meta["cases"]:
+        if c["kind"] == "zi_blocks":
+            b = z[f"b_{c['order']}"]
+            assert np.allclose(orc.lfilter_zi_fir(b), sig.lfilter_zi(b, [1.0]), rtol=1e-12, atol=1e-15)
+            assert np.allclose(z[f"zi0_{c['order']}"][0], orc.lfilter_zi_fir(b), rtol=1e-12, atol=1e-15)
+            outs = []
+            for k, (a, e) in enumerate(c["blocks"]):
+                # the reference stores the state back as a (T-1, C) array, so every later call
+                # finds len(zi) != channels and starts again from lfilter_zi (see classes/filter.py)
+                zi = np.tile(orc.lfilter_zi_fir(b)[:, None], (1, x.shape[1]))
+                y, zf = orc.lfilter_fir(b, x[a:e], zi)
+                outs.append(y)
+                close(zf, z[f"zi_{c['order']}_{k}"], tol=1e-12)
+            close(np.concatenate(outs), z[f"y_zi_{c['order']}"], tol=1e-12)
+        elif c["kind"] == "zero_phase":
+            close(orc.filtfilt_fir(z[f"b_{c['order']}"], x), z[f"y_zp_{c['order']}"], tol=1e-12)
+        elif c["kind"] == "bank_zero_phase":
+            outs = [orc.filtfilt_fir(b, x) for b in z["bank_taps"]]
+            if c["mode"] == "Parallel":
+                close(np.stack(outs, axis=1), z["y_bank_zp_Parallel"], tol=1e-12)
+            elif c["mode"] == "Summed":
+                close(sum(outs), z["y_bank_zp_Summed"], tol=1e-12)
+            else:
+                y = x
+                for b in z["bank_taps"]:
+                    y = orc.filtfilt_fir(b, y)
+                close(y, z["y_bank_zp_Sequential"], tol=1e-12)
+        elif c["kind"] == "long":
+            y = orc.lfilter_fir(z["b_long"], z["x_long"].astype(np.float64))
+            close(y, z["y_long"], tol=1e-6)  # stored as float32
+
+
 def test_chirp_pair_config1():
     """BASELINE.json configs[0]: the reference's own example chirps (16-bit PCM fixtures)."""
     meta, z = load_golden("chirp_pair")
