@@ -16,6 +16,7 @@
 #include "kernels_finish.hpp"
 #include "kernels_generic.hpp"
 #include "kernels_welch4096.hpp"
+#include "kernels_welch4096_r8.hpp"
 
 using namespace dsk;
 
@@ -29,6 +30,7 @@ struct ds_ctx {
     std::map<int, float2*> tw;  // twiddle tables by length
     std::map<std::pair<int64_t, int64_t>, float2*> blue;  // Bluestein chirp-filter spectra by (L, M)
     float2* w4_tables = nullptr;  // welch4096::host_tables()
+    float2* w4r8_tables = nullptr;  // welch4096r8::host_tables()
     void* ws = nullptr;         // kernel workspace (spectra, partials)
     size_t ws_bytes = 0;
     void* io = nullptr;  // staging for the host-pointer entry points
@@ -102,6 +104,7 @@ extern "C" void ds_destroy(ds_ctx* c) {
     (void)hipStreamSynchronize(c->stream);
     for (auto& kv : c->tw) (void)hipFree(kv.second);
     if (c->w4_tables) (void)hipFree(c->w4_tables);
+    if (c->w4r8_tables) (void)hipFree(c->w4r8_tables);
     for (auto& kv : c->blue) (void)hipFree(kv.second);
     for (auto& r : c->prof_recs) {
         (void)hipEventDestroy(r.a);
@@ -478,11 +481,24 @@ static int welch4096_run(ds_ctx* c, const float* x, int64_t ldx, const float* y,
         ldy < n_samples)
         return fail(c, DS_ERR_ARG, "ds_welch_tf: bad shape");
     if (mode < DS_TF_H1 || mode > DS_TF_H3) return fail(c, DS_ERR_ARG, "welch: unsupported transfer function type");
-    if (!c->w4_tables) {
+    // variant: radix-16 / 256 threads / two waves per SIMD (default, 108-118 us on the headline
+    // shape) or radix-8 / 512 threads / four waves per SIMD (DSPTOOLBOX_AMD_WELCH_VARIANT=r8,
+    // 129-140 us: the third LDS exchange and barrier cost more than the extra waves hide)
+    static int variant = -1;
+    if (variant < 0) {
+        const char* e = getenv("DSPTOOLBOX_AMD_WELCH_VARIANT");
+        variant = (e && !strcmp(e, "r8")) ? 8 : 16;
+    }
+    const bool r8 = variant == 8;
+    float2*& tables = r8 ? c->w4r8_tables : c->w4_tables;
+    if (!tables) {
         std::vector<float2> h;
-        w4::host_tables(h);
-        HIPCHK(c, hipMalloc((void**)&c->w4_tables, sizeof(float2) * h.size()));
-        HIPCHK(c, hipMemcpyAsync(c->w4_tables, h.data(), sizeof(float2) * h.size(), hipMemcpyHostToDevice, c->stream));
+        if (r8)
+            welch4096r8::host_tables(h);
+        else
+            w4::host_tables(h);
+        HIPCHK(c, hipMalloc((void**)&tables, sizeof(float2) * h.size()));
+        HIPCHK(c, hipMemcpyAsync(tables, h.data(), sizeof(float2) * h.size(), hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
     }
     w4::Plan pl = w4::plan(n_frames, n_cy);
@@ -495,13 +511,14 @@ static int welch4096_run(ds_ctx* c, const float* x, int64_t ldx, const float* y,
     float* pyy = cv.take<float>((size_t)pl.n_chunks * n_cy * w4::NB);
     const bool half = hop == 2048;
     w4::Args ax{x, n_samples, ldx, 1, hop, n_frames, pl.n_pairs, detrend, pl.n_chunks, pl.ppc, window,
-                c->w4_tables, xs, px, pxy, pyy};
-    if (half)
-        CHK(launch(c, "welch4096_x", w4::k_x<true>, dim3(pl.n_pairs), w4::NT, w4::LDS_BYTES, ax));
-    else
-        CHK(launch(c, "welch4096_x", w4::k_x<false>, dim3(pl.n_pairs), w4::NT, w4::LDS_BYTES, ax));
+                tables, xs, px, pxy, pyy};
+    const int nt = r8 ? welch4096r8::NT : w4::NT;
+    const size_t lds_x = r8 ? welch4096r8::LDS_BYTES : w4::LDS_BYTES;
+    const size_t lds_y = r8 ? welch4096r8::LDS_BYTES : w4::LDS_BYTES_2;
+    auto kx = r8 ? (half ? welch4096r8::k_x<true> : welch4096r8::k_x<false>) : (half ? w4::k_x<true> : w4::k_x<false>);
+    auto ky = r8 ? (half ? welch4096r8::k_y<true> : welch4096r8::k_y<false>) : (half ? w4::k_y<true> : w4::k_y<false>);
+    CHK(launch(c, "welch4096_x", kx, dim3(pl.n_pairs), nt, lds_x, ax));
     {
-        struct A3 { const float* px; int n; float* sxx; };
         hipLaunchKernelGGL(w4::k_sxx, dim3((w4::NB + 7) / 8), dim3(256), 0, c->stream, (const float*)px,
                            pl.n_pairs, sxx);
         HIPCHK(c, hipGetLastError());
@@ -510,13 +527,7 @@ static int welch4096_run(ds_ctx* c, const float* x, int64_t ldx, const float* y,
     ay.sig = y;
     ay.ld = ldy;
     ay.n_ch = n_cy;
-    {
-        dim3 grid(pl.n_chunks * n_cy);
-        if (half)
-            CHK(launch(c, "welch4096_main", w4::k_y<true>, grid, w4::NT, w4::LDS_BYTES_2, ay));
-        else
-            CHK(launch(c, "welch4096_main", w4::k_y<false>, grid, w4::NT, w4::LDS_BYTES_2, ay));
-    }
+    CHK(launch(c, "welch4096_main", ky, dim3(pl.n_chunks * n_cy), nt, lds_y, ay));
     WelchFinArgs f{sxx, pxy, pyy, pl.n_chunks, 1, 1, n_cy, 0, mode,
                    FinishPar{norm_scale / (double)n_frames, factor, halve_edges, amp_sqrt, w4::NB},
                    tf, coh};
@@ -1132,6 +1143,16 @@ extern "C" int ds_fir_ola_dev(ds_ctx* c, const float* x, int n_ch, int64_t ldx, 
     }
     return fail(c, DS_ERR_ARG, "ds_fir_ola: invalid filter bank apply mode");
 }
+
+#if W4_TIMING
+// dev only (built with -DW4_TIMING=1): read and reset the per-phase cycle stamps
+extern "C" int ds_debug_welch_timing(unsigned long long out[16]) {
+    unsigned long long z[16] = {};
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(welch4096::w4_timing), sizeof(z)) != hipSuccess) return -1;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(welch4096::w4_timing), z, sizeof(z)) != hipSuccess) return -1;
+    return 0;
+}
+#endif
 
 // ---- host-pointer entry points -------------------------------------------------
 struct Stage {  // device staging out of ctx->io

@@ -43,6 +43,23 @@ namespace welch4096 {
 #define W4_ABLATE 0  // timing-only diagnostics (wrong results): 1 no xs loads, 2 no sample loads, 4 no LDS
 #endif
 
+#ifndef W4_TIMING
+#define W4_TIMING 0  // dev only: per-phase s_memtime stamps of wave 0 / workgroup 0 -> w4_timing[]
+#endif
+#if W4_TIMING
+__device__ unsigned long long w4_timing[16];
+#define W4_TS(i)                                                  \
+    do {                                                          \
+        __builtin_amdgcn_sched_barrier(0);                        \
+        unsigned long long t_ = __builtin_amdgcn_s_memtime();     \
+        __builtin_amdgcn_sched_barrier(0);                        \
+        if ((i) > 0) w4_ph[(i)-1] += t_ - w4_prev;                \
+        w4_prev = t_;                                             \
+    } while (0)
+#else
+#define W4_TS(i)
+#endif
+
 constexpr int N = 4096, NT = 256, NB = N / 2 + 1;
 constexpr int L1S = 272, L2S = 18;
 constexpr int BUF_C = 256 * L2S;  // 4608 complex >= 16 * 272
@@ -98,28 +115,46 @@ struct Tw {
 // hazards are write-after-read across iterations, which the two barriers already order.
 template <bool TWO_BUF>
 __device__ __forceinline__ void fft4096(float2 (&v)[16], const Tw& tw, float2* __restrict__ buf,
-                                        const float2* __restrict__ tw2, int tid) {
+                                        const float2* __restrict__ tw2, int tid
+#if W4_TIMING
+                                        , unsigned long long (&w4_ph)[12], unsigned long long& w4_prev
+#endif
+) {
     float2* __restrict__ bufB = TWO_BUF ? buf + BUF_C : buf;
     dft16(v);
 #pragma unroll
     for (int k1 = 1; k1 < 16; ++k1) v[pos16(k1)] = cmul(v[pos16(k1)], tw.w[k1 - 1]);
+    W4_TS(2);
     const int k1u = tid >> 4, n3 = tid & 15;
     if (!(W4_ABLATE & 4)) {
         if (!TWO_BUF) __syncthreads();  // previous readers of buf are done
 #pragma unroll
         for (int k1 = 0; k1 < 16; ++k1) buf[k1 * L1S + tid] = v[pos16(k1)];
+    }
+    // the pass-2 twiddles do not depend on the exchange: fetch them (into the registers the
+    // stored values just left) before the barrier, so their latency hides behind it
+    float2 w2[15];
+#pragma unroll
+    for (int k2 = 1; k2 < 16; ++k2) w2[k2 - 1] = tw2[k2 * 16 + n3];
+    if (!(W4_ABLATE & 4)) {
+        W4_TS(3);
         __syncthreads();
+        W4_TS(4);
 #pragma unroll
         for (int n2 = 0; n2 < 16; ++n2) v[n2] = buf[k1u * L1S + 16 * n2 + n3];
     }
+    W4_TS(5);
     dft16(v);
 #pragma unroll
-    for (int k2 = 1; k2 < 16; ++k2) v[pos16(k2)] = cmul(v[pos16(k2)], tw2[k2 * 16 + n3]);
+    for (int k2 = 1; k2 < 16; ++k2) v[pos16(k2)] = cmul(v[pos16(k2)], w2[k2 - 1]);
+    W4_TS(6);
     if (!(W4_ABLATE & 4)) {
         if (!TWO_BUF) __syncthreads();  // all pass-2 reads done
 #pragma unroll
         for (int k2 = 0; k2 < 16; ++k2) bufB[(16 * k2 + k1u) * L2S + n3] = v[pos16(k2)];
+        W4_TS(7);
         __syncthreads();
+        W4_TS(8);
         const float4* row = reinterpret_cast<const float4*>(bufB + tid * L2S);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -128,7 +163,9 @@ __device__ __forceinline__ void fft4096(float2 (&v)[16], const Tw& tw, float2* _
             v[2 * j + 1] = make_float2(r.z, r.w);
         }
     }
+    W4_TS(9);
     dft16(v);
+    W4_TS(10);
 }
 
 struct Args {
@@ -155,6 +192,7 @@ __device__ __forceinline__ void init_tables(Tw& tw, float (&win)[16], float2* tw
 #pragma unroll
     for (int n1 = 0; n1 < 16; ++n1) win[n1] = window[tid + 256 * n1];
     tw2[tid] = twt[15 * 256 + tid];  // tw2[k2*16 + n3] = W256^(n3 k2)
+    __syncthreads();  // the table is read before the first exchange barrier of the transform
 }
 inline void host_tables(std::vector<float2>& t) {
     t.resize(TWT_LEN);
@@ -237,7 +275,12 @@ __global__ __launch_bounds__(NT) void k_x(Args p) {
         load_raw<HALF_HOP>(raw, p.sig, p.n_samples, (int64_t)(2 * pr) * p.hop, p.hop, tid);
         window_pair<HALF_HOP>(v, raw, 2 * pr + 1 < p.n_frames, win);
     }
+#if W4_TIMING
+    unsigned long long w4_ph[12] = {}, w4_prev = 0;
+    fft4096<false>(v, tw, buf, tw2, tid, w4_ph, w4_prev);
+#else
     fft4096<false>(v, tw, buf, tw2, tid);
+#endif
     if (p.detrend && tid == 0) v[pos16(0)] = make_float2(0.f, 0.f);
     float4* xo = reinterpret_cast<float4*>(p.xs + (int64_t)pr * N) + tid;
 #pragma unroll
@@ -317,8 +360,12 @@ __global__ __launch_bounds__(NT, 2) void k_y(Args p) {
         // and the input spectrum of pair pr are in flight while pair pr is transformed
         Raw<HALF_HOP> raw;
         if (p0 < p1) load_raw<HALF_HOP>(raw, ch, p.n_samples, (int64_t)(2 * p0) * p.hop, p.hop, tid);
+#if W4_TIMING
+        unsigned long long w4_ph[12] = {}, w4_prev = 0;
+#endif
         for (int pr = p0; pr < p1; ++pr) {
             float2 v[16];
+            W4_TS(0);
             window_pair<HALF_HOP>(v, raw, 2 * pr + 1 < p.n_frames, win);
             if (!(W4_ABLATE & 2) && pr + 1 < p1)
                 load_raw<HALF_HOP>(raw, ch, p.n_samples, (int64_t)(2 * pr + 2) * p.hop, p.hop, tid);
@@ -335,7 +382,12 @@ __global__ __launch_bounds__(NT, 2) void k_y(Args p) {
                     xw[2 * g + 1] = make_float2(q.z, q.w);
                 }
             }
+            W4_TS(1);
+#if W4_TIMING
+            fft4096<TWO_BUF>(v, tw, buf, tw2, tid, w4_ph, w4_prev);
+#else
             fft4096<TWO_BUF>(v, tw, buf, tw2, tid);
+#endif
 #pragma unroll
             for (int k3 = 0; k3 < 16; ++k3) {
                 float2 w = xw[k3];
@@ -344,7 +396,14 @@ __global__ __launch_bounds__(NT, 2) void k_y(Args p) {
                 T[k3].y = fmaf(w.x, z.y, fmaf(-w.y, z.x, T[k3].y));
                 P[k3] = fmaf(z.x, z.x, fmaf(z.y, z.y, P[k3]));
             }
+            W4_TS(11);
         }
+#if W4_TIMING
+        if (blockIdx.x == 0 && tid == 0) {
+            for (int i = 0; i < 11; ++i) atomicAdd(&w4_timing[i], w4_ph[i]);
+            atomicAdd(&w4_timing[15], (unsigned long long)(p1 - p0));
+        }
+#endif
     }
     if (p.detrend && tid == 0) P[0] = 0.f;  // xs bin 0 is already 0 -> T[0] = 0
     // fold k <-> N-k once per chunk, through LDS
