@@ -16,7 +16,6 @@
 #include "kernels_finish.hpp"
 #include "kernels_generic.hpp"
 #include "kernels_welch4096.hpp"
-#include "kernels_welch4096_r8.hpp"
 
 using namespace dsk;
 
@@ -30,7 +29,6 @@ struct ds_ctx {
     std::map<int, float2*> tw;  // twiddle tables by length
     std::map<std::pair<int64_t, int64_t>, float2*> blue;  // Bluestein chirp-filter spectra by (L, M)
     float2* w4_tables = nullptr;  // welch4096::host_tables()
-    float2* w4r8_tables = nullptr;  // welch4096r8::host_tables()
     void* ws = nullptr;         // kernel workspace (spectra, partials)
     size_t ws_bytes = 0;
     void* io = nullptr;  // staging for the host-pointer entry points
@@ -104,7 +102,6 @@ extern "C" void ds_destroy(ds_ctx* c) {
     (void)hipStreamSynchronize(c->stream);
     for (auto& kv : c->tw) (void)hipFree(kv.second);
     if (c->w4_tables) (void)hipFree(c->w4_tables);
-    if (c->w4r8_tables) (void)hipFree(c->w4r8_tables);
     for (auto& kv : c->blue) (void)hipFree(kv.second);
     for (auto& r : c->prof_recs) {
         (void)hipEventDestroy(r.a);
@@ -481,24 +478,11 @@ static int welch4096_run(ds_ctx* c, const float* x, int64_t ldx, const float* y,
         ldy < n_samples)
         return fail(c, DS_ERR_ARG, "ds_welch_tf: bad shape");
     if (mode < DS_TF_H1 || mode > DS_TF_H3) return fail(c, DS_ERR_ARG, "welch: unsupported transfer function type");
-    // variant: radix-16 / 256 threads / two waves per SIMD (default, 108-118 us on the headline
-    // shape) or radix-8 / 512 threads / four waves per SIMD (DSPTOOLBOX_AMD_WELCH_VARIANT=r8,
-    // 129-140 us: the third LDS exchange and barrier cost more than the extra waves hide)
-    static int variant = -1;
-    if (variant < 0) {
-        const char* e = getenv("DSPTOOLBOX_AMD_WELCH_VARIANT");
-        variant = (e && !strcmp(e, "r8")) ? 8 : 16;
-    }
-    const bool r8 = variant == 8;
-    float2*& tables = r8 ? c->w4r8_tables : c->w4_tables;
-    if (!tables) {
+    if (!c->w4_tables) {
         std::vector<float2> h;
-        if (r8)
-            welch4096r8::host_tables(h);
-        else
-            w4::host_tables(h);
-        HIPCHK(c, hipMalloc((void**)&tables, sizeof(float2) * h.size()));
-        HIPCHK(c, hipMemcpyAsync(tables, h.data(), sizeof(float2) * h.size(), hipMemcpyHostToDevice, c->stream));
+        w4::host_tables(h);
+        HIPCHK(c, hipMalloc((void**)&c->w4_tables, sizeof(float2) * h.size()));
+        HIPCHK(c, hipMemcpyAsync(c->w4_tables, h.data(), sizeof(float2) * h.size(), hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
     }
     w4::Plan pl = w4::plan(n_frames, n_cy);
@@ -511,13 +495,10 @@ static int welch4096_run(ds_ctx* c, const float* x, int64_t ldx, const float* y,
     float* pyy = cv.take<float>((size_t)pl.n_chunks * n_cy * w4::NB);
     const bool half = hop == 2048;
     w4::Args ax{x, n_samples, ldx, 1, hop, n_frames, pl.n_pairs, detrend, pl.n_chunks, pl.ppc, window,
-                tables, xs, px, pxy, pyy};
-    const int nt = r8 ? welch4096r8::NT : w4::NT;
-    const size_t lds_x = r8 ? welch4096r8::LDS_BYTES : w4::LDS_BYTES;
-    const size_t lds_y = r8 ? welch4096r8::LDS_BYTES : w4::LDS_BYTES_2;
-    auto kx = r8 ? (half ? welch4096r8::k_x<true> : welch4096r8::k_x<false>) : (half ? w4::k_x<true> : w4::k_x<false>);
-    auto ky = r8 ? (half ? welch4096r8::k_y<true> : welch4096r8::k_y<false>) : (half ? w4::k_y<true> : w4::k_y<false>);
-    CHK(launch(c, "welch4096_x", kx, dim3(pl.n_pairs), nt, lds_x, ax));
+                c->w4_tables, xs, px, pxy, pyy};
+    auto kx = half ? w4::k_x<true> : w4::k_x<false>;
+    auto ky = half ? w4::k_y<true> : w4::k_y<false>;
+    CHK(launch(c, "welch4096_x", kx, dim3(pl.n_pairs), w4::NT, w4::LDS_BYTES, ax));
     {
         hipLaunchKernelGGL(w4::k_sxx, dim3((w4::NB + 7) / 8), dim3(256), 0, c->stream, (const float*)px,
                            pl.n_pairs, sxx);
@@ -527,7 +508,7 @@ static int welch4096_run(ds_ctx* c, const float* x, int64_t ldx, const float* y,
     ay.sig = y;
     ay.ld = ldy;
     ay.n_ch = n_cy;
-    CHK(launch(c, "welch4096_main", ky, dim3(pl.n_chunks * n_cy), nt, lds_y, ay));
+    CHK(launch(c, "welch4096_main", ky, dim3(pl.n_chunks * n_cy), w4::NT, w4::LDS_BYTES_2, ay));
     WelchFinArgs f{sxx, pxy, pyy, pl.n_chunks, 1, 1, n_cy, 0, mode,
                    FinishPar{norm_scale / (double)n_frames, factor, halve_edges, amp_sqrt, w4::NB},
                    tf, coh};

@@ -580,34 +580,6 @@ def test_welch4096_fast_path_vs_oracle(overlap, n, n_cy):
             assert e1 < TOL and e2 < TOL, (mode, det, e1, e2)
 
 
-def test_welch4096_radix8_variant_vs_oracle():
-    """The alternative radix-8 / 512-thread headline kernels (selected per process by
-    DSPTOOLBOX_AMD_WELCH_VARIANT=r8) give the same transfer functions."""
-    import subprocess
-    import sys
-    code = (
-        "import numpy as np\n"
-        "from dsptoolbox_amd import backend\n"
-        "from dsptoolbox_amd.generators import sweep_and_responses\n"
-        "from oracle import dsp_oracle as orc\n"
-        "x, y = sweep_and_responses(n_samples=2**18 + 777, n_channels=5, fs_hz=48000)\n"
-        "fr = np.fft.rfftfreq(4096, 1 / 48000); m = (fr >= 30) & (fr <= 19000)\n"
-        "worst = 0.0\n"
-        "for ov in (50, 75):\n"
-        "    for det in (True, False):\n"
-        "        tf, coh = backend.welch_transfer_function(y, x, 48000, 4096, 'H1', detrend=det, overlap_percent=ov)\n"
-        "        rt, rc = orc.compute_transfer_function(y, x, 48000, 4096, 'H1', detrend=det, overlap_percent=ov)\n"
-        "        worst = max(worst, orc.rel_max(tf[m], rt[m]), orc.rel_max(coh[m], rc[m]))\n"
-        "print('WORST', worst)\n")
-    env = dict(os.environ, DSPTOOLBOX_AMD_WELCH_VARIANT="r8")
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    out = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True,
-                         timeout=600)
-    assert out.returncode == 0, out.stderr[-2000:]
-    worst = float(out.stdout.strip().split("WORST")[-1])
-    assert worst < TOL, worst
-
-
 @pytest.mark.parametrize("n", [2**15, 2**17, 2**20])
 def test_big_fft_whole_signal(n):
     """Lengths beyond one workgroup's LDS use the four-step path: whole-signal spectrum
