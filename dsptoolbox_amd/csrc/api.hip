@@ -490,26 +490,21 @@ static int welch4096_run(ds_ctx* c, const float* x, int64_t ldx, const float* y,
     Carver cv(c->ws);
     float2* xs = cv.take<float2>((size_t)pl.n_pairs * w4::N);
     float* px = cv.take<float>((size_t)pl.n_pairs * w4::NB);
-    float* sxx = cv.take<float>(w4::NB);
+    float* psx = cv.take<float>((size_t)pl.n_chunks * w4::NB);
     float2* pxy = cv.take<float2>((size_t)pl.n_chunks * n_cy * w4::NB);
     float* pyy = cv.take<float>((size_t)pl.n_chunks * n_cy * w4::NB);
     const bool half = hop == 2048;
     w4::Args ax{x, n_samples, ldx, 1, hop, n_frames, pl.n_pairs, detrend, pl.n_chunks, pl.ppc, window,
-                c->w4_tables, xs, px, pxy, pyy};
+                c->w4_tables, xs, px, pxy, pyy, psx};
     auto kx = half ? w4::k_x<true> : w4::k_x<false>;
     auto ky = half ? w4::k_y<true> : w4::k_y<false>;
     CHK(launch(c, "welch4096_x", kx, dim3(pl.n_pairs), w4::NT, w4::LDS_BYTES, ax));
-    {
-        hipLaunchKernelGGL(w4::k_sxx, dim3((w4::NB + 7) / 8), dim3(256), 0, c->stream, (const float*)px,
-                           pl.n_pairs, sxx);
-        HIPCHK(c, hipGetLastError());
-    }
     w4::Args ay = ax;
     ay.sig = y;
     ay.ld = ldy;
     ay.n_ch = n_cy;
     CHK(launch(c, "welch4096_main", ky, dim3(pl.n_chunks * n_cy), w4::NT, w4::LDS_BYTES_2, ay));
-    WelchFinArgs f{sxx, pxy, pyy, pl.n_chunks, 1, 1, n_cy, 0, mode,
+    WelchFinArgs f{psx, pxy, pyy, pl.n_chunks, pl.n_chunks, 1, n_cy, 0, mode,
                    FinishPar{norm_scale / (double)n_frames, factor, halve_edges, amp_sqrt, w4::NB},
                    tf, coh};
     int64_t total = (int64_t)w4::NB * n_cy;

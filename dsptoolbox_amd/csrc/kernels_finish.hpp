@@ -49,6 +49,28 @@ __device__ __forceinline__ cd finish_cplx(cd s, int b, const FinishPar& f) {
     return f.amp_sqrt ? csqrt_principal(s) : s;
 }
 
+// frame sums -> H1 / H2 / H3 and coherence (transfer_functions.py:525-534)
+__device__ __forceinline__ void tf_from_sums(double sxx, cd sxy, double syy, int b, int mode,
+                                             const FinishPar& fin, float2& tf, float& coh) {
+    cd gxy = finish_cplx(sxy, b, fin);
+    double gxx = finish_real(sxx, b, fin), gyy = finish_real(syy, b, fin);
+    double axy2 = gxy.x * gxy.x + gxy.y * gxy.y;
+    cd h;
+    if (mode == 1) {  // H1 = Gxy / Gxx
+        h = cd{gxy.x / gxx, gxy.y / gxx};
+    } else if (mode == 2) {  // H2 = Gyy / Gyx, Gyx = finish(conj(Sxy)) = conj(Gxy) ...
+        // ... except where Sxy is exactly real and negative (DC / Nyquist bins): the
+        // reference takes the principal root of (-a + 0j) for Gxy AND for Gyx.
+        cd gyx = (sxy.y == 0.0) ? gxy : cd{gxy.x, -gxy.y};
+        h = cd{gyy * gyx.x / axy2, -gyy * gyx.y / axy2};  // Gyy / Gyx = Gyy conj(Gyx)/|Gyx|^2
+    } else {  // H3 = Gxy/|Gxy| * sqrt(Gyy/Gxx)
+        double s = sqrt(gyy / gxx) / sqrt(axy2);
+        h = cd{gxy.x * s, gxy.y * s};
+    }
+    tf = make_float2((float)h.x, (float)h.y);
+    coh = (float)(axy2 / gxx / gyy);
+}
+
 // kind: 0 = transfer function + coherence, 1 = auto spectra (psd), 2 = cross spectra (csd)
 struct WelchFinArgs {
     const float* pxx;   // [q][n_cx][nb]
@@ -87,27 +109,12 @@ __global__ void k_welch_finish(WelchFinArgs p) {
         p.coh[idx] = (float)finish_real(sxx, b, p.fin);
         return;
     }
-    cd gxy = finish_cplx(sxy, b, p.fin);
     if (p.kind == 2) {
+        cd gxy = finish_cplx(sxy, b, p.fin);
         p.tf[idx] = make_float2((float)gxy.x, (float)gxy.y);
         return;
     }
-    double gxx = finish_real(sxx, b, p.fin), gyy = finish_real(syy, b, p.fin);
-    double axy2 = gxy.x * gxy.x + gxy.y * gxy.y;
-    cd h;
-    if (p.mode == 1) {  // H1 = Gxy / Gxx
-        h = cd{gxy.x / gxx, gxy.y / gxx};
-    } else if (p.mode == 2) {  // H2 = Gyy / Gyx, Gyx = finish(conj(Sxy)) = conj(Gxy) ...
-        // ... except where Sxy is exactly real and negative (DC / Nyquist bins): the
-        // reference takes the principal root of (-a + 0j) for Gxy AND for Gyx.
-        cd gyx = (sxy.y == 0.0) ? gxy : cd{gxy.x, -gxy.y};
-        h = cd{gyy * gyx.x / axy2, -gyy * gyx.y / axy2};  // Gyy / Gyx = Gyy conj(Gyx)/|Gyx|^2
-    } else {  // H3 = Gxy/|Gxy| * sqrt(Gyy/Gxx)
-        double s = sqrt(gyy / gxx) / sqrt(axy2);
-        h = cd{gxy.x * s, gxy.y * s};
-    }
-    p.tf[idx] = make_float2((float)h.x, (float)h.y);
-    p.coh[idx] = (float)(axy2 / gxx / gyy);
+    tf_from_sums(sxx, sxy, syy, b, p.mode, p.fin, p.tf[idx], p.coh[idx]);
 }
 
 // Median over frames (average="median", standard/_spectral_methods.py:153-162): per (channel, bin)

@@ -13,7 +13,7 @@
 //             Sxy[k] = (T[k] + conj T[N-k])/2 ,  Syy[k] = (P[k] + P[N-k])/2 ,  k <= 2048
 //           which is exact because both halves of a pair belong to the same channel:
 //             conj(W[k]) Z[k] + conj( conj(W[N-k]) Z[N-k] ) = 2 (conj(X_a) Y_a + conj(X_b) Y_b).
-//   k_sxx : sum of px over pairs (fp64) -> one "chunk" for k_welch_finish
+//           every workgroup of a chunk also sums a slice of the chunk's px rows (fp64) -> psx[q]
 //   k_welch_finish (kernels_finish.hpp): chunks -> H, coherence.
 //
 // FFT: 4096 = 16 x 16 x 16, 256 threads, 16 complex values per thread,
@@ -180,6 +180,7 @@ struct Args {
     float* px;          // [n_pairs][NB]
     float2* pxy;        // [n_chunks][n_ch][NB]
     float* pyy;         // [n_chunks][n_ch][NB]
+    float* psx;         // [n_chunks][NB]: px summed over the pairs of a chunk (k_y)
 };
 
 // twt: fp64-computed tables, [15][256] W4096^(t k1) (k1 = 1..15) then [16][16] W256^(n3 k2)
@@ -301,23 +302,6 @@ __global__ __launch_bounds__(NT) void k_x(Args p) {
     for (int k = tid; k < NB; k += NT) po[k] = 0.5f * (pw[k] + pw[(N - k) & (N - 1)]);
 }
 
-__global__ void k_sxx(const float* px, int n_pairs, float* sxx) {
-    // block = 8 bins x 32 pair groups
-    __shared__ double red[32][8];
-    const int bl = threadIdx.x & 7, g = threadIdx.x >> 3;
-    const int k = blockIdx.x * 8 + bl;
-    double s = 0.0;
-    if (k < NB)
-        for (int pr = g; pr < n_pairs; pr += 32) s += (double)px[(int64_t)pr * NB + k];
-    red[g][bl] = s;
-    __syncthreads();
-    if (g == 0 && k < NB) {
-        double t = 0.0;
-        for (int i = 0; i < 32; ++i) t += red[i][bl];
-        sxx[k] = (float)t;
-    }
-}
-
 // ---- output channels ---------------------------------------------------------
 // Two workgroups per CU (<= 256 VGPRs, 2 x 37 KB of LDS each).  Occupancy 3 (<= 168 VGPRs:
 // on-the-fly Hann window, input spectrum loaded where used) and 4 were built and measured:
@@ -348,6 +332,30 @@ __global__ __launch_bounds__(NT, 2) void k_y(Args p) {
     init_tables(tw, win, tw2, p.window, p.twt, tid);
     const float* ch = p.sig + (int64_t)c * p.ld;
     const int p0 = q * p.ppc, p1 = min(p0 + p.ppc, p.n_pairs);
+    {
+        // Input auto-spectrum of this chunk: the px rows k_x wrote, summed in fp64 -- instead of a
+        // separate reduction kernel every workgroup of the chunk takes a slice of the bins
+        // (8 row groups x 32 bins per sweep, independent loads, combined through LDS).
+        double* red = reinterpret_cast<double*>(lds);  // [8][32], before the first transform
+        const int bpc = (NB + p.n_ch - 1) / p.n_ch;
+        const int b0 = c * bpc, b1 = min(b0 + bpc, NB);
+        const int rg = tid >> 5, kl = tid & 31;
+        for (int kb = b0; kb < b1; kb += 32) {
+            const int k = kb + kl;
+            double sum = 0.0;
+            if (k < b1)
+                for (int pr = p0 + rg; pr < p1; pr += 8) sum += (double)p.px[(int64_t)pr * NB + k];
+            red[rg * 32 + kl] = sum;
+            __syncthreads();
+            if (rg == 0 && k < b1) {
+                double t = 0.0;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) t += red[j * 32 + kl];
+                p.psx[(int64_t)q * NB + k] = (float)t;
+            }
+            __syncthreads();
+        }
+    }
     float2 T[16];
     float P[16];
 #pragma unroll
@@ -462,7 +470,7 @@ inline Plan plan(int n_frames, int n_cy) {
     pl.n_chunks = (pl.n_pairs + pl.ppc - 1) / pl.ppc;
     auto pad = [](size_t b) { return (b + 255) & ~size_t(255); };
     pl.bytes = pad(sizeof(float2) * (size_t)pl.n_pairs * N) + pad(sizeof(float) * (size_t)pl.n_pairs * NB) +
-               pad(sizeof(float) * NB) + pad(sizeof(float2) * (size_t)pl.n_chunks * n_cy * NB) +
+               pad(sizeof(float) * (size_t)pl.n_chunks * NB) + pad(sizeof(float2) * (size_t)pl.n_chunks * n_cy * NB) +
                pad(sizeof(float) * (size_t)pl.n_chunks * n_cy * NB);
     return pl;
 }
