@@ -34,6 +34,7 @@ SIGNATURES = {
     "ds_max_fft_len": (C.c_int, []),
     "ds_profile_enable": (C.c_int, [ctx_p, C.c_int]),
     "ds_profile_report": (C.c_char_p, [ctx_p]),
+    "ds_profile_only": (C.c_int, [ctx_p, C.c_char_p]),
     "ds_stft_r2c_dev": (C.c_int, [ctx_p, f32_p, i64, C.c_int, i64, C.c_int, C.c_int, C.c_int, i64,
                                   C.c_int, f32_p, C.c_int, C.c_float, C.c_float, C.c_int, c32_p]),
     "ds_stft_r2c": (C.c_int, [ctx_p, f32_p, i64, C.c_int, C.c_int, C.c_int, C.c_int, i64, C.c_int,
@@ -169,6 +170,11 @@ class Context:
 
     def profile_enable(self, on: bool = True):
         self.check(self.lib.ds_profile_enable(self.handle, int(on)), "ds_profile_enable")
+
+    def profile_only(self, kernel_name: str | None):
+        """Bracket only launches of this kernel name (None: all kernels)."""
+        self.check(self.lib.ds_profile_only(self.handle, kernel_name.encode() if kernel_name else None),
+                   "ds_profile_only")
 
     def profile_report(self) -> dict:
         """{kernel: (total_ms, launches)} since the previous report."""

@@ -45,6 +45,7 @@ struct ds_ctx {
     std::vector<ProfRec> prof_recs;
     std::vector<hipEvent_t> prof_pool;
     std::string prof_text;
+    std::string prof_only;  // non-empty: only launches of this kernel name are bracketed
 };
 
 static int fail(ds_ctx* c, int code, const std::string& msg) {
@@ -172,6 +173,12 @@ extern "C" int ds_profile_enable(ds_ctx* c, int on) {
     return DS_OK;
 }
 
+extern "C" int ds_profile_only(ds_ctx* c, const char* kernel_name) {
+    if (!c) return fail(c, DS_ERR_ARG, "ds_profile_only: null ctx");
+    c->prof_only = kernel_name ? kernel_name : "";
+    return DS_OK;
+}
+
 // "name total_ms count\n" per kernel since the last call; synchronises the stream
 extern "C" const char* ds_profile_report(ds_ctx* c) {
     if (!c) return "";
@@ -242,14 +249,15 @@ static int launch(ds_ctx* c, const char* name, K kernel, dim3 grid, int threads,
     if (lds > 64 * 1024)
         HIPCHK(c, hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     ds_ctx::ProfRec rec{name, nullptr, nullptr};
-    if (c->prof) {
+    const bool prof = c->prof && (c->prof_only.empty() || c->prof_only == name);
+    if (prof) {
         CHK(prof_event(c, &rec.a));
         CHK(prof_event(c, &rec.b));
         HIPCHK(c, hipEventRecord(rec.a, c->stream));
     }
     hipLaunchKernelGGL(kernel, grid, dim3(threads), lds, c->stream, args);
     HIPCHK(c, hipGetLastError());
-    if (c->prof) {
+    if (prof) {
         HIPCHK(c, hipEventRecord(rec.b, c->stream));
         c->prof_recs.push_back(rec);
     }

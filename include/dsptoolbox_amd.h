@@ -76,6 +76,9 @@ int         ds_timer_stop(ds_ctx* ctx, float* elapsed_ms);
  * previous report (string owned by the context).                             */
 int         ds_profile_enable(ds_ctx* ctx, int on);
 const char* ds_profile_report(ds_ctx* ctx);
+/* restrict the bracketing to one kernel name (NULL or "": all kernels): every
+ * event pair costs ~3 us of stream time, which matters for 10 us kernels      */
+int         ds_profile_only(ds_ctx* ctx, const char* kernel_name);
 /* max FFT length one workgroup transforms inside LDS (complex points)       */
 int         ds_max_fft_len(void);
 
