@@ -188,6 +188,29 @@ def _stft(x, fs_hz: int, window_length_samples: int, window_type, overlap_percen
     return time_s, freqs_hz, stft
 
 
+def _istft(stft, nfft: int, W: int, step: int, window, scale: float, frame_offset: int,
+           n_frames_total: int):
+    """Frame-wise irfft (length nfft, cropped to W) * scale * window, overlap-added at
+    (frame + frame_offset) * step and divided by the squared-window envelope clipped at 1e-4
+    (standard/_framed_signal_representation.py:70-137).  stft (B, F, C) -> (total_length, C)."""
+    if nfft & (nfft - 1) or nfft < 8:
+        raise NotImplementedError("fft_length_samples must be a power of two >= 8 on the GPU path")
+    if np.isrealobj(stft):
+        stft = stft.astype(np.complex128)
+    sp = np.ascontiguousarray(stft, dtype=np.complex64)
+    n_bins, n_frames, n_ch = sp.shape
+    if W > nfft:  # the reference's `td_framed *= window[:, None, None]` cannot broadcast either
+        raise ValueError(f"operands could not be broadcast together with shapes ({nfft},{n_frames},{n_ch}) ({W},1,1)")
+    # length of the reference's reconstruction buffer (same float expression, :112-115)
+    total_length = int(step * n_frames_total + W * (1 - step / W))
+    out = np.empty((n_ch, total_length), dtype=np.float32)
+    w32 = np.ascontiguousarray(window, dtype=np.float32)
+    ctx = get_context()
+    ctx.check(ctx.lib.ds_istft(ctx.handle, _ptr(sp), n_bins, n_frames, n_ch, nfft, W, step, frame_offset,
+                               n_frames_total, _ptr(w32), float(scale), total_length, _ptr(out)), "ds_istft")
+    return np.ascontiguousarray(out.T).astype(np.float64)
+
+
 def _csm_welch(time_data, sampling_rate_hz: int, window_length_samples: int, window_type,
                overlap_percent, detrend: bool, average: str, scaling: SpectrumScaling):
     """-> (f (B,), csm (B, C, C) complex128)."""

@@ -360,6 +360,28 @@ extern "C" int ds_stft_r2c_dev(ds_ctx* c, const float* x, int64_t n_samples, int
     return DS_OK;
 }
 
+// ---- inverse STFT ----------------------------------------------------------
+extern "C" int ds_istft_dev(ds_ctx* c, const ds_c32* stft, int n_bins, int n_frames, int n_ch, int nfft,
+                            int W, int step, int frame_offset, int n_frames_total, const float* window,
+                            float scale, int64_t total_length, float* out, int64_t ld_out) {
+    if (!c || !stft || !window || !out) return fail(c, DS_ERR_ARG, "ds_istft: null argument");
+    if (n_bins <= 0 || n_frames <= 0 || n_ch <= 0 || W <= 0 || step <= 0 || step > W || frame_offset < 0 ||
+        n_frames_total < n_frames + frame_offset || total_length <= 0 || ld_out < total_length)
+        return fail(c, DS_ERR_ARG, "ds_istft: bad shape");
+    if (W > nfft) return fail(c, DS_ERR_ARG, "ds_istft: window longer than the FFT length");
+    CHK(check_fft_len(c, nfft, "ds_istft nfft"));
+    const float2* tw;
+    CHK(get_twiddles(c, nfft, &tw));
+    CHK(reserve(c, &c->ws, &c->ws_bytes, sizeof(float) * (size_t)n_ch * n_frames * W));
+    float* frames = (float*)c->ws;
+    IstftArgs a{(const float2*)stft, n_bins, n_frames, n_ch, W, window, tw, scale, frames};
+    DISPATCH_N(nfft, CHK(launch(c, "istft", k_istft<NN>, dim3((n_frames + 1) / 2, n_ch), Cfg<NN>::NT,
+                                Cfg<NN>::LDS_BYTES, a)));
+    IstftOlaArgs o{frames, n_frames, n_ch, W, step, frame_offset, n_frames_total, window, total_length, ld_out, out};
+    CHK(launch(c, "istft_ola", k_istft_ola, dim3((unsigned)((total_length + 255) / 256), n_ch), 256, 0, o));
+    return DS_OK;
+}
+
 // ---- Welch -----------------------------------------------------------------
 struct WelchPlan {
     int n_chunks, fpc;
@@ -1162,6 +1184,25 @@ extern "C" int ds_stft_r2c(ds_ctx* c, const float* x, int64_t n_samples, int n_c
     CHK(ds_stft_r2c_dev(c, dx, n_samples, n_ch, n_samples, W, hop, nfft, pad_front, n_frames, dw, detrend,
                         scale, edge_scale, power, (ds_c32*)dout));
     return ds_download(c, out, dout, no * 8);
+}
+
+extern "C" int ds_istft(ds_ctx* c, const ds_c32* stft, int n_bins, int n_frames, int n_ch, int nfft, int W,
+                        int step, int frame_offset, int n_frames_total, const float* window, float scale,
+                        int64_t total_length, float* out) {
+    if (!c || !stft || !window || !out) return fail(c, DS_ERR_ARG, "ds_istft: null argument");
+    if (n_bins <= 0 || n_frames <= 0 || n_ch <= 0 || W <= 0 || total_length <= 0)
+        return fail(c, DS_ERR_ARG, "ds_istft: bad shape");
+    size_t ns = (size_t)n_bins * n_frames * n_ch, no = (size_t)n_ch * total_length;
+    CHK(stage_reserve(c, Carver::pad(ns * 8) + Carver::pad((size_t)W * 4) + Carver::pad(no * 4)));
+    Carver cv(c->io);
+    float2* ds = cv.take<float2>(ns);
+    float* dw = cv.take<float>(W);
+    float* dout = cv.take<float>(no);
+    CHK(ds_upload(c, ds, stft, ns * 8));
+    CHK(ds_upload(c, dw, window, (size_t)W * 4));
+    CHK(ds_istft_dev(c, (const ds_c32*)ds, n_bins, n_frames, n_ch, nfft, W, step, frame_offset, n_frames_total,
+                     dw, scale, total_length, dout, total_length));
+    return ds_download(c, out, dout, no * 4);
 }
 
 extern "C" int ds_welch_tf(ds_ctx* c, const float* x, int n_cx, const float* y, int n_cy,

@@ -473,6 +473,85 @@ __global__ __launch_bounds__(Cfg<N>::NT) void k_deconv(DeconvArgs p) {
     }
 }
 
+// ---------------------------------------------------------------- inverse STFT
+// (reference: transforms.istft, transforms/transforms.py:444-586)
+// k_istft: grid = (ceil(F/2), C).  Frames (f0, f0+1) of channel c: Z = A + i B from the one-sided
+// spectra stft[(k*F + f)*C + c] (bins beyond n_bins are zero, imaginary parts of bins 0 and N/2
+// ignored, like numpy.fft.irfft), inverse transform, * scale * window, first W samples ->
+// frames[(c*F + f)*W + n].
+struct IstftArgs {
+    const float2* stft;
+    int n_bins, n_frames, n_ch, W;
+    const float* window;
+    const float2* tw;
+    float scale;
+    float* frames;
+};
+
+template <int N>
+__global__ __launch_bounds__(Cfg<N>::NT) void k_istft(IstftArgs p) {
+    using C = Cfg<N>;
+    extern __shared__ __align__(16) float2 buf[];
+    const int tid = threadIdx.x;
+    const int f0 = 2 * blockIdx.x, c = blockIdx.y;
+    const bool v1 = f0 + 1 < p.n_frames;
+    const int64_t F = p.n_frames, Cn = p.n_ch;
+    for (int k = tid; k <= N / 2; k += C::NT) {
+        float2 A = make_float2(0.f, 0.f), B = make_float2(0.f, 0.f);
+        if (k < p.n_bins) {
+            A = p.stft[((int64_t)k * F + f0) * Cn + c];
+            if (v1) B = p.stft[((int64_t)k * F + f0 + 1) * Cn + c];
+        }
+        if (k == 0 || k == N / 2) {
+            buf[lidx(k)] = make_float2(A.x, B.x);
+        } else {
+            buf[lidx(k)] = make_float2(A.x - B.y, A.y + B.x);      // A + i B
+            buf[lidx(N - k)] = make_float2(A.x + B.y, B.x - A.y);  // conj(A) + i conj(B)
+        }
+    }
+    __syncthreads();
+    float2 v[C::VMAX];
+    fft<N, true, false, false>(v, buf, p.tw, tid);
+    float* oa = p.frames + ((int64_t)c * F + f0) * p.W;
+    float* ob = oa + p.W;
+    for (int n = tid; n < p.W && n < N; n += C::NT) {
+        const float2 z = buf[lidx(n)];
+        const float w = p.window[n] * p.scale;
+        oa[n] = z.x * w;
+        if (v1) ob[n] = z.y * w;
+    }
+}
+
+// k_istft_ola: out[c*ld + n] = sum_f frames[c][f][n - (f + off)*step] / max(sum_f' w^2[n - f'*step], 1e-4)
+// over the frames that cover sample n (f' = f + off runs over n_total frame slots; the reference
+// adds a zero frame before and after the data when the signal was not padded, off = 1).
+struct IstftOlaArgs {
+    const float* frames;
+    int n_frames, n_ch, W, step, off, n_total;
+    const float* window;
+    int64_t total_length, ld;
+    float* out;
+};
+__global__ void k_istft_ola(IstftOlaArgs p) {
+    const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int c = blockIdx.y;
+    if (n >= p.total_length) return;
+    int64_t lo = (n - p.W + p.step) / p.step;  // ceil((n - W + 1) / step) for n - W + 1 > 0
+    if (n - p.W + 1 <= 0) lo = 0;
+    int64_t hi = n / p.step;
+    if (hi > p.n_total - 1) hi = p.n_total - 1;
+    double acc = 0.0, env = 0.0;
+    for (int64_t fs = lo; fs <= hi; ++fs) {
+        const int m = (int)(n - fs * p.step);
+        const float w = p.window[m];
+        env += (double)w * (double)w;
+        const int64_t f = fs - p.off;
+        if (f >= 0 && f < p.n_frames) acc += (double)p.frames[((int64_t)c * p.n_frames + f) * p.W + m];
+    }
+    if (env < 1e-4) env = 1e-4;
+    p.out[(int64_t)c * p.ld + n] = (float)(acc / env);
+}
+
 // ---------------------------------------------------------------- FIR block convolution
 // tap spectra: grid.x = ceil(n_filt/2); hs[k*N + m] = fft(taps_k zero padded)[m] / N
 struct FirTapsArgs {

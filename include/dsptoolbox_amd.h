@@ -136,6 +136,25 @@ int ds_welch_csd(ds_ctx* ctx, const float* x, const float* y, int n_ch,
                  int detrend, int average, int amp_sqrt, double norm_scale, double factor,
                  int halve_edges, ds_c32* csd);
 
+/* ---- inverse STFT: replaces transforms.istft, transforms/transforms.py:444-586
+ * (np.fft.irfft of every frame + _reconstruct_framed_signal,
+ * standard/_framed_signal_representation.py:70-137: windowed overlap-add divided by
+ * the squared-window envelope clipped at 1e-4).
+ * stft[b][f][c] (n_bins x n_frames x n_ch, the layout ds_stft_r2c writes); frames are
+ * inverse transformed with length nfft (bins beyond nfft/2 dropped, missing ones zero),
+ * scaled by `scale` (the irfft normalisation divided by the physical-unit factor),
+ * cropped to W samples and windowed; frame f sits at sample (f + frame_offset)*step of
+ * an output of total_length samples whose envelope counts n_frames_total window
+ * positions (the reference adds an empty frame before and after unpadded data:
+ * frame_offset 1, n_frames_total n_frames + 2).  out[c][n], planar.             */
+int ds_istft_dev(ds_ctx* ctx, const ds_c32* stft_dev, int n_bins, int n_frames, int n_ch,
+                 int nfft, int W, int step, int frame_offset, int n_frames_total,
+                 const float* window_dev, float scale, int64_t total_length,
+                 float* out_dev, int64_t ld_out);
+int ds_istft(ds_ctx* ctx, const ds_c32* stft, int n_bins, int n_frames, int n_ch, int nfft,
+             int W, int step, int frame_offset, int n_frames_total, const float* window,
+             float scale, int64_t total_length, float* out);
+
 /* ---- cross-spectral matrix: replaces _csm_welch, _spectral_methods.py:285-371
  * csm[b][i][j], B x C x C; lower triangle csm[b][i2][i1] (i2>=i1) =
  * finish(mean or median over frames of conj(X_i1) X_i2), upper = its conjugate

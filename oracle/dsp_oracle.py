@@ -292,6 +292,57 @@ def stft(x, fs_hz: int, window_length_samples: int, window_spec,
 
 
 # --------------------------------------------------------------------------
+# inverse STFT  (transforms/transforms.py:444-586, standard/_framed_signal_representation.py:
+# 70-137, standard/_standard_backend.py:408-427)
+# --------------------------------------------------------------------------
+def pad_trim(td, desired_length: int):
+    """helpers/other.py:216-259 for a (N, C) array, padding / trimming at the end."""
+    n = td.shape[0]
+    if n >= desired_length:
+        return td[:desired_length].copy()
+    return np.concatenate([td, np.zeros((desired_length - n, td.shape[1]), dtype=td.dtype)])
+
+
+def reconstruct_framed_signal(td_framed, step_size: int, window, safety_threshold=1e-4):
+    """Overlap-add of windowed frames divided by the squared-window envelope (clipped)."""
+    td_framed = td_framed * window[:, None, None]
+    W, F = td_framed.shape[0], td_framed.shape[1]
+    total_length = int(step_size * F + W * (1 - step_size / W))
+    td = np.zeros((total_length, td_framed.shape[-1]))
+    envelope = np.zeros(total_length)
+    start = 0
+    for i in range(F):
+        td[start:start + W, :] += td_framed[:, i, :]
+        envelope[start:start + W] += window**2
+        start += step_size
+    envelope = np.clip(envelope, a_min=safety_threshold, a_max=None)
+    return td / envelope[:, None]
+
+
+def istft(stft_data, fs_hz, window_length_samples: int, window_spec, overlap_percent: float,
+          fft_length_samples, padding: bool, scaling: str, original_length=None):
+    """transforms.istft; original_length: the `original_signal` branch (_pad_trim to it)."""
+    window = get_window(window_spec, window_length_samples)
+    td_framed = np.fft.irfft(stft_data, axis=0, n=fft_length_samples, norm=fft_norm(scaling))
+    td_framed = td_framed[:window_length_samples, ...]
+    if has_physical_units(scaling):
+        td_framed = td_framed / get_scaling_factor(scaling, fft_length_samples, fs_hz, window)
+    step = int((1 - overlap_percent / 100) * len(window))
+    if padding:
+        td = reconstruct_framed_signal(td_framed, step, window)
+        overlap = int(overlap_percent / 100 * len(window))
+        td = td[overlap:-overlap, :]
+    else:
+        extra = np.zeros_like(td_framed[:, 0, :])[:, None, :]
+        td_framed = np.append(np.append(extra, td_framed, axis=1), extra, axis=1)
+        td = reconstruct_framed_signal(td_framed, step, window)
+        td = td[step:-step, :]
+    if original_length is not None:
+        td = pad_trim(td, original_length)
+    return td
+
+
+# --------------------------------------------------------------------------
 # CSM  (standard/_spectral_methods.py:285-443)
 # --------------------------------------------------------------------------
 def csm_welch(td, fs_hz: int, window_length_samples: int, window_spec,

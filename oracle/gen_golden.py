@@ -115,8 +115,47 @@ def gen_fir_state(dsp):
     save("fir_state", dict(cases=cases, fs=fs), arrs)
 
 
+def gen_istft(dsp):
+    """transforms.istft (transforms/transforms.py:444-586) on spectrograms of the reference's own
+    Signal.get_spectrogram, with the original signal and with an explicit parameter dict."""
+    from dsptoolbox.standard.enums import SpectrumScaling, Window
+    fs = 48000
+    rng = np.random.default_rng(21)
+    x = rng.standard_normal((6000, 2)) * 0.2
+    cases, arrs = [], {"x": x}
+    variants = [
+        dict(W=256, ov=50.0, nfft=None, pad=True, sc="FFTBackward", win="Hann"),
+        dict(W=256, ov=75.0, nfft=512, pad=True, sc="FFTBackward", win="Hann"),
+        dict(W=512, ov=50.0, nfft=None, pad=False, sc="FFTBackward", win="Hann"),
+        dict(W=256, ov=50.0, nfft=None, pad=True, sc="AmplitudeSpectrum", win="Hamming"),
+        dict(W=128, ov=60.0, nfft=None, pad=True, sc="FFTOrthogonal", win="Hann"),
+    ]
+    for i, v in enumerate(variants):
+        s = dsp.Signal(None, x.copy(), fs)
+        s.set_spectrogram_parameters(window_length_samples=v["W"], window_type=Window[v["win"]],
+                                     overlap_percent=v["ov"], fft_length_samples=v["nfft"],
+                                     detrend=False, padding=v["pad"], scaling=SpectrumScaling[v["sc"]])
+        t, f, sp = s.get_spectrogram()
+        arrs[f"stft_{i}"] = sp
+        rec = dsp.transforms.istft(sp, original_signal=s)
+        arrs[f"rec_sig_{i}"] = rec.time_data
+        if v["nfft"] is not None or not SpectrumScaling[v["sc"]].has_physical_units():
+            # (with fft_length None the parameter-dict branch only works for scalings without
+            # physical units: get_scaling_factor needs a length)
+            rec2 = dsp.transforms.istft(sp, parameters=dict(s._spectrogram_parameters), sampling_rate_hz=fs)
+            arrs[f"rec_par_{i}"] = rec2.time_data
+        v = dict(v)
+        v["has_par"] = f"rec_par_{i}" in arrs
+        cases.append(v)
+    save("istft", dict(cases=cases, fs=fs), arrs)
+
+
 def main():
     dsp = import_reference()
+    if "--only-istft" in sys.argv:
+        import warnings
+        warnings.simplefilter("ignore")
+        return gen_istft(dsp)
     if "--only-fir-state" in sys.argv:
         import warnings
         warnings.simplefilter("ignore")
@@ -390,6 +429,7 @@ def main():
               ir_head=ir.time_data[:48000], ir_tail=ir.time_data[-4096:],
               ir_peak=np.array([np.max(np.abs(ir.time_data))])))
     gen_fir_state(dsp)
+    gen_istft(dsp)
 
 
 if __name__ == "__main__":

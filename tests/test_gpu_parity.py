@@ -335,6 +335,36 @@ def test_fir_long_filters_vs_oracle():
         assert relmax(y, r) < TOL, (name, relmax(y, r))
 
 
+def test_istft_golden_and_round_trip():
+    """transforms.istft against the reference's outputs, and the reference's own fidelity test
+    (tests/test_transforms.py:102-134): get_spectrogram -> istft reproduces the signal."""
+    from dsptoolbox_amd.standard.enums import SpectrumScaling as S
+    meta, z = load_golden("istft")
+    fs = meta["fs"]
+    x = z["x"]
+    for i, c in enumerate(meta["cases"]):
+        s = dsp.Signal(None, x.copy(), fs)
+        s.set_spectrogram_parameters(window_length_samples=c["W"], window_type=Window[c["win"]],
+                                     overlap_percent=c["ov"], fft_length_samples=c["nfft"], detrend=False,
+                                     padding=c["pad"], scaling=S[c["sc"]])
+        rec = dsp.transforms.istft(z[f"stft_{i}"], original_signal=s)
+        assert relmax(rec.time_data, z[f"rec_sig_{i}"]) < TOL, (c, relmax(rec.time_data, z[f"rec_sig_{i}"]))
+        if c["has_par"]:
+            rec2 = dsp.transforms.istft(z[f"stft_{i}"], parameters=dict(s._spectrogram_parameters),
+                                        sampling_rate_hz=fs)
+            assert rec2.time_data.shape == z[f"rec_par_{i}"].shape
+            assert relmax(rec2.time_data, z[f"rec_par_{i}"]) < TOL
+    # device STFT -> device inverse STFT, larger signal
+    rng = np.random.default_rng(31)
+    y = rng.standard_normal((100000, 3)) * 0.3
+    for W, nfft in ((1024, None), (512, 1024), (4096, None)):
+        s = dsp.Signal(None, y.copy(), fs)
+        s.set_spectrogram_parameters(window_length_samples=W, fft_length_samples=nfft)
+        t, f, sp = s.get_spectrogram()
+        rec = dsp.transforms.istft(sp, original_signal=s)
+        assert relmax(rec.time_data, y) < 2 * TOL, (W, relmax(rec.time_data, y))
+
+
 def test_fir_design_matches_lfilter():
     """reference tests/test_classes.py:495-512: FIR filter_signal == scipy.signal.lfilter."""
     import scipy.signal as sig

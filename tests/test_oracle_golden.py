@@ -167,6 +167,24 @@ def test_fir_state_zero_phase_long():
             close(y, z["y_long"], tol=1e-6)  # stored as float32
 
 
+def test_istft():
+    """transforms.istft incl. its quirks (step from the un-rounded overlap, empty edge frames)."""
+    meta, z = load_golden("istft")
+    x = z["x"]
+    for i, c in enumerate(meta["cases"]):
+        sp = z[f"stft_{i}"]
+        r = orc.istft(sp, meta["fs"], c["W"], c["win"].lower(), c["ov"], c["nfft"], c["pad"], c["sc"],
+                      original_length=x.shape[0])
+        close(r, z[f"rec_sig_{i}"], tol=1e-12)
+        if c["has_par"]:
+            r2 = orc.istft(sp, meta["fs"], c["W"], c["win"].lower(), c["ov"], c["nfft"], c["pad"], c["sc"])
+            assert r2.shape == z[f"rec_par_{i}"].shape
+            close(r2, z[f"rec_par_{i}"], tol=1e-12)
+        # the oracle's own forward transform reproduces the stored spectrogram
+        _, _, s2 = orc.stft(x, meta["fs"], c["W"], c["win"].lower(), c["ov"], c["nfft"], False, c["pad"], c["sc"])
+        close(s2, sp, tol=1e-12)
+
+
 def test_chirp_pair_config1():
     """BASELINE.json configs[0]: the reference's own example chirps (16-bit PCM fixtures)."""
     meta, z = load_golden("chirp_pair")
