@@ -603,6 +603,17 @@ def filterbank_fir(taps_list, td, mode: str):
     raise ValueError("Invalid filter bank apply mode")
 
 
+def convolve_rir_on_signal(td, rir, keep_peak_level=True, keep_length=True):
+    """room_acoustics/room_acoustics.py:216-266 (oaconvolve and convolve agree to rounding)."""
+    td = np.asarray(td, dtype=np.float64)
+    out = oaconvolve(td, np.asarray(rir, dtype=np.float64).reshape(-1, 1), axes=0, mode="full")
+    if keep_length:
+        out = out[: td.shape[0], ...]
+    if keep_peak_level:
+        out = out * (np.max(np.abs(td), axis=0) / np.max(np.abs(out), axis=0))[None, ...]
+    return out
+
+
 # --------------------------------------------------------------------------
 # parity metrics (BASELINE.md: max-norm relative and relative L2)
 # --------------------------------------------------------------------------

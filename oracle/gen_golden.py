@@ -150,8 +150,29 @@ def gen_istft(dsp):
     save("istft", dict(cases=cases, fs=fs), arrs)
 
 
+def gen_rir(dsp):
+    """room_acoustics.convolve_rir_on_signal (room_acoustics/room_acoustics.py:216-266)."""
+    fs = 48000
+    rng = np.random.default_rng(23)
+    x = rng.standard_normal((40000, 2)) * 0.2
+    cases, arrs = [], {"x": x.astype(np.float32)}
+    for i, (T, kp, kl) in enumerate(((1500, True, True), (12000, True, False), (12000, False, True))):
+        h = rng.standard_normal(T) * np.exp(-np.arange(T) / (T / 6.0)) * 0.1
+        sig = dsp.Signal(None, x.astype(np.float32).astype(np.float64), fs)
+        rir = dsp.ImpulseResponse(None, h.copy(), fs, constrain_amplitude=False)
+        o = dsp.room_acoustics.convolve_rir_on_signal(sig, rir, keep_peak_level=kp, keep_length=kl)
+        arrs[f"h_{i}"] = np.asarray(rir.time_data[:, 0])
+        arrs[f"y_{i}"] = o.time_data.astype(np.float32)
+        cases.append(dict(taps=T, keep_peak_level=kp, keep_length=kl, note="x / y stored as float32"))
+    save("rir", dict(cases=cases, fs=fs), arrs)
+
+
 def main():
     dsp = import_reference()
+    if "--only-rir" in sys.argv:
+        import warnings
+        warnings.simplefilter("ignore")
+        return gen_rir(dsp)
     if "--only-istft" in sys.argv:
         import warnings
         warnings.simplefilter("ignore")
@@ -430,6 +451,7 @@ def main():
               ir_peak=np.array([np.max(np.abs(ir.time_data))])))
     gen_fir_state(dsp)
     gen_istft(dsp)
+    gen_rir(dsp)
 
 
 if __name__ == "__main__":

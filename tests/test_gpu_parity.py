@@ -365,6 +365,20 @@ def test_istft_golden_and_round_trip():
         assert relmax(rec.time_data, y) < 2 * TOL, (W, relmax(rec.time_data, y))
 
 
+def test_convolve_rir_on_signal_golden():
+    meta, z = load_golden("rir")
+    fs = meta["fs"]
+    x = z["x"].astype(np.float64)
+    for i, c in enumerate(meta["cases"]):
+        sig = dsp.Signal(None, x.copy(), fs)
+        rir = dsp.ImpulseResponse(None, z[f"h_{i}"].copy(), fs, constrain_amplitude=False)
+        o = dsp.room_acoustics.convolve_rir_on_signal(sig, rir, keep_peak_level=c["keep_peak_level"],
+                                                      keep_length=c["keep_length"])
+        assert o.time_data.shape == z[f"y_{i}"].shape
+        assert relmax(o.time_data, z[f"y_{i}"]) < TOL, (c, relmax(o.time_data, z[f"y_{i}"]))
+        assert np.array_equal(sig.time_data, x)
+
+
 def test_fir_design_matches_lfilter():
     """reference tests/test_classes.py:495-512: FIR filter_signal == scipy.signal.lfilter."""
     import scipy.signal as sig

@@ -185,6 +185,15 @@ def test_istft():
         close(s2, sp, tol=1e-12)
 
 
+def test_convolve_rir_on_signal():
+    meta, z = load_golden("rir")
+    x = z["x"].astype(np.float64)
+    for i, c in enumerate(meta["cases"]):
+        y = orc.convolve_rir_on_signal(x, z[f"h_{i}"], c["keep_peak_level"], c["keep_length"])
+        assert y.shape == z[f"y_{i}"].shape
+        close(y, z[f"y_{i}"], tol=1e-6)  # stored as float32
+
+
 def test_chirp_pair_config1():
     """BASELINE.json configs[0]: the reference's own example chirps (16-bit PCM fixtures)."""
     meta, z = load_golden("chirp_pair")
