@@ -379,6 +379,31 @@ def test_convolve_rir_on_signal_golden():
         assert np.array_equal(sig.time_data, x)
 
 
+def test_library_rccl_communicator_single_rank():
+    """ds_comm_unique_id / ds_comm_init / ds_bcast / ds_comm_destroy with a one-rank communicator:
+    checks the dlopen of RCCL, the by-value id hand-over and the broadcast call on this GPU (the
+    multi-rank use is rehearsed with gloo in tests/test_distributed_cpu.py and by bench.py)."""
+    import ctypes as C
+    from dsptoolbox_amd._lib import Context, DeviceBuffer
+    ctx = Context(0)
+    try:
+        ident = C.create_string_buffer(128)
+        ctx.check(ctx.lib.ds_comm_unique_id(ident), "ds_comm_unique_id")
+        assert any(b != 0 for b in ident.raw)
+        ctx.check(ctx.lib.ds_comm_init(ctx.handle, 1, 0, ident.raw), "ds_comm_init")
+        data = np.arange(4096, dtype=np.float32)
+        buf = DeviceBuffer.from_array(ctx, data)
+        ctx.check(ctx.lib.ds_bcast(ctx.handle, C.c_void_p(buf.ptr), data.nbytes, 0), "ds_bcast")
+        ctx.sync()
+        assert np.array_equal(buf.to_array(data.shape, np.float32), data)
+        ctx.check(ctx.lib.ds_comm_destroy(ctx.handle), "ds_comm_destroy")
+        # a broadcast without a communicator is an error, not a crash
+        assert ctx.lib.ds_bcast(ctx.handle, C.c_void_p(buf.ptr), data.nbytes, 0) != 0
+        buf.free()
+    finally:
+        ctx.close()
+
+
 def test_fir_design_matches_lfilter():
     """reference tests/test_classes.py:495-512: FIR filter_signal == scipy.signal.lfilter."""
     import scipy.signal as sig
