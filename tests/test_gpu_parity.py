@@ -610,6 +610,105 @@ def test_fir_bank_4097_taps():
     assert relmax(yq, orc.filterbank_fir(list(taps[:2]), x, "Sequential")) < TOL
 
 
+def test_fir_bank_full_size_properties():
+    """config 3 at full size (32 x 4097 taps, 8 x 2^22 samples, 4.3 GB of output kept on the
+    device): an impulse train must come out as shifted copies of the taps, wherever the impulses
+    fall relative to the 12288-sample block grid; a second run on 2x + the train checks linearity
+    on noise at sampled windows."""
+    import ctypes as C
+    from dsptoolbox_amd._lib import DeviceBuffer, get_context
+    from dsptoolbox_amd.generators import fir_bank_taps
+    ctx = get_context()
+    n, n_ch, K, T = 2**22, 8, 32, 4097
+    taps = fir_bank_taps(K, T, 48000).astype(np.float32)
+    x = np.zeros((n_ch, n), dtype=np.float32)
+    pos = {c: np.arange(5000 + 977 * c, n - T, 100003 + 131 * c) for c in range(n_ch)}
+    for c in range(n_ch):
+        x[c, pos[c]] = 1.0 + 0.25 * c
+    d_x = DeviceBuffer.from_array(ctx, x)
+    d_t = DeviceBuffer.from_array(ctx, taps)
+    d_y = DeviceBuffer(ctx, K * n_ch * n * 4)
+
+    def run():
+        ctx.check(ctx.lib.ds_fir_ola_dev(ctx.handle, C.c_void_p(d_x.ptr), n_ch, n, n, C.c_void_p(d_t.ptr), K, T,
+                                         backend.DS_FB_PARALLEL, C.c_void_p(d_y.ptr), n), "ds_fir_ola_dev")
+        ctx.sync()
+
+    def window(k, c, start, length):
+        out = np.empty(length, dtype=np.float32)
+        ctx.download(d_y.ptr + 4 * ((k * n_ch + c) * n + start), out)
+        return out
+
+    run()
+    rng = np.random.default_rng(0)
+    worst = 0.0
+    for k in (0, 7, 19, 31):
+        for c in (0, 3, 7):
+            for p0 in rng.choice(pos[c], 5, replace=False):
+                got = window(k, c, int(p0), T).astype(np.float64)
+                ref = taps[k].astype(np.float64) * (1.0 + 0.25 * c)
+                worst = max(worst, np.max(np.abs(got - ref)) / np.max(np.abs(ref)))
+            # between impulses (spacing > taps) the output is silent
+            gap = window(k, c, int(pos[c][3]) + T + 10, 20000)
+            assert np.max(np.abs(gap)) < 1e-6 * np.max(np.abs(taps[k]))
+    assert worst < TOL, worst
+    # linearity on noise: y(2 a + train) = 2 y(a) + y(train) at sampled windows
+    a = (rng.standard_normal((n_ch, n)) * 0.1).astype(np.float32)
+    train = [window(5, 2, 12288 * j - 100, 4000) for j in (1, 57, 300)]
+    ctx.upload(d_x.ptr, a)
+    run()
+    ya = [window(5, 2, 12288 * j - 100, 4000) for j in (1, 57, 300)]
+    ctx.upload(d_x.ptr, (2.0 * a + x).astype(np.float32))
+    run()
+    for j, t0, y0 in zip((1, 57, 300), train, ya):
+        yc = window(5, 2, 12288 * j - 100, 4000)
+        scale = max(np.max(np.abs(y0)), 1e-30)
+        assert np.max(np.abs(yc - (2.0 * y0 + t0))) / scale < 4 * TOL
+    for d in (d_x, d_t, d_y):
+        d.free()
+
+
+def test_csm_full_size_properties():
+    """config 4 at full size (64 mics x 512 000 samples, nfft 1024): Hermitian, the diagonal is
+    the Welch auto spectrum, and the 4 x 4 sub-block equals the CSM of those 4 channels alone
+    (oracle, which finishes the sub-problem in seconds)."""
+    rng = np.random.default_rng(4)
+    n = 512000
+    x = (0.1 * rng.standard_normal((n, 64)) + 0.2 * rng.standard_normal(n)[:, None])
+    f, csm = backend._csm_welch(x, 48000, 1024, Window.Hann, 50, True, "mean", SpectrumScaling.FFTBackward)
+    assert csm.shape == (513, 64, 64)
+    assert np.max(np.abs(csm - np.conj(np.swapaxes(csm, 1, 2)))) <= 1e-7 * np.max(np.abs(csm))
+    psd = backend._welch(x, None, 48000, Window.Hann, 1024, 50, True, "mean", SpectrumScaling.FFTBackward)
+    diag = np.einsum("bii->bi", csm)
+    assert relmax(diag.real, psd, True) < 2 * TOL and np.max(np.abs(diag.imag)) == 0.0
+    sel = [0, 17, 40, 63]
+    fr, ref = orc.csm_welch_batched(x[:, sel], 48000, 1024, "hann", 50, True, "FFTBackward")
+    assert relmax(csm[:, sel][:, :, sel], ref, True) < TOL
+
+
+def test_deconvolve_full_size_properties():
+    """config 5 at full size (1024 stereo items x 8192 samples, one shared sweep): every 64th
+    item against the oracle, and the batch result of an item equals its own single-item call."""
+    from dsptoolbox_amd.generators import exponential_sweep
+    rng = np.random.default_rng(5)
+    n, items = 8192, 1024
+    x = exponential_sweep(n, 48000)[:, None]
+    h = rng.standard_normal((items, 2, 32)) * np.exp(-np.arange(32) / 6.0)
+    X = np.fft.rfft(x[:, 0], 2 * n)
+    y = np.fft.irfft(np.fft.rfft(h, 2 * n, axis=-1) * X, 2 * n, axis=-1)[..., :n]  # (items, 2, n)
+    y = np.ascontiguousarray(np.swapaxes(y, 1, 2)) + 1e-4 * rng.standard_normal((items, n, 2))
+    den = backend.rfft_spectrum(x, n)
+    eps, _ = orc.regularization_eps(den[:, 0], np.fft.rfftfreq(n, 1 / 48000), 48000, None, -30.0)
+    inv = backend.regularized_inverse(den, eps)[:, 0]
+    out = backend.spectral_division(y, n, inv, n)
+    assert out.shape == (items, n, 2)
+    for i in range(0, items, 64):
+        assert relmax(out[i], orc.spectral_deconvolve(y[i], x, 48000)) < TOL, i
+    for i in (1, 511, 1023):
+        single = backend.spectral_division(y[i:i + 1], n, inv, n)[0]
+        assert np.array_equal(single, out[i])
+
+
 def test_edge_cases():
     # signal shorter than one window, single channel, odd channel counts
     x = np.random.default_rng(1).standard_normal((100, 1))
