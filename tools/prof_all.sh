@@ -7,13 +7,14 @@ export TMPDIR=/tmp
 for W in welch_h1 fir_bank csm deconv; do
   OUT=gpurun_out/prof_${TAG}_$W
   mkdir -p $OUT
+  # kernel trace: the bench command itself (defaults); PMC passes: fewer steps, no CPU leg
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py --workload $W > $OUT/trace.log 2>&1
   CMD="python3 bench.py --workload $W --steps 10 --warmup 2 --no-cpu-baseline"
-  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $CMD > $OUT/trace.log 2>&1
   rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_MFMA --output-format csv -d $OUT/pmc1 -- $CMD > $OUT/pmc1.log 2>&1
   rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc2 -- $CMD > $OUT/pmc2.log 2>&1
   rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc3 -- $CMD > $OUT/pmc3.log 2>&1
   rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d $OUT/pmc4 -- $CMD > $OUT/pmc4.log 2>&1
   python3 tools/prof_summary.py $OUT > $OUT/summary.txt 2>&1
-  tail -1 $OUT/trace.log | cut -c1-400 > $OUT/bench_line.txt
+  grep "^{\"metric" $OUT/trace.log > $OUT/bench_line.txt
 done
 echo done
