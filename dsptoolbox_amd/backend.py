@@ -188,6 +188,21 @@ def _stft(x, fs_hz: int, window_length_samples: int, window_type, overlap_percen
     return time_s, freqs_hz, stft
 
 
+def _das_map(csm, h):
+    """Re(h^H csm h) per grid point and bin: csm (F, C, C), h (F, C, G) -> (G, F) float64."""
+    cs = np.ascontiguousarray(csm, dtype=np.complex64)
+    hs = np.ascontiguousarray(h, dtype=np.complex64)
+    assert cs.ndim == 3 and hs.ndim == 3 and cs.shape[1] == cs.shape[2], "csm must be (bins, C, C)"
+    assert hs.shape[0] == cs.shape[0] and hs.shape[1] == cs.shape[1], \
+        "steering vector must be (bins, C, grid points)"
+    n_bins, n_ch, n_grid = hs.shape
+    out = np.empty((n_grid, n_bins), dtype=np.float32)
+    ctx = get_context()
+    ctx.check(ctx.lib.ds_das_map(ctx.handle, _ptr(cs), _ptr(hs), n_bins, n_ch, n_grid, _ptr(out)),
+              "ds_das_map")
+    return out.astype(np.float64)
+
+
 def _istft(stft, nfft: int, W: int, step: int, window, scale: float, frame_offset: int,
            n_frames_total: int):
     """Frame-wise irfft (length nfft, cropped to W) * scale * window, overlap-added at

@@ -656,6 +656,33 @@ extern "C" int ds_csm_spec(ds_ctx* c, const ds_c32* X, int n_bins, int n_frames,
     return ds_download(c, csm, dc, no * 8);
 }
 
+// ---- delay-and-sum beamformer map ---------------------------------------------------
+extern "C" int ds_das_map_dev(ds_ctx* c, const ds_c32* csm, const ds_c32* h, int n_bins, int n_ch,
+                              int n_grid, float* map) {
+    if (!c || !csm || !h || !map) return fail(c, DS_ERR_ARG, "ds_das_map: null argument");
+    if (n_bins <= 0 || n_ch <= 0 || n_grid <= 0) return fail(c, DS_ERR_ARG, "ds_das_map: bad shape");
+    if (n_bins > 65535) return fail(c, DS_ERR_UNSUP, "ds_das_map: more than 65535 bins per call is not built yet");
+    DasArgs a{(const float2*)csm, (const float2*)h, n_bins, n_ch, n_grid, map};
+    CHK(launch(c, "das_map", k_das_map, dim3((n_grid + 127) / 128, n_bins), 256, 0, a));
+    return DS_OK;
+}
+
+extern "C" int ds_das_map(ds_ctx* c, const ds_c32* csm, const ds_c32* h, int n_bins, int n_ch, int n_grid,
+                          float* map) {
+    if (!c || !csm || !h || !map) return fail(c, DS_ERR_ARG, "ds_das_map: null argument");
+    if (n_bins <= 0 || n_ch <= 0 || n_grid <= 0) return fail(c, DS_ERR_ARG, "ds_das_map: bad shape");
+    size_t nc = (size_t)n_bins * n_ch * n_ch, nh = (size_t)n_bins * n_ch * n_grid, nm = (size_t)n_grid * n_bins;
+    CHK(reserve(c, &c->io, &c->io_bytes, Carver::pad(nc * 8) + Carver::pad(nh * 8) + Carver::pad(nm * 4) + 4096));
+    Carver cv(c->io);
+    float2* dc = cv.take<float2>(nc);
+    float2* dh = cv.take<float2>(nh);
+    float* dm = cv.take<float>(nm);
+    CHK(ds_upload(c, dc, csm, nc * 8));
+    CHK(ds_upload(c, dh, h, nh * 8));
+    CHK(ds_das_map_dev(c, (const ds_c32*)dc, (const ds_c32*)dh, n_bins, n_ch, n_grid, dm));
+    return ds_download(c, map, dm, nm * 4);
+}
+
 // ---- four-step FFT for 2^15 .. 2^24 points (kernels_bigfft.hpp) -------------------
 static int big_rows_ct(int n2) {
     int nt = dsfft::threads_for(n2);

@@ -366,4 +366,60 @@ __global__ __launch_bounds__(256) void k_csm_gemm(CsmArgs p) {
     }
 }
 
+// ---------------------------------------------------------------- delay-and-sum beamformer map
+// (reference: BeamformerDASFrequency.get_beamformer_map, beamforming/beamforming.py:853-858)
+// map[g][f] = Re( h_f[:, g]^H  CSM_f  h_f[:, g] ) for every grid point g and frequency bin f.
+// grid = (ceil(G/128), F), 4 waves, one 32-point grid tile per wave.  Per tile of 32 channels
+// the product M = CSM_f[rows, :] h_f[:, tile] runs on the fp32 MFMA pipe (32x32x2, four real
+// products per complex one); the epilogue contracts M with conj(h) over the channels in fp64.
+struct DasArgs {
+    const float2* csm;  // [F][C][C]
+    const float2* h;    // [F][C][G]
+    int n_bins, n_ch, n_grid;
+    float* map;  // [G][F]
+};
+
+__global__ __launch_bounds__(256) void k_das_map(DasArgs p) {
+    const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
+    const int f = blockIdx.y;
+    const int C = p.n_ch, G = p.n_grid;
+    const int g = (blockIdx.x * 4 + w) * 32 + (l & 31);
+    const int kh = l >> 5;
+    const float2* Cf = p.csm + (int64_t)f * C * C;
+    const float2* Hf = p.h + (int64_t)f * C * G;
+    const bool gv = g < G;
+    double part = 0.0;
+    for (int i0 = 0; i0 < C; i0 += 32) {
+        f32x16 mr = {0}, mi = {0};
+        const int ci = i0 + (l & 31);
+        constexpr int U = 4;
+        for (int s0 = 0; 2 * s0 < C; s0 += U) {
+            float2 a[U], b[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int k = 2 * (s0 + u) + kh;
+                a[u] = (ci < C && k < C) ? Cf[(int64_t)ci * C + k] : make_float2(0.f, 0.f);
+                b[u] = (gv && k < C) ? Hf[(int64_t)k * G + g] : make_float2(0.f, 0.f);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                mr = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].x, b[u].x, mr, 0, 0, 0);
+                mr = __builtin_amdgcn_mfma_f32_32x32x2f32(-a[u].y, b[u].y, mr, 0, 0, 0);
+                mi = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].x, b[u].y, mi, 0, 0, 0);
+                mi = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].y, b[u].x, mi, 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int c = i0 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+            if (gv && c < C) {
+                const float2 hv = Hf[(int64_t)c * G + g];
+                part += (double)hv.x * (double)mr[r] + (double)hv.y * (double)mi[r];
+            }
+        }
+    }
+    part += __shfl_xor(part, 32);
+    if (kh == 0 && gv) p.map[(int64_t)g * p.n_bins + f] = (float)part;
+}
+
 }  // namespace dsk

@@ -136,6 +136,16 @@ int ds_welch_csd(ds_ctx* ctx, const float* x, const float* y, int n_ch,
                  int detrend, int average, int amp_sqrt, double norm_scale, double factor,
                  int halve_edges, ds_c32* csd);
 
+/* ---- delay-and-sum beamformer map on the CSM: replaces the grid x bin loop of
+ * BeamformerDASFrequency.get_beamformer_map, beamforming/beamforming.py:853-858:
+ * map[g][f] = Re( h_f[:, g]^H  CSM_f  h_f[:, g] ); csm[f][i][j] (n_bins x n_ch x n_ch, the
+ * selected bins, diagonal already treated by the caller), h[f][c][g] (the steering
+ * vectors, n_bins x n_ch x n_grid), map[g][f].  fp32 MFMA.                        */
+int ds_das_map_dev(ds_ctx* ctx, const ds_c32* csm_dev, const ds_c32* h_dev, int n_bins, int n_ch,
+                   int n_grid, float* map_dev);
+int ds_das_map(ds_ctx* ctx, const ds_c32* csm, const ds_c32* h, int n_bins, int n_ch, int n_grid,
+               float* map);
+
 /* ---- inverse STFT: replaces transforms.istft, transforms/transforms.py:444-586
  * (np.fft.irfft of every frame + _reconstruct_framed_signal,
  * standard/_framed_signal_representation.py:70-137: windowed overlap-add divided by

@@ -603,6 +603,23 @@ def filterbank_fir(taps_list, td, mode: str):
     raise ValueError("Invalid filter bank apply mode")
 
 
+def das_map(f, csm, h, remove_csm_diagonal=True):
+    """beamforming/beamforming.py:838-876: Re(h^H CSM h) per grid point and bin, optional
+    diagonal removal (energy-compensated), clipping of negative values, Simpson integration."""
+    from scipy.integrate import simpson
+    csm = np.array(csm, dtype=np.complex128)
+    h = np.asarray(h, dtype=np.complex128)
+    C = csm.shape[1]
+    if remove_csm_diagonal:
+        csm *= C / (C - 1)
+        for i in range(len(f)):
+            np.fill_diagonal(csm[i], 0)
+    m = np.einsum("fcg,fcd,fdg->gf", h.conj(), csm, h).real
+    if remove_csm_diagonal:
+        m[m < 0] = 0
+    return simpson(m, dx=f[1] - f[0], axis=1) if len(f) > 1 else m.squeeze()
+
+
 def convolve_rir_on_signal(td, rir, keep_peak_level=True, keep_length=True):
     """room_acoustics/room_acoustics.py:216-266 (oaconvolve and convolve agree to rounding)."""
     td = np.asarray(td, dtype=np.float64)

@@ -167,8 +167,51 @@ def gen_rir(dsp):
     save("rir", dict(cases=cases, fs=fs), arrs)
 
 
+def gen_das(dsp):
+    """BeamformerDASFrequency.get_beamformer_map (beamforming/beamforming.py:799-880): the
+    quadratic forms h^H CSM h per grid point and bin, diagonal removal, clipping and Simpson
+    integration.  Stored: the selected bins, the raw CSM slice, the steering vectors the
+    reference built, and its final maps."""
+    from dsptoolbox.helpers.other import (_get_fractional_octave_bandwidth,
+                                          find_nearest_points_index_in_vector)
+    fs = 10_000
+    rng = np.random.default_rng(29)
+    n_mics = 12
+    pts = dict(x=rng.uniform(-0.3, 0.3, n_mics), y=rng.uniform(-0.3, 0.3, n_mics), z=np.zeros(n_mics))
+    ma = dsp.beamforming.MicArray(pts)
+    src = dsp.Signal(None, rng.standard_normal(20_000) * 0.3, fs)
+    s = dsp.beamforming.MonopoleSource(src, [0.05, 0.3, 0.5]).get_signals_on_array(ma)
+    s.set_spectrum_parameters(window_length_samples=512)
+    g = dsp.beamforming.Regular2DGrid(np.arange(-0.3, 0.3, 0.05), np.arange(-0.5, 0.5, 0.05), ["x", "y"],
+                                      value3=0.5)
+    cases, arrs = [], {}
+    f_all, csm_all = s.get_csm()
+    for i, (form, fc, frac, rm) in enumerate((("TrueLocation", 2000.0, 3, True), ("Classic", 1500.0, 0, True),
+                                              ("TruePower", 2500.0, 4, False), ("Inverse", 1200.0, 6, True))):
+        st = dsp.beamforming.SteeringVector(formulation=dsp.beamforming.SteeringVectorType[form])
+        bf = dsp.beamforming.BeamformerDASFrequency(s, ma, g, st)
+        m = bf.get_beamformer_map(fc, frac, remove_csm_diagonal=rm)
+        ids = find_nearest_points_index_in_vector(_get_fractional_octave_bandwidth(fc, frac), f_all)
+        id1, id2 = int(ids[0]), int(ids[1])
+        if id1 == id2:
+            id2 += 1
+        f = f_all[id1:id2]
+        h = st.get_vector(f * np.pi * 2 / bf.c, grid=g, mic=ma)
+        arrs[f"f_{i}"] = f
+        arrs[f"csm_{i}"] = csm_all[id1:id2]
+        arrs[f"h_{i}"] = h
+        arrs[f"map_{i}"] = m
+        cases.append(dict(formulation=form, center_hz=fc, octave_fraction=frac, remove_csm_diagonal=rm,
+                          bins=[id1, id2], grid_shape=list(m.shape)))
+    save("das", dict(cases=cases, fs=fs, n_mics=n_mics), arrs)
+
+
 def main():
     dsp = import_reference()
+    if "--only-das" in sys.argv:
+        import warnings
+        warnings.simplefilter("ignore")
+        return gen_das(dsp)
     if "--only-rir" in sys.argv:
         import warnings
         warnings.simplefilter("ignore")
@@ -452,6 +495,7 @@ def main():
     gen_fir_state(dsp)
     gen_istft(dsp)
     gen_rir(dsp)
+    gen_das(dsp)
 
 
 if __name__ == "__main__":

@@ -404,6 +404,30 @@ def test_library_rccl_communicator_single_rank():
         ctx.close()
 
 
+def test_das_map_golden_and_large():
+    """Delay-and-sum beamformer maps: the reference's outputs (4 steering formulations, with and
+    without diagonal removal), and a 64-mic / 3000-point / 40-bin problem against the oracle."""
+    meta, z = load_golden("das")
+    for i, c in enumerate(meta["cases"]):
+        m = dsp.beamforming.delay_and_sum_map(z[f"f_{i}"], z[f"csm_{i}"], z[f"h_{i}"], c["remove_csm_diagonal"])
+        assert relmax(m.reshape(c["grid_shape"]), z[f"map_{i}"]) < TOL, (c, relmax(m.reshape(c["grid_shape"]), z[f"map_{i}"]))
+    rng = np.random.default_rng(41)
+    F, Cn, G = 40, 64, 3000
+    a = rng.standard_normal((F, Cn, 70)) + 1j * rng.standard_normal((F, Cn, 70))
+    csm = a @ np.conj(np.swapaxes(a, 1, 2)) / 70
+    mic = rng.uniform(-0.5, 0.5, (Cn, 3))
+    grid = np.c_[rng.uniform(-1, 1, (G, 2)), np.full(G, 1.5)]
+    r = np.linalg.norm(mic[:, None, :] - grid[None, :, :], axis=-1)  # (C, G)
+    f = np.linspace(1000.0, 2000.0, F)
+    h = np.exp(-2j * np.pi * f[:, None, None] / 343.0 * r[None]) / r[None] / Cn
+    for rm in (True, False):
+        m = dsp.beamforming.delay_and_sum_map(f, csm, h, rm)
+        assert relmax(m, orc.das_map(f, csm, h, rm)) < TOL, rm
+    q = dsp.beamforming.quadratic_form_map(csm, h)
+    assert q.shape == (G, F)
+    assert relmax(q, np.einsum("fcg,fcd,fdg->gf", h.conj(), csm, h).real) < TOL
+
+
 def test_fir_design_matches_lfilter():
     """reference tests/test_classes.py:495-512: FIR filter_signal == scipy.signal.lfilter."""
     import scipy.signal as sig

@@ -194,6 +194,13 @@ def test_convolve_rir_on_signal():
         close(y, z[f"y_{i}"], tol=1e-6)  # stored as float32
 
 
+def test_das_map():
+    meta, z = load_golden("das")
+    for i, c in enumerate(meta["cases"]):
+        m = orc.das_map(z[f"f_{i}"], z[f"csm_{i}"], z[f"h_{i}"], c["remove_csm_diagonal"])
+        close(m.reshape(c["grid_shape"]), z[f"map_{i}"], tol=1e-12)
+
+
 def test_chirp_pair_config1():
     """BASELINE.json configs[0]: the reference's own example chirps (16-bit PCM fixtures)."""
     meta, z = load_golden("chirp_pair")
