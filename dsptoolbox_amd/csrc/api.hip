@@ -336,22 +336,27 @@ extern "C" int ds_stft_r2c_dev(ds_ctx* c, const float* x, int64_t n_samples, int
     CHK(check_fft_len(c, nfft, "ds_stft_r2c nfft"));
     const float2* tw;
     CHK(get_twiddles(c, nfft, &tw));
-    // channel tile: ct teams of NT threads (<= 1024 threads, <= ~70 KB of LDS so two
-    // workgroups share a CU)
+    // channel tile: ct teams of NT threads (<= 1024 threads, <= 74 KB of LDS so two
+    // workgroups share a CU; 8 channels = 64-byte runs of the (bins, frames, channels) output for
+    // nfft 1024: 0.16 ms instead of 0.23 ms with 4 on the 64-mic CSM shape)
     int ct = 1;
     size_t lds = 0;
     int threads = 0;
     DISPATCH_N(nfft, {
         const size_t per = (size_t)stft_ch_stride<NN>() * sizeof(float2);
-        ct = std::min<int>({16, 1024 / Cfg<NN>::NT, std::max<int>(1, (int)((70 * 1024) / per)), n_ch});
+        ct = std::min<int>({16, 1024 / Cfg<NN>::NT, std::max<int>(1, (int)((74 * 1024) / per)), n_ch});
+        if (const char* e = getenv("DSPTOOLBOX_AMD_STFT_CT")) {
+            int v = atoi(e);
+            if (v >= 1 && v <= 1024 / Cfg<NN>::NT && (size_t)v * per <= 150 * 1024) ct = std::min(v, std::max(1, n_ch));
+        }
         while (ct & (ct - 1)) ct &= ct - 1;  // power of two (shift-only index math in the kernel)
         lds = per * ct;
         threads = ct * Cfg<NN>::NT;
     });
-    // frame pairs per workgroup: enough workgroups to fill the chip several times over, then
-    // amortise the pipeline fill over a few pairs
+    // frame pairs per workgroup: as few as keep the whole grid resident at once (two workgroups
+    // on each of the 256 CUs: no second, partly filled round), at most 16
     const int n_fp = (n_frames + 1) / 2, n_ct = (n_ch + ct - 1) / ct;
-    int fpw = std::max(1, std::min(8, (int)(((int64_t)n_fp * n_ct) / 2048)));
+    int fpw = std::max(1, std::min(16, (int)(((int64_t)n_fp * n_ct + 511) / 512)));
     if (const char* e = getenv("DSPTOOLBOX_AMD_STFT_FPW")) fpw = std::max(1, atoi(e));
     StftArgs a{x, n_samples, ld, pad_front, n_ch, W, hop, n_frames, detrend, power, ct, fpw, window, tw,
                scale, edge_scale, (float2*)out};
@@ -624,7 +629,14 @@ extern "C" int ds_csm_dev(ds_ctx* c, const float* x, int n_ch, int64_t ld, int64
     CsmArgs a{X, n_ch, n_frames,
               FinishPar{norm_scale / (double)n_frames, factor, halve_edges, amp_sqrt, nb},
               (float2*)csm};
-    CHK(launch(c, "csm_gemm", k_csm_gemm, dim3(nb, nt * (nt + 1) / 2), 256, 0, a));
+    // up to 64 channels: one workgroup per bin shares the operand loads between the three tile
+    // pairs (the spectra of an even-length real transform are purely real at both edge bins,
+    // which the kernel relies on)
+    static const bool no64 = getenv("DSPTOOLBOX_AMD_CSM_GENERIC") != nullptr;
+    if (n_ch <= 64 && n_frames >= 8 && nb >= 3 && !no64)
+        CHK(launch(c, "csm_gemm", k_csm_gemm64, dim3(nb - 1), 256, 0, a));
+    else
+        CHK(launch(c, "csm_gemm", k_csm_gemm, dim3(nb, nt * (nt + 1) / 2), 256, 0, a));
     return DS_OK;
 }
 

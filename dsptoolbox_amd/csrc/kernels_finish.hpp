@@ -14,7 +14,7 @@ struct cd {
 };
 
 __device__ __forceinline__ cd csqrt_principal(cd z) {
-    double r = hypot(z.x, z.y);
+    double r = sqrt(z.x * z.x + z.y * z.y);  // (no overflow protection needed at these magnitudes)
     if (r == 0.0) return cd{0.0, z.y};
     if (z.x >= 0.0) {
         double t = sqrt(0.5 * (r + z.x));
@@ -281,88 +281,187 @@ struct CsmArgs {
     float2* csm;
 };
 
+// Combine the four waves' partial 32x32 tiles (fp64, through LDS), apply the Welch finish and
+// store the tile and its conjugate mirror.  All 256 threads call this together.
+__device__ __forceinline__ void csm_tile_epilogue(float (&red)[4][2][16][64], const f32x16& re, const f32x16& im,
+                                                  int I, int J, int b, const CsmArgs& p) {
+    const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
+    const int C = p.n_ch, F = p.n_frames;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        red[w][0][r][l] = re[r];
+        red[w][1][r][l] = im[r];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+        const int r = w * 4 + rr;
+        cd g{0.0, 0.0};
+#pragma unroll
+        for (int ww = 0; ww < 4; ++ww) {
+            g.x += (double)red[ww][0][r][l];
+            g.y += (double)red[ww][1][r][l];
+        }
+        const int i = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), j = l & 31;
+        const int gi = 32 * I + i, gj = 32 * J + j;
+        if (gi < C && gj < C && gi >= gj) {
+            float2* out = p.csm + (int64_t)b * C * C;
+            if (gi == gj) {
+                double d = finish_real(g.x, b, p.fin);
+                out[(int64_t)gi * C + gj] = make_float2((float)d, 0.f);
+            } else {
+                bool real_bin = false;
+                if (F == 1 && g.y == 0.0) {
+                    // one frame (_csm_fft) at a purely real bin (DC / Nyquist): numpy's
+                    // `csm[[0, -1]] /= 2.0` (complex / real) turns every -0 imaginary part of
+                    // a negative real element into +0, so BOTH mirror elements take the +i
+                    // branch of the square root (the matrix is not Hermitian there).
+                    g.y = 0.0;
+                    real_bin = true;
+                }
+                cd v = finish_cplx(g, b, p.fin);
+                out[(int64_t)gi * C + gj] = make_float2((float)v.x, (float)v.y);
+                if (real_bin) {
+                    cd u = finish_cplx(cd{g.x, 0.0}, b, p.fin);
+                    out[(int64_t)gj * C + gi] = make_float2((float)u.x, (float)u.y);
+                } else {
+                    out[(int64_t)gj * C + gi] = make_float2((float)v.x, (float)-v.y);
+                }
+            }
+        }
+    }
+}
+
+// generic: grid = (bins, tile pairs I >= J of 32 x 32 channels)
 __global__ __launch_bounds__(256) void k_csm_gemm(CsmArgs p) {
     __shared__ float red[4][2][16][64];
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
     const int b = blockIdx.x;
     int I = 0;
-    {
-        int tp = blockIdx.y;
-        while ((I + 1) * (I + 2) / 2 <= tp) ++I;
-        tp -= I * (I + 1) / 2;
-        // J = tp
-        const int J = tp;
-        const int C = p.n_ch, F = p.n_frames;
-        const int ci = 32 * I + (l & 31), cj = 32 * J + (l & 31);
-        const float2* Xb = p.X + (int64_t)b * F * C;
-        f32x16 re = {0}, im = {0};
-        // k-steps (2 frames each) w, w+4, w+8, ... ; U of them are loaded before their 4*U MFMAs
-        // are issued, so the global-load latency hides behind the matrix pipe
-        constexpr int U = 4;
-        const int fo = l >> 5;
-        for (int s0 = w; 2 * s0 < F; s0 += 4 * U) {
-            float2 a[U], bb[U];
+    int tp = blockIdx.y;
+    while ((I + 1) * (I + 2) / 2 <= tp) ++I;
+    tp -= I * (I + 1) / 2;
+    const int J = tp;
+    const int C = p.n_ch, F = p.n_frames;
+    const int ci = 32 * I + (l & 31), cj = 32 * J + (l & 31);
+    const float2* Xb = p.X + (int64_t)b * F * C;
+    f32x16 re = {0}, im = {0};
+    // k-steps (2 frames each) w, w+4, w+8, ... ; U of them are loaded before their 4*U MFMAs
+    // are issued, so the global-load latency hides behind the matrix pipe
+    constexpr int U = 4;
+    const int fo = l >> 5;
+    for (int s0 = w; 2 * s0 < F; s0 += 4 * U) {
+        float2 a[U], bb[U];
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int f = 2 * (s0 + 4 * u) + fo;
-                a[u] = make_float2(0.f, 0.f);
-                bb[u] = make_float2(0.f, 0.f);
-                if (f < F) {
-                    if (ci < C) a[u] = Xb[(int64_t)f * C + ci];
-                    if (cj < C) bb[u] = Xb[(int64_t)f * C + cj];
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                re = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].x, bb[u].x, re, 0, 0, 0);
-                re = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].y, bb[u].y, re, 0, 0, 0);
-                im = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].y, bb[u].x, im, 0, 0, 0);
-                im = __builtin_amdgcn_mfma_f32_32x32x2f32(-a[u].x, bb[u].y, im, 0, 0, 0);
+        for (int u = 0; u < U; ++u) {
+            const int f = 2 * (s0 + 4 * u) + fo;
+            a[u] = make_float2(0.f, 0.f);
+            bb[u] = make_float2(0.f, 0.f);
+            if (f < F) {
+                if (ci < C) a[u] = Xb[(int64_t)f * C + ci];
+                if (cj < C) bb[u] = Xb[(int64_t)f * C + cj];
             }
         }
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            red[w][0][r][l] = re[r];
-            red[w][1][r][l] = im[r];
+        for (int u = 0; u < U; ++u) {
+            re = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].x, bb[u].x, re, 0, 0, 0);
+            re = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].y, bb[u].y, re, 0, 0, 0);
+            im = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].y, bb[u].x, im, 0, 0, 0);
+            im = __builtin_amdgcn_mfma_f32_32x32x2f32(-a[u].x, bb[u].y, im, 0, 0, 0);
         }
+    }
+    csm_tile_epilogue(red, re, im, I, J, b, p);
+}
+
+// Up to 64 channels: ONE workgroup per frequency bin computes all three 32 x 32 tile pairs from
+// the same two operand loads per k-step (12 MFMAs per KiB of operands instead of 4: the generic
+// kernel is bound by the operand traffic from L2, not by the matrix pipe).  grid = bins - 1
+// workgroups, two per CU on the 64-mic shape: workgroup j < bins - 2 takes bin j + 1; the last
+// one takes the two purely real bins (DC and Nyquist), which need one MFMA per tile pair and
+// k-step instead of four (their imaginary parts are exactly zero and the imaginary accumulator
+// of the full form stays +0), so every workgroup has about the same amount of work.
+template <bool REAL_BIN>
+__device__ __forceinline__ void csm64_bin(float (&red)[4][2][16][64], int b, const CsmArgs& p) {
+    const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
+    const int C = p.n_ch, F = p.n_frames;
+    const int c0 = l & 31, c1 = 32 + (l & 31);
+    const float2* Xb = p.X + (int64_t)b * F * C;
+    f32x16 re00 = {0}, im00 = {0}, re10 = {0}, im10 = {0}, re11 = {0}, im11 = {0};
+    constexpr int U = 4;
+    const int fo = l >> 5;
+    // operands of U k-steps (2 frames each; this wave takes k-steps w, w+4, ...) are fetched one
+    // whole iteration (12 U MFMAs) ahead of their use.  No branch per load (hipcc would drain
+    // vmcnt at each): channels beyond C and frames beyond F are read from a clamped address and
+    // zeroed by a select.
+    const int c0c = min(c0, C - 1), c1c = min(c1, C - 1);
+    const float m0 = c0 < C ? 1.f : 0.f, m1 = c1 < C ? 1.f : 0.f;
+    // raw loads only (clamped addresses): the masks are applied when the batch is consumed, one
+    // iteration later, so nothing here waits for the data
+    auto fetch = [&](int s0, float2 (&r0)[U], float2 (&r1)[U]) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const float2* row = Xb + (int64_t)min(2 * (s0 + 4 * u) + fo, F - 1) * C;
+            r0[u] = row[c0c];
+            r1[u] = row[c1c];
+        }
+    };
+    auto consume = [&](int s0, const float2 (&r0)[U], const float2 (&r1)[U]) {
+        float2 x0[U], x1[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const float v = (2 * (s0 + 4 * u) + fo) < F ? 1.f : 0.f;
+            x0[u] = make_float2(r0[u].x * (m0 * v), r0[u].y * (m0 * v));
+            x1[u] = make_float2(r1[u].x * (m1 * v), r1[u].y * (m1 * v));
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            // tile (I, J): A operand = rows of tile I, B operand = columns of tile J
+            re00 = __builtin_amdgcn_mfma_f32_32x32x2f32(x0[u].x, x0[u].x, re00, 0, 0, 0);
+            re10 = __builtin_amdgcn_mfma_f32_32x32x2f32(x1[u].x, x0[u].x, re10, 0, 0, 0);
+            re11 = __builtin_amdgcn_mfma_f32_32x32x2f32(x1[u].x, x1[u].x, re11, 0, 0, 0);
+            if (!REAL_BIN) {
+                re00 = __builtin_amdgcn_mfma_f32_32x32x2f32(x0[u].y, x0[u].y, re00, 0, 0, 0);
+                im00 = __builtin_amdgcn_mfma_f32_32x32x2f32(x0[u].y, x0[u].x, im00, 0, 0, 0);
+                im00 = __builtin_amdgcn_mfma_f32_32x32x2f32(-x0[u].x, x0[u].y, im00, 0, 0, 0);
+                re10 = __builtin_amdgcn_mfma_f32_32x32x2f32(x1[u].y, x0[u].y, re10, 0, 0, 0);
+                im10 = __builtin_amdgcn_mfma_f32_32x32x2f32(x1[u].y, x0[u].x, im10, 0, 0, 0);
+                im10 = __builtin_amdgcn_mfma_f32_32x32x2f32(-x1[u].x, x0[u].y, im10, 0, 0, 0);
+                re11 = __builtin_amdgcn_mfma_f32_32x32x2f32(x1[u].y, x1[u].y, re11, 0, 0, 0);
+                im11 = __builtin_amdgcn_mfma_f32_32x32x2f32(x1[u].y, x1[u].x, im11, 0, 0, 0);
+                im11 = __builtin_amdgcn_mfma_f32_32x32x2f32(-x1[u].x, x1[u].y, im11, 0, 0, 0);
+            }
+        }
+    };
+    // two register sets used alternately (no copies of values that are still in flight)
+    float2 a0[U], a1[U], b0[U], b1[U];
+    fetch(w, a0, a1);
+    for (int s0 = w; 2 * s0 < F; s0 += 8 * U) {
+        fetch(s0 + 4 * U, b0, b1);
+        __builtin_amdgcn_sched_barrier(0);  // the next batch is in flight during these MFMAs
+        consume(s0, a0, a1);
+        if (2 * (s0 + 4 * U) >= F) break;
+        fetch(s0 + 8 * U, a0, a1);
+        __builtin_amdgcn_sched_barrier(0);
+        consume(s0 + 4 * U, b0, b1);
+    }
+    csm_tile_epilogue(red, re00, im00, 0, 0, b, p);
+    if (C > 32) {
+        __syncthreads();  // red is reused
+        csm_tile_epilogue(red, re10, im10, 1, 0, b, p);
         __syncthreads();
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr) {
-            const int r = w * 4 + rr;
-            cd g{0.0, 0.0};
-#pragma unroll
-            for (int ww = 0; ww < 4; ++ww) {
-                g.x += (double)red[ww][0][r][l];
-                g.y += (double)red[ww][1][r][l];
-            }
-            const int i = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), j = l & 31;
-            const int gi = 32 * I + i, gj = 32 * J + j;
-            if (gi < C && gj < C && gi >= gj) {
-                float2* out = p.csm + (int64_t)b * C * C;
-                if (gi == gj) {
-                    double d = finish_real(g.x, b, p.fin);
-                    out[(int64_t)gi * C + gj] = make_float2((float)d, 0.f);
-                } else {
-                    bool real_bin = false;
-                    if (F == 1 && g.y == 0.0) {
-                        // one frame (_csm_fft) at a purely real bin (DC / Nyquist): numpy's
-                        // `csm[[0, -1]] /= 2.0` (complex / real) turns every -0 imaginary part of
-                        // a negative real element into +0, so BOTH mirror elements take the +i
-                        // branch of the square root (the matrix is not Hermitian there).
-                        g.y = 0.0;
-                        real_bin = true;
-                    }
-                    cd v = finish_cplx(g, b, p.fin);
-                    out[(int64_t)gi * C + gj] = make_float2((float)v.x, (float)v.y);
-                    if (real_bin) {
-                        cd u = finish_cplx(cd{g.x, 0.0}, b, p.fin);
-                        out[(int64_t)gj * C + gi] = make_float2((float)u.x, (float)u.y);
-                    } else {
-                        out[(int64_t)gj * C + gi] = make_float2((float)v.x, (float)-v.y);
-                    }
-                }
-            }
-        }
+        csm_tile_epilogue(red, re11, im11, 1, 1, b, p);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_csm_gemm64(CsmArgs p) {
+    __shared__ float red[4][2][16][64];
+    const int nb = p.fin.nb;
+    if ((int)blockIdx.x < nb - 2) {
+        csm64_bin<false>(red, (int)blockIdx.x + 1, p);
+    } else {
+        csm64_bin<true>(red, 0, p);
+        __syncthreads();
+        csm64_bin<true>(red, nb - 1, p);
     }
 }
 
