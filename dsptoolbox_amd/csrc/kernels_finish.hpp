@@ -488,33 +488,53 @@ __global__ __launch_bounds__(256) void k_das_map(DasArgs p) {
     const float2* Hf = p.h + (int64_t)f * C * G;
     const bool gv = g < G;
     double part = 0.0;
+    const int gc = min(g, G - 1);
+    const float mg = gv ? 1.f : 0.f;
+    constexpr int U = 4;
     for (int i0 = 0; i0 < C; i0 += 32) {
         f32x16 mr = {0}, mi = {0};
         const int ci = i0 + (l & 31);
-        constexpr int U = 4;
-        for (int s0 = 0; 2 * s0 < C; s0 += U) {
-            float2 a[U], b[U];
+        const int cic = min(ci, C - 1);
+        const float mc = ci < C ? 1.f : 0.f;
+        // branch-free loads from clamped addresses, masked when consumed; two register sets used
+        // alternately so the next batch is in flight during the current batch's MFMAs
+        auto fetch = [&](int s0, float2 (&a)[U], float2 (&b)[U]) {
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const int k = 2 * (s0 + u) + kh;
-                a[u] = (ci < C && k < C) ? Cf[(int64_t)ci * C + k] : make_float2(0.f, 0.f);
-                b[u] = (gv && k < C) ? Hf[(int64_t)k * G + g] : make_float2(0.f, 0.f);
+                const int k = min(2 * (s0 + u) + kh, C - 1);
+                a[u] = Cf[(int64_t)cic * C + k];
+                b[u] = Hf[(int64_t)k * G + gc];
             }
+        };
+        auto consume = [&](int s0, const float2 (&ra)[U], const float2 (&rb)[U]) {
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                mr = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].x, b[u].x, mr, 0, 0, 0);
-                mr = __builtin_amdgcn_mfma_f32_32x32x2f32(-a[u].y, b[u].y, mr, 0, 0, 0);
-                mi = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].x, b[u].y, mi, 0, 0, 0);
-                mi = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].y, b[u].x, mi, 0, 0, 0);
+                const float v = (2 * (s0 + u) + kh) < C ? 1.f : 0.f;
+                const float2 a = make_float2(ra[u].x * (mc * v), ra[u].y * (mc * v));
+                const float2 b = make_float2(rb[u].x * (mg * v), rb[u].y * (mg * v));
+                mr = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, mr, 0, 0, 0);
+                mr = __builtin_amdgcn_mfma_f32_32x32x2f32(-a.y, b.y, mr, 0, 0, 0);
+                mi = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.y, mi, 0, 0, 0);
+                mi = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.x, mi, 0, 0, 0);
             }
+        };
+        float2 a0[U], b0[U], a1[U], b1[U];
+        fetch(0, a0, b0);
+        for (int s0 = 0; 2 * s0 < C; s0 += 2 * U) {
+            fetch(s0 + U, a1, b1);
+            __builtin_amdgcn_sched_barrier(0);
+            consume(s0, a0, b0);
+            if (2 * (s0 + U) >= C) break;
+            fetch(s0 + 2 * U, a0, b0);
+            __builtin_amdgcn_sched_barrier(0);
+            consume(s0 + U, a1, b1);
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int c = i0 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-            if (gv && c < C) {
-                const float2 hv = Hf[(int64_t)c * G + g];
-                part += (double)hv.x * (double)mr[r] + (double)hv.y * (double)mi[r];
-            }
+            const float2 hv = Hf[(int64_t)min(c, C - 1) * G + gc];
+            const double t = (double)hv.x * (double)mr[r] + (double)hv.y * (double)mi[r];
+            part += (gv && c < C) ? t : 0.0;
         }
     }
     part += __shfl_xor(part, 32);
