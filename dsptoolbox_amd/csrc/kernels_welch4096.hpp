@@ -269,11 +269,13 @@ __global__ __launch_bounds__(NT) void k_x(Args p) {
     const int tid = threadIdx.x, pr = blockIdx.x;
     Tw tw;
     float win[16];
-    init_tables(tw, win, tw2, p.window, p.twt, tid);
     float2 v[16];
     {
+        // one transform per workgroup: the kernel is a latency chain, so the samples are
+        // requested before the tables (whose barrier would otherwise be waited for first)
         Raw<HALF_HOP> raw;
         load_raw<HALF_HOP>(raw, p.sig, p.n_samples, (int64_t)(2 * pr) * p.hop, p.hop, tid);
+        init_tables(tw, win, tw2, p.window, p.twt, tid);
         window_pair<HALF_HOP>(v, raw, 2 * pr + 1 < p.n_frames, win);
     }
 #if W4_TIMING
