@@ -33,6 +33,8 @@ struct ds_ctx {
     size_t ws_bytes = 0;
     void* io = nullptr;  // staging for the host-pointer entry points
     size_t io_bytes = 0;
+    void* aux = nullptr;  // small persistent scratch (combined FIR taps, cascade ping-pong buffer)
+    size_t aux_bytes = 0;
     // RCCL (dlopen'ed lazily)
     void* rccl = nullptr;
     void* comm = nullptr;
@@ -111,6 +113,7 @@ extern "C" void ds_destroy(ds_ctx* c) {
     for (auto& e : c->prof_pool) (void)hipEventDestroy(e);
     if (c->ws) (void)hipFree(c->ws);
     if (c->io) (void)hipFree(c->io);
+    if (c->aux) (void)hipFree(c->aux);
     (void)hipEventDestroy(c->ev0);
     (void)hipEventDestroy(c->ev1);
     (void)hipStreamDestroy(c->stream);
@@ -1131,15 +1134,15 @@ extern "C" int ds_fir_ola_dev(ds_ctx* c, const float* x, int n_ch, int64_t ldx, 
     if (n_ch <= 0 || n_samples <= 0 || n_filt <= 0 || n_taps <= 0 || ldx < n_samples || ld_y < n_samples)
         return fail(c, DS_ERR_ARG, "ds_fir_ola: bad shape");
     if (mode == DS_FB_PARALLEL) return fir_once(c, x, n_ch, ldx, n_samples, taps, n_filt, n_taps, y, ld_y);
+    // (combined taps and the cascade's intermediate signal live in the context's aux scratch: no
+    // allocation, free or synchronisation per call; everything stays ordered on the stream)
     if (mode == DS_FB_SUMMED) {
         // sum_k (x * b_k) = x * (sum_k b_k): one filter with the summed taps
-        float* bs = nullptr;
-        HIPCHK(c, hipMalloc((void**)&bs, sizeof(float) * n_taps));
+        CHK(reserve(c, &c->aux, &c->aux_bytes, sizeof(float) * (size_t)n_taps));
+        float* bs = (float*)c->aux;
         hipLaunchKernelGGL(k_sum_taps, dim3((n_taps + 255) / 256), dim3(256), 0, c->stream, taps, n_filt, n_taps, bs);
-        int r = fir_once(c, x, n_ch, ldx, n_samples, bs, 1, n_taps, y, ld_y);
-        (void)hipStreamSynchronize(c->stream);
-        (void)hipFree(bs);
-        return r;
+        HIPCHK(c, hipGetLastError());
+        return fir_once(c, x, n_ch, ldx, n_samples, bs, 1, n_taps, y, ld_y);
     }
     if (mode == DS_FB_SEQUENTIAL) {
         // ((x*b1)[:N]*b2)[:N]... = (x*(b1*b2*...))[:N] for causal filters: when the combined
@@ -1147,11 +1150,12 @@ extern "C" int ds_fir_ola_dev(ds_ctx* c, const float* x, int n_ch, int64_t ldx, 
         // filter once -- no fp32 round trip of the intermediate signals through HBM.
         const int64_t n_comb = (int64_t)n_filt * (n_taps - 1) + 1;
         if (n_filt > 1 && n_comb - 1 <= kMaxBigFft / 2 && (double)n_comb * n_taps <= 1.0e10) {
-            double *pa = nullptr, *pb = nullptr;
-            float* bf = nullptr;
-            HIPCHK(c, hipMalloc((void**)&pa, sizeof(double) * n_comb));
-            HIPCHK(c, hipMalloc((void**)&pb, sizeof(double) * n_comb));
-            HIPCHK(c, hipMalloc((void**)&bf, sizeof(float) * n_comb));
+            CHK(reserve(c, &c->aux, &c->aux_bytes,
+                        2 * Carver::pad(sizeof(double) * (size_t)n_comb) + Carver::pad(sizeof(float) * (size_t)n_comb)));
+            Carver cv(c->aux);
+            double* pa = cv.take<double>((size_t)n_comb);
+            double* pb = cv.take<double>((size_t)n_comb);
+            float* bf = cv.take<float>((size_t)n_comb);
             hipLaunchKernelGGL(k_taps_to_f64, dim3((n_taps + 255) / 256), dim3(256), 0, c->stream, taps, n_taps, pa);
             int len = n_taps;
             for (int k = 1; k < n_filt; ++k) {
@@ -1162,29 +1166,25 @@ extern "C" int ds_fir_ola_dev(ds_ctx* c, const float* x, int n_ch, int64_t ldx, 
                 len = nl;
             }
             hipLaunchKernelGGL(k_f64_to_taps, dim3((len + 255) / 256), dim3(256), 0, c->stream, pa, len, bf);
-            int r = fir_once(c, x, n_ch, ldx, n_samples, bf, 1, len, y, ld_y);
-            (void)hipStreamSynchronize(c->stream);
-            (void)hipFree(pa);
-            (void)hipFree(pb);
-            (void)hipFree(bf);
-            return r;
+            HIPCHK(c, hipGetLastError());
+            return fir_once(c, x, n_ch, ldx, n_samples, bf, 1, len, y, ld_y);
         }
         // long cascades: stage by stage, each truncated to n_samples like the reference loop
         float* tmp = nullptr;
-        if (n_filt > 1) HIPCHK(c, hipMalloc((void**)&tmp, sizeof(float) * (size_t)n_ch * n_samples));
+        if (n_filt > 1) {
+            CHK(reserve(c, &c->aux, &c->aux_bytes, sizeof(float) * (size_t)n_ch * n_samples));
+            tmp = (float*)c->aux;
+        }
         const float* src = x;
         int64_t lds = ldx;
-        int r = DS_OK;
-        for (int k = 0; k < n_filt && r == DS_OK; ++k) {
+        for (int k = 0; k < n_filt; ++k) {
             float* dst = ((n_filt - 1 - k) % 2 == 0) ? y : tmp;  // ping-pong, last stage lands in y
             int64_t ldd = (dst == y) ? ld_y : n_samples;
-            r = fir_once(c, src, n_ch, lds, n_samples, taps + (int64_t)k * n_taps, 1, n_taps, dst, ldd);
+            CHK(fir_once(c, src, n_ch, lds, n_samples, taps + (int64_t)k * n_taps, 1, n_taps, dst, ldd));
             src = dst;
             lds = ldd;
         }
-        (void)hipStreamSynchronize(c->stream);
-        if (tmp) (void)hipFree(tmp);
-        return r;
+        return DS_OK;
     }
     return fail(c, DS_ERR_ARG, "ds_fir_ola: invalid filter bank apply mode");
 }
