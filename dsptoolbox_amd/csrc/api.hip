@@ -16,6 +16,7 @@
 #include "kernels_finish.hpp"
 #include "kernels_generic.hpp"
 #include "kernels_welch4096.hpp"
+#include "kernels_fir16k.hpp"
 
 using namespace dsk;
 
@@ -29,6 +30,7 @@ struct ds_ctx {
     std::map<int, float2*> tw;  // twiddle tables by length
     std::map<std::pair<int64_t, int64_t>, float2*> blue;  // Bluestein chirp-filter spectra by (L, M)
     float2* w4_tables = nullptr;  // welch4096::host_tables()
+    float2* fir16k_tables = nullptr;  // fir16k::host_tables()
     void* ws = nullptr;         // kernel workspace (spectra, partials)
     size_t ws_bytes = 0;
     void* io = nullptr;  // staging for the host-pointer entry points
@@ -105,6 +107,7 @@ extern "C" void ds_destroy(ds_ctx* c) {
     (void)hipStreamSynchronize(c->stream);
     for (auto& kv : c->tw) (void)hipFree(kv.second);
     if (c->w4_tables) (void)hipFree(c->w4_tables);
+    if (c->fir16k_tables) (void)hipFree(c->fir16k_tables);
     for (auto& kv : c->blue) (void)hipFree(kv.second);
     for (auto& r : c->prof_recs) {
         (void)hipEventDestroy(r.a);
@@ -1087,14 +1090,40 @@ static int fir_once(ds_ctx* c, const float* x, int n_ch, int64_t ldx, int64_t n_
     if (n_taps - 1 > N / 2) return fir_long(c, x, n_ch, ldx, n_samples, taps, n_filt, n_taps, y, ld_y);
     const float2* tw;
     CHK(get_twiddles(c, N, &tw));
-    CHK(reserve(c, &c->ws, &c->ws_bytes, sizeof(float2) * (size_t)n_filt * N));
-    float2* hs = (float2*)c->ws;
+    static const bool no16k = getenv("DSPTOOLBOX_AMD_FIR_GENERIC") != nullptr;
+    const bool use16k = N == fir16k::NBIG && !no16k;
+    CHK(reserve(c, &c->ws, &c->ws_bytes, (use16k ? 2 : 1) * Carver::pad(sizeof(float2) * (size_t)n_filt * N)));
+    Carver cvw(c->ws);
+    float2* hs = cvw.take<float2>((size_t)n_filt * N);
     {
         FirTapsArgs a{taps, n_filt, n_taps, tw, hs};
         DISPATCH_N(N, CHK(launch(c, "fir_taps", k_fir_taps<NN>, dim3((n_filt + 1) / 2), Cfg<NN>::NT, Cfg<NN>::LDS_BYTES, a)));
     }
     const int L = N - (n_taps - 1);
     const int64_t n_blocks = (n_samples + L - 1) / L;
+    if (use16k) {
+        // 16384-point blocks: four 4096-point register transforms per block (kernels_fir16k.hpp)
+        if (!c->w4_tables) {
+            std::vector<float2> h;
+            welch4096::host_tables(h);
+            HIPCHK(c, hipMalloc((void**)&c->w4_tables, sizeof(float2) * h.size()));
+            HIPCHK(c, hipMemcpyAsync(c->w4_tables, h.data(), sizeof(float2) * h.size(), hipMemcpyHostToDevice, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+        }
+        if (!c->fir16k_tables) {
+            std::vector<float2> h;
+            fir16k::host_tables(h);
+            HIPCHK(c, hipMalloc((void**)&c->fir16k_tables, sizeof(float2) * h.size()));
+            HIPCHK(c, hipMemcpyAsync(c->fir16k_tables, h.data(), sizeof(float2) * h.size(), hipMemcpyHostToDevice, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+        }
+        float2* hperm = cvw.take<float2>((size_t)n_filt * N);
+        fir16k::PermArgs pa{hs, n_filt, hperm};
+        CHK(launch(c, "fir_taps", fir16k::k_permute, dim3((unsigned)(((int64_t)n_filt * N + 255) / 256)), 256, 0, pa));
+        fir16k::Args a{x, n_samples, ldx, ld_y, n_ch, n_filt, n_taps, c->w4_tables, c->fir16k_tables, hperm, y};
+        CHK(launch(c, "fir", fir16k::k_fir, dim3((unsigned)n_blocks, (n_ch + 1) / 2), fir16k::NTB, fir16k::LDS_BYTES, a));
+        return DS_OK;
+    }
     FirArgs a{x, n_samples, ldx, ld_y, n_ch, n_filt, n_taps, tw, hs, y};
     dim3 grid((unsigned)n_blocks, (n_ch + 1) / 2);
     DISPATCH_N(N, CHK(launch(c, "fir", k_fir<NN>, grid, Cfg<NN>::NT, Cfg<NN>::LDS_BYTES, a)));
