@@ -85,11 +85,14 @@ __device__ __forceinline__ void ifft4096(float2 (&v)[16], const float2* __restri
 #pragma unroll
     for (int j = 0; j < 8; ++j) row[j] = make_float4(v[2 * j].x, v[2 * j].y, v[2 * j + 1].x, v[2 * j + 1].y);
     const int k1u = t >> 4, n3 = t & 15;
+    float2 w2[15];  // W256 twiddles: fetched behind the barrier into the registers v just left
+#pragma unroll
+    for (int k2 = 1; k2 < 16; ++k2) w2[k2 - 1] = tw2[k2 * 16 + n3];
     __syncthreads();
 #pragma unroll
     for (int k2 = 0; k2 < 16; ++k2) v[w4::pos16(k2)] = buf[(16 * k2 + k1u) * w4::L2S + n3];
 #pragma unroll
-    for (int k2 = 1; k2 < 16; ++k2) v[w4::pos16(k2)] = cmulc(v[w4::pos16(k2)], tw2[k2 * 16 + n3]);
+    for (int k2 = 1; k2 < 16; ++k2) v[w4::pos16(k2)] = cmulc(v[w4::pos16(k2)], w2[k2 - 1]);
     idft16(v);  // v[n2]
     __syncthreads();  // every read of the row image is done before it is overwritten
 #pragma unroll
