@@ -17,6 +17,7 @@
 #include "kernels_generic.hpp"
 #include "kernels_welch4096.hpp"
 #include "kernels_fir16k.hpp"
+#include "kernels_deconv8k.hpp"
 
 using namespace dsk;
 
@@ -31,6 +32,7 @@ struct ds_ctx {
     std::map<std::pair<int64_t, int64_t>, float2*> blue;  // Bluestein chirp-filter spectra by (L, M)
     float2* w4_tables = nullptr;  // welch4096::host_tables()
     float2* fir16k_tables = nullptr;  // fir16k::host_tables()
+    float2* deconv8k_tables = nullptr;  // deconv8k::host_tables()
     void* ws = nullptr;         // kernel workspace (spectra, partials)
     size_t ws_bytes = 0;
     void* io = nullptr;  // staging for the host-pointer entry points
@@ -108,6 +110,7 @@ extern "C" void ds_destroy(ds_ctx* c) {
     for (auto& kv : c->tw) (void)hipFree(kv.second);
     if (c->w4_tables) (void)hipFree(c->w4_tables);
     if (c->fir16k_tables) (void)hipFree(c->fir16k_tables);
+    if (c->deconv8k_tables) (void)hipFree(c->deconv8k_tables);
     for (auto& kv : c->blue) (void)hipFree(kv.second);
     for (auto& r : c->prof_recs) {
         (void)hipEventDestroy(r.a);
@@ -316,6 +319,7 @@ static int check_fft_len(ds_ctx* c, int n, const char* what) {
     return DS_OK;
 }
 
+static int upload_table_fwd(ds_ctx* c, float2** slot, const std::vector<float2>& h);
 static size_t stft_big_ws(int n_ch, int n_frames, int64_t nfft);
 static int stft_big(ds_ctx* c, Carver& cv, const float* x, int n_ch, int64_t ld, int64_t n_samples,
                     int W, int hop, int64_t nfft, int64_t pad_front, int n_frames, const float* window,
@@ -1010,6 +1014,26 @@ extern "C" int ds_deconv_dev(ds_ctx* c, const float* y, int n_items, int n_ch, i
                           n_out, ld_out, ir);
     }
     CHK(check_fft_len(c, n_fft, "ds_deconv n_fft"));
+    static const bool no8k = getenv("DSPTOOLBOX_AMD_DECONV_GENERIC") != nullptr;
+    if (n_fft == deconv8k::N && !r_per_channel && !no8k) {
+        // 8192 points, one inverse spectrum for all channels: two register-resident 4096-point
+        // transforms per channel pair, the packed spectrum multiplied directly (kernels_deconv8k.hpp)
+        if (!c->w4_tables) {
+            std::vector<float2> h;
+            welch4096::host_tables(h);
+            CHK(upload_table_fwd(c, &c->w4_tables, h));
+        }
+        if (!c->deconv8k_tables) {
+            std::vector<float2> h;
+            deconv8k::host_tables(h);
+            CHK(upload_table_fwd(c, &c->deconv8k_tables, h));
+        }
+        deconv8k::Args a8{y, n_samples, ld, n_out, ld_out, n_ch, c->w4_tables, c->deconv8k_tables,
+                          (const float2*)r, ir};
+        CHK(launch(c, "deconv", deconv8k::k_deconv, dim3((n_ch + 1) / 2, n_items), deconv8k::NTB,
+                   deconv8k::LDS_BYTES, a8));
+        return DS_OK;
+    }
     const float2* tw;
     CHK(get_twiddles(c, n_fft, &tw));
     DeconvArgs a{y, n_samples, ld, n_out, ld_out, n_ch, r_per_channel, tw, (const float2*)r, ir};
@@ -1019,6 +1043,14 @@ extern "C" int ds_deconv_dev(ds_ctx* c, const float* y, int n_items, int n_ch, i
 }
 
 // ---- FIR ---------------------------------------------------------------------
+static int upload_table_fwd(ds_ctx* c, float2** slot, const std::vector<float2>& h) {
+    if (*slot) return DS_OK;
+    HIPCHK(c, hipMalloc((void**)slot, sizeof(float2) * h.size()));
+    HIPCHK(c, hipMemcpyAsync(*slot, h.data(), sizeof(float2) * h.size(), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return DS_OK;
+}
+
 static int fir_block_len(int n_taps) {
     int n = 1024;
     while (n < 4 * n_taps && n < kMaxFft) n <<= 1;

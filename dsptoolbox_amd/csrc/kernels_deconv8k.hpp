@@ -1,0 +1,166 @@
+// Spectral division for 8192-point transforms with ONE inverse spectrum shared by all channels
+// (the batched config: many responses against one sweep): ir = irfft(rfft(y) R), two channels per
+// complex transform, on the register-resident 4096-point transform of kernels_welch4096.hpp.
+//
+//   8192 = 2 x 4096, 512 threads = 2 groups of 256; group q owns the sub-spectrum Z[2k' + q]:
+//       b_q[n'] = (z[n'] + (-1)^q z[n' + 4096]) W8192^(n' q) ,  Z[2k'+q] = FFT4096(b_q)[k']
+//       g_q = IFFT4096( Z[2k'+q] Rf[2k'+q] ) ,  y[n' + 4096 j] = sum_q (-1)^(jq) W8192^(-n' q) g_q[n']
+//   z = ya + i yb.  Because both channels see the same real impulse response, its full
+//   Hermitian spectrum Rf multiplies the PACKED spectrum directly (no separation of the two
+//   channels): Rf[k] = R[k], Rf[N-k] = conj R[k], and the real parts of R[0], R[N/2] (numpy's irfft
+//   ignores the imaginary parts there).  74 KB of LDS: two workgroups per CU.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <cmath>
+#include <vector>
+
+#include "kernels_fir16k.hpp"
+
+namespace deconv8k {
+
+namespace w4 = welch4096;
+using fir16k::cmul;
+using fir16k::cmulc;
+constexpr int N = 8192, M = 4096, NTB = 512;
+constexpr int LDS_BYTES = (2 * w4::BUF_C + 256) * 8;  // 75 776 B
+
+// twn: [256] W8192^t then [16] W32^n1  (fp64-computed)
+constexpr int TWN_LEN = 256 + 16;
+inline void host_tables(std::vector<float2>& t) {
+    t.resize(TWN_LEN);
+    for (int tt = 0; tt < 256; ++tt) {
+        double a = -2.0 * M_PI * (double)tt / 8192.0;
+        t[tt] = make_float2((float)std::cos(a), (float)std::sin(a));
+    }
+    for (int n1 = 0; n1 < 16; ++n1) {
+        double a = -2.0 * M_PI * (double)n1 / 32.0;
+        t[256 + n1] = make_float2((float)std::cos(a), (float)std::sin(a));
+    }
+}
+
+struct Args {
+    const float* y;
+    int64_t n_samples, ld, n_out, ld_out;
+    int n_ch;
+    const float2* twt;    // welch4096::host_tables()
+    const float2* twn;    // host_tables() above
+    const float2* r;      // [N/2+1] shared inverse spectrum
+    float* ir;
+};
+
+// grid = (ceil(n_ch/2), n_items)
+__global__ __launch_bounds__(NTB, 4) void k_deconv(Args p) {
+    extern __shared__ __align__(16) float2 lds[];
+    const int tid = threadIdx.x, t = tid & 255;
+    const int q = __builtin_amdgcn_readfirstlane(tid >> 8);
+    float2* buf = lds + q * w4::BUF_C;
+    float2* tw2 = lds + 2 * w4::BUF_C;
+    float2* comb = lds;  // [2][4096] recombination image, overlays the exchange buffers
+    const int ca = 2 * blockIdx.x, cb = ca + 1;
+    const bool vb = cb < p.n_ch;
+    const int64_t item = blockIdx.y;
+    const float* ya = p.y + (item * p.n_ch + ca) * p.ld;
+    const float* yb = vb ? ya + p.ld : ya;
+    const float mb = vb ? 1.f : 0.f;
+    if (tid < 256) tw2[tid] = p.twt[15 * 256 + tid];
+    const float2 wt = p.twn[t];
+    const float2* c32 = p.twn + 256;
+
+    // The shared inverse spectrum in the register layout: slot s = pos16(k3) holds bin
+    // k = 2 (t + 256 k3) + q, gathered straight from the one-sided r (32 KB, L2 resident; a
+    // separate permutation launch would cost 6 us of a 50 us step) before anything else, so the
+    // loads are in flight during the forward transform.  Rf[k] = R[k], Rf[N-k] = conj R[k], real
+    // at k = 0 and N/2; 1/N folded in.  Branch-free index math.
+    float2 rf[16];
+    {
+        const float inv = 1.0f / (float)N;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const int k3 = (s >> 2) + 4 * (s & 3);
+            const int k = 2 * (t + 256 * k3) + q;
+            const float2 r = p.r[min(k, N - k)];
+            const float sg = (k == 0 || k == N / 2) ? 0.f : (k < N / 2 ? inv : -inv);
+            rf[s] = make_float2(r.x * inv, r.y * sg);
+        }
+    }
+
+    // ---- forward
+    float2 v[16];
+    {
+        const int last = (int)(p.n_samples < (int64_t)N ? p.n_samples : (int64_t)N) - 1;
+#pragma unroll
+        for (int n1 = 0; n1 < 16; ++n1) {
+            float2 z[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int g = t + 256 * n1 + M * j;
+                const int cg = g > last ? last : g;  // clamp + select: no branch per load
+                const float a = ya[cg], b = yb[cg];
+                const float ok = (g == cg) ? 1.f : 0.f;
+                z[j] = make_float2(a * ok, b * (ok * mb));
+            }
+            if (q == 0)
+                v[n1] = make_float2(z[0].x + z[1].x, z[0].y + z[1].y);
+            else
+                v[n1] = cmul(make_float2(z[0].x - z[1].x, z[0].y - z[1].y), cmul(wt, c32[n1]));
+        }
+    }
+    __syncthreads();  // W256 table written
+    {
+        w4::Tw tw;
+#pragma unroll
+        for (int k1 = 1; k1 < 16; ++k1) tw.w[k1 - 1] = p.twt[(k1 - 1) * 256 + t];
+        w4::fft4096<false>(v, tw, buf, tw2, t);
+    }
+    // ---- multiply by the shared inverse spectrum (fetched at the top of the kernel)
+#pragma unroll
+    for (int s = 0; s < 16; ++s) v[s] = cmul(v[s], rf[s]);
+    __syncthreads();  // the forward transform's last exchange image has been read
+    fir16k::ifft4096(v, p.twt, buf, tw2, t);
+    __syncthreads();  // both groups have read their last exchange image: the buffers become comb
+#pragma unroll
+    for (int n1 = 0; n1 < 16; ++n1)
+        comb[q * M + t + 256 * n1] = (q == 0) ? v[n1] : cmulc(v[n1], cmul(wt, c32[n1]));
+    __syncthreads();
+    // ---- y[n'] = u0 + u1, y[n' + 4096] = u0 - u1; four consecutive samples per thread and chunk
+    float* oa = p.ir + (item * p.n_ch + ca) * p.ld_out;
+    float* ob = oa + p.ld_out;
+    const bool plain = p.n_out >= N && (p.ld_out & 3) == 0;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        const int n0 = 2048 * c + 4 * tid;
+        const float4* s0 = reinterpret_cast<const float4*>(comb + n0);
+        const float4* s1 = reinterpret_cast<const float4*>(comb + M + n0);
+        const float4 a0 = s0[0], a1 = s0[1], b0 = s1[0], b1 = s1[1];
+        const float4 lo_x = make_float4(a0.x + b0.x, a0.z + b0.z, a1.x + b1.x, a1.z + b1.z);
+        const float4 lo_y = make_float4(a0.y + b0.y, a0.w + b0.w, a1.y + b1.y, a1.w + b1.w);
+        const float4 hi_x = make_float4(a0.x - b0.x, a0.z - b0.z, a1.x - b1.x, a1.z - b1.z);
+        const float4 hi_y = make_float4(a0.y - b0.y, a0.w - b0.w, a1.y - b1.y, a1.w - b1.w);
+        if (plain) {
+            *reinterpret_cast<float4*>(oa + n0) = lo_x;
+            *reinterpret_cast<float4*>(oa + n0 + M) = hi_x;
+            if (vb) {
+                *reinterpret_cast<float4*>(ob + n0) = lo_y;
+                *reinterpret_cast<float4*>(ob + n0 + M) = hi_y;
+            }
+        } else {
+            const float lx[4] = {lo_x.x, lo_x.y, lo_x.z, lo_x.w}, ly[4] = {lo_y.x, lo_y.y, lo_y.z, lo_y.w};
+            const float hx[4] = {hi_x.x, hi_x.y, hi_x.z, hi_x.w}, hy[4] = {hi_y.x, hi_y.y, hi_y.z, hi_y.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (n0 + i < p.n_out) {
+                    oa[n0 + i] = lx[i];
+                    if (vb) ob[n0 + i] = ly[i];
+                }
+                if (n0 + i + M < p.n_out) {
+                    oa[n0 + i + M] = hx[i];
+                    if (vb) ob[n0 + i + M] = hy[i];
+                }
+            }
+        }
+    }
+}
+
+}  // namespace deconv8k
