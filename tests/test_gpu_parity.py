@@ -585,10 +585,13 @@ def test_headline_full_size_properties():
     assert relmax(coh[m, :3], rc[m]) < TOL
 
 
-def test_csm_64ch_vs_oracle():
+@pytest.mark.parametrize("n_ch", [64, 40, 33, 70])
+def test_csm_64ch_vs_oracle(n_ch):
+    """64 / 40 / 33 channels: one workgroup per bin (k_csm_gemm64, partly filled second tile);
+    70 channels: the generic tile-pair kernel."""
     rng = np.random.default_rng(4)
     n = 40000
-    x = 0.1 * rng.standard_normal((n, 64)) + 0.2 * rng.standard_normal(n)[:, None]
+    x = 0.1 * rng.standard_normal((n, n_ch)) + 0.2 * rng.standard_normal(n)[:, None]
     f, csm = backend._csm_welch(x, 48000, 1024, Window.Hann, 50, True, "mean",
                                 SpectrumScaling.FFTBackward)
     fr, ref = orc.csm_welch_batched(x, 48000, 1024, "hann", 50, True, "FFTBackward")
