@@ -320,6 +320,19 @@ def test_fir_state_zero_phase_long_golden():
                                                               activate_zi=True, zero_phase=True)
 
 
+@pytest.mark.parametrize("n_taps,n,n_ch", [(2049, 50001, 3), (3000, 70000, 2), (8193, 40000, 1), (4097, 12288 * 3, 2),
+                                            (4097, 5000, 5)])
+def test_fir_16k_blocks_vs_oracle(n_taps, n, n_ch):
+    """The 16384-point block kernel (2049 .. 8193 taps): other tap counts than 4097 (element-wise
+    tested stores), odd channel counts, lengths that are / are not whole blocks, one short block."""
+    rng = np.random.default_rng(n_taps + n)
+    x = rng.standard_normal((n, n_ch)) * 0.1
+    taps = [rng.standard_normal(n_taps) * np.exp(-np.arange(n_taps) / (n_taps / 5.0)) * 0.05 for _ in range(2)]
+    y = backend.fir_filter_bank(x, taps, backend.DS_FB_PARALLEL)
+    r = np.transpose(orc.filterbank_fir(taps, x, "Parallel"), (2, 0, 1))
+    assert relmax(y, r) < TOL, relmax(y, r)
+
+
 def test_fir_long_filters_vs_oracle():
     """> 8193 taps: overlap-save on the four-step FFT, several blocks, bank modes."""
     rng = np.random.default_rng(91)
