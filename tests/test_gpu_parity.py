@@ -726,6 +726,24 @@ def test_csm_full_size_properties():
     assert relmax(csm[:, sel][:, :, sel], ref, True) < TOL
 
 
+def test_spectral_division_8192_edge_shapes():
+    """The 8192-point shared-spectrum kernel: zero-padded input, odd channel counts, truncated
+    output (element-wise tested stores), and the per-channel-spectrum fallback."""
+    rng = np.random.default_rng(12)
+    nfft = 8192
+    r = (rng.standard_normal(nfft // 2 + 1) + 1j * rng.standard_normal(nfft // 2 + 1)) * 0.3
+    for n, n_ch, n_out in ((8192, 2, 8192), (6000, 3, 6000), (8192, 1, 5001), (100, 5, 8192)):
+        y = rng.standard_normal((4, n, n_ch))
+        ref = np.fft.irfft(np.fft.rfft(y, n=nfft, axis=1) * r[None, :, None], n=nfft, axis=1)[:, :n_out]
+        got = backend.spectral_division(y, nfft, r, n_out)
+        assert got.shape == ref.shape
+        assert relmax(got, ref) < TOL, (n, n_ch, n_out, relmax(got, ref))
+    rc = np.stack([r, 0.5 * r, r.conj()], axis=1)  # per-channel spectra: generic kernel
+    y = rng.standard_normal((2, 8192, 3))
+    ref = np.fft.irfft(np.fft.rfft(y, n=nfft, axis=1) * rc[None], n=nfft, axis=1)
+    assert relmax(backend.spectral_division(y, nfft, rc, nfft), ref) < TOL
+
+
 def test_deconvolve_full_size_properties():
     """config 5 at full size (1024 stereo items x 8192 samples, one shared sweep): every 64th
     item against the oracle, and the batch result of an item equals its own single-item call."""
