@@ -145,9 +145,10 @@ def welch_transfer_function(output_td, input_td, fs_hz: int, window_length_sampl
     return tf.astype(np.complex128), coh.astype(np.float64)
 
 
-def _stft(x, fs_hz: int, window_length_samples: int, window_type, overlap_percent: float,
-          fft_length_samples, detrend: bool, padding: bool, scaling: SpectrumScaling):
-    """-> (time_s (F,), freqs_hz (B,), stft (B', F, C))."""
+def _stft_plan(x, fs_hz: int, window_length_samples: int, window_type, overlap_percent: float,
+               fft_length_samples, padding: bool, scaling: SpectrumScaling):
+    """Argument checks and launch parameters of the STFT (shared by _stft and the fused
+    spectrogram consumers)."""
     assert window_length_samples in [2**k for k in range(4, 17)], (
         "Window length should be a power of 2 between [16, 65536] or [2**4, 2**16]")
     assert overlap_percent >= 0 and overlap_percent < 100, \
@@ -175,17 +176,66 @@ def _stft(x, fs_hz: int, window_length_samples: int, window_type, overlap_percen
         norm = scaling.fft_norm()
         scale = 1.0 if norm == "backward" else (1.0 / nfft if norm == "forward" else nfft**-0.5)
         edge, power = 1.0, 0
-    B = nfft // 2 + 1
-    out = np.empty((B, n_frames, n_ch), dtype=np.complex64)
-    w32 = window.astype(np.float32)
-    ctx = get_context()
-    ctx.check(ctx.lib.ds_stft_r2c(ctx.handle, _ptr(xp), n, n_ch, W, hop, nfft, pad_front, n_frames,
-                                  _ptr(w32), int(bool(detrend)), scale, edge, power, _ptr(out)),
-              "ds_stft_r2c")
-    stft = out.real.astype(np.float64) if power else out.astype(np.complex128)
     time_s = np.linspace(0, n_padded / fs_hz, n_frames)
     freqs_hz = np.fft.rfftfreq(W, 1 / fs_hz)
-    return time_s, freqs_hz, stft
+    return dict(xp=xp, n=n, n_ch=n_ch, W=W, hop=hop, nfft=nfft, pad_front=pad_front, n_frames=n_frames,
+                w32=window.astype(np.float32), scale=scale, edge=edge, power=power, B=nfft // 2 + 1,
+                time_s=time_s, freqs_hz=freqs_hz)
+
+
+def _stft(x, fs_hz: int, window_length_samples: int, window_type, overlap_percent: float,
+          fft_length_samples, detrend: bool, padding: bool, scaling: SpectrumScaling):
+    """-> (time_s (F,), freqs_hz (B,), stft (B', F, C))."""
+    pl = _stft_plan(x, fs_hz, window_length_samples, window_type, overlap_percent, fft_length_samples,
+                    padding, scaling)
+    out = np.empty((pl["B"], pl["n_frames"], pl["n_ch"]), dtype=np.complex64)
+    ctx = get_context()
+    ctx.check(ctx.lib.ds_stft_r2c(ctx.handle, _ptr(pl["xp"]), pl["n"], pl["n_ch"], pl["W"], pl["hop"],
+                                  pl["nfft"], pl["pad_front"], pl["n_frames"], _ptr(pl["w32"]),
+                                  int(bool(detrend)), pl["scale"], pl["edge"], pl["power"], _ptr(out)),
+              "ds_stft_r2c")
+    stft = out.real.astype(np.float64) if pl["power"] else out.astype(np.complex128)
+    return pl["time_s"], pl["freqs_hz"], stft
+
+
+def _spectrogram_band_power(x, fs_hz: int, window_length_samples: int, window_type, overlap_percent: float,
+                            fft_length_samples, detrend: bool, padding: bool, scaling: SpectrumScaling,
+                            band_filters, to_db: bool, dct_abs: bool):
+    """STFT -> sum_b filters[band, b] |stft[b]|^2 (-> dB -> |DCT-II| over bands), everything on the
+    device: the spectrogram never travels to the host.  band_filters (bands, B').
+    -> (time_s, freqs_hz, out (bands, F, C) float64)."""
+    pl = _stft_plan(x, fs_hz, window_length_samples, window_type, overlap_percent, fft_length_samples,
+                    padding, scaling)
+    filt = np.ascontiguousarray(band_filters, dtype=np.float32)
+    assert filt.ndim == 2 and filt.shape[1] == pl["B"], (
+        f"Shape of the mel filter matrix {filt.shape} does not match the STFT "
+        f"{(pl['B'], pl['n_frames'], pl['n_ch'])}")
+    n_bands = filt.shape[0]
+    nz = filt != 0
+    b0 = np.where(nz.any(axis=1), nz.argmax(axis=1), 0).astype(np.int32)
+    b1 = np.where(nz.any(axis=1), filt.shape[1] - nz[:, ::-1].argmax(axis=1), 0).astype(np.int32)
+    ctx = get_context()
+    n_fc = pl["n_frames"] * pl["n_ch"]
+    d_x = DeviceBuffer.from_array(ctx, pl["xp"])
+    d_w = DeviceBuffer.from_array(ctx, pl["w32"])
+    d_s = DeviceBuffer(ctx, pl["B"] * n_fc * 8)
+    d_f = DeviceBuffer.from_array(ctx, filt)
+    d_b0, d_b1 = DeviceBuffer.from_array(ctx, b0), DeviceBuffer.from_array(ctx, b1)
+    d_o = DeviceBuffer(ctx, n_bands * n_fc * 4)
+    try:
+        ctx.check(ctx.lib.ds_stft_r2c_dev(ctx.handle, C.c_void_p(d_x.ptr), pl["n"], pl["n_ch"], pl["n"], pl["W"],
+                                          pl["hop"], pl["nfft"], pl["pad_front"], pl["n_frames"],
+                                          C.c_void_p(d_w.ptr), int(bool(detrend)), pl["scale"], pl["edge"],
+                                          pl["power"], C.c_void_p(d_s.ptr)), "ds_stft_r2c_dev")
+        ctx.check(ctx.lib.ds_band_power_dev(ctx.handle, C.c_void_p(d_s.ptr), pl["B"], n_fc, C.c_void_p(d_f.ptr),
+                                            C.c_void_p(d_b0.ptr), C.c_void_p(d_b1.ptr), n_bands,
+                                            int(bool(to_db)), int(bool(dct_abs)), C.c_void_p(d_o.ptr)),
+                  "ds_band_power_dev")
+        out = d_o.to_array((n_bands, pl["n_frames"], pl["n_ch"]), np.float32)
+    finally:
+        for d in (d_x, d_w, d_s, d_f, d_b0, d_b1, d_o):
+            d.free()
+    return pl["time_s"], pl["freqs_hz"], out.astype(np.float64)
 
 
 def _das_map(csm, h):

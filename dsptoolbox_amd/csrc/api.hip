@@ -397,6 +397,52 @@ extern "C" int ds_istft_dev(ds_ctx* c, const ds_c32* stft, int n_bins, int n_fra
     return DS_OK;
 }
 
+// ---- band powers of a spectrogram (mel spectrogram / MFCC) ----------------------------------
+extern "C" int ds_band_power_dev(ds_ctx* c, const ds_c32* stft, int n_bins, int64_t n_fc, const float* weights,
+                                 const int* band_start, const int* band_stop, int n_bands, int to_db,
+                                 int dct_abs, float* out) {
+    if (!c || !stft || !weights || !band_start || !band_stop || !out)
+        return fail(c, DS_ERR_ARG, "ds_band_power: null argument");
+    if (n_bins <= 0 || n_fc <= 0 || n_bands <= 0 || n_bands > 65535)
+        return fail(c, DS_ERR_ARG, "ds_band_power: bad shape");
+    float* dst = out;
+    if (dct_abs) {
+        CHK(reserve(c, &c->ws, &c->ws_bytes, sizeof(float) * (size_t)n_bands * n_fc));
+        dst = (float*)c->ws;
+    }
+    BandPowerArgs a{(const float2*)stft, weights, band_start, band_stop, n_bins, n_bands, n_fc, to_db, dst};
+    const unsigned gx = (unsigned)((n_fc + 255) / 256);
+    CHK(launch(c, "band_power", k_band_power, dim3(gx, n_bands), 256, 0, a));
+    if (dct_abs) {
+        DctArgs d{dst, n_bands, n_fc, out};
+        CHK(launch(c, "dct2_abs", k_dct2_abs, dim3(gx, n_bands), 256, 0, d));
+    }
+    return DS_OK;
+}
+
+extern "C" int ds_band_power(ds_ctx* c, const ds_c32* stft, int n_bins, int64_t n_fc, const float* weights,
+                             const int* band_start, const int* band_stop, int n_bands, int to_db, int dct_abs,
+                             float* out) {
+    if (!c || !stft || !weights || !band_start || !band_stop || !out)
+        return fail(c, DS_ERR_ARG, "ds_band_power: null argument");
+    if (n_bins <= 0 || n_fc <= 0 || n_bands <= 0) return fail(c, DS_ERR_ARG, "ds_band_power: bad shape");
+    const size_t ns = (size_t)n_bins * n_fc, nw = (size_t)n_bands * n_bins, no = (size_t)n_bands * n_fc;
+    CHK(reserve(c, &c->io, &c->io_bytes,
+                Carver::pad(ns * 8) + Carver::pad(nw * 4) + 2 * Carver::pad((size_t)n_bands * 4) + Carver::pad(no * 4) + 4096));
+    Carver cv(c->io);
+    float2* dx = cv.take<float2>(ns);
+    float* dw = cv.take<float>(nw);
+    int* d0 = cv.take<int>(n_bands);
+    int* d1 = cv.take<int>(n_bands);
+    float* dout = cv.take<float>(no);
+    CHK(ds_upload(c, dx, stft, ns * 8));
+    CHK(ds_upload(c, dw, weights, nw * 4));
+    CHK(ds_upload(c, d0, band_start, (size_t)n_bands * 4));
+    CHK(ds_upload(c, d1, band_stop, (size_t)n_bands * 4));
+    CHK(ds_band_power_dev(c, (const ds_c32*)dx, n_bins, n_fc, dw, d0, d1, n_bands, to_db, dct_abs, dout));
+    return ds_download(c, out, dout, no * 4);
+}
+
 // ---- Welch -----------------------------------------------------------------
 struct WelchPlan {
     int n_chunks, fpc;

@@ -552,6 +552,61 @@ __global__ void k_istft_ola(IstftOlaArgs p) {
     p.out[(int64_t)c * p.ld + n] = (float)(acc / env);
 }
 
+// ---------------------------------------------------------------- band powers of a spectrogram
+// (reference: np.tensordot(mel_filters, np.abs(stft)**2, axes=(-1, 0)) followed by to_db(., False),
+// transforms/transforms.py:181-184 and :421-424).  grid = (ceil(F*C / 256), n_bands).
+//   out[(band*F + f)*C + c] = sum_b w[band][b] |X[b][f][c]|^2  over b in [b0[band], b1[band])
+// (the filters are banded: only their non-zero bin range is read), optionally
+// 10 log10(max(., DBL_MIN)).  fp64 accumulation.
+struct BandPowerArgs {
+    const float2* X;  // [n_bins][F][C]
+    const float* w;   // [n_bands][n_bins]
+    const int* b0;
+    const int* b1;
+    int n_bins, n_bands;
+    int64_t n_fc;  // F * C
+    int to_db;
+    float* out;
+};
+__global__ void k_band_power(BandPowerArgs p) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int band = blockIdx.y;
+    if (i >= p.n_fc) return;
+    const float* w = p.w + (int64_t)band * p.n_bins;
+    double acc = 0.0;
+    for (int b = p.b0[band]; b < p.b1[band]; ++b) {
+        const float2 x = p.X[(int64_t)b * p.n_fc + i];
+        acc += (double)w[b] * ((double)x.x * (double)x.x + (double)x.y * (double)x.y);
+    }
+    if (p.to_db) {
+        const double a = fabs(acc);
+        acc = 10.0 * log10(a < 2.2250738585072014e-308 ? 2.2250738585072014e-308 : a);
+    }
+    p.out[(int64_t)band * p.n_fc + i] = (float)acc;
+}
+
+// |DCT-II| along the band axis (scipy.fft.dct(type=2, axis=0), unnormalised), NaN -> 0:
+//   out[k][i] = | 2 sum_n x[n][i] cos(pi k (2n + 1) / (2 N)) |      (mfcc, transforms.py:426-429)
+struct DctArgs {
+    const float* x;  // [N][n_fc]
+    int n;
+    int64_t n_fc;
+    float* out;
+};
+__global__ void k_dct2_abs(DctArgs p) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int k = blockIdx.y;
+    if (i >= p.n_fc) return;
+    double acc = 0.0;
+    for (int n = 0; n < p.n; ++n) {
+        double s, c;
+        sincospi((double)k * (double)(2 * n + 1) / (double)(2 * p.n), &s, &c);
+        acc += (double)p.x[(int64_t)n * p.n_fc + i] * c;
+    }
+    acc = fabs(2.0 * acc);
+    p.out[(int64_t)k * p.n_fc + i] = (acc != acc) ? 0.f : (float)acc;
+}
+
 // ---------------------------------------------------------------- FIR block convolution
 // tap spectra: grid.x = ceil(n_filt/2); hs[k*N + m] = fft(taps_k zero padded)[m] / N
 struct FirTapsArgs {

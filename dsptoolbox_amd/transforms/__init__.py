@@ -1,5 +1,5 @@
-"""transforms: the inverse STFT of dsptoolbox/transforms/transforms.py:444-586 on the device
-(SURVEY.md section 8(f), row 1).  Same signature, parameter handling and quirks as the reference;
+"""transforms: the inverse STFT (dsptoolbox/transforms/transforms.py:444-586, SURVEY.md section 8(f)
+row 1) and the STFT consumers log_mel_spectrogram / mfcc (:113-203, :335-441, row 4) on the device.  Same signature, parameter handling and quirks as the reference;
 the frame-wise inverse FFTs and the windowed overlap-add with the squared-window envelope
 (standard/_framed_signal_representation.py:70-137) run in the HIP library (ds_istft)."""
 
@@ -11,7 +11,7 @@ from scipy.signal import get_window
 from .. import backend
 from ..classes.signal import Signal
 
-__all__ = ["istft"]
+__all__ = ["istft", "mel_filterbank", "log_mel_spectrogram", "mfcc"]
 
 
 def _pad_trim(td: np.ndarray, desired_length: int) -> np.ndarray:
@@ -67,3 +67,93 @@ def istft(stft, original_signal: Signal | None = None, parameters: dict | None =
         td = _pad_trim(td, original_signal.time_data.shape[0])
         return original_signal.copy_with_new_time_data(td)
     return Signal(None, time_data=td, sampling_rate_hz=sampling_rate_hz)
+
+
+def _hz2mel(f):
+    """helpers/frequency_conversion.py:7-25"""
+    return 2595 * np.log10(1 + f / 700)
+
+
+def _mel2hz(mel):
+    """helpers/frequency_conversion.py:28-46"""
+    return 700 * (10 ** (mel / 2595) - 1)
+
+
+def mel_filterbank(f_hz, range_hz=None, n_bands: int = 40, normalize: bool = True):
+    """Equidistant mel triangle filters (bands, frequency) and their centre frequencies in mel
+    (transforms/transforms.py:206-277).  Host-side parameter preparation."""
+    f_hz = np.squeeze(f_hz)
+    assert f_hz.ndim == 1, "f_hz should be a 1D-array"
+    n_bands = int(n_bands)
+    if range_hz is None:
+        range_hz = f_hz[[0, -1]]
+    else:
+        range_hz = np.atleast_1d(np.asarray(range_hz).squeeze())
+        assert len(range_hz) == 2, "range_hz should be an array with exactly two values!"
+        range_hz = np.sort(range_hz)
+        assert range_hz[-1] <= f_hz[-1], (
+            f"Upper frequency in range {range_hz[-1]} is bigger than nyquist frequency {f_hz[-1]}")
+        assert range_hz[0] >= 0, "Lower frequency in range must be positive"
+    range_mel = _hz2mel(range_hz)
+    mel_center_freqs = np.linspace(range_mel[0], range_mel[1], n_bands + 2, endpoint=True)
+    bands_hz = _mel2hz(mel_center_freqs)
+    inds = np.array([np.argmin(np.abs(b - f_hz)) for b in bands_hz], dtype=int)
+    mel_filters = np.zeros((n_bands, len(f_hz)))
+    for n in range(n_bands):
+        ni = n + 1
+        mel_filters[n, inds[ni - 1]:inds[ni]] = np.linspace(0, 1, inds[ni] - inds[ni - 1], endpoint=False)
+        mel_filters[n, inds[ni]:inds[ni + 1]] = np.linspace(1, 0, inds[ni + 1] - inds[ni], endpoint=False)
+        if normalize:
+            mel_filters[n, :] /= np.sum(mel_filters[n, :])
+    return mel_filters, mel_center_freqs[1:-1]
+
+
+def _band_power(signal: Signal, filters, f_hz_check, to_db: bool, dct_abs: bool):
+    par = signal._spectrogram_parameters
+    return backend._spectrogram_band_power(
+        signal.time_data, signal.sampling_rate_hz, par["window_length_samples"], par["window_type"],
+        par["overlap_percent"], par["fft_length_samples"], par["detrend"], par["padding"], par["scaling"],
+        filters, to_db, dct_abs)
+
+
+def _spectrogram_axes(signal: Signal):
+    par = signal._spectrogram_parameters
+    pl = backend._stft_plan(signal.time_data, signal.sampling_rate_hz, par["window_length_samples"],
+                            par["window_type"], par["overlap_percent"], par["fft_length_samples"],
+                            par["padding"], par["scaling"])
+    return pl["time_s"], pl["freqs_hz"], pl["B"]
+
+
+def log_mel_spectrogram(s: Signal, channel: int = 0, range_hz=None, n_bands: int = 40,
+                        generate_plot: bool = True, stft_parameters: dict | None = None):
+    """-> (time_s, f_mel, log_mel_sp (bands, time frame, channel)); STFT, |.|^2, the mel filter
+    contraction and the dB conversion run on the device."""
+    if generate_plot:
+        raise NotImplementedError("plotting is outside the GPU hot path: pass generate_plot=False")
+    if stft_parameters is not None:
+        s.set_spectrogram_parameters(**stft_parameters)
+    time_s, f_hz, n_bins = _spectrogram_axes(s)
+    mfilt, f_mel = mel_filterbank(f_hz, range_hz, n_bands, normalize=True)
+    assert mfilt.shape[1] == n_bins, \
+        "the frequency vector (window length) and the STFT (fft length) have different bin counts"
+    _, _, log_mel_sp = _band_power(s, mfilt, f_hz, True, False)
+    return time_s, f_mel, log_mel_sp
+
+
+def mfcc(signal: Signal, channel: int = 0, mel_filters=None, generate_plot: bool = True,
+         stft_parameters: dict | None = None):
+    """-> (time_s, f_mel, mfcc (cepstral coefficients, time frame, channel))."""
+    if generate_plot:
+        raise NotImplementedError("plotting is outside the GPU hot path: pass generate_plot=False")
+    if stft_parameters is not None:
+        signal.set_spectrogram_parameters(**stft_parameters)
+    time_s, f, n_bins = _spectrogram_axes(signal)
+    if mel_filters is None:
+        mel_filters, f_mel = mel_filterbank(f, None, n_bands=40)
+    else:
+        mel_filters = np.asarray(mel_filters)
+        f_mel = np.array([0, mel_filters.shape[0]])
+    assert mel_filters.shape[1] == n_bins, (
+        f"Shape of the mel filter matrix {mel_filters.shape} does not match the STFT")
+    _, _, out = _band_power(signal, mel_filters, f, True, True)
+    return time_s, f_mel, out

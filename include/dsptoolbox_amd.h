@@ -136,6 +136,20 @@ int ds_welch_csd(ds_ctx* ctx, const float* x, const float* y, int n_ch,
                  int detrend, int average, int amp_sqrt, double norm_scale, double factor,
                  int halve_edges, ds_c32* csd);
 
+/* ---- band powers of a spectrogram: replaces np.tensordot(mel_filters, |stft|^2) + to_db in
+ * log_mel_spectrogram / mfcc, transforms/transforms.py:181-184, 421-429.
+ * stft[b][fc] (n_bins x n_fc, n_fc = frames * channels, the layout ds_stft_r2c writes),
+ * weights[band][b]; only bins band_start[band] <= b < band_stop[band] are read (the
+ * filters are banded).  out[band][fc] = sum_b w |X|^2, then 10 log10(max(., DBL_MIN)) if
+ * to_db, then |DCT-II along the band axis| with NaN -> 0 if dct_abs (MFCC).          */
+int ds_band_power_dev(ds_ctx* ctx, const ds_c32* stft_dev, int n_bins, int64_t n_fc,
+                      const float* weights_dev, const int* band_start_dev,
+                      const int* band_stop_dev, int n_bands, int to_db, int dct_abs,
+                      float* out_dev);
+int ds_band_power(ds_ctx* ctx, const ds_c32* stft, int n_bins, int64_t n_fc, const float* weights,
+                  const int* band_start, const int* band_stop, int n_bands, int to_db,
+                  int dct_abs, float* out);
+
 /* ---- delay-and-sum beamformer map on the CSM: replaces the grid x bin loop of
  * BeamformerDASFrequency.get_beamformer_map, beamforming/beamforming.py:853-858:
  * map[g][f] = Re( h_f[:, g]^H  CSM_f  h_f[:, g] ); csm[f][i][j] (n_bins x n_ch x n_ch, the

@@ -603,6 +603,50 @@ def filterbank_fir(taps_list, td, mode: str):
     raise ValueError("Invalid filter bank apply mode")
 
 
+def mel_filterbank(f_hz, range_hz=None, n_bands=40, normalize=True):
+    """transforms/transforms.py:206-277"""
+    f_hz = np.squeeze(f_hz)
+    if range_hz is None:
+        range_hz = f_hz[[0, -1]]
+    range_hz = np.sort(np.atleast_1d(np.asarray(range_hz, dtype=np.float64).squeeze()))
+    range_mel = 2595 * np.log10(1 + range_hz / 700)
+    centers = np.linspace(range_mel[0], range_mel[1], n_bands + 2, endpoint=True)
+    bands_hz = 700 * (10 ** (centers / 2595) - 1)
+    inds = np.array([np.argmin(np.abs(b - f_hz)) for b in bands_hz], dtype=int)
+    m = np.zeros((n_bands, len(f_hz)))
+    for n in range(n_bands):
+        ni = n + 1
+        m[n, inds[ni - 1]:inds[ni]] = np.linspace(0, 1, inds[ni] - inds[ni - 1], endpoint=False)
+        m[n, inds[ni]:inds[ni + 1]] = np.linspace(1, 0, inds[ni + 1] - inds[ni], endpoint=False)
+        if normalize:
+            m[n, :] /= np.sum(m[n, :])
+    return m, centers[1:-1]
+
+
+def to_db_power(x):
+    """helpers/gain_and_level.py:158-200 with amplitude_input=False and the default floor."""
+    return 10.0 * np.log10(np.clip(np.abs(x), a_min=np.finfo(np.float64).smallest_normal, a_max=None))
+
+
+def log_mel_spectrogram(stft_data, f_hz, range_hz=None, n_bands=40):
+    """transforms/transforms.py:177-184 on a given spectrogram (B, F, C)."""
+    mfilt, f_mel = mel_filterbank(f_hz, range_hz, n_bands, normalize=True)
+    return f_mel, to_db_power(np.tensordot(mfilt, np.abs(stft_data) ** 2.0, axes=(-1, 0)))
+
+
+def mfcc(stft_data, f_hz, mel_filters=None):
+    """transforms/transforms.py:413-429"""
+    from scipy.fft import dct
+    if mel_filters is None:
+        mel_filters, f_mel = mel_filterbank(f_hz, None, n_bands=40)
+    else:
+        f_mel = np.array([0, mel_filters.shape[0]])
+    sp = np.tensordot(mel_filters, np.abs(stft_data) ** 2.0, axes=(-1, 0))
+    out = np.abs(dct(to_db_power(sp), type=2, axis=0))
+    np.nan_to_num(out, copy=False, nan=0)
+    return f_mel, out
+
+
 def das_map(f, csm, h, remove_csm_diagonal=True):
     """beamforming/beamforming.py:838-876: Re(h^H CSM h) per grid point and bin, optional
     diagonal removal (energy-compensated), clipping of negative values, Simpson integration."""

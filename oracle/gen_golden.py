@@ -206,8 +206,40 @@ def gen_das(dsp):
     save("das", dict(cases=cases, fs=fs, n_mics=n_mics), arrs)
 
 
+def gen_mel(dsp):
+    """transforms.log_mel_spectrogram / mfcc / mel_filterbank (transforms/transforms.py:113-441),
+    generate_plot=False."""
+    from dsptoolbox.standard.enums import SpectrumScaling
+    fs = 16000
+    rng = np.random.default_rng(33)
+    n = 12000
+    t = np.arange(n) / fs
+    x = np.stack([0.3 * rng.standard_normal(n) + 0.5 * np.sin(2 * np.pi * 440 * t),
+                  0.1 * rng.standard_normal(n) * (1 + np.sin(2 * np.pi * 3 * t))], axis=1)
+    cases, arrs = [], {"x": x}
+    for i, (W, nfft, sc, rng_hz, nb) in enumerate(((512, None, "FFTBackward", None, 40),
+                                                   (256, None, "AmplitudeSpectrum", [100.0, 6000.0], 24),
+                                                   (512, None, "PowerSpectralDensity", None, 32))):
+        s = dsp.Signal(None, x.copy(), fs)
+        s.set_spectrogram_parameters(window_length_samples=W, fft_length_samples=nfft,
+                                     scaling=SpectrumScaling[sc])
+        t_, f_mel, lm = dsp.transforms.log_mel_spectrogram(s, range_hz=rng_hz, n_bands=nb, generate_plot=False)
+        arrs[f"t_{i}"], arrs[f"fmel_{i}"], arrs[f"logmel_{i}"] = t_, f_mel, lm
+        t2, f_mel2, mf = dsp.transforms.mfcc(s, generate_plot=False)
+        arrs[f"fmel2_{i}"], arrs[f"mfcc_{i}"] = f_mel2, mf
+        _, f_hz, _ = s.get_spectrogram()
+        mfilt, _ = dsp.transforms.mel_filterbank(f_hz, rng_hz, nb, normalize=True)
+        arrs[f"mfilt_{i}"] = mfilt
+        cases.append(dict(W=W, nfft=nfft, scaling=sc, range_hz=rng_hz, n_bands=nb))
+    save("mel", dict(cases=cases, fs=fs), arrs)
+
+
 def main():
     dsp = import_reference()
+    if "--only-mel" in sys.argv:
+        import warnings
+        warnings.simplefilter("ignore")
+        return gen_mel(dsp)
     if "--only-das" in sys.argv:
         import warnings
         warnings.simplefilter("ignore")
@@ -496,6 +528,7 @@ def main():
     gen_istft(dsp)
     gen_rir(dsp)
     gen_das(dsp)
+    gen_mel(dsp)
 
 
 if __name__ == "__main__":

@@ -441,6 +441,46 @@ def test_das_map_golden_and_large():
     assert relmax(q, np.einsum("fcg,fcd,fdg->gf", h.conj(), csm, h).real) < TOL
 
 
+def test_mel_spectrogram_and_mfcc_golden():
+    """log_mel_spectrogram / mfcc (STFT, |.|^2, mel contraction, dB, DCT on the device) against
+    the reference's outputs.  The values are decibels: the comparison is relative to the largest
+    magnitude (some tens of dB), i.e. an absolute error of ~1e-5 dB."""
+    from dsptoolbox_amd.standard.enums import SpectrumScaling as S
+    meta, z = load_golden("mel")
+    fs = meta["fs"]
+    for i, c in enumerate(meta["cases"]):
+        s = dsp.Signal(None, z["x"].copy(), fs)
+        s.set_spectrogram_parameters(window_length_samples=c["W"], fft_length_samples=c["nfft"],
+                                     scaling=S[c["scaling"]])
+        t, f_mel, lm = dsp.transforms.log_mel_spectrogram(s, range_hz=c["range_hz"], n_bands=c["n_bands"],
+                                                          generate_plot=False)
+        assert np.allclose(t, z[f"t_{i}"]) and np.allclose(f_mel, z[f"fmel_{i}"])
+        ref = z[f"logmel_{i}"]
+        assert lm.shape == ref.shape
+        # Digital silence (the all-zero frame the padding appends) is exactly 0 in the reference and
+        # hits its -3076.5 dB floor; on the device that frame shares a complex transform with its
+        # neighbour and keeps ~1e-9 of the neighbour's amplitude (fp32), i.e. about -180 dB.
+        floor = ref < -1000.0
+        assert np.all(lm[floor] < -150.0)
+        assert relmax(lm[~floor], ref[~floor]) < TOL, (c, relmax(lm[~floor], ref[~floor]))
+        t2, f_mel2, mf = dsp.transforms.mfcc(s, generate_plot=False)
+        refm = z[f"mfcc_{i}"]
+        assert np.allclose(f_mel2, z[f"fmel2_{i}"]) and mf.shape == refm.shape
+        ok = ~np.any(z[f"logmel_{i}"] < -1000.0, axis=0) if ref.shape[0] == refm.shape[0] else \
+            np.abs(refm).max(axis=0) < 1e4  # frames that contain a floor value have huge coefficients
+        ok = np.broadcast_to(ok[None], refm.shape)
+        if np.max(np.abs(refm[ok])) == 0.0:
+            # 40 default bands over 129 bins: empty triangles -> NaN filters -> the reference's
+            # nan_to_num turns every coefficient into 0; the device does the same
+            assert np.array_equal(mf[ok], refm[ok])
+        else:
+            assert relmax(mf[ok], refm[ok]) < TOL, (c, relmax(mf[ok], refm[ok]))
+        mfilt, _ = dsp.transforms.mel_filterbank(np.fft.rfftfreq(c["W"], 1 / fs), c["range_hz"], c["n_bands"])
+        assert np.array_equal(mfilt, z[f"mfilt_{i}"])
+    with pytest.raises(NotImplementedError):
+        dsp.transforms.log_mel_spectrogram(dsp.Signal(None, z["x"].copy(), fs))
+
+
 def test_fir_design_matches_lfilter():
     """reference tests/test_classes.py:495-512: FIR filter_signal == scipy.signal.lfilter."""
     import scipy.signal as sig

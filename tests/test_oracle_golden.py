@@ -201,6 +201,21 @@ def test_das_map():
         close(m.reshape(c["grid_shape"]), z[f"map_{i}"], tol=1e-12)
 
 
+def test_mel_spectrogram_and_mfcc():
+    meta, z = load_golden("mel")
+    x = z["x"]
+    for i, c in enumerate(meta["cases"]):
+        t, f_hz, sp = orc.stft(x, meta["fs"], c["W"], "hann", 50.0, c["nfft"], False, True, c["scaling"])
+        mfilt, _ = orc.mel_filterbank(f_hz, c["range_hz"], c["n_bands"], True)
+        close(mfilt, z[f"mfilt_{i}"], tol=1e-13)
+        f_mel, lm = orc.log_mel_spectrogram(sp, f_hz, c["range_hz"], c["n_bands"])
+        close(f_mel, z[f"fmel_{i}"], tol=1e-13)
+        close(lm, z[f"logmel_{i}"], tol=1e-11)
+        f_mel2, mf = orc.mfcc(sp, f_hz)
+        close(f_mel2, z[f"fmel2_{i}"], tol=1e-13)
+        close(mf, z[f"mfcc_{i}"], tol=1e-11)
+
+
 def test_chirp_pair_config1():
     """BASELINE.json configs[0]: the reference's own example chirps (16-bit PCM fixtures)."""
     meta, z = load_golden("chirp_pair")
