@@ -99,6 +99,43 @@ def welch_transfer_function_sharded(output_td, input_td, fs_hz: int, window_leng
     return gather_channel_shards(tf, n_cy, 1), gather_channel_shards(coh, n_cy, 1)
 
 
+def fir_filter_bank_sharded(x, taps_list, mode: int, compute=None, gather: bool = True):
+    """FIR filter bank with the independent units sharded across ranks (SURVEY section 8(e),
+    config 3): Parallel -> the bands, Sequential / Summed -> the channels.  `compute(x, taps, mode)`
+    defaults to the HIP path (backend.fir_filter_bank: Parallel -> (K, N, C), else (N, C)); the
+    input / taps are expected on every rank (broadcast them first if only rank 0 holds them)."""
+    from . import backend
+    if compute is None:
+        compute = backend.fir_filter_bank
+    rank, ws = world()
+    x = np.asarray(x)
+    n, n_ch = x.shape
+    if mode == backend.DS_FB_PARALLEL:
+        a, b = shard_range(len(taps_list), ws, rank)
+        local = compute(x, taps_list[a:b], mode) if b > a else np.zeros((0, n, n_ch))
+        return gather_channel_shards(local, len(taps_list), axis=0) if gather else local
+    a, b = shard_range(n_ch, ws, rank)
+    local = compute(x[:, a:b], taps_list, mode) if b > a else np.zeros((n, 0))
+    return gather_channel_shards(local, n_ch, axis=1) if gather else local
+
+
+def spectral_division_sharded(num_td, n_fft: int, inverse_spectrum, n_out: int, compute=None,
+                              gather: bool = True):
+    """Batched spectral division (M, N, C) with the items sharded across ranks (config 5); the
+    inverse spectrum (32 KB) is expected on every rank."""
+    if compute is None:
+        from . import backend
+        compute = backend.spectral_division
+    rank, ws = world()
+    num_td = np.asarray(num_td)
+    assert num_td.ndim == 3, "a batch of items (M, N, C) is sharded; single items are not"
+    m = num_td.shape[0]
+    a, b = shard_range(m, ws, rank)
+    local = compute(num_td[a:b], n_fft, inverse_spectrum, n_out) if b > a else \
+        np.zeros((0, n_out, num_td.shape[2]))
+    return gather_channel_shards(local, m, axis=0) if gather else local
+
+
 def init_library_comm(ctx, exchange=None) -> bool:
     """Create the library's RCCL communicator (ds_comm_*): rank 0 makes the 128-byte id,
     `exchange(bytes) -> bytes` hands it to every rank (default: torch.distributed

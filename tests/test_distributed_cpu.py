@@ -54,6 +54,29 @@ def _worker(rank, world, port, q):
         # more ranks than units: empty shards
         tf3, _ = dd.welch_transfer_function_sharded(y[:, :1], xb, 48000, 256, "H1", compute=compute)
         ok = ok and tf3.shape == (129, 1)
+        # FIR bank: bands sharded (Parallel), channels sharded (Summed); batched deconvolution:
+        # items sharded -- the oracle stands in for the device call
+        from dsptoolbox_amd import backend
+        taps = [rng.standard_normal(31) for _ in range(5)]
+        xs = rng.standard_normal((2000, 3))
+
+        def fir(xx, tt, mode):
+            name = {backend.DS_FB_PARALLEL: "Parallel", backend.DS_FB_SUMMED: "Summed"}[mode]
+            r = orc.filterbank_fir(list(tt), xx, name)
+            return np.transpose(r, (2, 0, 1)) if name == "Parallel" else r
+
+        yp = dd.fir_filter_bank_sharded(xs, taps, backend.DS_FB_PARALLEL, compute=fir)
+        ok = ok and np.array_equal(yp, fir(xs, taps, backend.DS_FB_PARALLEL)) and yp.shape == (5, 2000, 3)
+        ysum = dd.fir_filter_bank_sharded(xs, taps, backend.DS_FB_SUMMED, compute=fir)
+        ok = ok and np.array_equal(ysum, fir(xs, taps, backend.DS_FB_SUMMED))
+        items = rng.standard_normal((7, 256, 2))
+        rinv = rng.standard_normal(129) + 1j * rng.standard_normal(129)
+
+        def div(it, nfft, r, n_out):
+            return np.fft.irfft(np.fft.rfft(it, n=nfft, axis=1) * r[None, :, None], n=nfft, axis=1)[:, :n_out]
+
+        d = dd.spectral_division_sharded(items, 256, rinv, 200, compute=div)
+        ok = ok and np.array_equal(d, div(items, 256, rinv, 200)) and d.shape == (7, 200, 2)
         q.put((rank, bool(ok), dd.shard_range(n_cy, world, rank)))
     finally:
         dist.destroy_process_group()
