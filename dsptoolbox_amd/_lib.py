@@ -63,6 +63,8 @@ SIGNATURES = {
                            C.c_int, f32_p, C.c_float, i64, f32_p]),
     "ds_csm_dev": (C.c_int, [ctx_p, f32_p, C.c_int, i64, i64, C.c_int, C.c_int, C.c_int, f32_p,
                              C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, c32_p]),
+    "ds_csm_bins_dev": (C.c_int, [ctx_p, f32_p, C.c_int, i64, i64, C.c_int, C.c_int, C.c_int, f32_p,
+                                  C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, C.c_int, C.c_int, c32_p]),
     "ds_csm": (C.c_int, [ctx_p, f32_p, C.c_int, i64, C.c_int, C.c_int, C.c_int, f32_p, C.c_int,
                          C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, c32_p]),
     "ds_csm_spec_dev": (C.c_int, [ctx_p, c32_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double,

@@ -296,6 +296,36 @@ def _csm_welch(time_data, sampling_rate_hz: int, window_length_samples: int, win
     return np.fft.rfftfreq(W, 1 / sampling_rate_hz), out.astype(np.complex128)
 
 
+def _csm_welch_bins(time_data, sampling_rate_hz: int, window_length_samples: int, window_type,
+                    overlap_percent, detrend: bool, scaling: SpectrumScaling, bin_start: int,
+                    bin_stop: int):
+    """Rows [bin_start, bin_stop) of the Welch CSM (mean averaging): one rank's share when the
+    matrix is split by frequency bins.  -> (bin_stop - bin_start, C, C) complex128."""
+    _welch_checks(window_length_samples, overlap_percent, "mean")
+    W = int(window_length_samples)
+    window = _window_array(window_type, W)
+    xp = _planar_f32(time_data)
+    n_ch, n = xp.shape
+    hop, n_frames = _welch_framing(n, W, overlap_percent, window)
+    amp, norm_scale, factor, phys = _finish_params(scaling, W, sampling_rate_hz, window)
+    count = int(bin_stop) - int(bin_start)
+    if count <= 0:
+        return np.zeros((0, n_ch, n_ch), dtype=np.complex128)
+    ctx = get_context()
+    d_x = DeviceBuffer.from_array(ctx, xp)
+    d_w = DeviceBuffer.from_array(ctx, window.astype(np.float32))
+    d_c = DeviceBuffer(ctx, count * n_ch * n_ch * 8)
+    try:
+        ctx.check(ctx.lib.ds_csm_bins_dev(ctx.handle, C.c_void_p(d_x.ptr), n_ch, n, n, W, hop, n_frames,
+                                          C.c_void_p(d_w.ptr), int(bool(detrend)), amp, norm_scale, factor,
+                                          phys, int(bin_start), count, C.c_void_p(d_c.ptr)), "ds_csm_bins_dev")
+        out = d_c.to_array((count, n_ch, n_ch), np.complex64)
+    finally:
+        for d in (d_x, d_w, d_c):
+            d.free()
+    return out.astype(np.complex128)
+
+
 def _csm_fft(spectrum, scaling: SpectrumScaling, window, sampling_rate_hz: int):
     """Cross-spectral matrix of ONE whole-signal spectrum (B, C) (FFTBackward-normalised),
     dsptoolbox/standard/_spectral_methods.py:374-443.  -> (B, C, C) complex128."""

@@ -632,9 +632,10 @@ static int welch_csd_dev(ds_ctx* c, const float* x, const float* y, int n_ch, in
 }
 
 // ---- CSM -------------------------------------------------------------------
-extern "C" int ds_csm_dev(ds_ctx* c, const float* x, int n_ch, int64_t ld, int64_t n_samples, int W,
-                          int hop, int n_frames, const float* window, int detrend, int average,
-                          int amp_sqrt, double norm_scale, double factor, int halve_edges, ds_c32* csm) {
+static int csm_dev(ds_ctx* c, const float* x, int n_ch, int64_t ld, int64_t n_samples, int W, int hop,
+                   int n_frames, const float* window, int detrend, int average, int amp_sqrt,
+                   double norm_scale, double factor, int halve_edges, int bin_start, int bin_count,
+                   ds_c32* csm) {
     if (!c || !x || !window || !csm) return fail(c, DS_ERR_ARG, "ds_csm: null argument");
     if (n_ch < 1 || n_samples <= 0 || hop <= 0 || hop > W || n_frames <= 0 || ld < n_samples)
         return fail(c, DS_ERR_ARG, "ds_csm: bad shape");
@@ -643,6 +644,11 @@ extern "C" int ds_csm_dev(ds_ctx* c, const float* x, int n_ch, int64_t ld, int64
     const bool big = W > kMaxFft && is_pow2(W);
     if (!big) CHK(check_fft_len(c, W, "ds_csm window length"));
     const int nb = W / 2 + 1;
+    const bool all_bins = bin_start == 0 && bin_count == nb;
+    if (bin_start < 0 || bin_count <= 0 || bin_start + bin_count > nb)
+        return fail(c, DS_ERR_ARG, "ds_csm: bad bin range");
+    if (average == DS_AVG_MEDIAN && !all_bins)
+        return fail(c, DS_ERR_UNSUP, "ds_csm: a bin range with median averaging is not built yet");
     if (average == DS_AVG_MEDIAN) {
         // spectra of every frame [c][F][nb] -> per-pair, per-bin medians
         const size_t lds = ((size_t)8 * 2 * n_frames + 32) * sizeof(float);
@@ -684,16 +690,33 @@ extern "C" int ds_csm_dev(ds_ctx* c, const float* x, int n_ch, int64_t ld, int64
     const int nt = (n_ch + 31) / 32;
     CsmArgs a{X, n_ch, n_frames,
               FinishPar{norm_scale / (double)n_frames, factor, halve_edges, amp_sqrt, nb},
-              (float2*)csm};
+              (float2*)csm, bin_start};
     // up to 64 channels: one workgroup per bin shares the operand loads between the three tile
     // pairs (the spectra of an even-length real transform are purely real at both edge bins,
     // which the kernel relies on)
     static const bool no64 = getenv("DSPTOOLBOX_AMD_CSM_GENERIC") != nullptr;
-    if (n_ch <= 64 && n_frames >= 8 && nb >= 3 && !no64)
+    if (all_bins && n_ch <= 64 && n_frames >= 8 && nb >= 3 && !no64)
         CHK(launch(c, "csm_gemm", k_csm_gemm64, dim3(nb - 1), 256, 0, a));
     else
-        CHK(launch(c, "csm_gemm", k_csm_gemm, dim3(nb, nt * (nt + 1) / 2), 256, 0, a));
+        CHK(launch(c, "csm_gemm", k_csm_gemm, dim3(bin_count, nt * (nt + 1) / 2), 256, 0, a));
     return DS_OK;
+}
+
+extern "C" int ds_csm_dev(ds_ctx* c, const float* x, int n_ch, int64_t ld, int64_t n_samples, int W,
+                          int hop, int n_frames, const float* window, int detrend, int average,
+                          int amp_sqrt, double norm_scale, double factor, int halve_edges, ds_c32* csm) {
+    return csm_dev(c, x, n_ch, ld, n_samples, W, hop, n_frames, window, detrend, average, amp_sqrt, norm_scale,
+                   factor, halve_edges, 0, W / 2 + 1, csm);
+}
+
+// bins [bin_start, bin_start + bin_count) only (csm_dev[0] = matrix of bin_start): the multi-GPU
+// split of the CSM -- every rank transforms all channels and keeps its own bin range
+extern "C" int ds_csm_bins_dev(ds_ctx* c, const float* x, int n_ch, int64_t ld, int64_t n_samples, int W,
+                               int hop, int n_frames, const float* window, int detrend, int amp_sqrt,
+                               double norm_scale, double factor, int halve_edges, int bin_start,
+                               int bin_count, ds_c32* csm) {
+    return csm_dev(c, x, n_ch, ld, n_samples, W, hop, n_frames, window, detrend, DS_AVG_MEAN, amp_sqrt,
+                   norm_scale, factor, halve_edges, bin_start, bin_count, csm);
 }
 
 extern "C" int ds_csm_spec_dev(ds_ctx* c, const ds_c32* X, int n_bins, int n_frames, int n_ch,
@@ -704,7 +727,7 @@ extern "C" int ds_csm_spec_dev(ds_ctx* c, const ds_c32* X, int n_bins, int n_fra
     const int nt = (n_ch + 31) / 32;
     CsmArgs a{(const float2*)X, n_ch, n_frames,
               FinishPar{norm_scale / (double)n_frames, factor, halve_edges, amp_sqrt, n_bins},
-              (float2*)csm};
+              (float2*)csm, 0};
     CHK(launch(c, "csm_gemm", k_csm_gemm, dim3(n_bins, nt * (nt + 1) / 2), 256, 0, a));
     return DS_OK;
 }

@@ -278,7 +278,8 @@ struct CsmArgs {
     const float2* X;
     int n_ch, n_frames;
     FinishPar fin;
-    float2* csm;
+    float2* csm;  // matrix of bin b0 first
+    int b0;       // first bin of this call (generic kernel: a bin range for the multi-GPU split)
 };
 
 // Combine the four waves' partial 32x32 tiles (fp64, through LDS), apply the Welch finish and
@@ -305,7 +306,7 @@ __device__ __forceinline__ void csm_tile_epilogue(float (&red)[4][2][16][64], co
         const int i = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), j = l & 31;
         const int gi = 32 * I + i, gj = 32 * J + j;
         if (gi < C && gj < C && gi >= gj) {
-            float2* out = p.csm + (int64_t)b * C * C;
+            float2* out = p.csm + (int64_t)(b - p.b0) * C * C;
             if (gi == gj) {
                 double d = finish_real(g.x, b, p.fin);
                 out[(int64_t)gi * C + gj] = make_float2((float)d, 0.f);
@@ -336,7 +337,7 @@ __device__ __forceinline__ void csm_tile_epilogue(float (&red)[4][2][16][64], co
 __global__ __launch_bounds__(256) void k_csm_gemm(CsmArgs p) {
     __shared__ float red[4][2][16][64];
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
-    const int b = blockIdx.x;
+    const int b = blockIdx.x + p.b0;
     int I = 0;
     int tp = blockIdx.y;
     while ((I + 1) * (I + 2) / 2 <= tp) ++I;

@@ -99,6 +99,30 @@ def welch_transfer_function_sharded(output_td, input_td, fs_hz: int, window_leng
     return gather_channel_shards(tf, n_cy, 1), gather_channel_shards(coh, n_cy, 1)
 
 
+def csm_welch_sharded(time_data, sampling_rate_hz: int, window_length_samples: int, compute=None,
+                      gather: bool = True, **params):
+    """Welch cross-spectral matrix split by frequency bins: the
+    matrix does not shard by channel (all pairs are needed), so every rank transforms all
+    channels and keeps the bins of its shard -- redundant STFTs, no reduction between ranks.
+    `compute(td, fs, W, bin_start, bin_stop, **params) -> (bins, C, C)` defaults to the HIP path.
+    -> (f, csm (B, C, C)) on every rank (or this rank's rows with gather=False)."""
+    if compute is None:
+        from . import backend
+        from .standard.enums import SpectrumScaling, Window
+
+        def compute(td, fs, W, b0, b1, window_type=Window.Hann, overlap_percent=50.0, detrend=True,
+                    scaling=SpectrumScaling.FFTBackward):
+            return backend._csm_welch_bins(td, fs, W, window_type, overlap_percent, detrend, scaling, b0, b1)
+    rank, ws = world()
+    nb = window_length_samples // 2 + 1
+    a, b = shard_range(nb, ws, rank)
+    local = compute(time_data, sampling_rate_hz, window_length_samples, a, b, **params)
+    f = np.fft.rfftfreq(window_length_samples, 1 / sampling_rate_hz)
+    if not gather:
+        return f[a:b], local
+    return f, gather_channel_shards(local, nb, axis=0)
+
+
 def fir_filter_bank_sharded(x, taps_list, mode: int, compute=None, gather: bool = True):
     """FIR filter bank with the independent units sharded across ranks (SURVEY section 8(e),
     config 3): Parallel -> the bands, Sequential / Summed -> the channels.  `compute(x, taps, mode)`

@@ -190,6 +190,13 @@ int ds_csm_dev(ds_ctx* ctx, const float* x_dev, int n_ch, int64_t ld, int64_t n_
 int ds_csm(ds_ctx* ctx, const float* x, int n_ch, int64_t n_samples, int W, int hop,
            int n_frames, const float* window, int detrend, int average, int amp_sqrt,
            double norm_scale, double factor, int halve_edges, ds_c32* csm);
+/* bins [bin_start, bin_start + bin_count) only (csm_dev[0] is the matrix of bin_start, mean
+ * averaging): the multi-GPU split of the CSM -- every rank transforms all channels and keeps
+ * its own bin range, no reduction between ranks.                                         */
+int ds_csm_bins_dev(ds_ctx* ctx, const float* x_dev, int n_ch, int64_t ld, int64_t n_samples,
+                    int W, int hop, int n_frames, const float* window_dev, int detrend,
+                    int amp_sqrt, double norm_scale, double factor, int halve_edges,
+                    int bin_start, int bin_count, ds_c32* csm_dev);
 
 /* CSM from spectra that are already on hand: X[b][f][c] (n_bins x n_frames x n_ch, the
  * STFT layout) -> csm[b][i][j] = finish(norm_scale/n_frames * sum_f X_i conj X_j).

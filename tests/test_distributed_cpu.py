@@ -77,6 +77,12 @@ def _worker(rank, world, port, q):
 
         d = dd.spectral_division_sharded(items, 256, rinv, 200, compute=div)
         ok = ok and np.array_equal(d, div(items, 256, rinv, 200)) and d.shape == (7, 200, 2)
+        # CSM: frequency bins sharded
+        def csm_bins(td, fs, W, b0, b1, **kw):
+            return orc.csm_welch_batched(td, fs, W, "hann", 50, True, "FFTBackward")[1][b0:b1]
+
+        fcs, cs = dd.csm_welch_sharded(xs, 48000, 128, compute=csm_bins)
+        ok = ok and cs.shape == (65, 3, 3) and np.array_equal(cs, csm_bins(xs, 48000, 128, 0, 65))
         q.put((rank, bool(ok), dd.shard_range(n_cy, world, rank)))
     finally:
         dist.destroy_process_group()

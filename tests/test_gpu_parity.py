@@ -748,6 +748,21 @@ def test_fir_bank_full_size_properties():
         d.free()
 
 
+def test_csm_bin_ranges_match_the_full_matrix():
+    """ds_csm_bins_dev (one rank's share of the bins-sharded CSM) returns exactly the rows of the
+    full matrix, including the edge-bin handling at DC / Nyquist."""
+    rng = np.random.default_rng(44)
+    x = 0.1 * rng.standard_normal((30000, 6)) + 0.2 * rng.standard_normal(30000)[:, None]
+    for sc in (SpectrumScaling.FFTBackward, SpectrumScaling.PowerSpectralDensity):
+        f, full = backend._csm_welch(x, 48000, 512, Window.Hann, 50, True, "mean", sc)
+        fr, ref = orc.csm_welch_batched(x, 48000, 512, "hann", 50, True, sc.name)
+        for a, b in ((0, 257), (0, 100), (100, 257), (256, 257), (37, 38)):
+            part = backend._csm_welch_bins(x, 48000, 512, Window.Hann, 50, True, sc, a, b)
+            assert part.shape == (b - a, 6, 6)
+            assert relmax(part, ref[a:b], a == 0) < TOL
+            assert relmax(part, full[a:b], a == 0) < TOL
+
+
 def test_csm_full_size_properties():
     """config 4 at full size (64 mics x 512 000 samples, nfft 1024): Hermitian, the diagonal is
     the Welch auto spectrum, and the 4 x 4 sub-block equals the CSM of those 4 channels alone
