@@ -9,20 +9,40 @@ CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libdsptoolbox_amd.so")
 SOURCES = [os.path.join(CSRC, "api.hip")]
+# -fno-slp-vectorize: hipcc's SLP pass turns the complex butterflies into v_pk_* pairs glued
+# together with ~270 v_mov per FFT; scalar fp32 VALU code is 25 % faster here (measured on
+# MI355X, profiles/).
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-shared", "-fPIC"]
 
 
-def _newest_source_mtime() -> float:
-    newest = 0.0
+HASH_PATH = os.path.join(LIB_DIR, "libdsptoolbox_amd.srchash")
+
+
+def _source_hash() -> str:
+    """sha256 over the contents of every source the library is built from (names included).
+    Content, not modification times: a checkout or a copy to another machine touches every file
+    without changing anything, and must not trigger a two-minute rebuild."""
+    import hashlib
+    h = hashlib.sha256()
+    files = []
     for root in (CSRC, os.path.join(HERE, "..", "include")):
-        for dp, _, files in os.walk(root):
-            for f in files:
+        for dp, _, names in os.walk(root):
+            for f in names:
                 if f.endswith((".hip", ".hpp", ".h")):
-                    newest = max(newest, os.path.getmtime(os.path.join(dp, f)))
-    return newest
+                    files.append(os.path.join(dp, f))
+    for path in sorted(files, key=lambda q: os.path.relpath(q, HERE)):
+        h.update(os.path.relpath(path, HERE).encode())
+        with open(path, "rb") as fh:
+            h.update(fh.read())
+    h.update(" ".join(FLAGS).encode())
+    return h.hexdigest()
 
 
 def _up_to_date() -> bool:
-    return os.path.exists(LIB_PATH) and os.path.getmtime(LIB_PATH) >= _newest_source_mtime()
+    if not (os.path.exists(LIB_PATH) and os.path.exists(HASH_PATH)):
+        return False
+    with open(HASH_PATH) as fh:
+        return fh.read().strip() == _source_hash()
 
 
 def build_library(force: bool = False, verbose: bool = True) -> str:
@@ -40,17 +60,15 @@ def build_library(force: bool = False, verbose: bool = True) -> str:
             if not force and _up_to_date():  # another rank built it while we waited
                 return LIB_PATH
             hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-            # -fno-slp-vectorize: hipcc's SLP pass turns the complex butterflies into v_pk_*
-            # pairs glued together with ~270 v_mov per FFT; scalar fp32 VALU code is 25 %
-            # faster here (measured on MI355X, profiles/).
             tmp = LIB_PATH + f".tmp{os.getpid()}"
-            cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize",
-                   "-shared", "-fPIC", "-o", tmp] + SOURCES + ["-ldl"]
+            cmd = [hipcc] + FLAGS + ["-o", tmp] + SOURCES + ["-ldl"]
             if verbose:
                 print(" ".join(cmd), file=sys.stderr, flush=True)
             try:
                 subprocess.check_call(cmd, stdout=sys.stderr)
                 os.replace(tmp, LIB_PATH)
+                with open(HASH_PATH, "w") as fh:
+                    fh.write(_source_hash() + "\n")
             finally:
                 if os.path.exists(tmp):
                     os.remove(tmp)
