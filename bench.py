@@ -431,9 +431,13 @@ def main():
         achieved = alg / launches_per_step / (dom_ms * 1e-3) / 1e12
         roof = dict(bound="mfma", achieved=achieved, peak=MFMA_F32_PEAK_TFLOPS, unit="TFLOP/s",
                     frac=achieved / MFMA_F32_PEAK_TFLOPS, traffic=None)
-    hint = {"welch4096_main": "k_y<", "welch_yacc": "k_yacc", "fir": "k_fir<", "csm_gemm": "k_csm_gemm",
-            "deconv": "k_deconv"}.get(dom, dom)
-    traffic, src = pmc_traffic(args.workload, hint)
+    hints = {"welch4096_main": ("k_y<",), "welch_yacc": ("k_yacc",), "fir": ("fir16k::k_fir", "k_fir<"),
+             "csm_gemm": ("k_csm_gemm",), "deconv": ("k_deconv",)}.get(dom, (dom,))
+    traffic, src = None, None
+    for hint in hints:
+        traffic, src = pmc_traffic(args.workload, hint)
+        if traffic is not None:
+            break
     roof["traffic"] = traffic
     if src:
         roof["traffic_source"] = src + " (2*FETCH_SIZE + WRITE_SIZE) KiB"
