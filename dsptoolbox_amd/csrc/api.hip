@@ -26,6 +26,8 @@ static thread_local std::string g_err;
 struct ds_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t side = nullptr;  // second stream for a kernel that may run beside the main one
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::string err;
     std::map<int, float2*> tw;  // twiddle tables by length
@@ -94,6 +96,9 @@ extern "C" int ds_init(int device, ds_ctx** out) {
     c->device = device;
     HIPCHK(c, hipSetDevice(device));
     HIPCHK(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    HIPCHK(c, hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
+    HIPCHK(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+    HIPCHK(c, hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
     HIPCHK(c, hipEventCreate(&c->ev0));
     HIPCHK(c, hipEventCreate(&c->ev1));
     *out = c;
@@ -123,6 +128,9 @@ extern "C" void ds_destroy(ds_ctx* c) {
     (void)hipEventDestroy(c->ev0);
     (void)hipEventDestroy(c->ev1);
     (void)hipStreamDestroy(c->stream);
+    if (c->side) (void)hipStreamDestroy(c->side);
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     delete c;
 }
 
@@ -1221,8 +1229,34 @@ static int fir_once(ds_ctx* c, const float* x, int n_ch, int64_t ldx, int64_t n_
         float2* hperm = cvw.take<float2>((size_t)n_filt * N);
         fir16k::PermArgs pa{hs, n_filt, hperm};
         CHK(launch(c, "fir_taps", fir16k::k_permute, dim3((unsigned)(((int64_t)n_filt * N + 255) / 256)), 256, 0, pa));
-        fir16k::Args a{x, n_samples, ldx, ld_y, n_ch, n_filt, n_taps, c->w4_tables, c->fir16k_tables, hperm, y};
-        CHK(launch(c, "fir", fir16k::k_fir, dim3((unsigned)n_blocks, (n_ch + 1) / 2), fir16k::NTB, fir16k::LDS_BYTES, a));
+        fir16k::Args a{x, n_samples, ldx, ld_y, n_ch, n_filt, n_taps, c->w4_tables, c->fir16k_tables, hperm, y, 0};
+        // interior blocks of a 4097-tap filter with 16-byte aligned rows: the store-everything variant
+        int64_t n_plain = 0;
+        if (n_taps - 1 == fir16k::M && (ld_y & 3) == 0 && (((uintptr_t)y) & 15) == 0) n_plain = n_samples / L;
+        // The few ragged blocks go to the side stream so they run beside the main grid's last,
+        // partly filled round instead of after it (fork after the tap spectra, join at the end).
+        const bool ragged = n_blocks > n_plain;
+        if (ragged && n_plain > 0) {
+            HIPCHK(c, hipFuncSetAttribute((const void*)fir16k::k_fir<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          (int)fir16k::LDS_BYTES));
+            HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
+            HIPCHK(c, hipStreamWaitEvent(c->side, c->ev_fork, 0));
+            fir16k::Args ar = a;
+            ar.block0 = (int)n_plain;
+            hipLaunchKernelGGL(fir16k::k_fir<false>, dim3((unsigned)(n_blocks - n_plain), (n_ch + 1) / 2),
+                               dim3(fir16k::NTB), fir16k::LDS_BYTES, c->side, ar);
+            HIPCHK(c, hipGetLastError());
+            HIPCHK(c, hipEventRecord(c->ev_join, c->side));
+        }
+        if (n_plain > 0)
+            CHK(launch(c, "fir", fir16k::k_fir<true>, dim3((unsigned)n_plain, (n_ch + 1) / 2), fir16k::NTB,
+                       fir16k::LDS_BYTES, a));
+        if (ragged && n_plain > 0) {
+            HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
+        } else if (ragged) {
+            CHK(launch(c, "fir", fir16k::k_fir<false>, dim3((unsigned)n_blocks, (n_ch + 1) / 2), fir16k::NTB,
+                       fir16k::LDS_BYTES, a));
+        }
         return DS_OK;
     }
     FirArgs a{x, n_samples, ldx, ld_y, n_ch, n_filt, n_taps, tw, hs, y};

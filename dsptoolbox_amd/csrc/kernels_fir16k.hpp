@@ -148,9 +148,15 @@ struct Args {
     const float2* twn;    // host_tables() above
     const float2* hperm;  // [n_filt][4][8][256][2], 1/N folded in
     float* y;             // [(k*n_ch + c)*ld_y + n]
+    int block0;           // first block of this launch
 };
 
-// grid = (n_blocks, ceil(n_ch/2)); block j covers outputs [j L, (j+1) L), L = 16384 - (n_taps-1)
+// grid = (n_blocks, ceil(n_ch/2)); block j covers outputs [j L, (j+1) L), L = 16384 - (n_taps-1).
+// PLAIN: exactly 4096 discarded samples (4097 taps), whole block inside the signal, 16-byte aligned
+// rows: quarters 1..3 are stored whole with 16-byte stores and no test per store (the host launches
+// the interior blocks with PLAIN and the rest without: keeping both store paths in one kernel costs
+// registers the 128-VGPR budget does not have).
+template <bool PLAIN>
 __global__ __launch_bounds__(NTB) void k_fir(Args p) {
     extern __shared__ __align__(16) float2 lds[];
     const int tid = threadIdx.x, t = tid & 255;
@@ -160,7 +166,7 @@ __global__ __launch_bounds__(NTB) void k_fir(Args p) {
     float2* comb = lds;  // [4][4096] recombination image, overlays the exchange buffers
     const int T1 = p.n_taps - 1;
     const int L = NBIG - T1;
-    const int64_t out0 = (int64_t)blockIdx.x * L;
+    const int64_t out0 = (int64_t)(blockIdx.x + p.block0) * L;
     const int ca = 2 * blockIdx.y, cb = ca + 1;
     const bool vb = cb < p.n_ch;
     const float* xa = p.x + (int64_t)ca * p.ldx;
@@ -240,7 +246,6 @@ __global__ __launch_bounds__(NTB) void k_fir(Args p) {
         // LDS reads and 16-byte stores.  Interior blocks with exactly 4096 discarded samples
         // (4097 taps) store quarters 1..3 whole, without a test per store.
         const int n0 = 4 * (q * 256 + t);
-        const bool plain = T1 == M && out0 + L <= p.n_samples && ((out0 - T1) & 3) == 0 && (p.ld_y & 3) == 0;
         float2 u[4][4];  // [sub-spectrum][sample]
 #pragma unroll
         for (int qq = 0; qq < 4; ++qq) {
@@ -259,7 +264,7 @@ __global__ __launch_bounds__(NTB) void k_fir(Args p) {
             if (j == 2) return make_float2(u0.x - u1.x + u2.x - u3.x, u0.y - u1.y + u2.y - u3.y);
             return make_float2(u0.x + u1.y - u2.x - u3.y, u0.y - u1.x - u2.y + u3.x);  // u0 - i u1 - u2 + i u3
         };
-        if (plain) {
+        if (PLAIN) {
 #pragma unroll
             for (int j = 1; j < 4; ++j) {
                 const float2 y0 = quarter(j, 0), y1 = quarter(j, 1), y2 = quarter(j, 2), y3 = quarter(j, 3);
