@@ -249,15 +249,25 @@ __device__ __forceinline__ void load_raw(Raw<HALF_HOP>& r, const float* __restri
 }
 
 // z[n1] = frame_2p[n] w[n] + i frame_2p+1[n] w[n], n = tid + 256 n1
+// (An odd frame count leaves the last pair without a second frame.  With the reference's framing
+// F = ceil(N/hop) that frame would start at F*hop >= n_samples, so load_raw has already delivered
+// zeros for it; a caller that passes fewer frames is handled by drop_second() on that one pair.)
 template <bool HALF_HOP>
-__device__ __forceinline__ void window_pair(float2 (&v)[16], const Raw<HALF_HOP>& r, bool second,
-                                            const float (&win)[16]) {
-    const float m2 = second ? 1.f : 0.f;  // odd frame count: the last pair has no second frame
+__device__ __forceinline__ void window_pair(float2 (&v)[16], const Raw<HALF_HOP>& r, const float (&win)[16]) {
 #pragma unroll
     for (int n1 = 0; n1 < 16; ++n1) {
         float b = HALF_HOP ? r.s[n1 + 8] : r.s[16 + n1];
-        v[n1] = make_float2(r.s[n1] * win[n1], b * (win[n1] * m2));
+        v[n1] = make_float2(r.s[n1] * win[n1], b * win[n1]);
     }
+}
+
+// the last pair of an odd frame count when frame F would still overlap the signal
+__device__ __forceinline__ bool needs_drop(const Args& p, int pr) {
+    return pr == p.n_pairs - 1 && (p.n_frames & 1) && (int64_t)p.n_frames * p.hop < p.n_samples;
+}
+__device__ __forceinline__ void drop_second(float2 (&v)[16]) {
+#pragma unroll
+    for (int n1 = 0; n1 < 16; ++n1) v[n1].y = 0.f;
 }
 
 // ---- input spectra -----------------------------------------------------------
@@ -276,7 +286,8 @@ __global__ __launch_bounds__(NT) void k_x(Args p) {
         Raw<HALF_HOP> raw;
         load_raw<HALF_HOP>(raw, p.sig, p.n_samples, (int64_t)(2 * pr) * p.hop, p.hop, tid);
         init_tables(tw, win, tw2, p.window, p.twt, tid);
-        window_pair<HALF_HOP>(v, raw, 2 * pr + 1 < p.n_frames, win);
+        window_pair<HALF_HOP>(v, raw, win);
+        if (needs_drop(p, pr)) drop_second(v);
     }
 #if W4_TIMING
     unsigned long long w4_ph[12] = {}, w4_prev = 0;
@@ -376,7 +387,8 @@ __global__ __launch_bounds__(NT, 2) void k_y(Args p) {
         for (int pr = p0; pr < p1; ++pr) {
             float2 v[16];
             W4_TS(0);
-            window_pair<HALF_HOP>(v, raw, 2 * pr + 1 < p.n_frames, win);
+            window_pair<HALF_HOP>(v, raw, win);
+            if (needs_drop(p, pr)) drop_second(v);
             if (!(W4_ABLATE & 2) && pr + 1 < p1)
                 load_raw<HALF_HOP>(raw, ch, p.n_samples, (int64_t)(2 * pr + 2) * p.hop, p.hop, tid);
             float2 xw[16];

@@ -861,6 +861,32 @@ def test_welch4096_fast_path_vs_oracle(overlap, n, n_cy):
             assert e1 < TOL and e2 < TOL, (mode, det, e1, e2)
 
 
+def test_welch4096_explicit_frame_count():
+    """The C-ABI takes the frame count as an argument: an odd count smaller than ceil(N/hop) (the
+    reference's keep_last_frames=False framing) must not let frame F leak into the last pair."""
+    import ctypes as C
+    from dsptoolbox_amd._lib import get_context
+    rng = np.random.default_rng(8)
+    n, n_cy, W, hop, F = 50000, 3, 4096, 2048, 7
+    x = rng.standard_normal((1, n)).astype(np.float32)
+    y = (rng.standard_normal((n_cy, n)) * 0.3).astype(np.float32)
+    y[0] += np.convolve(x[0], [0.5, -0.2, 0.1])[:n].astype(np.float32)
+    w = np.hanning(W + 1)[:-1].astype(np.float32)
+    tf = np.empty((W // 2 + 1, n_cy), np.complex64)
+    coh = np.empty((W // 2 + 1, n_cy), np.float32)
+    ctx = get_context()
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    ctx.check(ctx.lib.ds_welch_tf(ctx.handle, p(x), 1, p(y), n_cy, n, W, hop, F, p(w), 0, 0, 1, 0, 1.0, 1.0, 0,
+                                  p(tf), p(coh)), "ds_welch_tf")
+    fr = np.stack([x[0, f * hop:f * hop + W] * w for f in range(F)]).astype(np.float64)
+    X = np.fft.rfft(fr, axis=1)
+    for c in range(n_cy):
+        Y = np.fft.rfft(np.stack([y[c, f * hop:f * hop + W] * w for f in range(F)]).astype(np.float64), axis=1)
+        sxy, sxx, syy = np.mean(np.conj(X) * Y, axis=0), np.mean(np.abs(X)**2, axis=0), np.mean(np.abs(Y)**2, axis=0)
+        assert relmax(tf[:, c], sxy / sxx) < TOL
+        assert relmax(coh[:, c], np.abs(sxy)**2 / sxx / syy) < TOL
+
+
 @pytest.mark.parametrize("n", [2**15, 2**17, 2**20])
 def test_big_fft_whole_signal(n):
     """Lengths beyond one workgroup's LDS use the four-step path: whole-signal spectrum
