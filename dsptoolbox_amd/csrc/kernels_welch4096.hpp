@@ -113,13 +113,18 @@ struct Tw {
 // The caller guarantees nobody still reads buf (one barrier before the first write here).
 // TWO_BUF: pass-1 and pass-2 images live in different buffers (bufA, bufB); then the only
 // hazards are write-after-read across iterations, which the two barriers already order.
-template <bool TWO_BUF>
+struct NoHook {
+    __device__ __forceinline__ void operator()() const {}
+};
+// `behind_ex1`: called after the first exchange image has been written, before its barrier: work
+// put there (issuing global loads) runs while the workgroup drains its LDS stores and waits.
+template <bool TWO_BUF, typename Hook = NoHook>
 __device__ __forceinline__ void fft4096(float2 (&v)[16], const Tw& tw, float2* __restrict__ buf,
                                         const float2* __restrict__ tw2, int tid
 #if W4_TIMING
                                         , unsigned long long (&w4_ph)[12], unsigned long long& w4_prev
 #endif
-) {
+                                        , Hook behind_ex1 = Hook()) {
     float2* __restrict__ bufB = TWO_BUF ? buf + BUF_C : buf;
     dft16(v);
 #pragma unroll
@@ -136,6 +141,7 @@ __device__ __forceinline__ void fft4096(float2 (&v)[16], const Tw& tw, float2* _
     float2 w2[15];
 #pragma unroll
     for (int k2 = 1; k2 < 16; ++k2) w2[k2 - 1] = tw2[k2 * 16 + n3];
+    behind_ex1();
     if (!(W4_ABLATE & 4)) {
         W4_TS(3);
         __syncthreads();
@@ -389,26 +395,34 @@ __global__ __launch_bounds__(NT, 2) void k_y(Args p) {
             W4_TS(0);
             window_pair<HALF_HOP>(v, raw, win);
             if (needs_drop(p, pr)) drop_second(v);
-            if (!(W4_ABLATE & 2) && pr + 1 < p1)
-                load_raw<HALF_HOP>(raw, ch, p.n_samples, (int64_t)(2 * pr + 2) * p.hop, p.hop, tid);
             float2 xw[16];
-            if (W4_ABLATE & 1) {
+            // The raw samples of the next pair and the input spectrum of this one are requested
+            // behind the first exchange's stores: the ~500 cycles it takes a wave to issue 32
+            // global loads overlap the LDS store drain and the barrier instead of preceding the
+            // first butterfly.  (They are consumed thousands of cycles later.)
+            auto issue_loads = [&]() {
+                __builtin_amdgcn_sched_barrier(0);
+                if (!(W4_ABLATE & 2) && pr + 1 < p1)
+                    load_raw<HALF_HOP>(raw, ch, p.n_samples, (int64_t)(2 * pr + 2) * p.hop, p.hop, tid);
+                if (W4_ABLATE & 1) {
 #pragma unroll
-                for (int k3 = 0; k3 < 16; ++k3) xw[k3] = tw.w[k3 % 15];
-            } else {
-                const float4* __restrict__ xp = reinterpret_cast<const float4*>(p.xs + (int64_t)pr * N) + tid;
+                    for (int k3 = 0; k3 < 16; ++k3) xw[k3] = tw.w[k3 % 15];
+                } else {
+                    const float4* __restrict__ xp = reinterpret_cast<const float4*>(p.xs + (int64_t)pr * N) + tid;
 #pragma unroll
-                for (int g = 0; g < 8; ++g) {
-                    float4 q = xp[256 * g];
-                    xw[2 * g] = make_float2(q.x, q.y);
-                    xw[2 * g + 1] = make_float2(q.z, q.w);
+                    for (int g = 0; g < 8; ++g) {
+                        float4 q = xp[256 * g];
+                        xw[2 * g] = make_float2(q.x, q.y);
+                        xw[2 * g + 1] = make_float2(q.z, q.w);
+                    }
                 }
-            }
+                __builtin_amdgcn_sched_barrier(0);
+            };
             W4_TS(1);
 #if W4_TIMING
-            fft4096<TWO_BUF>(v, tw, buf, tw2, tid, w4_ph, w4_prev);
+            fft4096<TWO_BUF>(v, tw, buf, tw2, tid, w4_ph, w4_prev, issue_loads);
 #else
-            fft4096<TWO_BUF>(v, tw, buf, tw2, tid);
+            fft4096<TWO_BUF>(v, tw, buf, tw2, tid, issue_loads);
 #endif
 #pragma unroll
             for (int k3 = 0; k3 < 16; ++k3) {
