@@ -118,13 +118,13 @@ struct NoHook {
 };
 // `behind_ex1`: called after the first exchange image has been written, before its barrier: work
 // put there (issuing global loads) runs while the workgroup drains its LDS stores and waits.
-template <bool TWO_BUF, typename Hook = NoHook>
+template <bool TWO_BUF, typename Hook = NoHook, typename Hook2 = NoHook>
 __device__ __forceinline__ void fft4096(float2 (&v)[16], const Tw& tw, float2* __restrict__ buf,
                                         const float2* __restrict__ tw2, int tid
 #if W4_TIMING
                                         , unsigned long long (&w4_ph)[12], unsigned long long& w4_prev
 #endif
-                                        , Hook behind_ex1 = Hook()) {
+                                        , Hook behind_ex1 = Hook(), Hook2 behind_ex2 = Hook2()) {
     float2* __restrict__ bufB = TWO_BUF ? buf + BUF_C : buf;
     dft16(v);
 #pragma unroll
@@ -158,6 +158,7 @@ __device__ __forceinline__ void fft4096(float2 (&v)[16], const Tw& tw, float2* _
         if (!TWO_BUF) __syncthreads();  // all pass-2 reads done
 #pragma unroll
         for (int k2 = 0; k2 < 16; ++k2) bufB[(16 * k2 + k1u) * L2S + n3] = v[pos16(k2)];
+        behind_ex2();
         W4_TS(7);
         __syncthreads();
         W4_TS(8);
@@ -404,6 +405,10 @@ __global__ __launch_bounds__(NT, 2) void k_y(Args p) {
                 __builtin_amdgcn_sched_barrier(0);
                 if (!(W4_ABLATE & 2) && pr + 1 < p1)
                     load_raw<HALF_HOP>(raw, ch, p.n_samples, (int64_t)(2 * pr + 2) * p.hop, p.hop, tid);
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            auto issue_xs = [&]() {
+                __builtin_amdgcn_sched_barrier(0);
                 if (W4_ABLATE & 1) {
 #pragma unroll
                     for (int k3 = 0; k3 < 16; ++k3) xw[k3] = tw.w[k3 % 15];
@@ -420,9 +425,9 @@ __global__ __launch_bounds__(NT, 2) void k_y(Args p) {
             };
             W4_TS(1);
 #if W4_TIMING
-            fft4096<TWO_BUF>(v, tw, buf, tw2, tid, w4_ph, w4_prev, issue_loads);
+            fft4096<TWO_BUF>(v, tw, buf, tw2, tid, w4_ph, w4_prev, issue_loads, issue_xs);
 #else
-            fft4096<TWO_BUF>(v, tw, buf, tw2, tid, issue_loads);
+            fft4096<TWO_BUF>(v, tw, buf, tw2, tid, issue_loads, issue_xs);
 #endif
 #pragma unroll
             for (int k3 = 0; k3 < 16; ++k3) {
