@@ -112,7 +112,7 @@ __global__ __launch_bounds__(NTB, 4) void k_deconv(Args p) {
         w4::Tw tw;
 #pragma unroll
         for (int k1 = 1; k1 < 16; ++k1) tw.w[k1 - 1] = p.twt[(k1 - 1) * 256 + t];
-        w4::fft4096<false>(v, tw, buf, tw2, t);
+        w4::fft4096_plain<false>(v, tw, buf, tw2, t);
     }
     // ---- multiply by the shared inverse spectrum (fetched at the top of the kernel)
 #pragma unroll

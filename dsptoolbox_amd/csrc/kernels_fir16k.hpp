@@ -210,7 +210,7 @@ __global__ __launch_bounds__(NTB) void k_fir(Args p) {
         w4::Tw tw;  // only the forward transform keeps its W4096 twiddles in registers
 #pragma unroll
         for (int k1 = 1; k1 < 16; ++k1) tw.w[k1 - 1] = p.twt[(k1 - 1) * 256 + t];
-        w4::fft4096<false>(v, tw, buf, tw2, t);
+        w4::fft4096_plain<false>(v, tw, buf, tw2, t);
     }
     float2 z[16];
 #pragma unroll

@@ -175,6 +175,18 @@ __device__ __forceinline__ void fft4096(float2 (&v)[16], const Tw& tw, float2* _
     W4_TS(10);
 }
 
+// the transform without the dev-only phase stamps (other kernels built on it)
+template <bool TWO_BUF>
+__device__ __forceinline__ void fft4096_plain(float2 (&v)[16], const Tw& tw, float2* __restrict__ buf,
+                                              const float2* __restrict__ tw2, int tid) {
+#if W4_TIMING
+    unsigned long long ph[12] = {}, prev = 0;
+    fft4096<TWO_BUF>(v, tw, buf, tw2, tid, ph, prev);
+#else
+    fft4096<TWO_BUF>(v, tw, buf, tw2, tid);
+#endif
+}
+
 struct Args {
     const float* sig;   // x (k_x) or y (k_y) planar
     int64_t n_samples, ld;
@@ -296,12 +308,7 @@ __global__ __launch_bounds__(NT) void k_x(Args p) {
         window_pair<HALF_HOP>(v, raw, win);
         if (needs_drop(p, pr)) drop_second(v);
     }
-#if W4_TIMING
-    unsigned long long w4_ph[12] = {}, w4_prev = 0;
-    fft4096<false>(v, tw, buf, tw2, tid, w4_ph, w4_prev);
-#else
-    fft4096<false>(v, tw, buf, tw2, tid);
-#endif
+    fft4096_plain<false>(v, tw, buf, tw2, tid);
     if (p.detrend && tid == 0) v[pos16(0)] = make_float2(0.f, 0.f);
     float4* xo = reinterpret_cast<float4*>(p.xs + (int64_t)pr * N) + tid;
 #pragma unroll
