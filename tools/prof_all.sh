@@ -1,10 +1,11 @@
 #!/bin/bash
 # rocprofv3 kernel-trace + PMC summaries for every bench workload (run on the GPU box).
-# usage: tools/prof_all.sh <tag>
+# usage: tools/prof_all.sh <tag> ["workload ..."]
 set -u
 TAG=${1:-r01}
 export TMPDIR=/tmp
-for W in welch_h1 fir_bank csm deconv; do
+WORKLOADS=${2:-"welch_h1 fir_bank csm deconv"}
+for W in $WORKLOADS; do
   OUT=gpurun_out/prof_${TAG}_$W
   mkdir -p $OUT
   # kernel trace: the bench command itself (defaults); PMC passes: fewer steps, no CPU leg
