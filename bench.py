@@ -95,6 +95,8 @@ class Dist:
         self.dist.broadcast_object_list(box, src=0)
         return box[0]
 
+    comm_hung = False
+
     def finish(self):
         if self.world > 1:
             try:
@@ -102,6 +104,9 @@ class Dist:
                 self.dist.destroy_process_group()
             except Exception:  # pragma: no cover - teardown only
                 pass
+        if self.comm_hung:  # a daemon thread is stuck inside the communicator set-up
+            sys.stdout.flush()
+            os._exit(0)
 
     def all_ok(self, ok: bool) -> bool:
         if self.world == 1:
@@ -120,6 +125,8 @@ def setup_rccl(ctx, dist: Dist):
         return False
     if dist.backend != "nccl":
         return False
+    if os.environ.get("BENCH_BCAST", "rccl") != "rccl":  # BENCH_BCAST=torch: torch.distributed broadcast
+        return False
     ident = C.create_string_buffer(128)
     ok = True
     if dist.rank == 0:
@@ -127,8 +134,22 @@ def setup_rccl(ctx, dist: Dist):
     raw = dist.bcast_bytes(ident.raw, 128)
     if not dist.all_ok(ok):
         return False
-    rc = ctx.lib.ds_comm_init(ctx.handle, dist.world, dist.rank, raw)
-    return dist.all_ok(rc == 0)
+    # ncclCommInitRank is collective: guard it with a watchdog so that a rendezvous problem
+    # degrades to the host broadcast instead of hanging the whole multi-GPU run
+    import threading
+    res = {}
+
+    def init():
+        res["rc"] = ctx.lib.ds_comm_init(ctx.handle, dist.world, dist.rank, raw)
+
+    th = threading.Thread(target=init, daemon=True)
+    th.start()
+    th.join(timeout=float(os.environ.get("BENCH_RCCL_TIMEOUT", "90")))
+    if th.is_alive():
+        dist.comm_hung = True  # leave through os._exit at the end
+        print(f"[bench] rank {dist.rank}: ds_comm_init did not return; using torch.distributed", file=sys.stderr,
+              flush=True)
+    return dist.all_ok(res.get("rc", -1) == 0)
 
 
 # ---------------------------------------------------------------------------
