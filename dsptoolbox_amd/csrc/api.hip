@@ -18,6 +18,7 @@
 #include "kernels_welch4096.hpp"
 #include "kernels_fir16k.hpp"
 #include "kernels_deconv8k.hpp"
+#include "kernels_stft1024.hpp"
 
 using namespace dsk;
 
@@ -35,6 +36,7 @@ struct ds_ctx {
     float2* w4_tables = nullptr;  // welch4096::host_tables()
     float2* fir16k_tables = nullptr;  // fir16k::host_tables()
     float2* deconv8k_tables = nullptr;  // deconv8k::host_tables()
+    float2* stft1k_tables = nullptr;  // stft1k::host_tables()
     void* ws = nullptr;         // kernel workspace (spectra, partials)
     size_t ws_bytes = 0;
     void* io = nullptr;  // staging for the host-pointer entry points
@@ -116,6 +118,7 @@ extern "C" void ds_destroy(ds_ctx* c) {
     if (c->w4_tables) (void)hipFree(c->w4_tables);
     if (c->fir16k_tables) (void)hipFree(c->fir16k_tables);
     if (c->deconv8k_tables) (void)hipFree(c->deconv8k_tables);
+    if (c->stft1k_tables) (void)hipFree(c->stft1k_tables);
     for (auto& kv : c->blue) (void)hipFree(kv.second);
     for (auto& r : c->prof_recs) {
         (void)hipEventDestroy(r.a);
@@ -352,6 +355,30 @@ extern "C" int ds_stft_r2c_dev(ds_ctx* c, const float* x, int64_t n_samples, int
                         scale, edge_scale, power, 1, (float2*)out);
     }
     CHK(check_fft_len(c, nfft, "ds_stft_r2c nfft"));
+    // 1024-point transforms (the reference's default frame): one wave per frame pair with the
+    // transform in registers (kernels_stft1024.hpp)
+    static const bool stft_generic = getenv("DSPTOOLBOX_AMD_STFT_GENERIC") != nullptr;
+    if (nfft == 1024 && (W == 1024 || (W < 1024 && !detrend)) && !stft_generic) {
+        if (!c->stft1k_tables) {
+            std::vector<float2> h;
+            stft1k::host_tables(h);
+            CHK(upload_table_fwd(c, &c->stft1k_tables, h));
+        }
+        int ct = std::min(8, n_ch);  // 8 channels: 64-byte runs of the output, 70 KB of LDS
+        if (const char* e = getenv("DSPTOOLBOX_AMD_STFT_CT")) {
+            int v = atoi(e);
+            if (v >= 1 && v <= 16) ct = std::min(v, n_ch);
+        }
+        while (ct & (ct - 1)) ct &= ct - 1;
+        const int n_fp = (n_frames + 1) / 2, n_ct = (n_ch + ct - 1) / ct;
+        int fpw = std::max(1, std::min(16, (int)(((int64_t)n_fp * n_ct + 511) / 512)));
+        if (const char* e = getenv("DSPTOOLBOX_AMD_STFT_FPW")) fpw = std::max(1, atoi(e));
+        StftArgs a{x, n_samples, ld, pad_front, n_ch, W, hop, n_frames, detrend, power, ct, fpw, window,
+                   c->stft1k_tables, scale, edge_scale, (float2*)out};
+        dim3 grid((unsigned)((n_fp + fpw - 1) / fpw), (unsigned)n_ct);
+        if (power) return launch(c, "stft", stft1k::k_stft1024<true>, grid, 64 * ct, stft1k::lds_bytes(ct), a);
+        return launch(c, "stft", stft1k::k_stft1024<false>, grid, 64 * ct, stft1k::lds_bytes(ct), a);
+    }
     const float2* tw;
     CHK(get_twiddles(c, nfft, &tw));
     // channel tile: ct teams of NT threads (<= 1024 threads, <= 74 KB of LDS so two

@@ -1,0 +1,212 @@
+// STFT with a 1024-point transform (the reference's default frame: 1024-sample window)
+// (standard/_spectral_methods.py:126-148, 260-268 with window_length_samples = 1024).
+//
+// The generic kernel (kernels_generic.hpp: k_stft<1024>) spends ~1500 VALU instructions per frame
+// pair -- padded-index arithmetic of the LDS passes, twiddles fetched from global memory, a
+// branchy in-place separation and read-out -- and is VALU-bound (rocprof: 48 M VALU instructions
+// per launch on the 64-microphone CSM shape = 55 us of issue alone).  Here one wave owns a frame
+// pair and keeps the transform in registers:
+//
+//   1024 = 16 x 16 x 4,  n = 64 n1 + 4 n2 + n3,  k = k1 + 16 k2 + 256 k3
+//   pass 1  lane t = 4 n2 + n3 : DFT16 over n1, times W1024^(t k1)        (table in LDS, shared)
+//   pass 2  lane u = 4 k1 + n3 : DFT16 over n2, times W64^(n3 k2)
+//   pass 3  lane v            : four radix-4 butterflies over n3 for the pairs (k1,k2) = v + 64 j
+//   -> lane v holds Z[v + 64 m], m = 0..15
+//
+// Two wave-local LDS exchanges (a wave's LDS operations execute in order: no s_barrier), then the
+// two packed real frames are separated against Z[N-k] (upper half through LDS) and written as the
+// row image  row 2k = frame f0 bin k, row 2k+1 = frame f0+1 bin k,  which the whole workgroup
+// streams out channel-fastest with one LDS read and one store per element and no index math:
+// out[(k F + f) C + c].
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <cmath>
+#include <vector>
+
+#include "kernels_generic.hpp"
+#include "kernels_welch4096.hpp"
+
+namespace stft1k {
+
+namespace w4 = welch4096;
+using dsk::FrameSrc;
+using dsk::RawPair;
+using dsk::StftArgs;
+using w4::cmul;
+using w4::pos16;
+
+constexpr int N = 1024, NB = N / 2 + 1;
+constexpr int S1 = 68;        // exchange-1 row stride (64 + 4: the 4-lane groups of pass 2 hit distinct banks)
+constexpr int REGION = 1088;  // complex per channel image: 16 * S1 >= 1026 rows, = 0 (mod 32)
+constexpr int TW1 = 15 * 64, TW_LEN = TW1 + 64;
+
+// channel stride: REGION + 32/ct complex, so the ct channels x 64/ct rows a wave reads in the
+// channel-fastest read-out fall on distinct banks; even (float4-aligned images)
+__host__ __device__ constexpr int ch_stride(int ct) { return REGION + (ct > 1 ? 32 / ct : 0); }
+inline size_t lds_bytes(int ct) { return ((size_t)ct * ch_stride(ct) + TW_LEN) * sizeof(float2); }
+
+// [15][64] W1024^(t k1) (k1 = 1..15), then [16][4] W64^(n3 k2); fp64-computed
+inline void host_tables(std::vector<float2>& t) {
+    t.resize(TW_LEN);
+    for (int k1 = 1; k1 < 16; ++k1)
+        for (int tt = 0; tt < 64; ++tt) {
+            double a = -2.0 * M_PI * (double)(tt * k1) / 1024.0;
+            t[(k1 - 1) * 64 + tt] = make_float2((float)std::cos(a), (float)std::sin(a));
+        }
+    for (int k2 = 0; k2 < 16; ++k2)
+        for (int n3 = 0; n3 < 4; ++n3) {
+            double a = -2.0 * M_PI * (double)(n3 * k2) / 64.0;
+            t[TW1 + k2 * 4 + n3] = make_float2((float)std::cos(a), (float)std::sin(a));
+        }
+}
+
+// order the LDS traffic of ONE wave (hardware executes it in program order; this keeps the
+// compiler from moving a read above the write of another lane it cannot see)
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// grid = (ceil(ceil(n_frames/2)/fpw), ceil(n_ch/ct)); block = ct waves; p.tw = host_tables();
+// p.W <= 1024 (shorter windows are zero-padded); detrend requires p.W == 1024, where removing the
+// frame mean only clears bin 0 (a constant has no other bin).
+template <bool POWER>
+__global__ __launch_bounds__(1024) void k_stft1024(StftArgs p) {
+    extern __shared__ __align__(16) float2 lds[];
+    const int team = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), t = threadIdx.x & 63;
+    const int CHS = ch_stride(p.ct);
+    float2* buf = lds + team * CHS;
+    float2* tw1 = lds + p.ct * CHS;
+    const float2* tw2 = tw1 + TW1;
+    for (int i = threadIdx.x; i < TW_LEN; i += blockDim.x) tw1[i] = p.tw[i];
+    const int c0 = blockIdx.y * p.ct;
+    const int ctv = min(p.ct, p.n_ch - c0);
+    const int c = c0 + team;
+    const float* xc = c < p.n_ch ? p.x + (int64_t)c * p.ld : nullptr;  // idle waves transform zeros
+    const int64_t F = p.n_frames, Cn = p.n_ch;
+    const int lct = __ffs(p.ct) - 1;
+    const int cl = threadIdx.x & (p.ct - 1), r0 = threadIdx.x >> lct;  // read-out: channel, first row
+    const int n_fp = (p.n_frames + 1) >> 1;
+    const int fp0 = blockIdx.x * p.fpw, fp1 = min(fp0 + p.fpw, n_fp);
+    auto src = [&](int fp, FrameSrc& a, FrameSrc& b) {
+        const int f0 = 2 * fp, f1 = f0 + 1;
+        a = FrameSrc{xc, (int64_t)f0 * p.hop - p.pad_front};
+        b = FrameSrc{f1 < p.n_frames ? xc : nullptr, (int64_t)f1 * p.hop - p.pad_front};
+    };
+    RawPair<N> raw;
+    FrameSrc a, b;
+    if (fp0 < fp1) {
+        src(fp0, a, b);
+        dsk::load_raw_pair<N>(raw, a, b, p.n_samples, p.W, t);
+    }
+    float win[16];
+#pragma unroll
+    for (int n1 = 0; n1 < 16; ++n1) win[n1] = p.window[min(t + 64 * n1, p.W - 1)] * (t + 64 * n1 < p.W ? 1.f : 0.f);
+    // Drain the loads above before the loop: otherwise the wait for them is merged into the loop body
+    // (vmcnt is a FIFO count) and stalls every iteration on the prefetch it has just issued.
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+    const int k1u = t >> 2, n3 = t & 3;
+    // 0.5 from the separation folded into the scale; lane 0 owns the edge bins 0 and N/2
+    const float sc = p.scale, sce = p.scale * p.edge_scale;
+    const float pe = p.scale, pee = p.scale * p.edge_scale * p.edge_scale;  // power mode
+    const float s0 = (t == 0) ? sce : sc, e0 = (t == 0) ? pee : pe;
+    const float dc = (p.detrend && t == 0) ? 0.f : 1.f;
+
+    for (int fp = fp0; fp < fp1; ++fp) {
+        const int f0 = 2 * fp;
+        const bool v1 = f0 + 1 < p.n_frames;
+        float2 v[16];
+        __syncthreads();  // tables written / the previous pair has been streamed out
+#pragma unroll
+        for (int n1 = 0; n1 < 16; ++n1) v[n1] = make_float2(raw.a[n1] * win[n1], raw.b[n1] * win[n1]);
+        if (fp + 1 < fp1) {
+            FrameSrc na, nb;
+            src(fp + 1, na, nb);
+            dsk::load_raw_pair<N>(raw, na, nb, p.n_samples, p.W, t);
+        }
+        // ---- pass 1
+        w4::dft16(v);
+#pragma unroll
+        for (int k1 = 1; k1 < 16; ++k1) v[pos16(k1)] = cmul(v[pos16(k1)], tw1[(k1 - 1) * 64 + t]);
+#pragma unroll
+        for (int k1 = 0; k1 < 16; ++k1) buf[k1 * S1 + t] = v[pos16(k1)];
+        wave_sync();
+#pragma unroll
+        for (int n2 = 0; n2 < 16; ++n2) v[n2] = buf[k1u * S1 + 4 * n2 + n3];
+        wave_sync();
+        // ---- pass 2
+        w4::dft16(v);
+#pragma unroll
+        for (int k2 = 1; k2 < 16; ++k2) v[pos16(k2)] = cmul(v[pos16(k2)], tw2[k2 * 4 + n3]);
+#pragma unroll
+        for (int k2 = 0; k2 < 16; ++k2) buf[64 * k2 + t] = v[pos16(k2)];  // [(k1 + 16 k2)][n3]
+        wave_sync();
+        // ---- pass 3: pair (k1,k2) = t + 64 j, radix 4 over n3 -> Z[t + 64 (j + 4 k3)]
+        float2 z[16];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float4* q = reinterpret_cast<const float4*>(buf + 4 * (t + 64 * j));
+            const float4 lo = q[0], hi = q[1];
+            float2 x0 = make_float2(lo.x, lo.y), x1 = make_float2(lo.z, lo.w);
+            float2 x2 = make_float2(hi.x, hi.y), x3 = make_float2(hi.z, hi.w);
+            w4::r4(x0, x1, x2, x3);
+            z[j] = x0;
+            z[j + 4] = x1;
+            z[j + 8] = x2;
+            z[j + 12] = x3;
+        }
+        wave_sync();
+        // ---- separation: bins k = t + 64 j (j < 8) against Z[N - k], which sits in the upper half
+#pragma unroll
+        for (int m = 8; m < 16; ++m) buf[t + 64 * m] = z[m];
+        wave_sync();
+        float2 qc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) qc[j] = buf[(N - (t + 64 * j)) & (N - 1)];
+        if (t == 0) qc[0] = z[0];  // bin 0 pairs with itself
+        wave_sync();
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float2 P = z[j], Q = qc[j];
+            float2 A = make_float2(0.5f * (P.x + Q.x), 0.5f * (P.y - Q.y));
+            float2 B = make_float2(0.5f * (P.y + Q.y), -0.5f * (P.x - Q.x));
+            if (POWER) {
+                const float e = (j == 0 ? e0 * dc : pe);
+                A = make_float2((A.x * A.x + A.y * A.y) * e, 0.f);
+                B = make_float2((B.x * B.x + B.y * B.y) * e, 0.f);
+            } else {
+                const float s = (j == 0 ? s0 * dc : sc);
+                A = make_float2(A.x * s, A.y * s);
+                B = make_float2(B.x * s, B.y * s);
+            }
+            *reinterpret_cast<float4*>(buf + 2 * (t + 64 * j)) = make_float4(A.x, A.y, B.x, B.y);
+        }
+        if (t == 0) {  // bin N/2 pairs with itself
+            const float2 P = z[8];
+            float4 r;
+            if (POWER)
+                r = make_float4(P.x * P.x * pee, 0.f, P.y * P.y * pee, 0.f);
+            else
+                r = make_float4(P.x * sce, 0.f, P.y * sce, 0.f);
+            *reinterpret_cast<float4*>(buf + N) = r;
+        }
+        __syncthreads();
+        // ---- read-out: rows r0 + 64 i of channel cl; row r -> out[((r>>1) F + f0 + (r&1)) C + c]
+        if (cl < ctv && (v1 || !(r0 & 1))) {
+            const float2* s = lds + cl * CHS + r0;
+            float2* o = p.out + ((int64_t)(r0 >> 1) * F + f0 + (r0 & 1)) * Cn + c0 + cl;
+            const int64_t ostep = 32 * F * Cn;
+            float2 g[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) g[i] = s[64 * i];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) o[i * ostep] = g[i];
+            if (r0 < 2) o[16 * ostep] = s[N];
+        }
+    }
+}
+
+}  // namespace stft1k

@@ -584,6 +584,42 @@ def test_welch_long_windows_vs_oracle(W):
                     assert orc.rel_l2(tf[1:], rt[1:]) < lim, (mode, avg)  # DC is 0/0 after detrending
 
 
+def test_stft_default_frame_kernel_vs_oracle():
+    """The 1024-sample frame has its own kernel (kernels_stft1024.hpp: one wave per frame pair, the
+    transform in registers): channel tiles with idle waves (1, 3, 5, 9, 17 channels), odd and even
+    frame counts, padding at both ends, detrend, amplitude and power scalings, overlaps."""
+    rng = np.random.default_rng(77)
+    worst = 0.0
+    for n_ch, n, ov, pad, det, sc in (
+            (1, 5000, 50, True, False, SpectrumScaling.FFTBackward),
+            (3, 20011, 50, True, True, SpectrumScaling.AmplitudeSpectrum),
+            (5, 16384, 75, False, False, SpectrumScaling.PowerSpectralDensity),
+            (8, 9999, 0, True, True, SpectrumScaling.PowerSpectrum),
+            (9, 30000, 50, False, True, SpectrumScaling.FFTForward),
+            (17, 12345, 25, True, False, SpectrumScaling.AmplitudeSpectralDensity),
+            (2, 1024, 50, True, False, SpectrumScaling.FFTOrthogonal),
+            (64, 8192, 50, True, False, SpectrumScaling.FFTBackward)):
+        x = rng.standard_normal((n, n_ch)) * 0.3 + 0.05
+        t, f, st = backend._stft(x, 48000, 1024, Window.Hann, ov, None, det, pad, sc)
+        rt, rf, rs = orc.stft(x, 48000, 1024, "hann", ov, None, det, pad, sc.name)
+        assert st.shape == rs.shape and np.allclose(t, rt) and np.array_equal(f, rf)
+        if det:  # the reference's DC bin after mean removal is rounding noise around 0
+            assert np.max(np.abs(st[0])) <= 1e-6 * np.max(np.abs(rs))
+        e = relmax(st, rs)
+        worst = max(worst, e)
+        assert e < TOL, (n_ch, n, ov, pad, det, sc, e)
+    # shorter windows zero-padded to 1024 points (no detrend: that case stays on the generic kernel)
+    for W, det in ((512, False), (256, False), (512, True)):
+        x = rng.standard_normal((20000, 3)) * 0.3 + 0.05
+        t, f, st = backend._stft(x, 48000, W, Window.Hann, 50, 1024, det, True, SpectrumScaling.FFTBackward)
+        rt, rf, rs = orc.stft(x, 48000, W, "hann", 50, 1024, det, True, "FFTBackward")
+        assert st.shape == rs.shape
+        e = relmax(st, rs)
+        worst = max(worst, e)
+        assert e < TOL, (W, det, e)
+    print("stft 1024-frame kernel worst rel-max", worst)
+
+
 def test_stft_and_csm_long_windows_vs_oracle():
     rng = np.random.default_rng(5)
     n = 200000
