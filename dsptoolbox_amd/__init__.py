@@ -2,7 +2,7 @@
 spectral hot path (Welch/H1-H3, STFT, CSM, spectral deconvolution, FIR filter
 banks) behind the reference's Signal / Filter / FilterBank API."""
 
-from . import beamforming, room_acoustics, transfer_functions, transforms
+from . import beamforming, filterbanks, room_acoustics, transfer_functions, transforms
 from .classes import Filter, FilterBank, ImpulseResponse, MultiBandSignal, Signal, Spectrum
 from .standard.enums import (FilterBankMode, FilterCoefficientsType, FilterPassType,
                              SpectrumMethod, SpectrumScaling, SpectrumType, Window)
@@ -12,4 +12,4 @@ __version__ = "0.1.0"
 __all__ = ["Signal", "ImpulseResponse", "Spectrum", "Filter", "FilterBank", "MultiBandSignal",
            "SpectrumMethod", "SpectrumScaling", "SpectrumType", "Window", "FilterBankMode",
            "FilterPassType", "FilterCoefficientsType", "TransferFunctionType",
-           "transfer_functions", "transforms", "room_acoustics", "beamforming"]
+           "transfer_functions", "transforms", "room_acoustics", "beamforming", "filterbanks"]

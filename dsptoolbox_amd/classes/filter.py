@@ -105,6 +105,15 @@ class Filter:
         else:
             self.__ba = ba
 
+    def get_coefficients(self, coefficients_mode: FilterCoefficientsType):
+        """Copy of the filter coefficients (classes/filter.py:927-966).  Only the ba form exists on
+        this path (filters are stored as ba; SOS / zpk conversions are IIR design work)."""
+        if coefficients_mode == FilterCoefficientsType.Ba:
+            return [self.ba[0].copy(), self.ba[1].copy()]
+        if coefficients_mode in (FilterCoefficientsType.Sos, FilterCoefficientsType.Zpk):
+            raise NotImplementedError("only FilterCoefficientsType.Ba is kept on the GPU FIR path")
+        raise ValueError(f"{coefficients_mode} is not valid. Use sos, ba or zpk")
+
     @property
     def metadata(self) -> dict:
         return dict(sampling_rate_hz=self.sampling_rate_hz, order=self.order,

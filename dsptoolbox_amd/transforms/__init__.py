@@ -1,5 +1,6 @@
 """transforms: the inverse STFT (dsptoolbox/transforms/transforms.py:444-586, SURVEY.md section 8(f)
-row 1) and the STFT consumers log_mel_spectrogram / mfcc (:113-203, :335-441, row 4) on the device.  Same signature, parameter handling and quirks as the reference;
+row 1) and the STFT consumers log_mel_spectrogram / mfcc / chroma_stft (:113-203, :335-441, :589-684,
+row 4) on the device.  Same signature, parameter handling and quirks as the reference;
 the frame-wise inverse FFTs and the windowed overlap-add with the squared-window envelope
 (standard/_framed_signal_representation.py:70-137) run in the HIP library (ds_istft)."""
 
@@ -11,7 +12,7 @@ from scipy.signal import get_window
 from .. import backend
 from ..classes.signal import Signal
 
-__all__ = ["istft", "mel_filterbank", "log_mel_spectrogram", "mfcc"]
+__all__ = ["istft", "mel_filterbank", "log_mel_spectrogram", "mfcc", "chroma_stft"]
 
 
 def _pad_trim(td: np.ndarray, desired_length: int) -> np.ndarray:
@@ -157,3 +158,34 @@ def mfcc(signal: Signal, channel: int = 0, mel_filters=None, generate_plot: bool
         f"Shape of the mel filter matrix {mel_filters.shape} does not match the STFT")
     _, _, out = _band_power(signal, mel_filters, f, True, True)
     return time_s, f_mel, out
+
+
+def _pitch2frequency(tuning_a_hz: float = 440):
+    """transforms/_transforms.py:10-26: frequencies of the MIDI pitches 0..127 (0 is C0)."""
+    return tuning_a_hz * 2 ** ((np.arange(128) - 69) / 12)
+
+
+def chroma_stft(signal: Signal, tuning_a_hz: float = 440, compression: float = 0.5, plot_channel: int = -1):
+    """Chroma features and pitch log-STFT (transforms/transforms.py:589-684).
+    -> (time_s, chroma_stft (12 notes C..B, time frame, channel), pitch_stft (128, time frame,
+    channel)).  The STFT, |.|^2 and the contraction onto the quarter-tone pitch bands run on the
+    device (the spectrogram never leaves it); the octave sums over the 128 pitch rows and the
+    logarithmic compression are done on the (128, F, C) result."""
+    assert tuning_a_hz > 0, "Tuning A4 must be greater than zero"
+    assert compression > 0, "Compression factor must be greater than zero"
+    if plot_channel != -1:
+        raise NotImplementedError("plotting is outside the GPU hot path: pass plot_channel=-1")
+    time_s, f, n_bins = _spectrogram_axes(signal)
+    pitch_frequencies = _pitch2frequency(tuning_a_hz)
+    pitch_transformation = np.zeros((len(pitch_frequencies), len(f)))
+    for ind, fn in enumerate(pitch_frequencies):
+        pitch_transformation[ind, (f >= fn * 2 ** (-1 / 24)) & (f < fn * 2 ** (1 / 24))] = 1
+    assert pitch_transformation.shape[1] == n_bins, \
+        "the frequency vector (window length) and the STFT (fft length) have different bin counts"
+    _, _, pitch_stft = _band_power(signal, pitch_transformation, f, False, False)
+    n_notes = 12
+    chroma_transformation = np.zeros((n_notes, len(pitch_frequencies)))
+    for i in range(n_notes):
+        chroma_transformation[i, i::n_notes] = 1
+    chroma = np.tensordot(chroma_transformation, pitch_stft, (1, 0))
+    return time_s, np.log(1 + compression * chroma), np.log(1 + compression * pitch_stft)

@@ -647,6 +647,116 @@ def mfcc(stft_data, f_hz, mel_filters=None):
     return f_mel, out
 
 
+def chroma_stft(stft_data, f_hz, tuning_a_hz=440, compression=0.5):
+    """transforms/transforms.py:640-665 on a given spectrogram (B, F, C): pitch bands of a quarter
+    tone around the 128 MIDI pitches (transforms/_transforms.py:10-26), summed over octaves,
+    log(1 + compression * .).  -> (chroma (12, F, C), pitch (128, F, C))."""
+    en = np.abs(stft_data) ** 2
+    pitch_f = tuning_a_hz * 2 ** ((np.arange(128) - 69) / 12)
+    pt = np.zeros((128, len(f_hz)))
+    for i, fn in enumerate(pitch_f):
+        pt[i, (f_hz >= fn * 2 ** (-1 / 24)) & (f_hz < fn * 2 ** (1 / 24))] = 1
+    ct = np.zeros((12, 128))
+    for i in range(12):
+        ct[i, i::12] = 1
+    pitch = np.tensordot(pt, en, (1, 0))
+    chroma = np.tensordot(ct, pitch, (1, 0))
+    return np.log(1 + compression * chroma), np.log(1 + compression * pitch)
+
+
+class FIRFilterOverlapSave:
+    """classes/fir_filter_realtime.py:75-157: one FFT block of next_fast_len(T + blocksize).
+    Literal, including the defect that irfft is called without its length: when
+    next_fast_len returns an ODD length L the inverse transform has L - 1 points and the block
+    output is not the convolution (the reference's test, tests/test_classes.py:1527-1554, uses a
+    48 000-tap response + 512, whose fast length is even)."""
+
+    def __init__(self, b):
+        self.fir = np.asarray(b, dtype=np.float64)
+
+    def prepare(self, blocksize_samples, n_channels):
+        import scipy.fft as sfft
+        self.blocksize = blocksize_samples
+        self.total_length = sfft.next_fast_len(len(self.fir) + blocksize_samples, True)
+        self.fir_spectrum = np.fft.rfft(self.fir, n=self.total_length)
+        self.buffer = np.zeros((self.total_length, n_channels))
+
+    def process_block(self, block, channel):
+        self.buffer[-self.blocksize:, channel] = block
+        out = np.fft.irfft(np.fft.rfft(self.buffer[:, channel]) * self.fir_spectrum)
+        self.buffer[:-self.blocksize, channel] = self.buffer[self.blocksize:, channel].copy()
+        return out[-self.blocksize:]
+
+
+class FIRUniformPartitioned:
+    """classes/fir_filter_realtime.py:160-240: uniform partitions of blocksize taps and a
+    frequency-domain delay line of the last n_partitions input spectra.  Literal, including the
+    ONE delay-line index shared by all channels (:227-229): driven channel after channel it
+    advances n_channels slots per block, so with several channels the result is the convolution
+    only when n_channels = 1 (mod n_partitions)."""
+
+    def __init__(self, fir):
+        self.fir = np.asarray(fir, dtype=np.float64)
+
+    def prepare(self, blocksize_samples, n_channels):
+        B = self.blocksize = blocksize_samples
+        self.n_partitions = len(self.fir) // B + 1
+        part = np.zeros((B, self.n_partitions))
+        for n in range(self.n_partitions):
+            seg = self.fir[n * B:(n + 1) * B]
+            part[:len(seg), n] = seg
+        self.partitioned_spectrum = np.fft.rfft(part, axis=0, n=2 * B)
+        self.buffer_ind = 0
+        self.buffer_spectra = np.zeros((B + 1, self.n_partitions, n_channels), dtype=np.complex128)
+        self.input_buffer = np.zeros((2 * B, n_channels))
+
+    def process_block(self, block, channel):
+        B = self.blocksize
+        self.input_buffer[:B, channel] = self.input_buffer[-B:, channel].copy()
+        self.input_buffer[-B:, channel] = block
+        self.buffer_spectra[:, self.buffer_ind, channel] = np.fft.rfft(self.input_buffer[:, channel])
+        out = np.sum(self.partitioned_spectrum
+                     * self.buffer_spectra[:, self.buffer_ind - np.arange(self.n_partitions), channel], axis=1)
+        self.buffer_ind = (self.buffer_ind + 1) % self.n_partitions
+        return np.fft.irfft(out)[-B:]
+
+
+class FIRUniformPartitionedMultichannel:
+    """classes/fir_filter_realtime.py:243-335: one impulse response per channel, all channels per
+    call.  The constructor passes the coefficients through Signal.from_time_data (:262), whose
+    default constrain_amplitude scales them to a peak of 1 when the peak exceeds 1
+    (classes/signal.py:222-301)."""
+
+    def __init__(self, fir):
+        fir = np.asarray(fir, dtype=np.float64)
+        fir = fir.reshape(-1, 1) if fir.ndim == 1 else fir
+        peak = np.max(np.abs(fir))
+        self.fir = fir / peak if peak > 1 else fir.copy()
+
+    def prepare(self, blocksize_samples):
+        B = self.blocksize = blocksize_samples
+        self.n_partitions = self.fir.shape[0] // B + 1
+        C = self.fir.shape[1]
+        part = np.zeros((B, self.n_partitions, C))
+        for n in range(self.n_partitions):
+            seg = self.fir[n * B:(n + 1) * B]
+            part[:len(seg), n, :] = seg
+        self.partitioned_spectrum = np.fft.rfft(part, axis=0, n=2 * B)
+        self.buffer_ind = 0
+        self.buffer_spectra = np.zeros((B + 1, self.n_partitions, C), dtype=np.complex128)
+        self.input_buffer = np.zeros((2 * B, C))
+
+    def process_block(self, block):
+        B = self.blocksize
+        self.input_buffer[:B] = self.input_buffer[-B:].copy()
+        self.input_buffer[-B:] = block
+        self.buffer_spectra[:, self.buffer_ind] = np.fft.rfft(self.input_buffer, axis=0)
+        out = np.sum(self.partitioned_spectrum
+                     * self.buffer_spectra[:, self.buffer_ind - np.arange(self.n_partitions), ...], axis=1)
+        self.buffer_ind = (self.buffer_ind + 1) % self.n_partitions
+        return np.fft.irfft(out, axis=0)[-B:]
+
+
 def das_map(f, csm, h, remove_csm_diagonal=True):
     """beamforming/beamforming.py:838-876: Re(h^H CSM h) per grid point and bin, optional
     diagonal removal (energy-compensated), clipping of negative values, Simpson integration."""

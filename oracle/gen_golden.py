@@ -234,8 +234,76 @@ def gen_mel(dsp):
     save("mel", dict(cases=cases, fs=fs), arrs)
 
 
+def gen_chroma(dsp):
+    """transforms.chroma_stft (transforms/transforms.py:589-684), no plot."""
+    from dsptoolbox.standard.enums import SpectrumScaling
+    fs = 22050
+    rng = np.random.default_rng(44)
+    n = 15000
+    t = np.arange(n) / fs
+    x = np.stack([0.05 * rng.standard_normal(n) + 0.5 * np.sin(2 * np.pi * 440 * t) + 0.3 * np.sin(2 * np.pi * 660 * t),
+                  0.2 * rng.standard_normal(n) + 0.4 * np.sin(2 * np.pi * 261.63 * t * (1 + 0.2 * t))], axis=1)
+    cases, arrs = [], {"x": x}
+    for i, (W, ov, pad, sc, tune, comp) in enumerate(((1024, 50, True, "FFTBackward", 440, 0.5),
+                                                      (2048, 75, False, "AmplitudeSpectrum", 442.0, 2.0),
+                                                      (1024, 50, True, "PowerSpectralDensity", 440, 10.0))):
+        s = dsp.Signal(None, x.copy(), fs)
+        s.set_spectrogram_parameters(window_length_samples=W, overlap_percent=ov, padding=pad,
+                                     scaling=SpectrumScaling[sc])
+        t_, chroma, pitch = dsp.transforms.chroma_stft(s, tuning_a_hz=tune, compression=comp)
+        arrs[f"t_{i}"], arrs[f"chroma_{i}"], arrs[f"pitch_{i}"] = t_, chroma, pitch
+        cases.append(dict(W=W, ov=ov, pad=pad, scaling=sc, tuning=tune, compression=comp))
+    save("chroma", dict(cases=cases, fs=fs), arrs)
+
+
+def gen_fir_stream(dsp):
+    """Block-streaming FIR classes (classes/fir_filter_realtime.py:75-335) driven as the
+    reference's tests do (tests/test_classes.py:1527-1580): seeded noise through a decaying
+    random impulse response, block by block."""
+    rng = np.random.default_rng(55)
+    fs = 48000
+    cases, arrs = [], {}
+    for i, (T, bs, n, n_ch) in enumerate(((700, 512, 5000, 1), (3840, 256, 6000, 1), (1500, 512, 4096, 2),
+                                           (512, 512, 2048, 3), (1536, 512, 5000, 1))):
+        fir = rng.standard_normal((T, n_ch)) * np.exp(-np.arange(T) / (T / 6))[:, None]
+        n_blocks = n // bs + 1
+        x = np.zeros((n_blocks * bs, n_ch))
+        x[:n] = rng.standard_normal((n, n_ch)) * 0.3
+        arrs[f"fir_{i}"], arrs[f"x_{i}"] = fir, x
+        outs = {}
+        for name, cls in (("ols", dsp.filterbanks.FIRFilterOverlapSave),
+                          ("upart", dsp.filterbanks.FIRUniformPartitioned)):
+            f = cls(fir[:, 0].copy())
+            f.prepare(bs, n_ch)
+            acc = np.zeros_like(x)
+            for b in range(n_blocks):
+                sl = slice(b * bs, (b + 1) * bs)
+                for ch in range(n_ch):
+                    acc[sl, ch] = f.process_block(x[sl, ch], ch)
+            outs[name] = acc
+        f = dsp.filterbanks.FIRUniformPartitionedMultichannel(fir.copy())
+        f.prepare(bs)
+        acc = np.zeros_like(x)
+        for b in range(n_blocks):
+            sl = slice(b * bs, (b + 1) * bs)
+            acc[sl, :] = f.process_block(x[sl, :])
+        outs["multi"] = acc
+        for k, v in outs.items():
+            arrs[f"{k}_{i}"] = v
+        cases.append(dict(T=T, blocksize=bs, n=n, n_ch=n_ch))
+    save("fir_stream", dict(cases=cases, fs=fs), arrs)
+
+
 def main():
     dsp = import_reference()
+    if "--only-chroma" in sys.argv:
+        import warnings
+        warnings.simplefilter("ignore")
+        return gen_chroma(dsp)
+    if "--only-fir-stream" in sys.argv:
+        import warnings
+        warnings.simplefilter("ignore")
+        return gen_fir_stream(dsp)
     if "--only-mel" in sys.argv:
         import warnings
         warnings.simplefilter("ignore")

@@ -584,6 +584,76 @@ def test_welch_long_windows_vs_oracle(W):
                     assert orc.rel_l2(tf[1:], rt[1:]) < lim, (mode, avg)  # DC is 0/0 after detrending
 
 
+def test_chroma_stft_golden():
+    """transforms.chroma_stft (STFT, |.|^2 and the pitch-band contraction on the device) against
+    the reference's outputs."""
+    from dsptoolbox_amd.standard.enums import SpectrumScaling as S
+    meta, z = load_golden("chroma")
+    for i, c in enumerate(meta["cases"]):
+        s = dsp.Signal(None, z["x"].copy(), meta["fs"])
+        s.set_spectrogram_parameters(window_length_samples=c["W"], overlap_percent=c["ov"],
+                                     padding=c["pad"], scaling=S[c["scaling"]])
+        t, chroma, pitch = dsp.transforms.chroma_stft(s, tuning_a_hz=c["tuning"], compression=c["compression"])
+        assert np.allclose(t, z[f"t_{i}"])
+        assert chroma.shape == z[f"chroma_{i}"].shape and pitch.shape == z[f"pitch_{i}"].shape
+        assert relmax(pitch, z[f"pitch_{i}"]) < TOL, (c, relmax(pitch, z[f"pitch_{i}"]))
+        assert relmax(chroma, z[f"chroma_{i}"]) < TOL, (c, relmax(chroma, z[f"chroma_{i}"]))
+    with pytest.raises(AssertionError):
+        dsp.transforms.chroma_stft(s, tuning_a_hz=-1)
+
+
+def test_fir_streaming_classes_golden():
+    """filterbanks.FIRFilterOverlapSave / FIRUniformPartitioned / FIRUniformPartitionedMultichannel
+    driven block by block as the reference's tests do (tests/test_classes.py:1527-1580), against the
+    reference's block outputs.  Where the reference itself is not the convolution (odd fast length;
+    one delay-line index shared by interleaved channels -- see classes/fir_filter_realtime.py here)
+    the comparison is against the causal convolution the classes document."""
+    import warnings
+    import scipy.fft as sfft
+    from scipy.signal import oaconvolve
+    meta, z = load_golden("fir_stream")
+    n_ref = 0
+    for i, c in enumerate(meta["cases"]):
+        fir, x, bs, C = z[f"fir_{i}"], z[f"x_{i}"], c["blocksize"], c["n_ch"]
+        n_blocks = x.shape[0] // bs
+        conv0 = np.stack([oaconvolve(x[:, ch], fir[:, 0])[: x.shape[0]] for ch in range(C)], axis=1)
+        even = sfft.next_fast_len(c["T"] + bs, True) % 2 == 0
+        f1 = dsp.filterbanks.FIRFilterOverlapSave(fir[:, 0].copy())
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            f1.prepare(bs, C)
+        assert (len(w) == 0) == even
+        f2 = dsp.filterbanks.FIRUniformPartitioned.from_filter(dsp.Filter.from_ba(fir[:, 0].copy(), [1.0], 48000))
+        f2.prepare(bs, C)
+        f3 = dsp.filterbanks.FIRUniformPartitionedMultichannel(fir.copy())
+        f3.prepare(bs)
+        a1, a2, a3 = np.zeros_like(x), np.zeros_like(x), np.zeros_like(x)
+        for b in range(n_blocks):
+            sl = slice(b * bs, (b + 1) * bs)
+            for ch in range(C):
+                a1[sl, ch] = f1.process_block(x[sl, ch], ch)
+                a2[sl, ch] = f2.process_block(x[sl, ch], ch)
+            a3[sl] = f3.process_block(x[sl])
+        if even:
+            assert relmax(a1, z[f"ols_{i}"]) < TOL
+            n_ref += 1
+        assert relmax(a1, conv0) < TOL
+        if C % f2.n_partitions == 1 % f2.n_partitions:
+            assert relmax(a2, z[f"upart_{i}"]) < TOL
+            n_ref += 1
+        assert relmax(a2, conv0) < TOL
+        assert relmax(a3, z[f"multi_{i}"]) < TOL, relmax(a3, z[f"multi_{i}"])
+        n_ref += 1
+    assert n_ref >= 12
+    # state handling
+    f1.reset_state()
+    assert np.array_equal(f1.process_block(np.zeros(bs), 0), np.zeros(bs))
+    with pytest.raises(NotImplementedError):
+        f1.process_sample(0.0, 0)
+    with pytest.raises(NotImplementedError):
+        f1.set_n_channels(2)
+
+
 def test_stft_default_frame_kernel_vs_oracle():
     """The 1024-sample frame has its own kernel (kernels_stft1024.hpp: one wave per frame pair, the
     transform in registers): channel tiles with idle waves (1, 3, 5, 9, 17 channels), odd and even

@@ -216,6 +216,59 @@ def test_mel_spectrogram_and_mfcc():
         close(mf, z[f"mfcc_{i}"], tol=1e-11)
 
 
+def test_chroma_stft():
+    meta, z = load_golden("chroma")
+    x = z["x"]
+    for i, c in enumerate(meta["cases"]):
+        t, f_hz, sp = orc.stft(x, meta["fs"], c["W"], "hann", float(c["ov"]), None, False, c["pad"], c["scaling"])
+        chroma, pitch = orc.chroma_stft(sp, f_hz, c["tuning"], c["compression"])
+        close(t, z[f"t_{i}"], tol=1e-13)
+        close(pitch, z[f"pitch_{i}"], tol=1e-11)
+        close(chroma, z[f"chroma_{i}"], tol=1e-11)
+
+
+def test_fir_streaming_classes():
+    """Block-wise overlap-save / uniformly partitioned FIR (classes/fir_filter_realtime.py) against
+    the reference's block outputs -- including the cases where the reference is not a convolution
+    (odd fast length, shared delay-line index, see the oracle's docstrings) -- and, where it is, the
+    property the reference tests (tests/test_classes.py:1527-1580): concatenated blocks = causal
+    convolution."""
+    import scipy.fft as sfft
+    from scipy.signal import oaconvolve
+    meta, z = load_golden("fir_stream")
+    n_conv = 0
+    for i, c in enumerate(meta["cases"]):
+        fir, x, bs, C = z[f"fir_{i}"], z[f"x_{i}"], c["blocksize"], c["n_ch"]
+        n_blocks = x.shape[0] // bs
+        f1 = orc.FIRFilterOverlapSave(fir[:, 0])
+        f1.prepare(bs, C)
+        f2 = orc.FIRUniformPartitioned(fir[:, 0])
+        f2.prepare(bs, C)
+        f3 = orc.FIRUniformPartitionedMultichannel(fir)
+        f3.prepare(bs)
+        a1, a2, a3 = np.zeros_like(x), np.zeros_like(x), np.zeros_like(x)
+        for b in range(n_blocks):
+            sl = slice(b * bs, (b + 1) * bs)
+            for ch in range(C):
+                a1[sl, ch] = f1.process_block(x[sl, ch], ch)
+            for ch in range(C):
+                a2[sl, ch] = f2.process_block(x[sl, ch], ch)
+            a3[sl] = f3.process_block(x[sl])
+        close(a1, z[f"ols_{i}"], tol=1e-11)
+        close(a2, z[f"upart_{i}"], tol=1e-11)
+        close(a3, z[f"multi_{i}"], tol=1e-11)
+        conv = lambda h: np.stack([oaconvolve(x[:, ch], h[:, min(ch, h.shape[1] - 1)])[: x.shape[0]]
+                                   for ch in range(C)], axis=1)
+        if sfft.next_fast_len(c["T"] + bs, True) % 2 == 0:
+            close(a1, conv(fir[:, :1]), tol=1e-11)
+            n_conv += 1
+        if C % f2.n_partitions == 1 % f2.n_partitions:
+            close(a2, conv(fir[:, :1]), tol=1e-11)
+            n_conv += 1
+        close(a3, conv(fir / max(1.0, np.max(np.abs(fir)))), tol=1e-11)
+    assert n_conv >= 4
+
+
 def test_chirp_pair_config1():
     """BASELINE.json configs[0]: the reference's own example chirps (16-bit PCM fixtures)."""
     meta, z = load_golden("chirp_pair")
