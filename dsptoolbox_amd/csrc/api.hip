@@ -19,6 +19,7 @@
 #include "kernels_fir16k.hpp"
 #include "kernels_deconv8k.hpp"
 #include "kernels_stft1024.hpp"
+#include "kernels_welch1024.hpp"
 
 using namespace dsk;
 
@@ -554,7 +555,7 @@ static int welch_common(ds_ctx* c, int kind, const float* x, int n_cx, int64_t l
                        FinishPar{norm_scale * (double)std::max(1, nbias), factor, halve_edges, amp_sqrt, nb},
                        out_c, out_r};
         int64_t total = (int64_t)nb * (kind == 1 ? n_cx : n_cy);
-        CHK(launch(c, "welch_finish", k_welch_finish, dim3((unsigned)((total + 255) / 256)), 256, 0, f));
+        CHK(launch(c, "welch_finish", k_welch_finish, dim3((unsigned)((total + 63) / 64)), 256, 0, f));
         return DS_OK;
     }
     const bool need_xs = kind != 1;
@@ -589,7 +590,7 @@ static int welch_common(ds_ctx* c, int kind, const float* x, int n_cx, int64_t l
                    FinishPar{norm_scale / (double)n_frames, factor, halve_edges, amp_sqrt, nb},
                    out_c, out_r};
     int64_t total = (int64_t)nb * (kind == 1 ? n_cx : n_cy);
-    CHK(launch(c, "welch_finish", k_welch_finish, dim3((unsigned)((total + 255) / 256)), 256, 0, f));
+    CHK(launch(c, "welch_finish", k_welch_finish, dim3((unsigned)((total + 63) / 64)), 256, 0, f));
     return DS_OK;
 }
 
@@ -634,7 +635,52 @@ static int welch4096_run(ds_ctx* c, const float* x, int64_t ldx, const float* y,
                    FinishPar{norm_scale / (double)n_frames, factor, halve_edges, amp_sqrt, w4::NB},
                    tf, coh};
     int64_t total = (int64_t)w4::NB * n_cy;
-    CHK(launch(c, "welch_finish", k_welch_finish, dim3((unsigned)((total + 255) / 256)), 256, 0, f));
+    CHK(launch(c, "welch_finish", k_welch_finish, dim3((unsigned)((total + 63) / 64)), 256, 0, f));
+    return DS_OK;
+}
+
+// window 1024 (the reference's default), one input channel: wave-level register transform
+// (kernels_welch1024.hpp)
+static int welch1024_run(ds_ctx* c, const float* x, int64_t ldx, const float* y, int n_cy, int64_t ldy,
+                         int64_t n_samples, int hop, int n_frames, const float* window, int detrend,
+                         int mode, int amp_sqrt, double norm_scale, double factor, int halve_edges,
+                         float2* tf, float* coh) {
+    namespace w1 = welch1k;
+    if (!x || !y || !window) return fail(c, DS_ERR_ARG, "ds_welch_tf: null argument");
+    if (n_cy <= 0 || n_samples <= 0 || hop <= 0 || hop > 1024 || n_frames <= 0 || ldx < n_samples ||
+        ldy < n_samples)
+        return fail(c, DS_ERR_ARG, "ds_welch_tf: bad shape");
+    if (mode < DS_TF_H1 || mode > DS_TF_H3) return fail(c, DS_ERR_ARG, "welch: unsupported transfer function type");
+    if (!c->stft1k_tables) {
+        std::vector<float2> h;
+        stft1k::host_tables(h);
+        CHK(upload_table_fwd(c, &c->stft1k_tables, h));
+    }
+    w1::Plan pl = w1::plan(n_frames, n_cy);
+    CHK(reserve(c, &c->ws, &c->ws_bytes, pl.bytes));
+    Carver cv(c->ws);
+    float2* xs = cv.take<float2>((size_t)pl.n_pairs * w1::N);
+    float* px = cv.take<float>((size_t)pl.n_pairs * w1::NB);
+    float* psx = cv.take<float>((size_t)pl.n_chunks * w1::NB);
+    float2* pxy = cv.take<float2>((size_t)pl.n_chunks * n_cy * w1::NB);
+    float* pyy = cv.take<float>((size_t)pl.n_chunks * n_cy * w1::NB);
+    const bool half = hop == 512;
+    w1::Args ax{x, n_samples, ldx, 1, hop, n_frames, pl.n_pairs, detrend, pl.n_chunks, pl.ppc, window,
+                c->stft1k_tables, (float4*)xs, px, pxy, pyy, psx};
+    auto kx = half ? w1::k_x<true> : w1::k_x<false>;
+    auto ky = half ? w1::k_y<true> : w1::k_y<false>;
+    CHK(launch(c, "welch1024_x", kx, dim3((pl.n_pairs + w1::WPB - 1) / w1::WPB), w1::NTB, w1::LDS_BYTES, ax));
+    w1::Args ay = ax;
+    ay.sig = y;
+    ay.ld = ldy;
+    ay.n_ch = n_cy;
+    const int n_grp = (n_cy + w1::WPB - 1) / w1::WPB;
+    CHK(launch(c, "welch1024_main", ky, dim3(pl.n_chunks * n_grp), w1::NTB, w1::LDS_BYTES, ay));
+    WelchFinArgs f{psx, pxy, pyy, pl.n_chunks, pl.n_chunks, 1, n_cy, 0, mode,
+                   FinishPar{norm_scale / (double)n_frames, factor, halve_edges, amp_sqrt, w1::NB},
+                   tf, coh};
+    int64_t total = (int64_t)w1::NB * n_cy;
+    CHK(launch(c, "welch_finish", k_welch_finish, dim3((unsigned)((total + 63) / 64)), 256, 0, f));
     return DS_OK;
 }
 
@@ -646,6 +692,10 @@ extern "C" int ds_welch_tf_dev(ds_ctx* c, const float* x, int n_cx, int64_t ldx,
     if (!tf || !coh) return fail(c, DS_ERR_ARG, "ds_welch_tf: null output");
     if (c && W == 4096 && n_cx == 1 && average == DS_AVG_MEAN && welch4096::enabled())
         return welch4096_run(c, x, ldx, y, n_cy, ldy, n_samples, hop, n_frames, window, detrend, mode,
+                             amp_sqrt, norm_scale, factor, halve_edges, (float2*)tf, coh);
+    static const bool no1k = getenv("DSPTOOLBOX_AMD_WELCH_GENERIC") != nullptr;
+    if (c && W == 1024 && n_cx == 1 && average == DS_AVG_MEAN && !no1k)
+        return welch1024_run(c, x, ldx, y, n_cy, ldy, n_samples, hop, n_frames, window, detrend, mode,
                              amp_sqrt, norm_scale, factor, halve_edges, (float2*)tf, coh);
     return welch_common(c, 0, x, n_cx, ldx, y, n_cy, ldy, n_samples, W, hop, n_frames, window, detrend,
                         average, mode, amp_sqrt, norm_scale, factor, halve_edges, (float2*)tf, coh);
@@ -972,7 +1022,7 @@ static int welch_big(ds_ctx* c, int kind, const float* x, int n_cx, int64_t ldx,
     WelchFinArgs f{pxx, pxy, pyy, 1, 1, n_cx, n_cy, kind, mode,
                    FinishPar{norm_scale / count, factor, halve_edges, amp_sqrt, nb}, out_c, out_r};
     int64_t total = (int64_t)nb * (kind == 1 ? n_cx : n_cy);
-    CHK(launch(c, "welch_finish", k_welch_finish, dim3((unsigned)((total + 255) / 256)), 256, 0, f));
+    CHK(launch(c, "welch_finish", k_welch_finish, dim3((unsigned)((total + 63) / 64)), 256, 0, f));
     return DS_OK;
 }
 

@@ -70,6 +70,53 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// The transform of one wave: v[n1] = z[t + 64 n1] (consumed) -> zo[m] = Z[t + 64 m].  `buf`: this
+// wave's LDS region (>= 16 * S1 complex, 16-byte aligned), tw1/tw2 the tables of host_tables() in
+// LDS.  Ends with buf free for reuse.
+struct NoHook {
+    __device__ __forceinline__ void operator()() const {}
+};
+// `behind_ex2` runs after the second exchange image has been written (v is dead there): global
+// loads issued from it overlap the LDS round trip and the last pass.
+template <typename Hook = NoHook>
+__device__ __forceinline__ void fft1024(float2 (&v)[16], float2 (&z)[16], float2* buf,
+                                        const float2* tw1, const float2* tw2, int t,
+                                        Hook behind_ex2 = Hook()) {
+    const int k1u = t >> 2, n3 = t & 3;
+    // ---- pass 1
+    w4::dft16(v);
+#pragma unroll
+    for (int k1 = 1; k1 < 16; ++k1) v[pos16(k1)] = cmul(v[pos16(k1)], tw1[(k1 - 1) * 64 + t]);
+#pragma unroll
+    for (int k1 = 0; k1 < 16; ++k1) buf[k1 * S1 + t] = v[pos16(k1)];
+    wave_sync();
+#pragma unroll
+    for (int n2 = 0; n2 < 16; ++n2) v[n2] = buf[k1u * S1 + 4 * n2 + n3];
+    wave_sync();
+    // ---- pass 2
+    w4::dft16(v);
+#pragma unroll
+    for (int k2 = 1; k2 < 16; ++k2) v[pos16(k2)] = cmul(v[pos16(k2)], tw2[k2 * 4 + n3]);
+#pragma unroll
+    for (int k2 = 0; k2 < 16; ++k2) buf[64 * k2 + t] = v[pos16(k2)];  // [(k1 + 16 k2)][n3]
+    behind_ex2();
+    wave_sync();
+    // ---- pass 3: pair (k1,k2) = t + 64 j, radix 4 over n3 -> Z[t + 64 (j + 4 k3)]
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float4* q = reinterpret_cast<const float4*>(buf + 4 * (t + 64 * j));
+        const float4 lo = q[0], hi = q[1];
+        float2 x0 = make_float2(lo.x, lo.y), x1 = make_float2(lo.z, lo.w);
+        float2 x2 = make_float2(hi.x, hi.y), x3 = make_float2(hi.z, hi.w);
+        w4::r4(x0, x1, x2, x3);
+        z[j] = x0;
+        z[j + 4] = x1;
+        z[j + 8] = x2;
+        z[j + 12] = x3;
+    }
+    wave_sync();
+}
+
 // grid = (ceil(ceil(n_frames/2)/fpw), ceil(n_ch/ct)); block = ct waves; p.tw = host_tables();
 // p.W <= 1024 (shorter windows are zero-padded); detrend requires p.W == 1024, where removing the
 // frame mean only clears bin 0 (a constant has no other bin).
@@ -108,7 +155,6 @@ __global__ __launch_bounds__(1024) void k_stft1024(StftArgs p) {
     // Drain the loads above before the loop: otherwise the wait for them is merged into the loop body
     // (vmcnt is a FIFO count) and stalls every iteration on the prefetch it has just issued.
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
-    const int k1u = t >> 2, n3 = t & 3;
     // 0.5 from the separation folded into the scale; lane 0 owns the edge bins 0 and N/2
     const float sc = p.scale, sce = p.scale * p.edge_scale;
     const float pe = p.scale, pee = p.scale * p.edge_scale * p.edge_scale;  // power mode
@@ -127,38 +173,8 @@ __global__ __launch_bounds__(1024) void k_stft1024(StftArgs p) {
             src(fp + 1, na, nb);
             dsk::load_raw_pair<N>(raw, na, nb, p.n_samples, p.W, t);
         }
-        // ---- pass 1
-        w4::dft16(v);
-#pragma unroll
-        for (int k1 = 1; k1 < 16; ++k1) v[pos16(k1)] = cmul(v[pos16(k1)], tw1[(k1 - 1) * 64 + t]);
-#pragma unroll
-        for (int k1 = 0; k1 < 16; ++k1) buf[k1 * S1 + t] = v[pos16(k1)];
-        wave_sync();
-#pragma unroll
-        for (int n2 = 0; n2 < 16; ++n2) v[n2] = buf[k1u * S1 + 4 * n2 + n3];
-        wave_sync();
-        // ---- pass 2
-        w4::dft16(v);
-#pragma unroll
-        for (int k2 = 1; k2 < 16; ++k2) v[pos16(k2)] = cmul(v[pos16(k2)], tw2[k2 * 4 + n3]);
-#pragma unroll
-        for (int k2 = 0; k2 < 16; ++k2) buf[64 * k2 + t] = v[pos16(k2)];  // [(k1 + 16 k2)][n3]
-        wave_sync();
-        // ---- pass 3: pair (k1,k2) = t + 64 j, radix 4 over n3 -> Z[t + 64 (j + 4 k3)]
         float2 z[16];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float4* q = reinterpret_cast<const float4*>(buf + 4 * (t + 64 * j));
-            const float4 lo = q[0], hi = q[1];
-            float2 x0 = make_float2(lo.x, lo.y), x1 = make_float2(lo.z, lo.w);
-            float2 x2 = make_float2(hi.x, hi.y), x3 = make_float2(hi.z, hi.w);
-            w4::r4(x0, x1, x2, x3);
-            z[j] = x0;
-            z[j + 4] = x1;
-            z[j + 8] = x2;
-            z[j + 12] = x3;
-        }
-        wave_sync();
+        fft1024(v, z, buf, tw1, tw2, t);
         // ---- separation: bins k = t + 64 j (j < 8) against Z[N - k], which sits in the upper half
 #pragma unroll
         for (int m = 8; m < 16; ++m) buf[t + 64 * m] = z[m];

@@ -1,0 +1,278 @@
+// Welch H1/H2/H3 with the reference's DEFAULT window (1024 samples,
+// classes/signal.py:497-508; tests/test_transfer_functions.py:716-737 call
+// compute_transfer_function with window_length_samples=1024) and ONE input channel: the algebra of
+// kernels_welch4096.hpp on the wave-level 1024-point transform of kernels_stft1024.hpp.
+//
+//   k_x : one WAVE per pair of input frames (2p, 2p+1):
+//           Wp = FFT1024( x_2p w + i x_2p+1 w )   -> xs[p][8][64] float4 (lane-major, L2 resident)
+//           (|Wp[k]|^2 + |Wp[N-k]|^2)/2           -> px[p][0..512]
+//   k_y : one wave per (chunk q of frame pairs, output channel c); the four waves of a workgroup
+//         take four channels of the SAME chunk, so they walk the same input spectra together
+//         (vector-L1 hits).  Per pair:  Zp = FFT1024( y_2p w + i y_2p+1 w ),
+//           T[k] += conj(Wp[k]) Zp[k] ,  P[k] += |Zp[k]|^2   (all 1024 bins, 16 per lane)
+//         folded k <-> N-k once per chunk.  No workgroup barrier inside the pair loop: a wave's LDS
+//         exchanges are ordered by the hardware.  Each workgroup also sums a slice of the chunk's
+//         px rows (fp64) -> psx[q].
+//   k_welch_finish (kernels_finish.hpp): chunks -> H, coherence.
+// Detrend = "skip bin 0" exactly as in kernels_welch4096.hpp.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "kernels_stft1024.hpp"
+
+namespace welch1k {
+
+using stft1k::fft1024;
+using stft1k::wave_sync;
+constexpr int N = 1024, NB = N / 2 + 1, NTB = 256, WPB = 4;  // waves per workgroup
+constexpr int REGION = stft1k::REGION;
+constexpr int LDS_BYTES = (WPB * REGION + stft1k::TW_LEN) * 8 + N * 4;  // 47 104 B: + the window
+
+struct Args {
+    const float* sig;  // x (k_x) or y (k_y), planar
+    int64_t n_samples, ld;
+    int n_ch, hop, n_frames, n_pairs, detrend;
+    int n_chunks, ppc;
+    const float* window;
+    const float2* twt;  // stft1k::host_tables()
+    float4* xs;         // [n_pairs][8][64]: lane t holds bins (t + 64*2g, t + 64*(2g+1))
+    float* px;          // [n_pairs][NB]
+    float2* pxy;        // [n_chunks][n_ch][NB]
+    float* pyy;         // [n_chunks][n_ch][NB]
+    float* psx;         // [n_chunks][NB]
+};
+
+// Raw samples of the frame pair (2p, 2p+1): HALF_HOP (hop == 512) -> 24 loads s[m] = ch[start +
+// t + 64 m] (frame a: m 0..15, frame b: m 8..23); otherwise 32.  Interior pairs load
+// unconditionally behind one wave-uniform test; the ragged tail clamps and selects.
+template <bool HALF_HOP>
+struct Raw {
+    float s[HALF_HOP ? 24 : 32];
+};
+template <bool HALF_HOP>
+__device__ __forceinline__ void load_raw(Raw<HALF_HOP>& r, const float* __restrict__ ch, int64_t n_samples,
+                                         int64_t start0, int hop, int t) {
+    const float* __restrict__ src = ch + start0;
+    const int64_t remain = n_samples - start0;
+    const int span = HALF_HOP ? 3 * 512 : hop + N;
+    constexpr int CNT = HALF_HOP ? 24 : 32;
+    if (remain >= span) {
+        if (HALF_HOP) {
+#pragma unroll
+            for (int m = 0; m < 24; ++m) r.s[m] = src[t + 64 * m];
+        } else {
+#pragma unroll
+            for (int n1 = 0; n1 < 16; ++n1) {
+                r.s[n1] = src[t + 64 * n1];
+                r.s[16 + n1] = src[hop + t + 64 * n1];
+            }
+        }
+    } else {
+        const int last = (int)(remain > (int64_t)(1 << 30) ? (1 << 30) : remain) - 1;  // >= 0
+#pragma unroll
+        for (int m = 0; m < CNT; ++m) {
+            const int i = HALF_HOP ? t + 64 * m : (m < 16 ? t + 64 * m : hop + t + 64 * (m - 16));
+            const float a = src[min(i, last)];
+            r.s[m] = i <= last ? a : 0.f;
+        }
+    }
+}
+template <bool HALF_HOP>
+__device__ __forceinline__ void window_pair(float2 (&v)[16], const Raw<HALF_HOP>& r, const float* winl, int t) {
+#pragma unroll
+    for (int n1 = 0; n1 < 16; ++n1) {
+        const float b = HALF_HOP ? r.s[n1 + 8] : r.s[16 + n1];
+        const float w = winl[t + 64 * n1];
+        v[n1] = make_float2(r.s[n1] * w, b * w);
+    }
+}
+// the last pair of an odd frame count when frame F would still overlap the signal
+__device__ __forceinline__ bool needs_drop(const Args& p, int pr) {
+    return pr == p.n_pairs - 1 && (p.n_frames & 1) && (int64_t)p.n_frames * p.hop < p.n_samples;
+}
+
+// twiddle tables and the window into LDS (the window is read from there at every pair: 16
+// registers less per lane than keeping it)
+__device__ __forceinline__ void load_tables(float2* tw1, float* winl, const Args& p) {
+    for (int i = threadIdx.x; i < stft1k::TW_LEN; i += NTB) tw1[i] = p.twt[i];
+    for (int i = threadIdx.x; i < N; i += NTB) winl[i] = p.window[i];
+}
+
+// ---- input spectra: grid = ceil(n_pairs / 4) ------------------------------------
+template <bool HALF_HOP>
+__global__ __launch_bounds__(NTB) void k_x(Args p) {
+    extern __shared__ __align__(16) float2 lds[];
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), t = threadIdx.x & 63;
+    float2* buf = lds + w * REGION;
+    float2* tw1 = lds + WPB * REGION;
+    const float2* tw2 = tw1 + stft1k::TW1;
+    const int pr = blockIdx.x * WPB + w;
+    const bool live = pr < p.n_pairs;
+    Raw<HALF_HOP> raw;
+    if (live) load_raw<HALF_HOP>(raw, p.sig, p.n_samples, (int64_t)(2 * pr) * p.hop, p.hop, t);
+    float* winl = reinterpret_cast<float*>(tw1 + stft1k::TW_LEN);
+    load_tables(tw1, winl, p);
+    __syncthreads();
+    if (!live) return;
+    float2 v[16], z[16];
+    window_pair<HALF_HOP>(v, raw, winl, t);
+    if (needs_drop(p, pr)) {
+#pragma unroll
+        for (int n1 = 0; n1 < 16; ++n1) v[n1].y = 0.f;
+    }
+    fft1024(v, z, buf, tw1, tw2, t);
+    if (p.detrend && t == 0) z[0] = make_float2(0.f, 0.f);
+    float4* xo = p.xs + (int64_t)pr * 512 + t;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) xo[64 * g] = make_float4(z[2 * g].x, z[2 * g].y, z[2 * g + 1].x, z[2 * g + 1].y);
+    float* pw = reinterpret_cast<float*>(buf);
+#pragma unroll
+    for (int m = 0; m < 16; ++m) pw[t + 64 * m] = z[m].x * z[m].x + z[m].y * z[m].y;
+    wave_sync();
+    float* po = p.px + (int64_t)pr * NB;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int k = t + 64 * j;
+        po[k] = 0.5f * (pw[k] + pw[(N - k) & (N - 1)]);
+    }
+    if (t == 0) po[512] = pw[512];
+}
+
+// ---- output channels: grid = n_chunks * ceil(n_ch / 4) ---------------------------
+template <bool HALF_HOP>
+__global__ __launch_bounds__(NTB, 3) void k_y(Args p) {
+    extern __shared__ __align__(16) float2 lds[];
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), t = threadIdx.x & 63;
+    float2* buf = lds + w * REGION;
+    float2* tw1 = lds + WPB * REGION;
+    const float2* tw2 = tw1 + stft1k::TW1;
+    const int n_grp = (p.n_ch + WPB - 1) / WPB;
+    // XCD-aware decode (workgroups b, b+8, ... share an XCD and its L2): whole chunks per XCD, so
+    // the input spectra a chunk's channel groups re-read stay in that L2
+    int q, g;
+    {
+        const int b = blockIdx.x;
+        if ((p.n_chunks & 7) == 0) {
+            const int per = p.n_chunks >> 3;
+            q = (b & 7) + 8 * ((b >> 3) % per);
+            g = (b >> 3) / per;
+        } else {
+            q = b % p.n_chunks;
+            g = b / p.n_chunks;
+        }
+    }
+    const int c = g * WPB + w;
+    const bool live = c < p.n_ch;
+    const int p0 = q * p.ppc, p1 = min(p0 + p.ppc, p.n_pairs);
+    const float* ch = p.sig + (int64_t)(live ? c : 0) * p.ld;
+    Raw<HALF_HOP> raw;
+    if (p0 < p1) load_raw<HALF_HOP>(raw, ch, p.n_samples, (int64_t)(2 * p0) * p.hop, p.hop, t);
+    float* winl = reinterpret_cast<float*>(tw1 + stft1k::TW_LEN);
+    load_tables(tw1, winl, p);
+    {
+        // input auto-spectrum of this chunk: this workgroup's slice of the bins, px rows summed in fp64
+        const int bpg = (NB + n_grp - 1) / n_grp;
+        const int b0 = g * bpg, b1 = min(b0 + bpg, NB);
+        for (int k = b0 + (int)threadIdx.x; k < b1; k += NTB) {
+            double sum = 0.0;
+            for (int pr = p0; pr < p1; ++pr) sum += (double)p.px[(int64_t)pr * NB + k];
+            p.psx[(int64_t)q * NB + k] = (float)sum;
+        }
+    }
+    __syncthreads();  // tables in LDS; the only workgroup barrier
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): keep the pre-loop loads out of the loop's wait counts
+    if (!live) return;
+    float2 T[16];
+    float P[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        T[j] = make_float2(0.f, 0.f);
+        P[j] = 0.f;
+    }
+    for (int pr = p0; pr < p1; ++pr) {
+        float2 v[16], z[16];
+        window_pair<HALF_HOP>(v, raw, winl, t);
+        if (needs_drop(p, pr)) {
+#pragma unroll
+            for (int n1 = 0; n1 < 16; ++n1) v[n1].y = 0.f;
+        }
+        if (pr + 1 < p1) load_raw<HALF_HOP>(raw, ch, p.n_samples, (int64_t)(2 * pr + 2) * p.hop, p.hop, t);
+        // this pair's input spectrum is requested behind the second exchange (registers of v free)
+        float4 xq[8];
+        auto issue_xs = [&]() {
+            __builtin_amdgcn_sched_barrier(0);
+            const float4* __restrict__ xp = p.xs + (int64_t)pr * 512 + t;
+#pragma unroll
+            for (int gg = 0; gg < 8; ++gg) xq[gg] = xp[64 * gg];
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        fft1024(v, z, buf, tw1, tw2, t, issue_xs);
+#pragma unroll
+        for (int gg = 0; gg < 8; ++gg) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const float2 xw = h ? make_float2(xq[gg].z, xq[gg].w) : make_float2(xq[gg].x, xq[gg].y);
+                const float2 zz = z[2 * gg + h];
+                float2& Tm = T[2 * gg + h];
+                Tm.x = fmaf(xw.x, zz.x, fmaf(xw.y, zz.y, Tm.x));  // conj(xw) zz
+                Tm.y = fmaf(xw.x, zz.y, fmaf(-xw.y, zz.x, Tm.y));
+                P[2 * gg + h] = fmaf(zz.x, zz.x, fmaf(zz.y, zz.y, P[2 * gg + h]));
+            }
+        }
+    }
+    if (p.detrend && t == 0) P[0] = 0.f;  // xs bin 0 is already 0 -> T[0] = 0
+    // fold k <-> N-k once per chunk through this wave's LDS region
+    const int64_t so = ((int64_t)q * p.n_ch + c) * NB;
+#pragma unroll
+    for (int m = 0; m < 16; ++m) buf[t + 64 * m] = T[m];
+    wave_sync();
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int k = t + 64 * j;
+        const float2 a = buf[k], b = buf[(N - k) & (N - 1)];
+        p.pxy[so + k] = make_float2(0.5f * (a.x + b.x), 0.5f * (a.y - b.y));
+    }
+    if (t == 0) p.pxy[so + 512] = make_float2(buf[512].x, 0.f);
+    wave_sync();
+    float* pw = reinterpret_cast<float*>(buf);
+#pragma unroll
+    for (int m = 0; m < 16; ++m) pw[t + 64 * m] = P[m];
+    wave_sync();
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int k = t + 64 * j;
+        p.pyy[so + k] = 0.5f * (pw[k] + pw[(N - k) & (N - 1)]);
+    }
+    if (t == 0) p.pyy[so + 512] = pw[512];
+}
+
+// ---- host side -------------------------------------------------------------------
+struct Plan {
+    int n_pairs, n_chunks, ppc;
+    size_t bytes;
+};
+inline Plan plan(int n_frames, int n_cy) {
+    Plan pl;
+    pl.n_pairs = (n_frames + 1) / 2;
+    const int n_grp = (n_cy + WPB - 1) / WPB;
+    // three workgroups per CU (768 on the 256 CUs) resident at once when there is enough work;
+    // fp32 accumulation chains stay <= 64 pairs
+    int want = (768 + n_grp - 1) / n_grp;
+    want = (want + 7) & ~7;
+    const int by_len = (pl.n_pairs + 63) / 64;
+    if (want < by_len) want = (by_len + 7) & ~7;
+    if (const char* e = getenv("DSPTOOLBOX_AMD_WELCH1K_CHUNKS")) {
+        if (atoi(e) > 0) want = atoi(e);
+    }
+    want = std::max(1, std::min(want, pl.n_pairs));
+    pl.ppc = (pl.n_pairs + want - 1) / want;
+    pl.n_chunks = (pl.n_pairs + pl.ppc - 1) / pl.ppc;
+    auto pad = [](size_t b) { return (b + 255) & ~size_t(255); };
+    pl.bytes = pad(sizeof(float2) * (size_t)pl.n_pairs * N) + pad(sizeof(float) * (size_t)pl.n_pairs * NB) +
+               pad(sizeof(float) * (size_t)pl.n_chunks * NB) + pad(sizeof(float2) * (size_t)pl.n_chunks * n_cy * NB) +
+               pad(sizeof(float) * (size_t)pl.n_chunks * n_cy * NB);
+    return pl;
+}
+
+}  // namespace welch1k

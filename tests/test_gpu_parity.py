@@ -654,6 +654,37 @@ def test_fir_streaming_classes_golden():
         f1.set_n_channels(2)
 
 
+def test_welch_default_window_kernel_vs_oracle():
+    """Welch H1/H2/H3 with the reference's default 1024-sample window and a 1-channel input runs on
+    its own kernels (kernels_welch1024.hpp: one wave per frame pair / per chunk and channel).
+    Channel counts around the 4-wave workgroup, overlaps 0 / 50 / 75 %, odd frame counts, ragged
+    tails, detrend, the three estimators, amplitude and power scalings."""
+    rng = np.random.default_rng(99)
+    worst = 0.0
+    for n_cy, n, ov, det, mode, sc in (
+            (1, 40000, 50, True, "H1", SpectrumScaling.FFTBackward),
+            (3, 70001, 50, False, "H2", SpectrumScaling.FFTBackward),
+            (4, 65536, 75, True, "H3", SpectrumScaling.PowerSpectralDensity),
+            (6, 50000, 0, True, "H1", SpectrumScaling.AmplitudeSpectrum),
+            (9, 33333, 50, False, "H1", SpectrumScaling.PowerSpectrum),
+            (64, 2**17, 50, True, "H1", SpectrumScaling.FFTBackward),
+            (2, 1500, 50, True, "H2", SpectrumScaling.FFTBackward),
+            (5, 2100, 50, False, "H1", SpectrumScaling.FFTBackward)):
+        x = rng.standard_normal((n, 1)) * 0.4 + 0.1
+        h = rng.standard_normal((64, n_cy)) * np.exp(-np.arange(64) / 10.0)[:, None]
+        y = np.stack([np.convolve(x[:, 0], h[:, c])[:n] for c in range(n_cy)], axis=1)
+        y += 0.05 * rng.standard_normal(y.shape) + 0.02
+        tf, coh = backend.welch_transfer_function(y, x, 48000, 1024, mode, overlap_percent=ov,
+                                                  detrend=det, scaling=sc)
+        rt, rc = orc.compute_transfer_function(y, x, 48000, 1024, mode, overlap_percent=ov, detrend=det,
+                                               scaling=sc.name)
+        sl = slice(1, None) if det else slice(None)  # detrended DC is 0/0 on both sides
+        e = max(relmax(tf[sl], rt[sl]), relmax(coh[sl], rc[sl]))
+        worst = max(worst, e)
+        assert e < TOL, (n_cy, n, ov, det, mode, sc, e)
+    print("welch 1024-window kernel worst rel-max", worst)
+
+
 def test_stft_default_frame_kernel_vs_oracle():
     """The 1024-sample frame has its own kernel (kernels_stft1024.hpp: one wave per frame pair, the
     transform in registers): channel tiles with idle waves (1, 3, 5, 9, 17 channels), odd and even
