@@ -684,6 +684,36 @@ static int welch1024_run(ds_ctx* c, const float* x, int64_t ldx, const float* y,
     return DS_OK;
 }
 
+// auto spectra of every channel, window 1024 (Signal.get_spectrum's default parameters)
+static int welch1024_psd_run(ds_ctx* c, const float* x, int n_cx, int64_t ldx, int64_t n_samples, int hop,
+                             int n_frames, const float* window, int detrend, int amp_sqrt, double norm_scale,
+                             double factor, int halve_edges, float* psd) {
+    namespace w1 = welch1k;
+    if (!x || !window) return fail(c, DS_ERR_ARG, "ds_welch_psd: null argument");
+    if (n_cx <= 0 || n_samples <= 0 || hop <= 0 || hop > 1024 || n_frames <= 0 || ldx < n_samples)
+        return fail(c, DS_ERR_ARG, "ds_welch_psd: bad shape");
+    if (!c->stft1k_tables) {
+        std::vector<float2> h;
+        stft1k::host_tables(h);
+        CHK(upload_table_fwd(c, &c->stft1k_tables, h));
+    }
+    w1::Plan pl = w1::plan(n_frames, n_cx);
+    CHK(reserve(c, &c->ws, &c->ws_bytes, Carver::pad(sizeof(float) * (size_t)pl.n_chunks * n_cx * w1::NB)));
+    Carver cv(c->ws);
+    float* pyy = cv.take<float>((size_t)pl.n_chunks * n_cx * w1::NB);
+    w1::Args a{x, n_samples, ldx, n_cx, hop, n_frames, pl.n_pairs, detrend, pl.n_chunks, pl.ppc, window,
+               c->stft1k_tables, nullptr, nullptr, nullptr, pyy, nullptr};
+    auto ky = hop == 512 ? w1::k_y<true, true> : w1::k_y<false, true>;
+    const int n_grp = (n_cx + w1::WPB - 1) / w1::WPB;
+    CHK(launch(c, "welch1024_main", ky, dim3(pl.n_chunks * n_grp), w1::NTB, w1::LDS_BYTES, a));
+    WelchFinArgs f{pyy, nullptr, nullptr, pl.n_chunks, pl.n_chunks, n_cx, 0, 1, 0,
+                   FinishPar{norm_scale / (double)n_frames, factor, halve_edges, amp_sqrt, w1::NB},
+                   nullptr, psd};
+    int64_t total = (int64_t)w1::NB * n_cx;
+    CHK(launch(c, "welch_finish", k_welch_finish, dim3((unsigned)((total + 63) / 64)), 256, 0, f));
+    return DS_OK;
+}
+
 extern "C" int ds_welch_tf_dev(ds_ctx* c, const float* x, int n_cx, int64_t ldx, const float* y,
                                int n_cy, int64_t ldy, int64_t n_samples, int W, int hop, int n_frames,
                                const float* window, int detrend, int average, int mode, int amp_sqrt,
@@ -705,6 +735,10 @@ extern "C" int ds_welch_psd_dev(ds_ctx* c, const float* x, int n_cx, int64_t ldx
                                 int average, int amp_sqrt, double norm_scale, double factor,
                                 int halve_edges, float* psd) {
     if (!psd) return fail(c, DS_ERR_ARG, "ds_welch_psd: null output");
+    static const bool no1k = getenv("DSPTOOLBOX_AMD_WELCH_GENERIC") != nullptr;
+    if (c && W == 1024 && average == DS_AVG_MEAN && !no1k)
+        return welch1024_psd_run(c, x, n_cx, ldx, n_samples, hop, n_frames, window, detrend, amp_sqrt,
+                                 norm_scale, factor, halve_edges, psd);
     return welch_common(c, 1, x, n_cx, ldx, nullptr, 0, 0, n_samples, W, hop, n_frames, window, detrend,
                         average, 0, amp_sqrt, norm_scale, factor, halve_edges, nullptr, psd);
 }

@@ -140,7 +140,8 @@ __global__ __launch_bounds__(NTB) void k_x(Args p) {
 }
 
 // ---- output channels: grid = n_chunks * ceil(n_ch / 4) ---------------------------
-template <bool HALF_HOP>
+// AUTO: auto spectra only (Signal.get_spectrum's default call): no input spectra, no cross sums.
+template <bool HALF_HOP, bool AUTO = false>
 __global__ __launch_bounds__(NTB, 3) void k_y(Args p) {
     extern __shared__ __align__(16) float2 lds[];
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), t = threadIdx.x & 63;
@@ -170,7 +171,7 @@ __global__ __launch_bounds__(NTB, 3) void k_y(Args p) {
     if (p0 < p1) load_raw<HALF_HOP>(raw, ch, p.n_samples, (int64_t)(2 * p0) * p.hop, p.hop, t);
     float* winl = reinterpret_cast<float*>(tw1 + stft1k::TW_LEN);
     load_tables(tw1, winl, p);
-    {
+    if (!AUTO) {
         // input auto-spectrum of this chunk: this workgroup's slice of the bins, px rows summed in fp64
         const int bpg = (NB + n_grp - 1) / n_grp;
         const int b0 = g * bpg, b1 = min(b0 + bpg, NB);
@@ -199,42 +200,50 @@ __global__ __launch_bounds__(NTB, 3) void k_y(Args p) {
         }
         if (pr + 1 < p1) load_raw<HALF_HOP>(raw, ch, p.n_samples, (int64_t)(2 * pr + 2) * p.hop, p.hop, t);
         // this pair's input spectrum is requested behind the second exchange (registers of v free)
-        float4 xq[8];
-        auto issue_xs = [&]() {
-            __builtin_amdgcn_sched_barrier(0);
-            const float4* __restrict__ xp = p.xs + (int64_t)pr * 512 + t;
+        if constexpr (AUTO) {
+            fft1024(v, z, buf, tw1, tw2, t);
 #pragma unroll
-            for (int gg = 0; gg < 8; ++gg) xq[gg] = xp[64 * gg];
-            __builtin_amdgcn_sched_barrier(0);
-        };
-        fft1024(v, z, buf, tw1, tw2, t, issue_xs);
+            for (int m = 0; m < 16; ++m) P[m] = fmaf(z[m].x, z[m].x, fmaf(z[m].y, z[m].y, P[m]));
+        } else {
+            float4 xq[8];
+            auto issue_xs = [&]() {
+                __builtin_amdgcn_sched_barrier(0);
+                const float4* __restrict__ xp = p.xs + (int64_t)pr * 512 + t;
 #pragma unroll
-        for (int gg = 0; gg < 8; ++gg) {
+                for (int gg = 0; gg < 8; ++gg) xq[gg] = xp[64 * gg];
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            fft1024(v, z, buf, tw1, tw2, t, issue_xs);
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const float2 xw = h ? make_float2(xq[gg].z, xq[gg].w) : make_float2(xq[gg].x, xq[gg].y);
-                const float2 zz = z[2 * gg + h];
-                float2& Tm = T[2 * gg + h];
-                Tm.x = fmaf(xw.x, zz.x, fmaf(xw.y, zz.y, Tm.x));  // conj(xw) zz
-                Tm.y = fmaf(xw.x, zz.y, fmaf(-xw.y, zz.x, Tm.y));
-                P[2 * gg + h] = fmaf(zz.x, zz.x, fmaf(zz.y, zz.y, P[2 * gg + h]));
+            for (int gg = 0; gg < 8; ++gg) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const float2 xw = h ? make_float2(xq[gg].z, xq[gg].w) : make_float2(xq[gg].x, xq[gg].y);
+                    const float2 zz = z[2 * gg + h];
+                    float2& Tm = T[2 * gg + h];
+                    Tm.x = fmaf(xw.x, zz.x, fmaf(xw.y, zz.y, Tm.x));  // conj(xw) zz
+                    Tm.y = fmaf(xw.x, zz.y, fmaf(-xw.y, zz.x, Tm.y));
+                    P[2 * gg + h] = fmaf(zz.x, zz.x, fmaf(zz.y, zz.y, P[2 * gg + h]));
+                }
             }
         }
     }
     if (p.detrend && t == 0) P[0] = 0.f;  // xs bin 0 is already 0 -> T[0] = 0
     // fold k <-> N-k once per chunk through this wave's LDS region
     const int64_t so = ((int64_t)q * p.n_ch + c) * NB;
+    if (!AUTO) {
 #pragma unroll
-    for (int m = 0; m < 16; ++m) buf[t + 64 * m] = T[m];
-    wave_sync();
+        for (int m = 0; m < 16; ++m) buf[t + 64 * m] = T[m];
+        wave_sync();
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int k = t + 64 * j;
-        const float2 a = buf[k], b = buf[(N - k) & (N - 1)];
-        p.pxy[so + k] = make_float2(0.5f * (a.x + b.x), 0.5f * (a.y - b.y));
+        for (int j = 0; j < 8; ++j) {
+            const int k = t + 64 * j;
+            const float2 a = buf[k], b = buf[(N - k) & (N - 1)];
+            p.pxy[so + k] = make_float2(0.5f * (a.x + b.x), 0.5f * (a.y - b.y));
+        }
+        if (t == 0) p.pxy[so + 512] = make_float2(buf[512].x, 0.f);
+        wave_sync();
     }
-    if (t == 0) p.pxy[so + 512] = make_float2(buf[512].x, 0.f);
-    wave_sync();
     float* pw = reinterpret_cast<float*>(buf);
 #pragma unroll
     for (int m = 0; m < 16; ++m) pw[t + 64 * m] = P[m];

@@ -682,6 +682,17 @@ def test_welch_default_window_kernel_vs_oracle():
         e = max(relmax(tf[sl], rt[sl]), relmax(coh[sl], rc[sl]))
         worst = max(worst, e)
         assert e < TOL, (n_cy, n, ov, det, mode, sc, e)
+    # auto spectra (Signal.get_spectrum's default parameters) on the same kernels
+    for n_ch, n, ov, det, sc in ((1, 30000, 50, True, SpectrumScaling.FFTBackward),
+                                 (3, 44100, 75, False, SpectrumScaling.PowerSpectralDensity),
+                                 (7, 20000, 0, True, SpectrumScaling.AmplitudeSpectralDensity),
+                                 (64, 2**16, 50, True, SpectrumScaling.PowerSpectrum)):
+        x = rng.standard_normal((n, n_ch)) * (0.1 + 0.05 * np.arange(n_ch)) + 0.03
+        psd = backend._welch(x, None, 48000, Window.Hann, 1024, ov, det, "mean", sc)
+        ref = orc.welch(x, None, 48000, "hann", 1024, ov, det, "mean", sc.name)
+        e = relmax(psd, ref, det)
+        worst = max(worst, e)
+        assert psd.shape == ref.shape and e < TOL, (n_ch, n, ov, det, sc, e)
     print("welch 1024-window kernel worst rel-max", worst)
 
 
