@@ -452,7 +452,7 @@ def main():
         achieved = alg / launches_per_step / (dom_ms * 1e-3) / 1e12
         roof = dict(bound="mfma", achieved=achieved, peak=MFMA_F32_PEAK_TFLOPS, unit="TFLOP/s",
                     frac=achieved / MFMA_F32_PEAK_TFLOPS, traffic=None)
-    hints = {"welch4096_main": ("k_y<",), "welch_yacc": ("k_yacc",), "fir": ("fir16k::k_fir", "k_fir<"),
+    hints = {"welch4096_main": ("k_y<",), "welch_yacc": ("k_yacc",), "fir": ("fir16k::k_fir<true>", "fir16k::k_fir", "k_fir<"),
              "csm_gemm": ("k_csm_gemm",), "deconv": ("k_deconv",)}.get(dom, (dom,))
     traffic, src = None, None
     for hint in hints:
