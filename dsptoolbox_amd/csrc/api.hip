@@ -496,6 +496,19 @@ static WelchPlan plan_welch(int n_frames, int units) {
 }
 
 // kind 0: tf+coh, 1: psd of x, 2: csd of (x[c], y[c])
+// Median kernels keep `series` float series of n_frames values per bin in LDS: the number of bins
+// per workgroup (8, 4, 2 or 1) that fits 150 KB; 0 if not even one does.
+static int median_bins_per_block(int series, int n_frames, size_t* lds) {
+    for (int bpb = 8; bpb >= 1; bpb >>= 1) {
+        const size_t need = ((size_t)bpb * series * n_frames + (size_t)bpb * series * 2) * sizeof(float);
+        if (need <= 150 * 1024) {
+            *lds = need;
+            return bpb;
+        }
+    }
+    return 0;
+}
+
 static int welch_common(ds_ctx* c, int kind, const float* x, int n_cx, int64_t ldx, const float* y,
                         int n_cy, int64_t ldy, int64_t n_samples, int W, int hop, int n_frames,
                         const float* window, int detrend, int average, int mode, int amp_sqrt,
@@ -524,9 +537,10 @@ static int welch_common(ds_ctx* c, int kind, const float* x, int n_cx, int64_t l
         // frame spectra of x (and y) -> per-bin medians -> the usual finish with bias n
         // (n = F or F-1, odd; the reference's `csd /= sum((-1)**(n+1)/n)` multiplies by n)
         const int nyc = kind == 1 ? 0 : n_cy;
-        const size_t lds = ((size_t)8 * 3 * n_frames + 48) * sizeof(float);
-        if (lds > 150 * 1024)
-            return fail(c, DS_ERR_UNSUP, "welch: median averaging over more than ~1590 frames is not built yet");
+        size_t lds = 0;
+        const int bpb = median_bins_per_block(3, n_frames, &lds);
+        if (!bpb)
+            return fail(c, DS_ERR_UNSUP, "welch: median averaging over more than 12 799 frames is not built yet");
         size_t mb = Carver::pad(sizeof(float2) * (size_t)n_cx * n_frames * nb) +
                     Carver::pad(sizeof(float2) * (size_t)nyc * n_frames * nb) +
                     Carver::pad(sizeof(float) * (size_t)pl.n_chunks * std::max(n_cx, nyc) * nb) +
@@ -548,8 +562,8 @@ static int welch_common(ds_ctx* c, int kind, const float* x, int n_cx, int64_t l
             XspecArgs ay{y, n_samples, ldy, nyc, W, hop, n_frames, detrend, pl.fpc, window, tw, ysp, scratch};
             DISPATCH_N(W, CHK(launch(c, "welch_xspec", k_xspec<NN>, dim3(pl.n_chunks, nyc), Cfg<NN>::NT, Cfg<NN>::LDS_BYTES, ay)));
         }
-        MedianArgs m{xsp, ysp, n_cx, nyc, n_frames, nb, kind, mxx, mxy, myy};
-        CHK(launch(c, "welch_median", k_welch_median, dim3((nb + 7) / 8, kind == 1 ? n_cx : n_cy), 256, lds, m));
+        MedianArgs m{xsp, ysp, n_cx, nyc, n_frames, nb, kind, bpb, mxx, mxy, myy};
+        CHK(launch(c, "welch_median", k_welch_median, dim3((nb + bpb - 1) / bpb, kind == 1 ? n_cx : n_cy), 256, lds, m));
         const int nbias = (n_frames & 1) ? n_frames : n_frames - 1;
         WelchFinArgs f{mxx, mxy, myy, 1, 1, n_cx, n_cy, kind, mode,
                        FinishPar{norm_scale * (double)std::max(1, nbias), factor, halve_edges, amp_sqrt, nb},
@@ -770,9 +784,10 @@ static int csm_dev(ds_ctx* c, const float* x, int n_ch, int64_t ld, int64_t n_sa
         return fail(c, DS_ERR_UNSUP, "ds_csm: a bin range with median averaging is not built yet");
     if (average == DS_AVG_MEDIAN) {
         // spectra of every frame [c][F][nb] -> per-pair, per-bin medians
-        const size_t lds = ((size_t)8 * 2 * n_frames + 32) * sizeof(float);
-        if (lds > 150 * 1024)
-            return fail(c, DS_ERR_UNSUP, "ds_csm: median averaging over more than ~2390 frames is not built yet");
+        size_t lds = 0;
+        const int bpb = median_bins_per_block(2, n_frames, &lds);
+        if (!bpb)
+            return fail(c, DS_ERR_UNSUP, "ds_csm: median averaging over more than 19 199 frames is not built yet");
         size_t bytes = Carver::pad(sizeof(float2) * (size_t)n_ch * n_frames * nb);
         WelchPlan pl = plan_welch(n_frames, n_ch);
         bytes += big ? stft_big_ws(n_ch, n_frames, W) : Carver::pad(sizeof(float) * (size_t)pl.n_chunks * n_ch * nb);
@@ -789,10 +804,10 @@ static int csm_dev(ds_ctx* c, const float* x, int n_ch, int64_t ld, int64_t n_sa
             DISPATCH_N(W, CHK(launch(c, "welch_xspec", k_xspec<NN>, dim3(pl.n_chunks, n_ch), Cfg<NN>::NT, Cfg<NN>::LDS_BYTES, ax)));
         }
         const int nbias = (n_frames & 1) ? n_frames : n_frames - 1;
-        CsmMedianArgs m{xsp, n_ch, n_frames,
+        CsmMedianArgs m{xsp, n_ch, n_frames, bpb,
                         FinishPar{norm_scale * (double)std::max(1, nbias), factor, halve_edges, amp_sqrt, nb},
                         (float2*)csm};
-        CHK(launch(c, "csm_median", k_csm_median, dim3((nb + 7) / 8, n_ch * (n_ch + 1) / 2), 256, lds, m));
+        CHK(launch(c, "csm_median", k_csm_median, dim3((nb + bpb - 1) / bpb, n_ch * (n_ch + 1) / 2), 256, lds, m));
         return DS_OK;
     }
     // the STFT buffer X[b][f][c] (+ the four-step scratch for long windows) in the workspace
@@ -1020,9 +1035,10 @@ static int welch_big(ds_ctx* c, int kind, const float* x, int n_cx, int64_t ldx,
     const int nb = W / 2 + 1;
     const int nyc = kind == 1 ? 0 : n_cy;
     const int nmax = std::max(n_cx, nyc);
-    const size_t med_lds = ((size_t)8 * 3 * n_frames + 48) * sizeof(float);
-    if (average == DS_AVG_MEDIAN && med_lds > 150 * 1024)
-        return fail(c, DS_ERR_UNSUP, "welch: median averaging over more than ~1590 frames is not built yet");
+    size_t med_lds = 0;
+    const int med_bpb = median_bins_per_block(3, n_frames, &med_lds);
+    if (average == DS_AVG_MEDIAN && !med_bpb)
+        return fail(c, DS_ERR_UNSUP, "welch: median averaging over more than 12 799 frames is not built yet");
     size_t bytes = stft_big_ws(nmax, n_frames, W) + Carver::pad(sizeof(float2) * (size_t)n_cx * n_frames * nb) +
                    Carver::pad(sizeof(float2) * (size_t)std::max(1, nyc) * n_frames * nb) +
                    Carver::pad(sizeof(float) * (size_t)n_cx * nb) +
@@ -1045,8 +1061,9 @@ static int welch_big(ds_ctx* c, int kind, const float* x, int n_cx, int64_t ldx,
     }
     double count = (double)n_frames;
     if (average == DS_AVG_MEDIAN) {
-        MedianArgs m{xsp, nyc ? ysp : nullptr, n_cx, nyc, n_frames, nb, kind, pxx, pxy, pyy};
-        CHK(launch(c, "welch_median", k_welch_median, dim3((nb + 7) / 8, kind == 1 ? n_cx : n_cy), 256, med_lds, m));
+        MedianArgs m{xsp, nyc ? ysp : nullptr, n_cx, nyc, n_frames, nb, kind, med_bpb, pxx, pxy, pyy};
+        CHK(launch(c, "welch_median", k_welch_median, dim3((nb + med_bpb - 1) / med_bpb, kind == 1 ? n_cx : n_cy), 256,
+                   med_lds, m));
         const int nbias = (n_frames & 1) ? n_frames : n_frames - 1;
         count = 1.0 / (double)std::max(1, nbias);
     } else {

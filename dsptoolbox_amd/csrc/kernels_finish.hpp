@@ -155,6 +155,7 @@ struct MedianArgs {
     const float2* xs;  // [n_cx][F][nb]
     const float2* ys;  // [n_cy][F][nb] or nullptr (auto spectra of xs only)
     int n_cx, n_cy, n_frames, nb, kind;  // kind as in WelchFinArgs
+    int bpb;      // bins per workgroup: 8, 4, 2 or 1 (what fits the LDS for this frame count)
     float* pxx;   // [n_cx][nb]
     float2* pxy;  // [n_cy][nb]
     float* pyy;   // [n_cy][nb]
@@ -177,19 +178,20 @@ __device__ __forceinline__ float median_of(const float* s, int F, int tid, int n
 }
 
 __global__ __launch_bounds__(256) void k_welch_median(MedianArgs p) {
-    extern __shared__ float ser[];  // [8 bins][3 series][F]  (+ 8*3*2 results)
+    extern __shared__ float ser[];  // [bpb bins][3 series][F]  (+ bpb*3*2 results)
     const int F = p.n_frames, nb = p.nb;
-    const int b0 = blockIdx.x * 8, c = blockIdx.y;
+    const int BP = p.bpb, lb = __ffs(BP) - 1;
+    const int b0 = blockIdx.x * BP, c = blockIdx.y;
     const int tid = threadIdx.x;
     const bool have_y = p.ys != nullptr;
     const int cx = p.n_cx == 1 ? 0 : c;
-    float* res = ser + (size_t)8 * 3 * F;  // [8][3][2]
+    float* res = ser + (size_t)BP * 3 * F;  // [bpb][3][2]
     // series 0: |X|^2 (kind 0: of xs[cx]; kind 1: of xs[c]); 1: Re conj(X) Y; 2: Im conj(X) Y; for kind 0
     // |Y|^2 replaces series 0 in a second sweep below
     const float2* X = p.xs + (size_t)(p.kind == 1 ? c : cx) * F * nb;
     const float2* Y = have_y ? p.ys + (size_t)c * F * nb : nullptr;
-    for (int i = tid; i < 8 * F; i += 256) {
-        const int bl = i & 7, f = i >> 3, b = b0 + bl;
+    for (int i = tid; i < BP * F; i += 256) {
+        const int bl = i & (BP - 1), f = i >> lb, b = b0 + bl;
         float2 xv = make_float2(0.f, 0.f), yv = make_float2(0.f, 0.f);
         if (b < nb) {
             xv = X[(size_t)f * nb + b];
@@ -201,10 +203,10 @@ __global__ __launch_bounds__(256) void k_welch_median(MedianArgs p) {
     }
     __syncthreads();
     const int ns = have_y ? 3 : 1;
-    for (int bl = 0; bl < 8; ++bl)
+    for (int bl = 0; bl < BP; ++bl)
         for (int q = 0; q < ns; ++q) median_of(ser + (bl * 3 + q) * F, F, tid, 256, res + (bl * 3 + q) * 2);
     __syncthreads();
-    if (tid < 8 && b0 + tid < nb) {
+    if (tid < BP && b0 + tid < nb) {
         const int b = b0 + tid;
         const float* r = res + tid * 6;
         const float mxx = 0.5f * (r[0] + r[1]);
@@ -223,9 +225,9 @@ __global__ __launch_bounds__(256) void k_welch_median(MedianArgs p) {
             ser[(bl * 3 + 0) * F + f] = yv.x * yv.x + yv.y * yv.y;
         }
         __syncthreads();
-        for (int bl = 0; bl < 8; ++bl) median_of(ser + (bl * 3) * F, F, tid, 256, res + (bl * 3) * 2);
+        for (int bl = 0; bl < BP; ++bl) median_of(ser + (bl * 3) * F, F, tid, 256, res + (bl * 3) * 2);
         __syncthreads();
-        if (tid < 8 && b0 + tid < nb) p.pyy[(size_t)c * nb + b0 + tid] = 0.5f * (res[tid * 6] + res[tid * 6 + 1]);
+        if (tid < BP && b0 + tid < nb) p.pyy[(size_t)c * nb + b0 + tid] = 0.5f * (res[tid * 6] + res[tid * 6 + 1]);
     }
 }
 
@@ -236,13 +238,15 @@ __global__ __launch_bounds__(256) void k_welch_median(MedianArgs p) {
 struct CsmMedianArgs {
     const float2* xs;
     int n_ch, n_frames;
+    int bpb;        // bins per workgroup: 8, 4, 2 or 1
     FinishPar fin;  // fin.scale already holds norm_scale * n_bias
     float2* csm;    // [nb][C][C]
 };
 __global__ __launch_bounds__(256) void k_csm_median(CsmMedianArgs p) {
-    extern __shared__ float ser[];  // [8 bins][2 series][F] (+ 8*2*2 results)
+    extern __shared__ float ser[];  // [bpb bins][2 series][F] (+ bpb*2*2 results)
     const int F = p.n_frames, nb = p.fin.nb, C = p.n_ch;
-    const int b0 = blockIdx.x * 8, tid = threadIdx.x;
+    const int BP = p.bpb, lb = __ffs(BP) - 1;
+    const int b0 = blockIdx.x * BP, tid = threadIdx.x;
     // triangular decode: pair index -> (i1 <= i2), rows of length C, C-1, ...
     int i1 = 0, rem = blockIdx.y;
     while (rem >= C - i1) {
@@ -250,11 +254,11 @@ __global__ __launch_bounds__(256) void k_csm_median(CsmMedianArgs p) {
         ++i1;
     }
     const int i2 = i1 + rem;
-    float* res = ser + (size_t)8 * 2 * F;
+    float* res = ser + (size_t)BP * 2 * F;
     const float2* X = p.xs + (size_t)i1 * F * nb;
     const float2* Y = p.xs + (size_t)i2 * F * nb;
-    for (int i = tid; i < 8 * F; i += 256) {
-        const int bl = i & 7, f = i >> 3, b = b0 + bl;
+    for (int i = tid; i < BP * F; i += 256) {
+        const int bl = i & (BP - 1), f = i >> lb, b = b0 + bl;
         float2 xv = make_float2(0.f, 0.f), yv = make_float2(0.f, 0.f);
         if (b < nb) {
             xv = X[(size_t)f * nb + b];
@@ -264,9 +268,9 @@ __global__ __launch_bounds__(256) void k_csm_median(CsmMedianArgs p) {
         ser[(bl * 2 + 1) * F + f] = xv.x * yv.y - xv.y * yv.x;
     }
     __syncthreads();
-    for (int q = 0; q < 16; ++q) median_of(ser + (size_t)q * F, F, tid, 256, res + q * 2);
+    for (int q = 0; q < 2 * BP; ++q) median_of(ser + (size_t)q * F, F, tid, 256, res + q * 2);
     __syncthreads();
-    if (tid < 8 && b0 + tid < nb) {
+    if (tid < BP && b0 + tid < nb) {
         const int b = b0 + tid;
         const float* r = res + tid * 4;
         cd m{0.5 * ((double)r[0] + (double)r[1]), 0.5 * ((double)r[2] + (double)r[3]) + 0.0};

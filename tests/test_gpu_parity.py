@@ -527,6 +527,26 @@ def test_transfer_function_median_vs_oracle():
             assert relmax(tf, rt, True) < TOL and relmax(coh, rc, True) < 10 * TOL, (mode, W)
 
 
+def test_median_many_frames_vs_oracle():
+    """Median averaging over more frames than eight bins' series fit in LDS: the kernels fall back
+    to 4, 2 or 1 bins per workgroup (up to 12 799 frames for Welch, 19 199 for the CSM)."""
+    rng = np.random.default_rng(79)
+    for n, W, ov in ((120000, 128, 50), (150000, 64, 50), (100000, 64, 75)):   # 1875, 4688, 6250 frames
+        x = rng.standard_normal((n, 1)) * 0.3
+        y = np.stack([np.convolve(x[:, 0], rng.standard_normal(8))[:n] for _ in range(2)], axis=1)
+        y += 0.05 * rng.standard_normal(y.shape)
+        tf, coh = backend.welch_transfer_function(y, x, 48000, W, "H1", overlap_percent=ov, average="median")
+        rt, rc = orc.compute_transfer_function(y, x, 48000, W, "H1", overlap_percent=ov, average="median")
+        assert relmax(tf, rt, True) < 2 * TOL and relmax(coh, rc, True) < 10 * TOL, (n, W, relmax(tf, rt, True))
+        psd = backend._welch(y, None, 48000, Window.Hann, W, ov, True, "median", SpectrumScaling.FFTBackward)
+        rp = orc.welch(y, None, 48000, "hann", W, ov, True, "median", "FFTBackward")
+        assert relmax(psd, rp, True) < 2 * TOL
+    x = rng.standard_normal((100000, 3)) * 0.3 + 0.4 * rng.standard_normal((100000, 1))
+    f, csm = backend._csm_welch(x, 48000, 64, Window.Hann, 50, True, "median", SpectrumScaling.FFTBackward)
+    rf, rcsm = orc.csm_welch(x, 48000, 64, "hann", 50, True, "median", "FFTBackward")   # 3125 frames
+    assert relmax(csm, rcsm) < 10 * TOL and orc.rel_l2(csm, rcsm) < TOL
+
+
 def test_csm_median_vs_oracle():
     """get_csm with average="median": the reference's pair loop of median-averaged _welch calls."""
     rng = np.random.default_rng(78)
