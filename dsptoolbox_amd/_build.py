@@ -61,7 +61,7 @@ def build_library(force: bool = False, verbose: bool = True) -> str:
                 return LIB_PATH
             hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
             tmp = LIB_PATH + f".tmp{os.getpid()}"
-            cmd = [hipcc] + FLAGS + ["-o", tmp] + SOURCES + ["-ldl"]
+            cmd = [hipcc] + FLAGS + ["-o", tmp] + SOURCES + ["-ldl", "-pthread"]
             if verbose:
                 print(" ".join(cmd), file=sys.stderr, flush=True)
             try:

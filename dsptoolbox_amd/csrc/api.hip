@@ -8,6 +8,7 @@
 #include <cstring>
 #include <map>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/dsptoolbox_amd.h"
@@ -81,6 +82,67 @@ static const int kMaxFft = 16384, kMinFft = 8;
 static const int64_t kMaxBigFft = (int64_t)1 << 24;  // four-step path (kernels_bigfft.hpp)
 
 extern "C" int ds_version(void) { return 100; }
+
+// ---- host marshalling helpers (no device work) --------------------------------
+static int host_threads(int threads, int64_t work_items) {
+    if (threads <= 0) {
+        unsigned hc = std::thread::hardware_concurrency();
+        threads = (int)std::min<unsigned>(16u, hc ? hc : 1u);
+        if (const char* e = getenv("DSPTOOLBOX_AMD_HOST_THREADS")) threads = std::max(1, atoi(e));
+    }
+    // below ~1 M elements a thread start costs more than it saves
+    const int64_t by_work = std::max<int64_t>(1, work_items / (1 << 20));
+    return (int)std::min<int64_t>(threads, by_work);
+}
+template <typename F>
+static void host_parallel(int threads, int64_t n, F body) {  // body(begin, end) over [0, n)
+    if (threads <= 1) {
+        body((int64_t)0, n);
+        return;
+    }
+    std::vector<std::thread> pool;
+    const int64_t per = ((n + threads - 1) / threads + 255) & ~(int64_t)255;
+    for (int t = 0; t < threads; ++t) {
+        const int64_t b = (int64_t)t * per, e = std::min(n, b + per);
+        if (b >= e) break;
+        pool.emplace_back([=]() { body(b, e); });
+    }
+    for (auto& th : pool) th.join();
+}
+extern "C" int ds_host_planar_f32(const double* src, int64_t n_samples, int n_ch, float* dst, int64_t ld,
+                                  int threads) {
+    if (!src || !dst || n_samples < 0 || n_ch <= 0 || ld < n_samples)
+        return fail(nullptr, DS_ERR_ARG, "ds_host_planar_f32: bad argument");
+    host_parallel(host_threads(threads, n_samples * n_ch), n_samples, [=](int64_t b, int64_t e) {
+        constexpr int64_t TILE = 256;  // samples per tile: TILE x n_ch doubles stay in the cache
+        for (int64_t s0 = b; s0 < e; s0 += TILE) {
+            const int64_t s1 = std::min(e, s0 + TILE);
+            for (int c = 0; c < n_ch; ++c) {
+                float* __restrict__ d = dst + (int64_t)c * ld;
+                const double* __restrict__ s = src + c;
+                for (int64_t n = s0; n < s1; ++n) d[n] = (float)s[n * n_ch];
+            }
+        }
+    });
+    return DS_OK;
+}
+extern "C" int ds_host_interleave_f64(const float* src, int64_t n_samples, int n_ch, int64_t ld, double* dst,
+                                      int threads) {
+    if (!src || !dst || n_samples < 0 || n_ch <= 0 || ld < n_samples)
+        return fail(nullptr, DS_ERR_ARG, "ds_host_interleave_f64: bad argument");
+    host_parallel(host_threads(threads, n_samples * n_ch), n_samples, [=](int64_t b, int64_t e) {
+        constexpr int64_t TILE = 256;
+        for (int64_t s0 = b; s0 < e; s0 += TILE) {
+            const int64_t s1 = std::min(e, s0 + TILE);
+            for (int c = 0; c < n_ch; ++c) {
+                const float* __restrict__ s = src + (int64_t)c * ld;
+                double* __restrict__ d = dst + c;
+                for (int64_t n = s0; n < s1; ++n) d[n * n_ch] = (double)s[n];
+            }
+        }
+    });
+    return DS_OK;
+}
 extern "C" int ds_max_fft_len(void) { return kMaxFft; }
 extern "C" int ds_device_count(void) {
     int n = 0;

@@ -249,6 +249,15 @@ int ds_fir_ola_dev(ds_ctx* ctx, const float* x_dev, int n_ch, int64_t ldx,
 int ds_fir_ola(ds_ctx* ctx, const float* x, int n_ch, int64_t n_samples,
                const float* taps, int n_filt, int n_taps, int mode, float* y);
 
+/* ---- host marshalling (no device work): the reference hands (samples, channels) float64
+ * C-order arrays (classes/signal.py:222-301) and expects the same back; the kernels take planar
+ * float32.  Multi-threaded cast + transpose on the host (numpy's strided cast takes 0.2 s for the
+ * 537 MB of the headline shape; this takes a fraction of it).  threads <= 0: min(16, cores).  */
+int ds_host_planar_f32(const double* src, int64_t n_samples, int n_ch, float* dst, int64_t ld,
+                       int threads);   /* dst[c*ld + n] = (float)src[n*n_ch + c] */
+int ds_host_interleave_f64(const float* src, int64_t n_samples, int n_ch, int64_t ld, double* dst,
+                           int threads); /* dst[n*n_ch + c] = (double)src[c*ld + n] */
+
 /* ---- multi-GPU: RCCL broadcast of shared inputs (sweep / taps / inverse) --
  * one process per GPU; rank 0 creates the id, the launcher (torch.distributed
  * store, file, MPI ...) hands the 128 bytes to every rank.                   */

@@ -125,6 +125,24 @@ def test_streaming_fir_classes_host_logic():
         m.process_block(np.zeros((2, 3)))
 
 
+def test_host_marshalling_helpers():
+    """ds_host_planar_f32 / ds_host_interleave_f64 (threaded cast + transpose at the boundary, no
+    device work) against numpy, incl. the thresholds below which numpy is used."""
+    from dsptoolbox_amd import backend
+    rng = np.random.default_rng(5)
+    for n, c in ((2**20 + 3, 3), (300001, 7), (2**21, 1), (1000, 2)):
+        y = rng.standard_normal((n, c))
+        a = backend._planar_f32(y)
+        assert a.dtype == np.float32 and a.flags.c_contiguous
+        assert np.array_equal(a, np.ascontiguousarray(y.T, dtype=np.float32))
+        b = backend._interleaved_f64(a)
+        assert b.dtype == np.float64 and np.array_equal(b, a.T.astype(np.float64))
+    v = rng.standard_normal((2**20 + 1, 4))[:, ::2]          # not C-contiguous: numpy path
+    assert np.array_equal(backend._planar_f32(v), np.ascontiguousarray(v.T, dtype=np.float32))
+    lib = load_library()
+    assert lib.ds_host_planar_f32(None, 10, 1, None, 10, 0) != 0   # argument check, no crash
+
+
 def test_compute_transfer_function_validation():
     a = dsp.Signal(None, np.zeros((100, 2)), 48000)
     b = dsp.Signal(None, np.zeros((100, 3)), 48000)

@@ -1,0 +1,27 @@
+"""Dev tool: end-to-end time of the Python API for config 2 (host float64 (N, C) arrays in,
+float64/complex128 out) split into host preparation, the C-ABI call (H2D + kernels + D2H) and the
+rest."""
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import dsptoolbox_amd as dsp  # noqa: E402
+from dsptoolbox_amd import backend  # noqa: E402
+from dsptoolbox_amd.generators import sweep_and_responses  # noqa: E402
+
+x, y = sweep_and_responses(2**20, 64, 48000)
+X = dsp.Signal(None, x, 48000)
+Y = dsp.Signal(None, y, 48000)
+X.set_spectrum_parameters(window_length_samples=4096, overlap_percent=50, detrend=True)
+for it in range(3):
+    t0 = time.perf_counter()
+    H = dsp.transfer_functions.compute_transfer_function(Y, X, 4096, dsp.TransferFunctionType.H1)
+    t1 = time.perf_counter()
+    print(f"compute_transfer_function end to end: {(t1 - t0) * 1e3:8.1f} ms")
+t0 = time.perf_counter()
+yp = backend._planar_f32(y)
+t1 = time.perf_counter()
+print(f"  host (N, C) float64 -> planar float32: {(t1 - t0) * 1e3:8.1f} ms for {y.nbytes / 1e6:.0f} MB")
