@@ -27,6 +27,7 @@ SIGNATURES = {
     "ds_free": (C.c_int, [ctx_p, C.c_void_p]),
     "ds_host_planar_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int64, C.c_int]),
     "ds_host_interleave_f64": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int64, C.c_void_p, C.c_int]),
+    "ds_host_widen_f64": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int]),
     "ds_upload": (C.c_int, [ctx_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "ds_download": (C.c_int, [ctx_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "ds_memset": (C.c_int, [ctx_p, C.c_void_p, C.c_int, C.c_size_t]),

@@ -62,6 +62,17 @@ def _interleaved_f64(planar: np.ndarray, dst: np.ndarray | None = None) -> np.nd
     return dst
 
 
+def _widen(a: np.ndarray) -> np.ndarray:
+    """float32 -> float64 / complex64 -> complex128 of a C-contiguous array (threaded for large ones)."""
+    wide = np.complex128 if a.dtype == np.complex64 else np.float64
+    if a.dtype in (np.float32, np.complex64) and a.flags.c_contiguous and a.size >= (1 << 20):
+        out = np.empty(a.shape, dtype=wide)
+        n = a.size * (2 if a.dtype == np.complex64 else 1)
+        if load_library().ds_host_widen_f64(_ptr(a), n, _ptr(out), 0) == 0:
+            return out
+    return a.astype(wide)
+
+
 def _ptr(a: np.ndarray):
     return a.ctypes.data_as(C.c_void_p)
 
@@ -214,7 +225,7 @@ def _stft(x, fs_hz: int, window_length_samples: int, window_type, overlap_percen
                                   pl["nfft"], pl["pad_front"], pl["n_frames"], _ptr(pl["w32"]),
                                   int(bool(detrend)), pl["scale"], pl["edge"], pl["power"], _ptr(out)),
               "ds_stft_r2c")
-    stft = out.real.astype(np.float64) if pl["power"] else out.astype(np.complex128)
+    stft = out.real.astype(np.float64) if pl["power"] else _widen(out)
     return pl["time_s"], pl["freqs_hz"], stft
 
 
@@ -293,7 +304,7 @@ def _istft(stft, nfft: int, W: int, step: int, window, scale: float, frame_offse
     ctx = get_context()
     ctx.check(ctx.lib.ds_istft(ctx.handle, _ptr(sp), n_bins, n_frames, n_ch, nfft, W, step, frame_offset,
                                n_frames_total, _ptr(w32), float(scale), total_length, _ptr(out)), "ds_istft")
-    return np.ascontiguousarray(out.T).astype(np.float64)
+    return _interleaved_f64(out)
 
 
 def _csm_welch(time_data, sampling_rate_hz: int, window_length_samples: int, window_type,
@@ -386,7 +397,12 @@ def spectral_division(num_td, n_fft: int, inverse_spectrum, n_out: int):
     batched = num_td.ndim == 3
     items = num_td if batched else num_td[None]
     m, n, n_ch = items.shape
-    yp = np.ascontiguousarray(np.transpose(items, (0, 2, 1)), dtype=np.float32)  # (M, C, N)
+    yp = np.empty((m, n_ch, n), dtype=np.float32)  # (M, C, N)
+    if n * n_ch >= (1 << 20):
+        for i in range(m):
+            yp[i] = _planar_f32(items[i])
+    else:
+        yp[...] = np.transpose(items, (0, 2, 1))
     r = np.asarray(inverse_spectrum)
     per_channel = r.ndim == 2
     rp = np.ascontiguousarray(r.T if per_channel else r, dtype=np.complex64)  # (C, B) or (B,)
@@ -395,7 +411,12 @@ def spectral_division(num_td, n_fft: int, inverse_spectrum, n_out: int):
     ctx = get_context()
     ctx.check(ctx.lib.ds_deconv(ctx.handle, _ptr(yp), m, n_ch, n, int(n_fft), _ptr(rp),
                                 int(per_channel), int(n_out), _ptr(out)), "ds_deconv")
-    res = np.transpose(out, (0, 2, 1)).astype(np.float64)
+    res = np.empty((m, n_out, n_ch), dtype=np.float64)
+    if n_out * n_ch >= (1 << 20):
+        for i in range(m):
+            _interleaved_f64(out[i], res[i])
+    else:
+        res[...] = np.transpose(out, (0, 2, 1))
     return res if batched else res[0]
 
 

@@ -126,6 +126,15 @@ extern "C" int ds_host_planar_f32(const double* src, int64_t n_samples, int n_ch
     });
     return DS_OK;
 }
+extern "C" int ds_host_widen_f64(const float* src, int64_t n, double* dst, int threads) {
+    if (!src || !dst || n < 0) return fail(nullptr, DS_ERR_ARG, "ds_host_widen_f64: bad argument");
+    host_parallel(host_threads(threads, n), n, [=](int64_t b, int64_t e) {
+        const float* __restrict__ s = src;
+        double* __restrict__ d = dst;
+        for (int64_t i = b; i < e; ++i) d[i] = (double)s[i];
+    });
+    return DS_OK;
+}
 extern "C" int ds_host_interleave_f64(const float* src, int64_t n_samples, int n_ch, int64_t ld, double* dst,
                                       int threads) {
     if (!src || !dst || n_samples < 0 || n_ch <= 0 || ld < n_samples)

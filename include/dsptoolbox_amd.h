@@ -257,6 +257,7 @@ int ds_host_planar_f32(const double* src, int64_t n_samples, int n_ch, float* ds
                        int threads);   /* dst[c*ld + n] = (float)src[n*n_ch + c] */
 int ds_host_interleave_f64(const float* src, int64_t n_samples, int n_ch, int64_t ld, double* dst,
                            int threads); /* dst[n*n_ch + c] = (double)src[c*ld + n] */
+int ds_host_widen_f64(const float* src, int64_t n, double* dst, int threads); /* dst[i] = (double)src[i] */
 
 /* ---- multi-GPU: RCCL broadcast of shared inputs (sweep / taps / inverse) --
  * one process per GPU; rank 0 creates the id, the launcher (torch.distributed

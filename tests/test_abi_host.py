@@ -139,6 +139,10 @@ def test_host_marshalling_helpers():
         assert b.dtype == np.float64 and np.array_equal(b, a.T.astype(np.float64))
     v = rng.standard_normal((2**20 + 1, 4))[:, ::2]          # not C-contiguous: numpy path
     assert np.array_equal(backend._planar_f32(v), np.ascontiguousarray(v.T, dtype=np.float32))
+    z = (rng.standard_normal((2**19 + 1, 3)) + 1j * rng.standard_normal((2**19 + 1, 3))).astype(np.complex64)
+    assert np.array_equal(backend._widen(z), z.astype(np.complex128))
+    f = rng.standard_normal(2**20 + 7).astype(np.float32)
+    assert np.array_equal(backend._widen(f), f.astype(np.float64))
     lib = load_library()
     assert lib.ds_host_planar_f32(None, 10, 1, None, 10, 0) != 0   # argument check, no crash
 
