@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of the MI355X spectral hot path.
 
-    python bench.py --gpus N --steps K --warmup W [--workload welch_h1|fir_bank|csm|deconv]
+    python bench.py --gpus N --steps K --warmup W [--workload welch_h1|welch_h1_1024|fir_bank|csm|deconv]
 
 Default workload (BASELINE.json configs[1], the one the metric is quoted on):
 64-channel Welch H1 transfer-function estimation, one sweep input channel,
@@ -41,7 +41,7 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="welch_h1",
-                    choices=["welch_h1", "fir_bank", "csm", "deconv"])
+                    choices=["welch_h1", "welch_h1_1024", "fir_bank", "csm", "deconv"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-channels", type=int, default=64,
                     help="output channels of the bounded CPU-baseline sample")
@@ -153,13 +153,13 @@ def setup_rccl(ctx, dist: Dist):
 
 
 # ---------------------------------------------------------------------------
-def welch_h1(args, ctx, dist):
+def welch_h1(args, ctx, dist, W=4096):
     from dsptoolbox_amd import backend
     from dsptoolbox_amd._lib import DeviceBuffer
     from dsptoolbox_amd.generators import exponential_sweep, sweep_and_responses
     from dsptoolbox_amd.standard.enums import SpectrumScaling, Window
 
-    n, n_cy, W = 2**20, 64, 4096
+    n, n_cy = 2**20, 64
     # per-rank independent batch (different response / noise seeds), shared sweep
     x, y = sweep_and_responses(n, n_cy, FS)
     if dist.rank > 0:
@@ -199,7 +199,7 @@ def welch_h1(args, ctx, dist):
     samples_per_step = (n_cy + 1) * n
     alg_bytes = (n_cy + 1) * n * 4 + B * n_cy * 8 + B * n_cy * 4
     info = dict(
-        workload="welch_h1: 64 output ch + 1 sweep input ch x 2^20 samples, nfft 4096, Hann, 50% overlap"
+        workload=f"welch_h1: 64 output ch + 1 sweep input ch x 2^20 samples, nfft {W}, Hann, 50% overlap"
                  + (", detrend" if args.detrend else ""),
         channels=n_cy, samples_per_channel=n, nfft=W, overlap_percent=50, frames=n_frames,
         parallelism=f"channel-batch x{dist.world}")
@@ -228,7 +228,7 @@ def welch_h1(args, ctx, dist):
                     parity_rel_max_vs_gpu=err)
 
     return step, samples_per_step, alg_bytes, "hbm", info, cpu_baseline, bcast_ms, \
-        ("welch4096_main", "welch_yacc")
+        ("welch4096_main", "welch1024_main", "welch_yacc")
 
 
 def fir_bank(args, ctx, dist):
@@ -393,7 +393,8 @@ def main():
     build_library()
     dist = Dist(args.gpus)
     ctx = Context(None)  # device = LOCAL_RANK (modulo the visible device count)
-    maker = dict(welch_h1=welch_h1, fir_bank=fir_bank, csm=csm, deconv=deconv)[args.workload]
+    maker = dict(welch_h1=welch_h1, welch_h1_1024=lambda a, c, d: welch_h1(a, c, d, W=1024),
+                 fir_bank=fir_bank, csm=csm, deconv=deconv)[args.workload]
     step, units, alg, bound, info, cpu_baseline, bcast_ms, dominant = maker(args, ctx, dist)
 
     # Warm-up; its last step is bracketed kernel by kernel (HIP events on the library's stream) to
@@ -452,7 +453,7 @@ def main():
         achieved = alg / launches_per_step / (dom_ms * 1e-3) / 1e12
         roof = dict(bound="mfma", achieved=achieved, peak=MFMA_F32_PEAK_TFLOPS, unit="TFLOP/s",
                     frac=achieved / MFMA_F32_PEAK_TFLOPS, traffic=None)
-    hints = {"welch4096_main": ("k_y<",), "welch_yacc": ("k_yacc",), "fir": ("fir16k::k_fir<true>", "fir16k::k_fir", "k_fir<"),
+    hints = {"welch4096_main": ("welch4096::k_y<",), "welch1024_main": ("welch1k::k_y<",), "welch_yacc": ("k_yacc",), "fir": ("fir16k::k_fir<true>", "fir16k::k_fir", "k_fir<"),
              "csm_gemm": ("k_csm_gemm",), "deconv": ("k_deconv",)}.get(dom, (dom,))
     traffic, src = None, None
     for hint in hints:

@@ -165,7 +165,8 @@ __global__ __launch_bounds__(NTB, 3) void k_y(Args p) {
     }
     const int c = g * WPB + w;
     const bool live = c < p.n_ch;
-    const int p0 = q * p.ppc, p1 = min(p0 + p.ppc, p.n_pairs);
+    // balanced split of the pairs over the chunks (n_chunks stays a multiple of 8 for the XCD mapping)
+    const int p0 = (int)((int64_t)q * p.n_pairs / p.n_chunks), p1 = (int)((int64_t)(q + 1) * p.n_pairs / p.n_chunks);
     const float* ch = p.sig + (int64_t)(live ? c : 0) * p.ld;
     Raw<HALF_HOP> raw;
     if (p0 < p1) load_raw<HALF_HOP>(raw, ch, p.n_samples, (int64_t)(2 * p0) * p.hop, p.hop, t);
@@ -275,8 +276,9 @@ inline Plan plan(int n_frames, int n_cy) {
         if (atoi(e) > 0) want = atoi(e);
     }
     want = std::max(1, std::min(want, pl.n_pairs));
+    if (want >= 8) want &= ~7;  // whole chunks per XCD: the input spectra a chunk re-reads stay in one L2
+    pl.n_chunks = want;         // chunk q = pairs [q n_pairs / n_chunks, (q+1) n_pairs / n_chunks)
     pl.ppc = (pl.n_pairs + want - 1) / want;
-    pl.n_chunks = (pl.n_pairs + pl.ppc - 1) / pl.ppc;
     auto pad = [](size_t b) { return (b + 255) & ~size_t(255); };
     pl.bytes = pad(sizeof(float2) * (size_t)pl.n_pairs * N) + pad(sizeof(float) * (size_t)pl.n_pairs * NB) +
                pad(sizeof(float) * (size_t)pl.n_chunks * NB) + pad(sizeof(float2) * (size_t)pl.n_chunks * n_cy * NB) +

@@ -358,7 +358,8 @@ __global__ __launch_bounds__(NT, 2) void k_y(Args p) {
     float win[16];
     init_tables(tw, win, tw2, p.window, p.twt, tid);
     const float* ch = p.sig + (int64_t)c * p.ld;
-    const int p0 = q * p.ppc, p1 = min(p0 + p.ppc, p.n_pairs);
+    // balanced split of the pairs over the chunks (n_chunks stays a multiple of 8 for the XCD mapping)
+    const int p0 = (int)((int64_t)q * p.n_pairs / p.n_chunks), p1 = (int)((int64_t)(q + 1) * p.n_pairs / p.n_chunks);
     {
         // Input auto-spectrum of this chunk: the px rows k_x wrote, summed in fp64 -- instead of a
         // separate reduction kernel every workgroup of the chunk takes a slice of the bins
@@ -494,6 +495,7 @@ inline int chunks_for(int n_pairs, int n_ch) {
         if (want < by_len) want = (by_len + 7) & ~7;
     }
     if (want > n_pairs) want = n_pairs;
+    if (want >= 8) want &= ~7;  // whole chunks per XCD
     if (want < 1) want = 1;
     return want;
 }
@@ -505,9 +507,8 @@ struct Plan {
 inline Plan plan(int n_frames, int n_cy) {
     Plan pl;
     pl.n_pairs = (n_frames + 1) / 2;
-    pl.n_chunks = chunks_for(pl.n_pairs, n_cy);
+    pl.n_chunks = chunks_for(pl.n_pairs, n_cy);  // chunk q = pairs [q n_pairs / n_chunks, (q+1) n_pairs / n_chunks)
     pl.ppc = (pl.n_pairs + pl.n_chunks - 1) / pl.n_chunks;
-    pl.n_chunks = (pl.n_pairs + pl.ppc - 1) / pl.ppc;
     auto pad = [](size_t b) { return (b + 255) & ~size_t(255); };
     pl.bytes = pad(sizeof(float2) * (size_t)pl.n_pairs * N) + pad(sizeof(float) * (size_t)pl.n_pairs * NB) +
                pad(sizeof(float) * (size_t)pl.n_chunks * NB) + pad(sizeof(float2) * (size_t)pl.n_chunks * n_cy * NB) +

@@ -4,7 +4,7 @@
 set -u
 TAG=${1:-r01}
 export TMPDIR=/tmp
-WORKLOADS=${2:-"welch_h1 fir_bank csm deconv"}
+WORKLOADS=${2:-"welch_h1 welch_h1_1024 fir_bank csm deconv"}
 for W in $WORKLOADS; do
   OUT=gpurun_out/prof_${TAG}_$W
   mkdir -p $OUT
