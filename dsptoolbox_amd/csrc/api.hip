@@ -38,7 +38,8 @@ struct ds_ctx {
     float2* w4_tables = nullptr;  // welch4096::host_tables()
     float2* fir16k_tables = nullptr;  // fir16k::host_tables()
     float2* deconv8k_tables = nullptr;  // deconv8k::host_tables()
-    float2* stft1k_tables = nullptr;  // stft1k::host_tables()
+    float2* stft1k_tables = nullptr;  // stft1k::host_tables<1024>()
+    float2* stft_wave_tables[2] = {nullptr, nullptr};  // stft1k::host_tables<512>(), <256>()
     void* ws = nullptr;         // kernel workspace (spectra, partials)
     size_t ws_bytes = 0;
     void* io = nullptr;  // staging for the host-pointer entry points
@@ -191,6 +192,8 @@ extern "C" void ds_destroy(ds_ctx* c) {
     if (c->fir16k_tables) (void)hipFree(c->fir16k_tables);
     if (c->deconv8k_tables) (void)hipFree(c->deconv8k_tables);
     if (c->stft1k_tables) (void)hipFree(c->stft1k_tables);
+    for (float2* t : c->stft_wave_tables)
+        if (t) (void)hipFree(t);
     for (auto& kv : c->blue) (void)hipFree(kv.second);
     for (auto& r : c->prof_recs) {
         (void)hipEventDestroy(r.a);
@@ -427,29 +430,48 @@ extern "C" int ds_stft_r2c_dev(ds_ctx* c, const float* x, int64_t n_samples, int
                         scale, edge_scale, power, 1, (float2*)out);
     }
     CHK(check_fft_len(c, nfft, "ds_stft_r2c nfft"));
-    // 1024-point transforms (the reference's default frame): one wave per frame pair with the
-    // transform in registers (kernels_stft1024.hpp)
+    // 256-, 512- and 1024-point transforms (1024 = the reference's default frame): wave-level
+    // register transforms, one frame pair per team of nfft/16 lanes (kernels_stft1024.hpp)
     static const bool stft_generic = getenv("DSPTOOLBOX_AMD_STFT_GENERIC") != nullptr;
-    if (nfft == 1024 && (W == 1024 || (W < 1024 && !detrend)) && !stft_generic) {
-        if (!c->stft1k_tables) {
+    if ((nfft == 1024 || nfft == 512 || nfft == 256) && (W == nfft || (W < nfft && !detrend)) && !stft_generic) {
+        const int slot = nfft == 1024 ? 0 : (nfft == 512 ? 1 : 2);
+        float2** tab = slot == 0 ? &c->stft1k_tables : &c->stft_wave_tables[slot - 1];
+        if (!*tab) {
             std::vector<float2> h;
-            stft1k::host_tables(h);
-            CHK(upload_table_fwd(c, &c->stft1k_tables, h));
+            if (nfft == 1024) stft1k::host_tables<1024>(h);
+            else if (nfft == 512) stft1k::host_tables<512>(h);
+            else stft1k::host_tables<256>(h);
+            CHK(upload_table_fwd(c, tab, h));
         }
-        int ct = std::min(8, n_ch);  // 8 channels: 64-byte runs of the output, 70 KB of LDS
+        // channels per workgroup: 8 x 64 lanes (64-byte runs of the output, 70 KB of LDS) at 1024
+        // points, 16 teams (128-byte runs) of 32 / 16 lanes at 512 / 256
+        const int lanes = nfft / 16;
+        int ct = std::min(nfft == 1024 ? 8 : 16, n_ch);
         if (const char* e = getenv("DSPTOOLBOX_AMD_STFT_CT")) {
             int v = atoi(e);
             if (v >= 1 && v <= 16) ct = std::min(v, n_ch);
         }
         while (ct & (ct - 1)) ct &= ct - 1;
+        const size_t lds = nfft == 1024 ? stft1k::lds_bytes<1024>(ct)
+                                        : (nfft == 512 ? stft1k::lds_bytes<512>(ct) : stft1k::lds_bytes<256>(ct));
+        const int threads = lanes * ct;
+        // frame pairs per workgroup: as few as keep the whole grid resident at once, at most 16
+        const int per_cu = std::max(1, std::min<int>({(int)((160 * 1024) / lds), 2048 / std::max(64, threads), 8}));
         const int n_fp = (n_frames + 1) / 2, n_ct = (n_ch + ct - 1) / ct;
-        int fpw = std::max(1, std::min(16, (int)(((int64_t)n_fp * n_ct + 511) / 512)));
+        const int64_t resident = 256 * (int64_t)per_cu;
+        int fpw = std::max(1, std::min(16, (int)(((int64_t)n_fp * n_ct + resident - 1) / resident)));
         if (const char* e = getenv("DSPTOOLBOX_AMD_STFT_FPW")) fpw = std::max(1, atoi(e));
         StftArgs a{x, n_samples, ld, pad_front, n_ch, W, hop, n_frames, detrend, power, ct, fpw, window,
-                   c->stft1k_tables, scale, edge_scale, (float2*)out};
+                   *tab, scale, edge_scale, (float2*)out};
         dim3 grid((unsigned)((n_fp + fpw - 1) / fpw), (unsigned)n_ct);
-        if (power) return launch(c, "stft", stft1k::k_stft1024<true>, grid, 64 * ct, stft1k::lds_bytes(ct), a);
-        return launch(c, "stft", stft1k::k_stft1024<false>, grid, 64 * ct, stft1k::lds_bytes(ct), a);
+        if (nfft == 1024)
+            return power ? launch(c, "stft", stft1k::k_stft_wave<1024, true>, grid, threads, lds, a)
+                         : launch(c, "stft", stft1k::k_stft_wave<1024, false>, grid, threads, lds, a);
+        if (nfft == 512)
+            return power ? launch(c, "stft", stft1k::k_stft_wave<512, true>, grid, threads, lds, a)
+                         : launch(c, "stft", stft1k::k_stft_wave<512, false>, grid, threads, lds, a);
+        return power ? launch(c, "stft", stft1k::k_stft_wave<256, true>, grid, threads, lds, a)
+                     : launch(c, "stft", stft1k::k_stft_wave<256, false>, grid, threads, lds, a);
     }
     const float2* tw;
     CHK(get_twiddles(c, nfft, &tw));

@@ -1,4 +1,4 @@
-// STFT with a 1024-point transform (the reference's default frame: 1024-sample window)
+// STFT with a 256-, 512- or 1024-point transform (1024 samples is the reference's default window)
 // (standard/_spectral_methods.py:126-148, 260-268 with window_length_samples = 1024).
 //
 // The generic kernel (kernels_generic.hpp: k_stft<1024>) spends ~1500 VALU instructions per frame
@@ -37,30 +37,43 @@ using dsk::StftArgs;
 using w4::cmul;
 using w4::pos16;
 
+// Geometry of the wave-level transform of N = 256, 512 or 1024 points: N = 16 x 16 x R3 on
+// L = N/16 lanes (1, 2 or 4 transforms per wave), 16 complex values per lane.
+template <int NN>
+struct Geo {
+    static_assert(NN == 256 || NN == 512 || NN == 1024, "wave-level transform: 256, 512 or 1024 points");
+    static constexpr int N = NN, L = NN / 16, R3 = NN / 256;
+    static constexpr int S1 = L + R3;   // exchange-1 row stride (the R3-lane groups of pass 2 spread over the banks)
+    static constexpr int REGION = ((16 * S1 > NN + 2 ? 16 * S1 : NN + 2) + 31) / 32 * 32;  // complex per image
+    static constexpr int TW1 = 15 * L, TW_LEN = TW1 + 16 * R3;
+};
 constexpr int N = 1024, NB = N / 2 + 1;
-constexpr int S1 = 68;        // exchange-1 row stride (64 + 4: the 4-lane groups of pass 2 hit distinct banks)
-constexpr int REGION = 1088;  // complex per channel image: 16 * S1 >= 1026 rows, = 0 (mod 32)
-constexpr int TW1 = 15 * 64, TW_LEN = TW1 + 64;
+constexpr int S1 = Geo<1024>::S1, REGION = Geo<1024>::REGION, TW1 = Geo<1024>::TW1, TW_LEN = Geo<1024>::TW_LEN;
 
-// channel stride: REGION + 32/ct complex, so the ct channels x 64/ct rows a wave reads in the
-// channel-fastest read-out fall on distinct banks; even (float4-aligned images)
-__host__ __device__ constexpr int ch_stride(int ct) { return REGION + (ct > 1 ? 32 / ct : 0); }
-inline size_t lds_bytes(int ct) { return ((size_t)ct * ch_stride(ct) + TW_LEN) * sizeof(float2); }
+// channel stride: REGION + 32/ct complex, so the ct channels x L/ct rows a wave reads in the
+// channel-fastest read-out fall on distinct banks; even (float4-aligned images): ct <= 16
+template <int NN>
+__host__ __device__ constexpr int ch_stride(int ct) { return Geo<NN>::REGION + (ct > 1 ? 32 / ct : 0); }
+template <int NN>
+inline size_t lds_bytes(int ct) { return ((size_t)ct * ch_stride<NN>(ct) + Geo<NN>::TW_LEN) * sizeof(float2); }
 
-// [15][64] W1024^(t k1) (k1 = 1..15), then [16][4] W64^(n3 k2); fp64-computed
+// [15][L] W_N^(t k1) (k1 = 1..15), then [16][R3] W_(16 R3)^(n3 k2); fp64-computed
+template <int NN>
 inline void host_tables(std::vector<float2>& t) {
-    t.resize(TW_LEN);
+    using G = Geo<NN>;
+    t.resize(G::TW_LEN);
     for (int k1 = 1; k1 < 16; ++k1)
-        for (int tt = 0; tt < 64; ++tt) {
-            double a = -2.0 * M_PI * (double)(tt * k1) / 1024.0;
-            t[(k1 - 1) * 64 + tt] = make_float2((float)std::cos(a), (float)std::sin(a));
+        for (int tt = 0; tt < G::L; ++tt) {
+            double a = -2.0 * M_PI * (double)(tt * k1) / (double)NN;
+            t[(k1 - 1) * G::L + tt] = make_float2((float)std::cos(a), (float)std::sin(a));
         }
     for (int k2 = 0; k2 < 16; ++k2)
-        for (int n3 = 0; n3 < 4; ++n3) {
-            double a = -2.0 * M_PI * (double)(n3 * k2) / 64.0;
-            t[TW1 + k2 * 4 + n3] = make_float2((float)std::cos(a), (float)std::sin(a));
+        for (int n3 = 0; n3 < G::R3; ++n3) {
+            double a = -2.0 * M_PI * (double)(n3 * k2) / (double)(16 * G::R3);
+            t[G::TW1 + k2 * G::R3 + n3] = make_float2((float)std::cos(a), (float)std::sin(a));
         }
 }
+inline void host_tables(std::vector<float2>& t) { host_tables<1024>(t); }
 
 // order the LDS traffic of ONE wave (hardware executes it in program order; this keeps the
 // compiler from moving a read above the write of another lane it cannot see)
@@ -70,72 +83,100 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// The transform of one wave: v[n1] = z[t + 64 n1] (consumed) -> zo[m] = Z[t + 64 m].  `buf`: this
-// wave's LDS region (>= 16 * S1 complex, 16-byte aligned), tw1/tw2 the tables of host_tables() in
-// LDS.  Ends with buf free for reuse.
 struct NoHook {
     __device__ __forceinline__ void operator()() const {}
 };
-// `behind_ex2` runs after the second exchange image has been written (v is dead there): global
-// loads issued from it overlap the LDS round trip and the last pass.
-template <typename Hook = NoHook>
-__device__ __forceinline__ void fft1024(float2 (&v)[16], float2 (&z)[16], float2* buf,
-                                        const float2* tw1, const float2* tw2, int t,
-                                        Hook behind_ex2 = Hook()) {
-    const int k1u = t >> 2, n3 = t & 3;
+// The transform of one team of L lanes: v[n1] = z[t + L n1] (consumed) -> zo[m] = Z[t + L m].
+// `buf`: the team's LDS region (>= Geo::REGION complex, 16-byte aligned), tw1/tw2 the tables of
+// host_tables<N>() in LDS.  Every lane of the wave must call it (wave-level ordering).  Ends with
+// buf free for reuse.  `behind_ex2` runs after the second exchange image has been written (v is
+// dead there): global loads issued from it overlap the LDS round trip and the last pass.
+template <int NN, typename Hook = NoHook>
+__device__ __forceinline__ void fft_wave(float2 (&v)[16], float2 (&z)[16], float2* buf,
+                                         const float2* tw1, const float2* tw2, int t,
+                                         Hook behind_ex2 = Hook()) {
+    using G = Geo<NN>;
+    constexpr int L = G::L, R3 = G::R3, S1 = G::S1;
+    const int k1u = t / R3, n3 = t % R3;
     // ---- pass 1
     w4::dft16(v);
 #pragma unroll
-    for (int k1 = 1; k1 < 16; ++k1) v[pos16(k1)] = cmul(v[pos16(k1)], tw1[(k1 - 1) * 64 + t]);
+    for (int k1 = 1; k1 < 16; ++k1) v[pos16(k1)] = cmul(v[pos16(k1)], tw1[(k1 - 1) * L + t]);
 #pragma unroll
     for (int k1 = 0; k1 < 16; ++k1) buf[k1 * S1 + t] = v[pos16(k1)];
     wave_sync();
 #pragma unroll
-    for (int n2 = 0; n2 < 16; ++n2) v[n2] = buf[k1u * S1 + 4 * n2 + n3];
+    for (int n2 = 0; n2 < 16; ++n2) v[n2] = buf[k1u * S1 + R3 * n2 + n3];
     wave_sync();
     // ---- pass 2
     w4::dft16(v);
+    if constexpr (R3 == 1) {
+        // 256 points: lane k1 already holds Z[k1 + 16 k2]
 #pragma unroll
-    for (int k2 = 1; k2 < 16; ++k2) v[pos16(k2)] = cmul(v[pos16(k2)], tw2[k2 * 4 + n3]);
+        for (int k2 = 0; k2 < 16; ++k2) z[k2] = v[pos16(k2)];
+        behind_ex2();
+    } else {
 #pragma unroll
-    for (int k2 = 0; k2 < 16; ++k2) buf[64 * k2 + t] = v[pos16(k2)];  // [(k1 + 16 k2)][n3]
-    behind_ex2();
-    wave_sync();
-    // ---- pass 3: pair (k1,k2) = t + 64 j, radix 4 over n3 -> Z[t + 64 (j + 4 k3)]
+        for (int k2 = 1; k2 < 16; ++k2) v[pos16(k2)] = cmul(v[pos16(k2)], tw2[k2 * R3 + n3]);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const float4* q = reinterpret_cast<const float4*>(buf + 4 * (t + 64 * j));
-        const float4 lo = q[0], hi = q[1];
-        float2 x0 = make_float2(lo.x, lo.y), x1 = make_float2(lo.z, lo.w);
-        float2 x2 = make_float2(hi.x, hi.y), x3 = make_float2(hi.z, hi.w);
-        w4::r4(x0, x1, x2, x3);
-        z[j] = x0;
-        z[j + 4] = x1;
-        z[j + 8] = x2;
-        z[j + 12] = x3;
+        for (int k2 = 0; k2 < 16; ++k2) buf[L * k2 + t] = v[pos16(k2)];  // [(k1 + 16 k2)][n3]
+        behind_ex2();
+        wave_sync();
+        // ---- pass 3: pair (k1,k2) = t + L j, radix R3 over n3 -> Z[t + L (j + (16/R3) k3)]
+        if constexpr (R3 == 4) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float4* q = reinterpret_cast<const float4*>(buf + 4 * (t + L * j));
+                const float4 lo = q[0], hi = q[1];
+                float2 x0 = make_float2(lo.x, lo.y), x1 = make_float2(lo.z, lo.w);
+                float2 x2 = make_float2(hi.x, hi.y), x3 = make_float2(hi.z, hi.w);
+                w4::r4(x0, x1, x2, x3);
+                z[j] = x0;
+                z[j + 4] = x1;
+                z[j + 8] = x2;
+                z[j + 12] = x3;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float4 q = *reinterpret_cast<const float4*>(buf + 2 * (t + L * j));
+                z[j] = make_float2(q.x + q.z, q.y + q.w);
+                z[j + 8] = make_float2(q.x - q.z, q.y - q.w);
+            }
+        }
+        wave_sync();
     }
-    wave_sync();
+}
+template <typename Hook = NoHook>
+__device__ __forceinline__ void fft1024(float2 (&v)[16], float2 (&z)[16], float2* buf,
+                                        const float2* tw1, const float2* tw2, int t,
+                                        Hook behind_ex2 = Hook()) {
+    fft_wave<1024, Hook>(v, z, buf, tw1, tw2, t, behind_ex2);
 }
 
-// grid = (ceil(ceil(n_frames/2)/fpw), ceil(n_ch/ct)); block = ct waves; p.tw = host_tables();
-// p.W <= 1024 (shorter windows are zero-padded); detrend requires p.W == 1024, where removing the
-// frame mean only clears bin 0 (a constant has no other bin).
-template <bool POWER>
-__global__ __launch_bounds__(1024) void k_stft1024(StftArgs p) {
+// grid = (ceil(ceil(n_frames/2)/fpw), ceil(n_ch/ct)); block = ct teams of L lanes; p.tw =
+// host_tables<NN>(); p.W <= NN (shorter windows are zero-padded); detrend requires p.W == NN, where
+// removing the frame mean only clears bin 0 (a constant has no other bin).
+template <int NN, bool POWER>
+__global__ __launch_bounds__(1024) void k_stft_wave(StftArgs p) {
+    using G = Geo<NN>;
+    constexpr int L = G::L;
     extern __shared__ __align__(16) float2 lds[];
-    const int team = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), t = threadIdx.x & 63;
-    const int CHS = ch_stride(p.ct);
+    // a 64-lane team is a wave: its index (and every LDS base derived from it) is wave-uniform
+    const int team = L == 64 ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : (int)threadIdx.x / L;
+    const int t = threadIdx.x % L;
+    const int CHS = ch_stride<NN>(p.ct);
     float2* buf = lds + team * CHS;
     float2* tw1 = lds + p.ct * CHS;
-    const float2* tw2 = tw1 + TW1;
-    for (int i = threadIdx.x; i < TW_LEN; i += blockDim.x) tw1[i] = p.tw[i];
+    const float2* tw2 = tw1 + G::TW1;
+    for (int i = threadIdx.x; i < G::TW_LEN; i += blockDim.x) tw1[i] = p.tw[i];
     const int c0 = blockIdx.y * p.ct;
     const int ctv = min(p.ct, p.n_ch - c0);
     const int c = c0 + team;
-    const float* xc = c < p.n_ch ? p.x + (int64_t)c * p.ld : nullptr;  // idle waves transform zeros
+    const float* xc = c < p.n_ch ? p.x + (int64_t)c * p.ld : nullptr;  // idle teams transform zeros
     const int64_t F = p.n_frames, Cn = p.n_ch;
     const int lct = __ffs(p.ct) - 1;
-    const int cl = threadIdx.x & (p.ct - 1), r0 = threadIdx.x >> lct;  // read-out: channel, first row
+    const int cl = threadIdx.x & (p.ct - 1), r0 = threadIdx.x >> lct;  // read-out: channel, first row (< L)
     const int n_fp = (p.n_frames + 1) >> 1;
     const int fp0 = blockIdx.x * p.fpw, fp1 = min(fp0 + p.fpw, n_fp);
     auto src = [&](int fp, FrameSrc& a, FrameSrc& b) {
@@ -143,15 +184,15 @@ __global__ __launch_bounds__(1024) void k_stft1024(StftArgs p) {
         a = FrameSrc{xc, (int64_t)f0 * p.hop - p.pad_front};
         b = FrameSrc{f1 < p.n_frames ? xc : nullptr, (int64_t)f1 * p.hop - p.pad_front};
     };
-    RawPair<N> raw;
+    RawPair<NN> raw;
     FrameSrc a, b;
     if (fp0 < fp1) {
         src(fp0, a, b);
-        dsk::load_raw_pair<N>(raw, a, b, p.n_samples, p.W, t);
+        dsk::load_raw_pair<NN>(raw, a, b, p.n_samples, p.W, t);
     }
     float win[16];
 #pragma unroll
-    for (int n1 = 0; n1 < 16; ++n1) win[n1] = p.window[min(t + 64 * n1, p.W - 1)] * (t + 64 * n1 < p.W ? 1.f : 0.f);
+    for (int n1 = 0; n1 < 16; ++n1) win[n1] = p.window[min(t + L * n1, p.W - 1)] * (t + L * n1 < p.W ? 1.f : 0.f);
     // Drain the loads above before the loop: otherwise the wait for them is merged into the loop body
     // (vmcnt is a FIFO count) and stalls every iteration on the prefetch it has just issued.
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
@@ -171,17 +212,17 @@ __global__ __launch_bounds__(1024) void k_stft1024(StftArgs p) {
         if (fp + 1 < fp1) {
             FrameSrc na, nb;
             src(fp + 1, na, nb);
-            dsk::load_raw_pair<N>(raw, na, nb, p.n_samples, p.W, t);
+            dsk::load_raw_pair<NN>(raw, na, nb, p.n_samples, p.W, t);
         }
         float2 z[16];
-        fft1024(v, z, buf, tw1, tw2, t);
-        // ---- separation: bins k = t + 64 j (j < 8) against Z[N - k], which sits in the upper half
+        fft_wave<NN>(v, z, buf, tw1, tw2, t);
+        // ---- separation: bins k = t + L j (j < 8) against Z[N - k], which sits in the upper half
 #pragma unroll
-        for (int m = 8; m < 16; ++m) buf[t + 64 * m] = z[m];
+        for (int m = 8; m < 16; ++m) buf[t + L * m] = z[m];
         wave_sync();
         float2 qc[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) qc[j] = buf[(N - (t + 64 * j)) & (N - 1)];
+        for (int j = 0; j < 8; ++j) qc[j] = buf[(NN - (t + L * j)) & (NN - 1)];
         if (t == 0) qc[0] = z[0];  // bin 0 pairs with itself
         wave_sync();
 #pragma unroll
@@ -198,7 +239,7 @@ __global__ __launch_bounds__(1024) void k_stft1024(StftArgs p) {
                 A = make_float2(A.x * s, A.y * s);
                 B = make_float2(B.x * s, B.y * s);
             }
-            *reinterpret_cast<float4*>(buf + 2 * (t + 64 * j)) = make_float4(A.x, A.y, B.x, B.y);
+            *reinterpret_cast<float4*>(buf + 2 * (t + L * j)) = make_float4(A.x, A.y, B.x, B.y);
         }
         if (t == 0) {  // bin N/2 pairs with itself
             const float2 P = z[8];
@@ -207,20 +248,20 @@ __global__ __launch_bounds__(1024) void k_stft1024(StftArgs p) {
                 r = make_float4(P.x * P.x * pee, 0.f, P.y * P.y * pee, 0.f);
             else
                 r = make_float4(P.x * sce, 0.f, P.y * sce, 0.f);
-            *reinterpret_cast<float4*>(buf + N) = r;
+            *reinterpret_cast<float4*>(buf + NN) = r;
         }
         __syncthreads();
-        // ---- read-out: rows r0 + 64 i of channel cl; row r -> out[((r>>1) F + f0 + (r&1)) C + c]
+        // ---- read-out: rows r0 + L i of channel cl; row r -> out[((r>>1) F + f0 + (r&1)) C + c]
         if (cl < ctv && (v1 || !(r0 & 1))) {
             const float2* s = lds + cl * CHS + r0;
             float2* o = p.out + ((int64_t)(r0 >> 1) * F + f0 + (r0 & 1)) * Cn + c0 + cl;
-            const int64_t ostep = 32 * F * Cn;
+            const int64_t ostep = (L / 2) * F * Cn;
             float2 g[16];
 #pragma unroll
-            for (int i = 0; i < 16; ++i) g[i] = s[64 * i];
+            for (int i = 0; i < 16; ++i) g[i] = s[L * i];
 #pragma unroll
             for (int i = 0; i < 16; ++i) o[i * ostep] = g[i];
-            if (r0 < 2) o[16 * ostep] = s[N];
+            if (r0 < 2) o[16 * ostep] = s[NN];
         }
     }
 }

@@ -717,8 +717,8 @@ def test_welch_default_window_kernel_vs_oracle():
 
 
 def test_stft_default_frame_kernel_vs_oracle():
-    """The 1024-sample frame has its own kernel (kernels_stft1024.hpp: one wave per frame pair, the
-    transform in registers): channel tiles with idle waves (1, 3, 5, 9, 17 channels), odd and even
+    """Frames of 256, 512 and 1024 points have their own kernel (kernels_stft1024.hpp: one frame pair
+    per team of nfft/16 lanes, the transform in registers): channel tiles with idle teams (1, 3, 5, 9, 17 channels), odd and even
     frame counts, padding at both ends, detrend, amplitude and power scalings, overlaps."""
     rng = np.random.default_rng(77)
     worst = 0.0
@@ -732,19 +732,21 @@ def test_stft_default_frame_kernel_vs_oracle():
             (2, 1024, 50, True, False, SpectrumScaling.FFTOrthogonal),
             (64, 8192, 50, True, False, SpectrumScaling.FFTBackward)):
         x = rng.standard_normal((n, n_ch)) * 0.3 + 0.05
-        t, f, st = backend._stft(x, 48000, 1024, Window.Hann, ov, None, det, pad, sc)
-        rt, rf, rs = orc.stft(x, 48000, 1024, "hann", ov, None, det, pad, sc.name)
-        assert st.shape == rs.shape and np.allclose(t, rt) and np.array_equal(f, rf)
-        if det:  # the reference's DC bin after mean removal is rounding noise around 0
-            assert np.max(np.abs(st[0])) <= 1e-6 * np.max(np.abs(rs))
-        e = relmax(st, rs)
-        worst = max(worst, e)
-        assert e < TOL, (n_ch, n, ov, pad, det, sc, e)
+        for W in (1024, 512, 256):   # 64, 32, 16 lanes per transform: 1, 2, 4 frame pairs per wave
+            t, f, st = backend._stft(x, 48000, W, Window.Hann, ov, None, det, pad, sc)
+            rt, rf, rs = orc.stft(x, 48000, W, "hann", ov, None, det, pad, sc.name)
+            assert st.shape == rs.shape and np.allclose(t, rt) and np.array_equal(f, rf)
+            if det:  # the reference's DC bin after mean removal is rounding noise around 0
+                assert np.max(np.abs(st[0])) <= 1e-6 * np.max(np.abs(rs))
+            e = relmax(st, rs)
+            worst = max(worst, e)
+            assert e < TOL, (W, n_ch, n, ov, pad, det, sc, e)
     # shorter windows zero-padded to 1024 points (no detrend: that case stays on the generic kernel)
-    for W, det in ((512, False), (256, False), (512, True)):
+    for W, nfft, det in ((512, 1024, False), (256, 1024, False), (512, 1024, True), (128, 256, False),
+                         (256, 512, False), (128, 512, True)):
         x = rng.standard_normal((20000, 3)) * 0.3 + 0.05
-        t, f, st = backend._stft(x, 48000, W, Window.Hann, 50, 1024, det, True, SpectrumScaling.FFTBackward)
-        rt, rf, rs = orc.stft(x, 48000, W, "hann", 50, 1024, det, True, "FFTBackward")
+        t, f, st = backend._stft(x, 48000, W, Window.Hann, 50, nfft, det, True, SpectrumScaling.FFTBackward)
+        rt, rf, rs = orc.stft(x, 48000, W, "hann", 50, nfft, det, True, "FFTBackward")
         assert st.shape == rs.shape
         e = relmax(st, rs)
         worst = max(worst, e)
