@@ -746,77 +746,88 @@ static int welch4096_run(ds_ctx* c, const float* x, int64_t ldx, const float* y,
     return DS_OK;
 }
 
-// window 1024 (the reference's default), one input channel: wave-level register transform
-// (kernels_welch1024.hpp)
-static int welch1024_run(ds_ctx* c, const float* x, int64_t ldx, const float* y, int n_cy, int64_t ldy,
-                         int64_t n_samples, int hop, int n_frames, const float* window, int detrend,
-                         int mode, int amp_sqrt, double norm_scale, double factor, int halve_edges,
-                         float2* tf, float* coh) {
+// twiddle tables of the wave-level transforms (stft1k::host_tables<N>), cached per context
+template <int NN>
+static int wave_tables(ds_ctx* c, const float2** out) {
+    float2** tab = NN == 1024 ? &c->stft1k_tables : &c->stft_wave_tables[NN == 512 ? 0 : 1];
+    if (!*tab) {
+        std::vector<float2> h;
+        stft1k::host_tables<NN>(h);
+        CHK(upload_table_fwd(c, tab, h));
+    }
+    *out = *tab;
+    return DS_OK;
+}
+
+// windows of 256 / 512 / 1024 samples (1024 = the reference's default), one input channel:
+// wave-level register transforms (kernels_welch1024.hpp)
+template <int NN>
+static int welch_wave_run(ds_ctx* c, const float* x, int64_t ldx, const float* y, int n_cy, int64_t ldy,
+                          int64_t n_samples, int hop, int n_frames, const float* window, int detrend,
+                          int mode, int amp_sqrt, double norm_scale, double factor, int halve_edges,
+                          float2* tf, float* coh) {
     namespace w1 = welch1k;
+    using W = w1::WG<NN>;
     if (!x || !y || !window) return fail(c, DS_ERR_ARG, "ds_welch_tf: null argument");
-    if (n_cy <= 0 || n_samples <= 0 || hop <= 0 || hop > 1024 || n_frames <= 0 || ldx < n_samples ||
+    if (n_cy <= 0 || n_samples <= 0 || hop <= 0 || hop > NN || n_frames <= 0 || ldx < n_samples ||
         ldy < n_samples)
         return fail(c, DS_ERR_ARG, "ds_welch_tf: bad shape");
     if (mode < DS_TF_H1 || mode > DS_TF_H3) return fail(c, DS_ERR_ARG, "welch: unsupported transfer function type");
-    if (!c->stft1k_tables) {
-        std::vector<float2> h;
-        stft1k::host_tables(h);
-        CHK(upload_table_fwd(c, &c->stft1k_tables, h));
-    }
-    w1::Plan pl = w1::plan(n_frames, n_cy);
+    const float2* tab;
+    CHK(wave_tables<NN>(c, &tab));
+    w1::Plan pl = w1::plan<NN>(n_frames, n_cy);
     CHK(reserve(c, &c->ws, &c->ws_bytes, pl.bytes));
     Carver cv(c->ws);
-    float2* xs = cv.take<float2>((size_t)pl.n_pairs * w1::N);
-    float* px = cv.take<float>((size_t)pl.n_pairs * w1::NB);
-    float* psx = cv.take<float>((size_t)pl.n_chunks * w1::NB);
-    float2* pxy = cv.take<float2>((size_t)pl.n_chunks * n_cy * w1::NB);
-    float* pyy = cv.take<float>((size_t)pl.n_chunks * n_cy * w1::NB);
-    const bool half = hop == 512;
+    float2* xs = cv.take<float2>((size_t)pl.n_pairs * NN);
+    float* px = cv.take<float>((size_t)pl.n_pairs * W::NB);
+    float* psx = cv.take<float>((size_t)pl.n_chunks * W::NB);
+    float2* pxy = cv.take<float2>((size_t)pl.n_chunks * n_cy * W::NB);
+    float* pyy = cv.take<float>((size_t)pl.n_chunks * n_cy * W::NB);
+    const bool half = hop == NN / 2;
     w1::Args ax{x, n_samples, ldx, 1, hop, n_frames, pl.n_pairs, detrend, pl.n_chunks, pl.ppc, window,
-                c->stft1k_tables, (float4*)xs, px, pxy, pyy, psx};
-    auto kx = half ? w1::k_x<true> : w1::k_x<false>;
-    auto ky = half ? w1::k_y<true> : w1::k_y<false>;
-    CHK(launch(c, "welch1024_x", kx, dim3((pl.n_pairs + w1::WPB - 1) / w1::WPB), w1::NTB, w1::LDS_BYTES, ax));
+                tab, (float4*)xs, px, pxy, pyy, psx};
+    auto kx = half ? w1::k_x<NN, true> : w1::k_x<NN, false>;
+    auto ky = half ? w1::k_y<NN, true> : w1::k_y<NN, false>;
+    CHK(launch(c, "welch1024_x", kx, dim3((pl.n_pairs + W::TPB - 1) / W::TPB), w1::NTB, W::LDS_BYTES, ax));
     w1::Args ay = ax;
     ay.sig = y;
     ay.ld = ldy;
     ay.n_ch = n_cy;
-    const int n_grp = (n_cy + w1::WPB - 1) / w1::WPB;
-    CHK(launch(c, "welch1024_main", ky, dim3(pl.n_chunks * n_grp), w1::NTB, w1::LDS_BYTES, ay));
+    const int n_grp = (n_cy + W::TPB - 1) / W::TPB;
+    CHK(launch(c, "welch1024_main", ky, dim3(pl.n_chunks * n_grp), w1::NTB, W::LDS_BYTES, ay));
     WelchFinArgs f{psx, pxy, pyy, pl.n_chunks, pl.n_chunks, 1, n_cy, 0, mode,
-                   FinishPar{norm_scale / (double)n_frames, factor, halve_edges, amp_sqrt, w1::NB},
+                   FinishPar{norm_scale / (double)n_frames, factor, halve_edges, amp_sqrt, W::NB},
                    tf, coh};
-    int64_t total = (int64_t)w1::NB * n_cy;
+    int64_t total = (int64_t)W::NB * n_cy;
     CHK(launch(c, "welch_finish", k_welch_finish, dim3((unsigned)((total + 63) / 64)), 256, 0, f));
     return DS_OK;
 }
 
-// auto spectra of every channel, window 1024 (Signal.get_spectrum's default parameters)
-static int welch1024_psd_run(ds_ctx* c, const float* x, int n_cx, int64_t ldx, int64_t n_samples, int hop,
-                             int n_frames, const float* window, int detrend, int amp_sqrt, double norm_scale,
-                             double factor, int halve_edges, float* psd) {
+// auto spectra of every channel (Signal.get_spectrum's default parameters: window 1024)
+template <int NN>
+static int welch_wave_psd_run(ds_ctx* c, const float* x, int n_cx, int64_t ldx, int64_t n_samples, int hop,
+                              int n_frames, const float* window, int detrend, int amp_sqrt, double norm_scale,
+                              double factor, int halve_edges, float* psd) {
     namespace w1 = welch1k;
+    using W = w1::WG<NN>;
     if (!x || !window) return fail(c, DS_ERR_ARG, "ds_welch_psd: null argument");
-    if (n_cx <= 0 || n_samples <= 0 || hop <= 0 || hop > 1024 || n_frames <= 0 || ldx < n_samples)
+    if (n_cx <= 0 || n_samples <= 0 || hop <= 0 || hop > NN || n_frames <= 0 || ldx < n_samples)
         return fail(c, DS_ERR_ARG, "ds_welch_psd: bad shape");
-    if (!c->stft1k_tables) {
-        std::vector<float2> h;
-        stft1k::host_tables(h);
-        CHK(upload_table_fwd(c, &c->stft1k_tables, h));
-    }
-    w1::Plan pl = w1::plan(n_frames, n_cx);
-    CHK(reserve(c, &c->ws, &c->ws_bytes, Carver::pad(sizeof(float) * (size_t)pl.n_chunks * n_cx * w1::NB)));
+    const float2* tab;
+    CHK(wave_tables<NN>(c, &tab));
+    w1::Plan pl = w1::plan<NN>(n_frames, n_cx);
+    CHK(reserve(c, &c->ws, &c->ws_bytes, Carver::pad(sizeof(float) * (size_t)pl.n_chunks * n_cx * W::NB)));
     Carver cv(c->ws);
-    float* pyy = cv.take<float>((size_t)pl.n_chunks * n_cx * w1::NB);
+    float* pyy = cv.take<float>((size_t)pl.n_chunks * n_cx * W::NB);
     w1::Args a{x, n_samples, ldx, n_cx, hop, n_frames, pl.n_pairs, detrend, pl.n_chunks, pl.ppc, window,
-               c->stft1k_tables, nullptr, nullptr, nullptr, pyy, nullptr};
-    auto ky = hop == 512 ? w1::k_y<true, true> : w1::k_y<false, true>;
-    const int n_grp = (n_cx + w1::WPB - 1) / w1::WPB;
-    CHK(launch(c, "welch1024_main", ky, dim3(pl.n_chunks * n_grp), w1::NTB, w1::LDS_BYTES, a));
+               tab, nullptr, nullptr, nullptr, pyy, nullptr};
+    auto ky = hop == NN / 2 ? w1::k_y<NN, true, true> : w1::k_y<NN, false, true>;
+    const int n_grp = (n_cx + W::TPB - 1) / W::TPB;
+    CHK(launch(c, "welch1024_main", ky, dim3(pl.n_chunks * n_grp), w1::NTB, W::LDS_BYTES, a));
     WelchFinArgs f{pyy, nullptr, nullptr, pl.n_chunks, pl.n_chunks, n_cx, 0, 1, 0,
-                   FinishPar{norm_scale / (double)n_frames, factor, halve_edges, amp_sqrt, w1::NB},
+                   FinishPar{norm_scale / (double)n_frames, factor, halve_edges, amp_sqrt, W::NB},
                    nullptr, psd};
-    int64_t total = (int64_t)w1::NB * n_cx;
+    int64_t total = (int64_t)W::NB * n_cx;
     CHK(launch(c, "welch_finish", k_welch_finish, dim3((unsigned)((total + 63) / 64)), 256, 0, f));
     return DS_OK;
 }
@@ -831,9 +842,11 @@ extern "C" int ds_welch_tf_dev(ds_ctx* c, const float* x, int n_cx, int64_t ldx,
         return welch4096_run(c, x, ldx, y, n_cy, ldy, n_samples, hop, n_frames, window, detrend, mode,
                              amp_sqrt, norm_scale, factor, halve_edges, (float2*)tf, coh);
     static const bool no1k = getenv("DSPTOOLBOX_AMD_WELCH_GENERIC") != nullptr;
-    if (c && W == 1024 && n_cx == 1 && average == DS_AVG_MEAN && !no1k)
-        return welch1024_run(c, x, ldx, y, n_cy, ldy, n_samples, hop, n_frames, window, detrend, mode,
-                             amp_sqrt, norm_scale, factor, halve_edges, (float2*)tf, coh);
+    if (c && (W == 1024 || W == 512 || W == 256) && n_cx == 1 && average == DS_AVG_MEAN && !no1k) {
+        auto run = W == 1024 ? welch_wave_run<1024> : (W == 512 ? welch_wave_run<512> : welch_wave_run<256>);
+        return run(c, x, ldx, y, n_cy, ldy, n_samples, hop, n_frames, window, detrend, mode, amp_sqrt,
+                   norm_scale, factor, halve_edges, (float2*)tf, coh);
+    }
     return welch_common(c, 0, x, n_cx, ldx, y, n_cy, ldy, n_samples, W, hop, n_frames, window, detrend,
                         average, mode, amp_sqrt, norm_scale, factor, halve_edges, (float2*)tf, coh);
 }
@@ -843,9 +856,12 @@ extern "C" int ds_welch_psd_dev(ds_ctx* c, const float* x, int n_cx, int64_t ldx
                                 int halve_edges, float* psd) {
     if (!psd) return fail(c, DS_ERR_ARG, "ds_welch_psd: null output");
     static const bool no1k = getenv("DSPTOOLBOX_AMD_WELCH_GENERIC") != nullptr;
-    if (c && W == 1024 && average == DS_AVG_MEAN && !no1k)
-        return welch1024_psd_run(c, x, n_cx, ldx, n_samples, hop, n_frames, window, detrend, amp_sqrt,
-                                 norm_scale, factor, halve_edges, psd);
+    if (c && (W == 1024 || W == 512 || W == 256) && average == DS_AVG_MEAN && !no1k) {
+        auto run = W == 1024 ? welch_wave_psd_run<1024>
+                             : (W == 512 ? welch_wave_psd_run<512> : welch_wave_psd_run<256>);
+        return run(c, x, n_cx, ldx, n_samples, hop, n_frames, window, detrend, amp_sqrt, norm_scale, factor,
+                   halve_edges, psd);
+    }
     return welch_common(c, 1, x, n_cx, ldx, nullptr, 0, 0, n_samples, W, hop, n_frames, window, detrend,
                         average, 0, amp_sqrt, norm_scale, factor, halve_edges, nullptr, psd);
 }

@@ -1,7 +1,9 @@
-// Welch H1/H2/H3 with the reference's DEFAULT window (1024 samples,
+// Welch H1/H2/H3 and auto spectra with windows of 256, 512 and 1024 samples (1024 is the
+// reference's DEFAULT window,
 // classes/signal.py:497-508; tests/test_transfer_functions.py:716-737 call
 // compute_transfer_function with window_length_samples=1024) and ONE input channel: the algebra of
-// kernels_welch4096.hpp on the wave-level 1024-point transform of kernels_stft1024.hpp.
+// kernels_welch4096.hpp on the wave-level transforms of kernels_stft1024.hpp (a team of L = N/16
+// lanes per transform: 1, 2 or 4 teams per wave).  Written out below for N = 1024, L = 64.
 //
 //   k_x : one WAVE per pair of input frames (2p, 2p+1):
 //           Wp = FFT1024( x_2p w + i x_2p+1 w )   -> xs[p][8][64] float4 (lane-major, L2 resident)
@@ -23,11 +25,17 @@
 
 namespace welch1k {
 
-using stft1k::fft1024;
+using stft1k::fft_wave;
 using stft1k::wave_sync;
-constexpr int N = 1024, NB = N / 2 + 1, NTB = 256, WPB = 4;  // waves per workgroup
-constexpr int REGION = stft1k::REGION;
-constexpr int LDS_BYTES = (WPB * REGION + stft1k::TW_LEN) * 8 + N * 4;  // 47 104 B: + the window
+constexpr int NTB = 256;  // threads per workgroup
+template <int NN>
+struct WG {
+    using G = stft1k::Geo<NN>;
+    static constexpr int N = NN, NB = NN / 2 + 1, L = G::L;
+    static constexpr int TPB = NTB / L;  // teams (frame pairs / channels) per workgroup: 4, 8, 16
+    static constexpr int REGION = G::REGION;
+    static constexpr int LDS_BYTES = (TPB * REGION + G::TW_LEN) * 8 + NN * 4;  // + the window
+};
 
 struct Args {
     const float* sig;  // x (k_x) or y (k_y), planar
@@ -35,8 +43,8 @@ struct Args {
     int n_ch, hop, n_frames, n_pairs, detrend;
     int n_chunks, ppc;
     const float* window;
-    const float2* twt;  // stft1k::host_tables()
-    float4* xs;         // [n_pairs][8][64]: lane t holds bins (t + 64*2g, t + 64*(2g+1))
+    const float2* twt;  // stft1k::host_tables<N>()
+    float4* xs;         // [n_pairs][8][L]: lane t holds bins (t + L*2g, t + L*(2g+1))
     float* px;          // [n_pairs][NB]
     float2* pxy;        // [n_chunks][n_ch][NB]
     float* pyy;         // [n_chunks][n_ch][NB]
@@ -50,40 +58,42 @@ template <bool HALF_HOP>
 struct Raw {
     float s[HALF_HOP ? 24 : 32];
 };
-template <bool HALF_HOP>
+template <int NN, bool HALF_HOP>
 __device__ __forceinline__ void load_raw(Raw<HALF_HOP>& r, const float* __restrict__ ch, int64_t n_samples,
                                          int64_t start0, int hop, int t) {
+    constexpr int L = NN / 16;
     const float* __restrict__ src = ch + start0;
     const int64_t remain = n_samples - start0;
-    const int span = HALF_HOP ? 3 * 512 : hop + N;
+    const int span = HALF_HOP ? 3 * (NN / 2) : hop + NN;
     constexpr int CNT = HALF_HOP ? 24 : 32;
     if (remain >= span) {
         if (HALF_HOP) {
 #pragma unroll
-            for (int m = 0; m < 24; ++m) r.s[m] = src[t + 64 * m];
+            for (int m = 0; m < 24; ++m) r.s[m] = src[t + L * m];
         } else {
 #pragma unroll
             for (int n1 = 0; n1 < 16; ++n1) {
-                r.s[n1] = src[t + 64 * n1];
-                r.s[16 + n1] = src[hop + t + 64 * n1];
+                r.s[n1] = src[t + L * n1];
+                r.s[16 + n1] = src[hop + t + L * n1];
             }
         }
     } else {
         const int last = (int)(remain > (int64_t)(1 << 30) ? (1 << 30) : remain) - 1;  // >= 0
 #pragma unroll
         for (int m = 0; m < CNT; ++m) {
-            const int i = HALF_HOP ? t + 64 * m : (m < 16 ? t + 64 * m : hop + t + 64 * (m - 16));
+            const int i = HALF_HOP ? t + L * m : (m < 16 ? t + L * m : hop + t + L * (m - 16));
             const float a = src[min(i, last)];
             r.s[m] = i <= last ? a : 0.f;
         }
     }
 }
-template <bool HALF_HOP>
+template <int NN, bool HALF_HOP>
 __device__ __forceinline__ void window_pair(float2 (&v)[16], const Raw<HALF_HOP>& r, const float* winl, int t) {
+    constexpr int L = NN / 16;
 #pragma unroll
     for (int n1 = 0; n1 < 16; ++n1) {
         const float b = HALF_HOP ? r.s[n1 + 8] : r.s[16 + n1];
-        const float w = winl[t + 64 * n1];
+        const float w = winl[t + L * n1];
         v[n1] = make_float2(r.s[n1] * w, b * w);
     }
 }
@@ -94,61 +104,69 @@ __device__ __forceinline__ bool needs_drop(const Args& p, int pr) {
 
 // twiddle tables and the window into LDS (the window is read from there at every pair: 16
 // registers less per lane than keeping it)
+template <int NN>
 __device__ __forceinline__ void load_tables(float2* tw1, float* winl, const Args& p) {
-    for (int i = threadIdx.x; i < stft1k::TW_LEN; i += NTB) tw1[i] = p.twt[i];
-    for (int i = threadIdx.x; i < N; i += NTB) winl[i] = p.window[i];
+    for (int i = threadIdx.x; i < stft1k::Geo<NN>::TW_LEN; i += NTB) tw1[i] = p.twt[i];
+    for (int i = threadIdx.x; i < NN; i += NTB) winl[i] = p.window[i];
 }
 
-// ---- input spectra: grid = ceil(n_pairs / 4) ------------------------------------
-template <bool HALF_HOP>
+// ---- input spectra: grid = ceil(n_pairs / TPB) -----------------------------------
+template <int NN, bool HALF_HOP>
 __global__ __launch_bounds__(NTB) void k_x(Args p) {
+    using W = WG<NN>;
+    constexpr int L = W::L, NB = W::NB;
     extern __shared__ __align__(16) float2 lds[];
-    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), t = threadIdx.x & 63;
-    float2* buf = lds + w * REGION;
-    float2* tw1 = lds + WPB * REGION;
-    const float2* tw2 = tw1 + stft1k::TW1;
-    const int pr = blockIdx.x * WPB + w;
+    // a 64-lane team is a wave: its index (and the LDS bases derived from it) is wave-uniform
+    const int w = L == 64 ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : (int)threadIdx.x / L;
+    const int t = threadIdx.x % L;
+    float2* buf = lds + w * W::REGION;
+    float2* tw1 = lds + W::TPB * W::REGION;
+    const float2* tw2 = tw1 + W::G::TW1;
+    const int pr = blockIdx.x * W::TPB + w;
     const bool live = pr < p.n_pairs;
     Raw<HALF_HOP> raw;
-    if (live) load_raw<HALF_HOP>(raw, p.sig, p.n_samples, (int64_t)(2 * pr) * p.hop, p.hop, t);
-    float* winl = reinterpret_cast<float*>(tw1 + stft1k::TW_LEN);
-    load_tables(tw1, winl, p);
+    if (live) load_raw<NN, HALF_HOP>(raw, p.sig, p.n_samples, (int64_t)(2 * pr) * p.hop, p.hop, t);
+    float* winl = reinterpret_cast<float*>(tw1 + W::G::TW_LEN);
+    load_tables<NN>(tw1, winl, p);
     __syncthreads();
     if (!live) return;
     float2 v[16], z[16];
-    window_pair<HALF_HOP>(v, raw, winl, t);
+    window_pair<NN, HALF_HOP>(v, raw, winl, t);
     if (needs_drop(p, pr)) {
 #pragma unroll
         for (int n1 = 0; n1 < 16; ++n1) v[n1].y = 0.f;
     }
-    fft1024(v, z, buf, tw1, tw2, t);
+    fft_wave<NN>(v, z, buf, tw1, tw2, t);
     if (p.detrend && t == 0) z[0] = make_float2(0.f, 0.f);
-    float4* xo = p.xs + (int64_t)pr * 512 + t;
+    float4* xo = p.xs + (int64_t)pr * (NN / 2) + t;
 #pragma unroll
-    for (int g = 0; g < 8; ++g) xo[64 * g] = make_float4(z[2 * g].x, z[2 * g].y, z[2 * g + 1].x, z[2 * g + 1].y);
+    for (int g = 0; g < 8; ++g) xo[L * g] = make_float4(z[2 * g].x, z[2 * g].y, z[2 * g + 1].x, z[2 * g + 1].y);
     float* pw = reinterpret_cast<float*>(buf);
 #pragma unroll
-    for (int m = 0; m < 16; ++m) pw[t + 64 * m] = z[m].x * z[m].x + z[m].y * z[m].y;
+    for (int m = 0; m < 16; ++m) pw[t + L * m] = z[m].x * z[m].x + z[m].y * z[m].y;
     wave_sync();
     float* po = p.px + (int64_t)pr * NB;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        const int k = t + 64 * j;
-        po[k] = 0.5f * (pw[k] + pw[(N - k) & (N - 1)]);
+        const int k = t + L * j;
+        po[k] = 0.5f * (pw[k] + pw[(NN - k) & (NN - 1)]);
     }
-    if (t == 0) po[512] = pw[512];
+    if (t == 0) po[NN / 2] = pw[NN / 2];
 }
 
-// ---- output channels: grid = n_chunks * ceil(n_ch / 4) ---------------------------
+// ---- output channels: grid = n_chunks * ceil(n_ch / TPB) --------------------------
 // AUTO: auto spectra only (Signal.get_spectrum's default call): no input spectra, no cross sums.
-template <bool HALF_HOP, bool AUTO = false>
+template <int NN, bool HALF_HOP, bool AUTO = false>
 __global__ __launch_bounds__(NTB, 3) void k_y(Args p) {
+    using W = WG<NN>;
+    constexpr int L = W::L, NB = W::NB, TPB = W::TPB;
     extern __shared__ __align__(16) float2 lds[];
-    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), t = threadIdx.x & 63;
-    float2* buf = lds + w * REGION;
-    float2* tw1 = lds + WPB * REGION;
-    const float2* tw2 = tw1 + stft1k::TW1;
-    const int n_grp = (p.n_ch + WPB - 1) / WPB;
+    const int w = L == 64 ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : (int)threadIdx.x / L;
+    const int t = threadIdx.x % L;
+    float2* buf = lds + w * W::REGION;
+    float2* tw1 = lds + TPB * W::REGION;
+    const float2* tw2 = tw1 + W::G::TW1;
+    const int n_grp = (p.n_ch + TPB - 1) / TPB;
     // XCD-aware decode (workgroups b, b+8, ... share an XCD and its L2): whole chunks per XCD, so
     // the input spectra a chunk's channel groups re-read stay in that L2
     int q, g;
@@ -163,15 +181,15 @@ __global__ __launch_bounds__(NTB, 3) void k_y(Args p) {
             g = b / p.n_chunks;
         }
     }
-    const int c = g * WPB + w;
+    const int c = g * TPB + w;
     const bool live = c < p.n_ch;
     // balanced split of the pairs over the chunks (n_chunks stays a multiple of 8 for the XCD mapping)
     const int p0 = (int)((int64_t)q * p.n_pairs / p.n_chunks), p1 = (int)((int64_t)(q + 1) * p.n_pairs / p.n_chunks);
     const float* ch = p.sig + (int64_t)(live ? c : 0) * p.ld;
     Raw<HALF_HOP> raw;
-    if (p0 < p1) load_raw<HALF_HOP>(raw, ch, p.n_samples, (int64_t)(2 * p0) * p.hop, p.hop, t);
-    float* winl = reinterpret_cast<float*>(tw1 + stft1k::TW_LEN);
-    load_tables(tw1, winl, p);
+    if (p0 < p1) load_raw<NN, HALF_HOP>(raw, ch, p.n_samples, (int64_t)(2 * p0) * p.hop, p.hop, t);
+    float* winl = reinterpret_cast<float*>(tw1 + W::G::TW_LEN);
+    load_tables<NN>(tw1, winl, p);
     if (!AUTO) {
         // input auto-spectrum of this chunk: this workgroup's slice of the bins, px rows summed in fp64
         const int bpg = (NB + n_grp - 1) / n_grp;
@@ -194,27 +212,27 @@ __global__ __launch_bounds__(NTB, 3) void k_y(Args p) {
     }
     for (int pr = p0; pr < p1; ++pr) {
         float2 v[16], z[16];
-        window_pair<HALF_HOP>(v, raw, winl, t);
+        window_pair<NN, HALF_HOP>(v, raw, winl, t);
         if (needs_drop(p, pr)) {
 #pragma unroll
             for (int n1 = 0; n1 < 16; ++n1) v[n1].y = 0.f;
         }
-        if (pr + 1 < p1) load_raw<HALF_HOP>(raw, ch, p.n_samples, (int64_t)(2 * pr + 2) * p.hop, p.hop, t);
-        // this pair's input spectrum is requested behind the second exchange (registers of v free)
+        if (pr + 1 < p1) load_raw<NN, HALF_HOP>(raw, ch, p.n_samples, (int64_t)(2 * pr + 2) * p.hop, p.hop, t);
         if constexpr (AUTO) {
-            fft1024(v, z, buf, tw1, tw2, t);
+            fft_wave<NN>(v, z, buf, tw1, tw2, t);
 #pragma unroll
             for (int m = 0; m < 16; ++m) P[m] = fmaf(z[m].x, z[m].x, fmaf(z[m].y, z[m].y, P[m]));
         } else {
+            // this pair's input spectrum is requested behind the second exchange (registers of v free)
             float4 xq[8];
             auto issue_xs = [&]() {
                 __builtin_amdgcn_sched_barrier(0);
-                const float4* __restrict__ xp = p.xs + (int64_t)pr * 512 + t;
+                const float4* __restrict__ xp = p.xs + (int64_t)pr * (NN / 2) + t;
 #pragma unroll
-                for (int gg = 0; gg < 8; ++gg) xq[gg] = xp[64 * gg];
+                for (int gg = 0; gg < 8; ++gg) xq[gg] = xp[L * gg];
                 __builtin_amdgcn_sched_barrier(0);
             };
-            fft1024(v, z, buf, tw1, tw2, t, issue_xs);
+            fft_wave<NN>(v, z, buf, tw1, tw2, t, issue_xs);
 #pragma unroll
             for (int gg = 0; gg < 8; ++gg) {
 #pragma unroll
@@ -230,31 +248,31 @@ __global__ __launch_bounds__(NTB, 3) void k_y(Args p) {
         }
     }
     if (p.detrend && t == 0) P[0] = 0.f;  // xs bin 0 is already 0 -> T[0] = 0
-    // fold k <-> N-k once per chunk through this wave's LDS region
+    // fold k <-> N-k once per chunk through this team's LDS region
     const int64_t so = ((int64_t)q * p.n_ch + c) * NB;
     if (!AUTO) {
 #pragma unroll
-        for (int m = 0; m < 16; ++m) buf[t + 64 * m] = T[m];
+        for (int m = 0; m < 16; ++m) buf[t + L * m] = T[m];
         wave_sync();
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const int k = t + 64 * j;
-            const float2 a = buf[k], b = buf[(N - k) & (N - 1)];
+            const int k = t + L * j;
+            const float2 a = buf[k], b = buf[(NN - k) & (NN - 1)];
             p.pxy[so + k] = make_float2(0.5f * (a.x + b.x), 0.5f * (a.y - b.y));
         }
-        if (t == 0) p.pxy[so + 512] = make_float2(buf[512].x, 0.f);
+        if (t == 0) p.pxy[so + NN / 2] = make_float2(buf[NN / 2].x, 0.f);
         wave_sync();
     }
     float* pw = reinterpret_cast<float*>(buf);
 #pragma unroll
-    for (int m = 0; m < 16; ++m) pw[t + 64 * m] = P[m];
+    for (int m = 0; m < 16; ++m) pw[t + L * m] = P[m];
     wave_sync();
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        const int k = t + 64 * j;
-        p.pyy[so + k] = 0.5f * (pw[k] + pw[(N - k) & (N - 1)]);
+        const int k = t + L * j;
+        p.pyy[so + k] = 0.5f * (pw[k] + pw[(NN - k) & (NN - 1)]);
     }
-    if (t == 0) p.pyy[so + 512] = pw[512];
+    if (t == 0) p.pyy[so + NN / 2] = pw[NN / 2];
 }
 
 // ---- host side -------------------------------------------------------------------
@@ -262,10 +280,12 @@ struct Plan {
     int n_pairs, n_chunks, ppc;
     size_t bytes;
 };
+template <int NN>
 inline Plan plan(int n_frames, int n_cy) {
+    using W = WG<NN>;
     Plan pl;
     pl.n_pairs = (n_frames + 1) / 2;
-    const int n_grp = (n_cy + WPB - 1) / WPB;
+    const int n_grp = (n_cy + W::TPB - 1) / W::TPB;
     // three workgroups per CU (768 on the 256 CUs) resident at once when there is enough work;
     // fp32 accumulation chains stay <= 64 pairs
     int want = (768 + n_grp - 1) / n_grp;
@@ -280,9 +300,9 @@ inline Plan plan(int n_frames, int n_cy) {
     pl.n_chunks = want;         // chunk q = pairs [q n_pairs / n_chunks, (q+1) n_pairs / n_chunks)
     pl.ppc = (pl.n_pairs + want - 1) / want;
     auto pad = [](size_t b) { return (b + 255) & ~size_t(255); };
-    pl.bytes = pad(sizeof(float2) * (size_t)pl.n_pairs * N) + pad(sizeof(float) * (size_t)pl.n_pairs * NB) +
-               pad(sizeof(float) * (size_t)pl.n_chunks * NB) + pad(sizeof(float2) * (size_t)pl.n_chunks * n_cy * NB) +
-               pad(sizeof(float) * (size_t)pl.n_chunks * n_cy * NB);
+    pl.bytes = pad(sizeof(float2) * (size_t)pl.n_pairs * NN) + pad(sizeof(float) * (size_t)pl.n_pairs * W::NB) +
+               pad(sizeof(float) * (size_t)pl.n_chunks * W::NB) + pad(sizeof(float2) * (size_t)pl.n_chunks * n_cy * W::NB) +
+               pad(sizeof(float) * (size_t)pl.n_chunks * n_cy * W::NB);
     return pl;
 }
 
