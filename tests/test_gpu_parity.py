@@ -724,6 +724,29 @@ def test_welch_default_window_kernel_vs_oracle():
     print("welch 1024-window kernel worst rel-max", worst)
 
 
+def test_register_kernels_tiny_and_ragged_signals():
+    """Signals shorter than one window, exactly one / two windows, one sample more: single frames,
+    frame pairs without a second frame, frames that are mostly zero padding -- on every window length
+    that has a register-resident kernel (auto spectra, H1 and the STFT)."""
+    rng = np.random.default_rng(123)
+    for W in (256, 512, 1024, 4096):
+        for n in (W // 4, W, W + 1, 3 * W // 2, 2 * W, 5 * W + 17):
+            x = rng.standard_normal((n, 3)) * 0.3 + 0.1
+            psd = backend._welch(x, None, 48000, Window.Hann, W, 50, False, "mean", SpectrumScaling.PowerSpectralDensity)
+            ref = orc.welch(x, None, 48000, "hann", W, 50, False, "mean", "PowerSpectralDensity")
+            assert psd.shape == ref.shape and relmax(psd, ref) < TOL, (W, n, relmax(psd, ref))
+            tf, coh = backend.welch_transfer_function(x[:, 1:], x[:, :1], 48000, W, "H1", detrend=False)
+            rt, rc = orc.compute_transfer_function(x[:, 1:], x[:, :1], 48000, W, "H1", detrend=False)
+            # one or two frames: H1 is a ratio of nearly identical numbers; the coherence is 1 +- rounding
+            assert tf.shape == rt.shape and np.all(np.isfinite(tf)) and orc.rel_l2(tf, rt) < 20 * TOL, (W, n)
+            assert np.max(np.abs(coh - rc)) < 2e-5, (W, n, np.max(np.abs(coh - rc)))
+            if W <= 1024:
+                for pad in (True, False):
+                    t, f, st = backend._stft(x, 48000, W, Window.Hann, 50, None, False, pad, SpectrumScaling.FFTBackward)
+                    rt_, rf_, rs = orc.stft(x, 48000, W, "hann", 50, None, False, pad, "FFTBackward")
+                    assert st.shape == rs.shape and relmax(st, rs) < TOL, (W, n, pad)
+
+
 def test_stft_default_frame_kernel_vs_oracle():
     """Frames of 256, 512 and 1024 points have their own kernel (kernels_stft1024.hpp: one frame pair
     per team of nfft/16 lanes, the transform in registers): channel tiles with idle teams (1, 3, 5, 9, 17 channels), odd and even
