@@ -1485,9 +1485,25 @@ static int fir_once(ds_ctx* c, const float* x, int n_ch, int64_t ldx, int64_t n_
             HIPCHK(c, hipGetLastError());
             HIPCHK(c, hipEventRecord(c->ev_join, c->side));
         }
-        if (n_plain > 0)
-            CHK(launch(c, "fir", fir16k::k_fir<true>, dim3((unsigned)n_plain, (n_ch + 1) / 2), fir16k::NTB,
+        if (n_plain > 0) {
+            // one workgroup per CU: split the filter loop over 1, 2 or 4 workgroups per block when that
+            // fills the last round better (cost ~ rounds x (filters per slice + 1 forward transform))
+            int split = 1;
+            {
+                const int64_t wgs = n_plain * ((n_ch + 1) / 2);
+                int64_t best = -1;
+                for (int s = 1; s <= 4 && s <= n_filt; s *= 2) {
+                    const int64_t cost = ((wgs * s + 255) / 256) * ((n_filt + s - 1) / s + 1);
+                    if (best < 0 || cost < best) {
+                        best = cost;
+                        split = s;
+                    }
+                }
+                if (const char* e = getenv("DSPTOOLBOX_AMD_FIR_SPLIT")) split = std::max(1, std::min(atoi(e), n_filt));
+            }
+            CHK(launch(c, "fir", fir16k::k_fir<true>, dim3((unsigned)n_plain, (n_ch + 1) / 2, split), fir16k::NTB,
                        fir16k::LDS_BYTES, a));
+        }
         if (ragged && n_plain > 0) {
             HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
         } else if (ragged) {

@@ -151,7 +151,7 @@ struct Args {
     int block0;           // first block of this launch
 };
 
-// grid = (n_blocks, ceil(n_ch/2)); block j covers outputs [j L, (j+1) L), L = 16384 - (n_taps-1).
+// grid = (n_blocks, ceil(n_ch/2), filter slices); block j covers outputs [j L, (j+1) L), L = 16384 - (n_taps-1).
 // PLAIN: exactly 4096 discarded samples (4097 taps), whole block inside the signal, 16-byte aligned
 // rows: quarters 1..3 are stored whole with 16-byte stores and no test per store (the host launches
 // the interior blocks with PLAIN and the rest without: keeping both store paths in one kernel costs
@@ -226,8 +226,12 @@ __global__ __launch_bounds__(NTB) void k_fir(Args p) {
             v[2 * j + 1] = make_float2(r.z, r.w);
         }
     };
-    load_taps(hq);
-    for (int k = 0; k < p.n_filt; ++k) {
+    // gridDim.z workgroups share a block: each applies a slice of the filters (the forward transform
+    // is repeated per slice; the host picks the split that fills the last round of workgroups best)
+    const int k0 = (int)((int64_t)blockIdx.z * p.n_filt / gridDim.z);
+    const int k1 = (int)((int64_t)(blockIdx.z + 1) * p.n_filt / gridDim.z);
+    load_taps(hq + (int64_t)k0 * (NBIG / 2));
+    for (int k = k0; k < k1; ++k) {
 #pragma unroll
         for (int s = 0; s < 16; ++s) v[s] = cmul(z[s], v[s]);
         __syncthreads();  // the previous filter's recombination reads are done
@@ -238,7 +242,7 @@ __global__ __launch_bounds__(NTB) void k_fir(Args p) {
 #pragma unroll
         for (int n1 = 0; n1 < 16; ++n1) comb[q * M + t + 256 * n1] = cmulc(v[n1], cmul(wt, c64[n1]));
         // the registers are free: fetch the next filter's tap spectrum behind the recombination
-        if (k + 1 < p.n_filt) load_taps(hq + (int64_t)(k + 1) * (NBIG / 2));
+        if (k + 1 < k1) load_taps(hq + (int64_t)(k + 1) * (NBIG / 2));
         __syncthreads();
         float* oa = p.y + ((int64_t)k * p.n_ch + ca) * p.ld_y + (out0 - T1);
         float* ob = oa + p.ld_y;
