@@ -746,6 +746,35 @@ static int welch4096_run(ds_ctx* c, const float* x, int64_t ldx, const float* y,
     return DS_OK;
 }
 
+// auto spectra of every channel with a 4096-sample window on the headline kernel (AUTO variant)
+static int welch4096_psd_run(ds_ctx* c, const float* x, int n_cx, int64_t ldx, int64_t n_samples, int hop,
+                             int n_frames, const float* window, int detrend, int amp_sqrt, double norm_scale,
+                             double factor, int halve_edges, float* psd) {
+    namespace w4 = welch4096;
+    if (!x || !window) return fail(c, DS_ERR_ARG, "ds_welch_psd: null argument");
+    if (n_cx <= 0 || n_samples <= 0 || hop <= 0 || hop > 4096 || n_frames <= 0 || ldx < n_samples)
+        return fail(c, DS_ERR_ARG, "ds_welch_psd: bad shape");
+    if (!c->w4_tables) {
+        std::vector<float2> h;
+        w4::host_tables(h);
+        CHK(upload_table_fwd(c, &c->w4_tables, h));
+    }
+    w4::Plan pl = w4::plan(n_frames, n_cx);
+    CHK(reserve(c, &c->ws, &c->ws_bytes, Carver::pad(sizeof(float) * (size_t)pl.n_chunks * n_cx * w4::NB)));
+    Carver cv(c->ws);
+    float* pyy = cv.take<float>((size_t)pl.n_chunks * n_cx * w4::NB);
+    w4::Args a{x, n_samples, ldx, n_cx, hop, n_frames, pl.n_pairs, detrend, pl.n_chunks, pl.ppc, window,
+               c->w4_tables, nullptr, nullptr, nullptr, pyy, nullptr};
+    auto ky = hop == 2048 ? w4::k_y<true, true> : w4::k_y<false, true>;
+    CHK(launch(c, "welch4096_main", ky, dim3(pl.n_chunks * n_cx), w4::NT, w4::LDS_BYTES_2, a));
+    WelchFinArgs f{pyy, nullptr, nullptr, pl.n_chunks, pl.n_chunks, n_cx, 0, 1, 0,
+                   FinishPar{norm_scale / (double)n_frames, factor, halve_edges, amp_sqrt, w4::NB},
+                   nullptr, psd};
+    int64_t total = (int64_t)w4::NB * n_cx;
+    CHK(launch(c, "welch_finish", k_welch_finish, dim3((unsigned)((total + 63) / 64)), 256, 0, f));
+    return DS_OK;
+}
+
 // twiddle tables of the wave-level transforms (stft1k::host_tables<N>), cached per context
 template <int NN>
 static int wave_tables(ds_ctx* c, const float2** out) {
@@ -856,6 +885,9 @@ extern "C" int ds_welch_psd_dev(ds_ctx* c, const float* x, int n_cx, int64_t ldx
                                 int halve_edges, float* psd) {
     if (!psd) return fail(c, DS_ERR_ARG, "ds_welch_psd: null output");
     static const bool no1k = getenv("DSPTOOLBOX_AMD_WELCH_GENERIC") != nullptr;
+    if (c && W == 4096 && average == DS_AVG_MEAN && welch4096::enabled() && !no1k)
+        return welch4096_psd_run(c, x, n_cx, ldx, n_samples, hop, n_frames, window, detrend, amp_sqrt,
+                                 norm_scale, factor, halve_edges, psd);
     if (c && (W == 1024 || W == 512 || W == 256) && average == DS_AVG_MEAN && !no1k) {
         auto run = W == 1024 ? welch_wave_psd_run<1024>
                              : (W == 512 ? welch_wave_psd_run<512> : welch_wave_psd_run<256>);

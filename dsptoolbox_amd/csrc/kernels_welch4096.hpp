@@ -333,7 +333,8 @@ __global__ __launch_bounds__(NT) void k_x(Args p) {
 // Two workgroups per CU (<= 256 VGPRs, 2 x 37 KB of LDS each).  Occupancy 3 (<= 168 VGPRs:
 // on-the-fly Hann window, input spectrum loaded where used) and 4 were built and measured:
 // the spills / exposed load latency cost more than the third workgroup hides (147 vs 108 us).
-template <bool HALF_HOP>
+// AUTO: auto spectra only (ds_welch_psd): no input spectra, no cross sums, no psx.
+template <bool HALF_HOP, bool AUTO = false>
 __global__ __launch_bounds__(NT, 2) void k_y(Args p) {
     constexpr bool TWO_BUF = true;
     extern __shared__ __align__(16) float2 lds[];
@@ -360,7 +361,7 @@ __global__ __launch_bounds__(NT, 2) void k_y(Args p) {
     const float* ch = p.sig + (int64_t)c * p.ld;
     // balanced split of the pairs over the chunks (n_chunks stays a multiple of 8 for the XCD mapping)
     const int p0 = (int)((int64_t)q * p.n_pairs / p.n_chunks), p1 = (int)((int64_t)(q + 1) * p.n_pairs / p.n_chunks);
-    {
+    if (!AUTO) {
         // Input auto-spectrum of this chunk: the px rows k_x wrote, summed in fp64 -- instead of a
         // separate reduction kernel every workgroup of the chunk takes a slice of the bins
         // (8 row groups x 32 bins per sweep, independent loads, combined through LDS).
@@ -416,6 +417,7 @@ __global__ __launch_bounds__(NT, 2) void k_y(Args p) {
                 __builtin_amdgcn_sched_barrier(0);
             };
             auto issue_xs = [&]() {
+                if (AUTO) return;
                 __builtin_amdgcn_sched_barrier(0);
                 if (W4_ABLATE & 1) {
 #pragma unroll
@@ -439,10 +441,12 @@ __global__ __launch_bounds__(NT, 2) void k_y(Args p) {
 #endif
 #pragma unroll
             for (int k3 = 0; k3 < 16; ++k3) {
-                float2 w = xw[k3];
                 float2 z = v[pos16(k3)];
-                T[k3].x = fmaf(w.x, z.x, fmaf(w.y, z.y, T[k3].x));   // conj(w) z
-                T[k3].y = fmaf(w.x, z.y, fmaf(-w.y, z.x, T[k3].y));
+                if (!AUTO) {
+                    float2 w = xw[k3];
+                    T[k3].x = fmaf(w.x, z.x, fmaf(w.y, z.y, T[k3].x));   // conj(w) z
+                    T[k3].y = fmaf(w.x, z.y, fmaf(-w.y, z.x, T[k3].y));
+                }
                 P[k3] = fmaf(z.x, z.x, fmaf(z.y, z.y, P[k3]));
             }
             W4_TS(11);
@@ -457,15 +461,17 @@ __global__ __launch_bounds__(NT, 2) void k_y(Args p) {
     if (p.detrend && tid == 0) P[0] = 0.f;  // xs bin 0 is already 0 -> T[0] = 0
     // fold k <-> N-k once per chunk, through LDS
     __syncthreads();
-#pragma unroll
-    for (int k3 = 0; k3 < 16; ++k3) buf[tid + 256 * k3] = T[k3];
-    __syncthreads();
     const int64_t so = ((int64_t)q * p.n_ch + c) * NB;
-    for (int k = tid; k < NB; k += NT) {
-        float2 a = buf[k], b = buf[(N - k) & (N - 1)];
-        p.pxy[so + k] = make_float2(0.5f * (a.x + b.x), 0.5f * (a.y - b.y));
+    if (!AUTO) {
+#pragma unroll
+        for (int k3 = 0; k3 < 16; ++k3) buf[tid + 256 * k3] = T[k3];
+        __syncthreads();
+        for (int k = tid; k < NB; k += NT) {
+            float2 a = buf[k], b = buf[(N - k) & (N - 1)];
+            p.pxy[so + k] = make_float2(0.5f * (a.x + b.x), 0.5f * (a.y - b.y));
+        }
+        __syncthreads();
     }
-    __syncthreads();
     float* pw = reinterpret_cast<float*>(buf);
 #pragma unroll
     for (int k3 = 0; k3 < 16; ++k3) pw[tid + 256 * k3] = P[k3];
