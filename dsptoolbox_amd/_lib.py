@@ -48,6 +48,9 @@ SIGNATURES = {
     "ds_welch_tf": (C.c_int, [ctx_p, f32_p, C.c_int, f32_p, C.c_int, i64, C.c_int, C.c_int, C.c_int,
                               f32_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double,
                               C.c_int, c32_p, f32_p]),
+    "ds_welch_tf_f64": (C.c_int, [ctx_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, i64, C.c_int, C.c_int, C.c_int,
+                                  f32_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double,
+                                  C.c_int, c32_p, f32_p]),
     "ds_welch_psd_dev": (C.c_int, [ctx_p, f32_p, C.c_int, i64, i64, C.c_int, C.c_int, C.c_int, f32_p,
                                    C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, f32_p]),
     "ds_welch_psd": (C.c_int, [ctx_p, f32_p, C.c_int, i64, C.c_int, C.c_int, C.c_int, f32_p, C.c_int,

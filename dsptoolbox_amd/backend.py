@@ -159,10 +159,24 @@ def welch_transfer_function(output_td, input_td, fs_hz: int, window_length_sampl
         raise ValueError("Unsupported transfer function type")
     W = int(window_length_samples)
     window = _window_array(window_type, W)
-    yp, xp = _planar_f32(output_td), _planar_f32(input_td)
-    n_cy, n = yp.shape
-    n_cx = xp.shape[0]
-    assert xp.shape[1] == n, "Signal lengths do not match"
+    yo, xi = np.asarray(output_td), np.asarray(input_td)
+    if yo.ndim == 1:
+        yo = yo[:, None]
+    if xi.ndim == 1:
+        xi = xi[:, None]
+    # large float64 C-order arrays (the reference's own layout) cross the boundary as they are: the
+    # library casts + transposes them in threads straight into pinned upload chunks
+    fused = all(a.ndim == 2 and a.dtype == np.float64 and a.flags.c_contiguous for a in (yo, xi)) \
+        and yo.size >= (1 << 20)
+    if fused:
+        n, n_cy = yo.shape
+        n_cx = xi.shape[1]
+        assert xi.shape[0] == n, "Signal lengths do not match"
+    else:
+        yp, xp = _planar_f32(yo), _planar_f32(xi)
+        n_cy, n = yp.shape
+        n_cx = xp.shape[0]
+        assert xp.shape[1] == n, "Signal lengths do not match"
     hop, n_frames = _welch_framing(n, W, overlap_percent, window)
     amp, norm_scale, factor, phys = _finish_params(scaling, W, fs_hz, window)
     w32 = window.astype(np.float32)
@@ -170,9 +184,14 @@ def welch_transfer_function(output_td, input_td, fs_hz: int, window_length_sampl
     tf = np.empty((B, n_cy), dtype=np.complex64)
     coh = np.empty((B, n_cy), dtype=np.float32)
     ctx = get_context()
-    ctx.check(ctx.lib.ds_welch_tf(ctx.handle, _ptr(xp), n_cx, _ptr(yp), n_cy, n, W, hop, n_frames,
-                                  _ptr(w32), int(bool(detrend)), DS_AVG[average], DS_TF[mode], amp,
-                                  norm_scale, factor, phys, _ptr(tf), _ptr(coh)), "ds_welch_tf")
+    if fused:
+        ctx.check(ctx.lib.ds_welch_tf_f64(ctx.handle, _ptr(xi), n_cx, _ptr(yo), n_cy, n, W, hop, n_frames,
+                                          _ptr(w32), int(bool(detrend)), DS_AVG[average], DS_TF[mode], amp,
+                                          norm_scale, factor, phys, _ptr(tf), _ptr(coh)), "ds_welch_tf_f64")
+    else:
+        ctx.check(ctx.lib.ds_welch_tf(ctx.handle, _ptr(xp), n_cx, _ptr(yp), n_cy, n, W, hop, n_frames,
+                                      _ptr(w32), int(bool(detrend)), DS_AVG[average], DS_TF[mode], amp,
+                                      norm_scale, factor, phys, _ptr(tf), _ptr(coh)), "ds_welch_tf")
     return tf.astype(np.complex128), coh.astype(np.float64)
 
 

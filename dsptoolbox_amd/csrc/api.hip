@@ -45,6 +45,9 @@ struct ds_ctx {
     void* io = nullptr;  // staging for the host-pointer entry points
     size_t io_bytes = 0;
     void* aux = nullptr;  // small persistent scratch (combined FIR taps, cascade ping-pong buffer)
+    void* pin[2] = {nullptr, nullptr};  // pinned host chunks of the fused float64 upload (double buffer)
+    hipEvent_t pin_ev[2] = {nullptr, nullptr};
+    bool pin_busy[2] = {false, false};
     size_t aux_bytes = 0;
     // RCCL (dlopen'ed lazily)
     void* rccl = nullptr;
@@ -203,6 +206,10 @@ extern "C" void ds_destroy(ds_ctx* c) {
     if (c->ws) (void)hipFree(c->ws);
     if (c->io) (void)hipFree(c->io);
     if (c->aux) (void)hipFree(c->aux);
+    for (int i = 0; i < 2; ++i) {
+        if (c->pin[i]) (void)hipHostFree(c->pin[i]);
+        if (c->pin_ev[i]) (void)hipEventDestroy(c->pin_ev[i]);
+    }
     (void)hipEventDestroy(c->ev0);
     (void)hipEventDestroy(c->ev1);
     (void)hipStreamDestroy(c->stream);
@@ -1691,6 +1698,75 @@ extern "C" int ds_istft(ds_ctx* c, const ds_c32* stft, int n_bins, int n_frames,
     CHK(ds_istft_dev(c, (const ds_c32*)ds, n_bins, n_frames, n_ch, nfft, W, step, frame_offset, n_frames_total,
                      dw, scale, total_length, dout, total_length));
     return ds_download(c, out, dout, no * 4);
+}
+
+// Fused boundary upload: (samples, channels) float64 C-order host array -> planar float32 device
+// rows.  Chunks of samples are cast + transposed by host threads straight into one of two pinned
+// buffers and sent with an asynchronous 2-D copy, so the cast of chunk k+1 overlaps the DMA of
+// chunk k (a pageable hipMemcpy of the pre-cast array moves ~13 GB/s; this path is bound by the
+// threads' cast, ~35 GB/s of float64 input).
+static const size_t kPinBytes = (size_t)32 << 20;
+static int upload_planar_f64(ds_ctx* c, const double* src, int64_t n_samples, int n_ch, float* dst_dev,
+                             int64_t ld) {
+    for (int i = 0; i < 2; ++i) {
+        if (!c->pin[i]) {
+            HIPCHK(c, hipHostMalloc(&c->pin[i], kPinBytes, hipHostMallocDefault));
+            HIPCHK(c, hipEventCreateWithFlags(&c->pin_ev[i], hipEventDisableTiming));
+        }
+    }
+    int64_t cs = (int64_t)(kPinBytes / ((size_t)n_ch * sizeof(float))) & ~(int64_t)255;
+    if (cs < 256) return fail(c, DS_ERR_UNSUP, "upload_planar_f64: too many channels for the staging chunk");
+    int k = 0;
+    for (int64_t s0 = 0; s0 < n_samples; s0 += cs, ++k) {
+        const int b = k & 1;
+        const int64_t cn = std::min(cs, n_samples - s0);
+        if (c->pin_busy[b]) HIPCHK(c, hipEventSynchronize(c->pin_ev[b]));  // its previous DMA has finished
+        float* pin = (float*)c->pin[b];
+        const double* sp = src + s0 * n_ch;
+        host_parallel(host_threads(0, cn * n_ch), cn, [=](int64_t lo, int64_t hi) {
+            constexpr int64_t TILE = 256;
+            for (int64_t t0 = lo; t0 < hi; t0 += TILE) {
+                const int64_t t1 = std::min(hi, t0 + TILE);
+                for (int ch = 0; ch < n_ch; ++ch) {
+                    float* __restrict__ d = pin + (int64_t)ch * cn;
+                    const double* __restrict__ q = sp + ch;
+                    for (int64_t n = t0; n < t1; ++n) d[n] = (float)q[n * n_ch];
+                }
+            }
+        });
+        HIPCHK(c, hipMemcpy2DAsync(dst_dev + s0, (size_t)ld * sizeof(float), pin, (size_t)cn * sizeof(float),
+                                   (size_t)cn * sizeof(float), (size_t)n_ch, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipEventRecord(c->pin_ev[b], c->stream));
+        c->pin_busy[b] = true;
+    }
+    return DS_OK;
+}
+
+// ds_welch_tf with the reference's own array layout at the boundary: x (n_samples, n_cx) and
+// y (n_samples, n_cy) float64 C-order (classes/signal.py:222-301), outputs as ds_welch_tf.
+extern "C" int ds_welch_tf_f64(ds_ctx* c, const double* x, int n_cx, const double* y, int n_cy,
+                               int64_t n_samples, int W, int hop, int n_frames, const float* window,
+                               int detrend, int average, int mode, int amp_sqrt, double norm_scale,
+                               double factor, int halve_edges, ds_c32* tf, float* coh) {
+    if (!c || !x || !y || !window || !tf || !coh) return fail(c, DS_ERR_ARG, "ds_welch_tf_f64: null argument");
+    if (n_cx <= 0 || n_cy <= 0 || n_samples <= 0 || W <= 0) return fail(c, DS_ERR_ARG, "ds_welch_tf_f64: bad shape");
+    size_t nx = (size_t)n_cx * n_samples, ny = (size_t)n_cy * n_samples, no = (size_t)(W / 2 + 1) * n_cy;
+    CHK(stage_reserve(c, Carver::pad(nx * 4) + Carver::pad(ny * 4) + Carver::pad((size_t)W * 4) +
+                             Carver::pad(no * 8) + Carver::pad(no * 4)));
+    Carver cv(c->io);
+    float* dx = cv.take<float>(nx);
+    float* dy = cv.take<float>(ny);
+    float* dw = cv.take<float>(W);
+    float2* dtf = cv.take<float2>(no);
+    float* dcoh = cv.take<float>(no);
+    CHK(upload_planar_f64(c, x, n_samples, n_cx, dx, n_samples));
+    CHK(upload_planar_f64(c, y, n_samples, n_cy, dy, n_samples));
+    CHK(ds_upload(c, dw, window, (size_t)W * 4));
+    CHK(ds_welch_tf_dev(c, dx, n_cx, n_samples, dy, n_cy, n_samples, n_samples, W, hop, n_frames, dw,
+                        detrend, average, mode, amp_sqrt, norm_scale, factor, halve_edges, (ds_c32*)dtf,
+                        dcoh));
+    CHK(ds_download(c, tf, dtf, no * 8));
+    return ds_download(c, coh, dcoh, no * 4);
 }
 
 extern "C" int ds_welch_tf(ds_ctx* c, const float* x, int n_cx, const float* y, int n_cy,

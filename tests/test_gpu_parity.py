@@ -724,6 +724,21 @@ def test_welch_default_window_kernel_vs_oracle():
     print("welch 1024-window kernel worst rel-max", worst)
 
 
+def test_fused_float64_upload_is_the_same_computation():
+    """welch_transfer_function hands large float64 C-order arrays to ds_welch_tf_f64 (threaded cast
+    + transpose into pinned chunks, asynchronous 2-D copies); the result must be bit-identical to
+    the planar-float32 entry point, for one chunk and for several (32 MB chunks)."""
+    rng = np.random.default_rng(321)
+    for n, c in ((300001, 5), (2**20, 40)):
+        x = rng.standard_normal((n, 1)) * 0.3
+        y = rng.standard_normal((n, c)) * 0.2 + 0.5 * x
+        tf_a, coh_a = backend.welch_transfer_function(y, x, 48000, 4096, "H1")            # fused path
+        yf = np.asfortranarray(y)                                                          # not C-order:
+        tf_b, coh_b = backend.welch_transfer_function(yf, x, 48000, 4096, "H1")           # numpy + ds_welch_tf
+        # (bin 0 is 0/0 = NaN on both sides with detrend)
+        assert np.array_equal(tf_a, tf_b, equal_nan=True) and np.array_equal(coh_a, coh_b, equal_nan=True), (n, c)
+
+
 def test_register_kernels_tiny_and_ragged_signals():
     """Signals shorter than one window, exactly one / two windows, one sample more: single frames,
     frame pairs without a second frame, frames that are mostly zero padding -- on every window length
