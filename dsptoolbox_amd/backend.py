@@ -73,6 +73,13 @@ def _widen(a: np.ndarray) -> np.ndarray:
     return a.astype(wide)
 
 
+def _fusable(a) -> bool:
+    """Large (N, C) float64 C-order array: crosses the boundary as it is (the *_f64 entry points cast
+    + transpose it in host threads straight into pinned upload chunks)."""
+    return isinstance(a, np.ndarray) and a.ndim == 2 and a.dtype == np.float64 and a.flags.c_contiguous \
+        and a.size >= (1 << 20)
+
+
 def _ptr(a: np.ndarray):
     return a.ctypes.data_as(C.c_void_p)
 
@@ -126,10 +133,18 @@ def _welch(x, y, fs_hz: int, window_type, window_length_samples: int, overlap_pe
     amp, norm_scale, factor, phys = _finish_params(scaling, W, fs_hz, window)
     avg = DS_AVG[average]
     ctx = get_context()
-    xp = _planar_f32(x)
-    n_ch, n = xp.shape
     w32 = window.astype(np.float32)
     B = W // 2 + 1
+    if auto and _fusable(x):
+        n, n_ch = x.shape
+        out = np.empty((B, n_ch), dtype=np.float32)
+        ctx.check(ctx.lib.ds_welch_psd_f64(ctx.handle, _ptr(x), n_ch, n, W, hop, n_frames, _ptr(w32),
+                                           int(bool(detrend)), avg, amp, norm_scale, factor, phys,
+                                           _ptr(out)), "ds_welch_psd_f64")
+        res = out.astype(np.complex128 if avg else np.float64)
+        return res if multi else res[:, 0]
+    xp = _planar_f32(x)
+    n_ch, n = xp.shape
     if auto:
         out = np.empty((B, n_ch), dtype=np.float32)
         ctx.check(ctx.lib.ds_welch_psd(ctx.handle, _ptr(xp), n_ch, n, W, hop, n_frames, _ptr(w32),
@@ -166,8 +181,7 @@ def welch_transfer_function(output_td, input_td, fs_hz: int, window_length_sampl
         xi = xi[:, None]
     # large float64 C-order arrays (the reference's own layout) cross the boundary as they are: the
     # library casts + transposes them in threads straight into pinned upload chunks
-    fused = all(a.ndim == 2 and a.dtype == np.float64 and a.flags.c_contiguous for a in (yo, xi)) \
-        and yo.size >= (1 << 20)
+    fused = _fusable(yo) and xi.ndim == 2 and xi.dtype == np.float64 and xi.flags.c_contiguous
     if fused:
         n, n_cy = yo.shape
         n_cx = xi.shape[1]
@@ -332,17 +346,27 @@ def _csm_welch(time_data, sampling_rate_hz: int, window_length_samples: int, win
     _welch_checks(window_length_samples, overlap_percent, average)
     W = int(window_length_samples)
     window = _window_array(window_type, W)
-    xp = _planar_f32(time_data)
-    n_ch, n = xp.shape
+    td = np.asarray(time_data)
+    fused = _fusable(td)
+    if fused:
+        n, n_ch = td.shape
+    else:
+        xp = _planar_f32(td)
+        n_ch, n = xp.shape
     hop, n_frames = _welch_framing(n, W, overlap_percent, window)
     amp, norm_scale, factor, phys = _finish_params(scaling, W, sampling_rate_hz, window)
     B = W // 2 + 1
     out = np.empty((B, n_ch, n_ch), dtype=np.complex64)
     w32 = window.astype(np.float32)
     ctx = get_context()
-    ctx.check(ctx.lib.ds_csm(ctx.handle, _ptr(xp), n_ch, n, W, hop, n_frames, _ptr(w32),
-                             int(bool(detrend)), DS_AVG[average], amp, norm_scale, factor, phys,
-                             _ptr(out)), "ds_csm")
+    if fused:
+        ctx.check(ctx.lib.ds_csm_f64(ctx.handle, _ptr(td), n_ch, n, W, hop, n_frames, _ptr(w32),
+                                     int(bool(detrend)), DS_AVG[average], amp, norm_scale, factor, phys,
+                                     _ptr(out)), "ds_csm_f64")
+    else:
+        ctx.check(ctx.lib.ds_csm(ctx.handle, _ptr(xp), n_ch, n, W, hop, n_frames, _ptr(w32),
+                                 int(bool(detrend)), DS_AVG[average], amp, norm_scale, factor, phys,
+                                 _ptr(out)), "ds_csm")
     return np.fft.rfftfreq(W, 1 / sampling_rate_hz), out.astype(np.complex128)
 
 

@@ -1794,10 +1794,10 @@ extern "C" int ds_welch_tf(ds_ctx* c, const float* x, int n_cx, const float* y, 
     return ds_download(c, coh, dcoh, no * 4);
 }
 
-extern "C" int ds_welch_psd(ds_ctx* c, const float* x, int n_cx, int64_t n_samples, int W, int hop,
-                            int n_frames, const float* window, int detrend, int average, int amp_sqrt,
-                            double norm_scale, double factor, int halve_edges, float* psd) {
-    if (!c || !x || !window || !psd) return fail(c, DS_ERR_ARG, "ds_welch_psd: null argument");
+static int welch_psd_host(ds_ctx* c, const float* x, const double* x64, int n_cx, int64_t n_samples, int W,
+                          int hop, int n_frames, const float* window, int detrend, int average, int amp_sqrt,
+                          double norm_scale, double factor, int halve_edges, float* psd) {
+    if (!c || (!x && !x64) || !window || !psd) return fail(c, DS_ERR_ARG, "ds_welch_psd: null argument");
     if (n_cx <= 0 || n_samples <= 0 || W <= 0) return fail(c, DS_ERR_ARG, "ds_welch_psd: bad shape");
     size_t nx = (size_t)n_cx * n_samples, no = (size_t)(W / 2 + 1) * n_cx;
     CHK(stage_reserve(c, Carver::pad(nx * 4) + Carver::pad((size_t)W * 4) + Carver::pad(no * 4)));
@@ -1805,11 +1805,26 @@ extern "C" int ds_welch_psd(ds_ctx* c, const float* x, int n_cx, int64_t n_sampl
     float* dx = cv.take<float>(nx);
     float* dw = cv.take<float>(W);
     float* dp = cv.take<float>(no);
-    CHK(ds_upload(c, dx, x, nx * 4));
+    if (x64)
+        CHK(upload_planar_f64(c, x64, n_samples, n_cx, dx, n_samples));
+    else
+        CHK(ds_upload(c, dx, x, nx * 4));
     CHK(ds_upload(c, dw, window, (size_t)W * 4));
     CHK(ds_welch_psd_dev(c, dx, n_cx, n_samples, n_samples, W, hop, n_frames, dw, detrend, average,
                          amp_sqrt, norm_scale, factor, halve_edges, dp));
     return ds_download(c, psd, dp, no * 4);
+}
+extern "C" int ds_welch_psd(ds_ctx* c, const float* x, int n_cx, int64_t n_samples, int W, int hop,
+                            int n_frames, const float* window, int detrend, int average, int amp_sqrt,
+                            double norm_scale, double factor, int halve_edges, float* psd) {
+    return welch_psd_host(c, x, nullptr, n_cx, n_samples, W, hop, n_frames, window, detrend, average, amp_sqrt,
+                          norm_scale, factor, halve_edges, psd);
+}
+extern "C" int ds_welch_psd_f64(ds_ctx* c, const double* x, int n_cx, int64_t n_samples, int W, int hop,
+                                int n_frames, const float* window, int detrend, int average, int amp_sqrt,
+                                double norm_scale, double factor, int halve_edges, float* psd) {
+    return welch_psd_host(c, nullptr, x, n_cx, n_samples, W, hop, n_frames, window, detrend, average, amp_sqrt,
+                          norm_scale, factor, halve_edges, psd);
 }
 
 extern "C" int ds_welch_csd(ds_ctx* c, const float* x, const float* y, int n_ch, int64_t n_samples,
@@ -1833,10 +1848,10 @@ extern "C" int ds_welch_csd(ds_ctx* c, const float* x, const float* y, int n_ch,
     return ds_download(c, csd, dc, no * 8);
 }
 
-extern "C" int ds_csm(ds_ctx* c, const float* x, int n_ch, int64_t n_samples, int W, int hop,
-                      int n_frames, const float* window, int detrend, int average, int amp_sqrt,
-                      double norm_scale, double factor, int halve_edges, ds_c32* csm) {
-    if (!c || !x || !window || !csm) return fail(c, DS_ERR_ARG, "ds_csm: null argument");
+static int csm_host(ds_ctx* c, const float* x, const double* x64, int n_ch, int64_t n_samples, int W, int hop,
+                    int n_frames, const float* window, int detrend, int average, int amp_sqrt,
+                    double norm_scale, double factor, int halve_edges, ds_c32* csm) {
+    if (!c || (!x && !x64) || !window || !csm) return fail(c, DS_ERR_ARG, "ds_csm: null argument");
     if (n_ch <= 0 || n_samples <= 0 || W <= 0) return fail(c, DS_ERR_ARG, "ds_csm: bad shape");
     size_t nx = (size_t)n_ch * n_samples, no = (size_t)(W / 2 + 1) * n_ch * n_ch;
     CHK(stage_reserve(c, Carver::pad(nx * 4) + Carver::pad((size_t)W * 4) + Carver::pad(no * 8)));
@@ -1844,11 +1859,26 @@ extern "C" int ds_csm(ds_ctx* c, const float* x, int n_ch, int64_t n_samples, in
     float* dx = cv.take<float>(nx);
     float* dw = cv.take<float>(W);
     float2* dc = cv.take<float2>(no);
-    CHK(ds_upload(c, dx, x, nx * 4));
+    if (x64)
+        CHK(upload_planar_f64(c, x64, n_samples, n_ch, dx, n_samples));
+    else
+        CHK(ds_upload(c, dx, x, nx * 4));
     CHK(ds_upload(c, dw, window, (size_t)W * 4));
     CHK(ds_csm_dev(c, dx, n_ch, n_samples, n_samples, W, hop, n_frames, dw, detrend, average, amp_sqrt,
                    norm_scale, factor, halve_edges, (ds_c32*)dc));
     return ds_download(c, csm, dc, no * 8);
+}
+extern "C" int ds_csm(ds_ctx* c, const float* x, int n_ch, int64_t n_samples, int W, int hop,
+                      int n_frames, const float* window, int detrend, int average, int amp_sqrt,
+                      double norm_scale, double factor, int halve_edges, ds_c32* csm) {
+    return csm_host(c, x, nullptr, n_ch, n_samples, W, hop, n_frames, window, detrend, average, amp_sqrt,
+                    norm_scale, factor, halve_edges, csm);
+}
+extern "C" int ds_csm_f64(ds_ctx* c, const double* x, int n_ch, int64_t n_samples, int W, int hop,
+                          int n_frames, const float* window, int detrend, int average, int amp_sqrt,
+                          double norm_scale, double factor, int halve_edges, ds_c32* csm) {
+    return csm_host(c, nullptr, x, n_ch, n_samples, W, hop, n_frames, window, detrend, average, amp_sqrt,
+                    norm_scale, factor, halve_edges, csm);
 }
 
 extern "C" int ds_rfft(ds_ctx* c, const float* x, int n_ch, int64_t n_samples, int n_fft, float scale,

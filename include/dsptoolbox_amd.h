@@ -125,6 +125,12 @@ int ds_welch_tf(ds_ctx* ctx, const float* x, int n_cx, const float* y, int n_cy,
 /* the same with the reference's array layout at the boundary: x (n_samples, n_cx), y (n_samples,
  * n_cy) float64 C-order (classes/signal.py:222-301).  The cast + transpose to planar float32 runs
  * on host threads straight into pinned chunks whose DMA overlaps the next chunk's cast.        */
+int ds_welch_psd_f64(ds_ctx* ctx, const double* x, int n_cx, int64_t n_samples, int W, int hop,
+                     int n_frames, const float* window, int detrend, int average, int amp_sqrt,
+                     double norm_scale, double factor, int halve_edges, float* psd);
+int ds_csm_f64(ds_ctx* ctx, const double* x, int n_ch, int64_t n_samples, int W, int hop,
+               int n_frames, const float* window, int detrend, int average, int amp_sqrt,
+               double norm_scale, double factor, int halve_edges, ds_c32* csm);
 int ds_welch_tf_f64(ds_ctx* ctx, const double* x, int n_cx, const double* y, int n_cy,
                     int64_t n_samples, int W, int hop, int n_frames, const float* window,
                     int detrend, int average, int mode, int amp_sqrt, double norm_scale,

@@ -737,6 +737,13 @@ def test_fused_float64_upload_is_the_same_computation():
         tf_b, coh_b = backend.welch_transfer_function(yf, x, 48000, 4096, "H1")           # numpy + ds_welch_tf
         # (bin 0 is 0/0 = NaN on both sides with detrend)
         assert np.array_equal(tf_a, tf_b, equal_nan=True) and np.array_equal(coh_a, coh_b, equal_nan=True), (n, c)
+        psd_a = backend._welch(y, None, 48000, Window.Hann, 1024, 50, True, "mean", SpectrumScaling.FFTBackward)
+        psd_b = backend._welch(yf, None, 48000, Window.Hann, 1024, 50, True, "mean", SpectrumScaling.FFTBackward)
+        assert np.array_equal(psd_a, psd_b, equal_nan=True), (n, c)
+        if c <= 8:
+            _, csm_a = backend._csm_welch(y, 48000, 1024, Window.Hann, 50, True, "mean", SpectrumScaling.FFTBackward)
+            _, csm_b = backend._csm_welch(yf, 48000, 1024, Window.Hann, 50, True, "mean", SpectrumScaling.FFTBackward)
+            assert np.array_equal(csm_a, csm_b, equal_nan=True), (n, c)
 
 
 def test_register_kernels_tiny_and_ragged_signals():
