@@ -55,6 +55,9 @@ SIGNATURES = {
                                    C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, f32_p]),
     "ds_welch_psd": (C.c_int, [ctx_p, f32_p, C.c_int, i64, C.c_int, C.c_int, C.c_int, f32_p, C.c_int,
                                C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, f32_p]),
+    "ds_stft_r2c_f64": (C.c_int, [ctx_p, C.c_void_p, i64, C.c_int, C.c_int, C.c_int, C.c_int, i64, C.c_int, f32_p,
+                                  C.c_int, C.c_float, C.c_float, C.c_int, C.c_void_p]),
+    "ds_fir_ola_f64": (C.c_int, [ctx_p, C.c_void_p, C.c_int, i64, f32_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "ds_welch_psd_f64": (C.c_int, [ctx_p, C.c_void_p, C.c_int, i64, C.c_int, C.c_int, C.c_int, f32_p, C.c_int,
                                    C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, f32_p]),
     "ds_csm_f64": (C.c_int, [ctx_p, C.c_void_p, C.c_int, i64, C.c_int, C.c_int, C.c_int, f32_p, C.c_int,

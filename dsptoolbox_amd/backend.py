@@ -210,7 +210,7 @@ def welch_transfer_function(output_td, input_td, fs_hz: int, window_length_sampl
 
 
 def _stft_plan(x, fs_hz: int, window_length_samples: int, window_type, overlap_percent: float,
-               fft_length_samples, padding: bool, scaling: SpectrumScaling):
+               fft_length_samples, padding: bool, scaling: SpectrumScaling, planar: bool = True):
     """Argument checks and launch parameters of the STFT (shared by _stft and the fused
     spectrogram consumers)."""
     assert window_length_samples in [2**k for k in range(4, 17)], (
@@ -227,8 +227,12 @@ def _stft_plan(x, fs_hz: int, window_length_samples: int, window_type, overlap_p
     if not check_COLA(window, nperseg=len(window), noverlap=overlap):
         warn("Selected window type and overlap do not meet the constant "
              "overlap and add constraint! Results might be distorted")
-    xp = _planar_f32(x)
-    n_ch, n = xp.shape
+    if planar:
+        xp = _planar_f32(x)
+        n_ch, n = xp.shape
+    else:  # the caller hands the (N, C) float64 array to a *_f64 entry point as it is
+        xp = None
+        n, n_ch = x.shape
     pad_front = overlap if padding else 0
     n_padded = n + 2 * pad_front
     n_frames = int(np.ceil(n_padded / hop))
@@ -250,6 +254,20 @@ def _stft_plan(x, fs_hz: int, window_length_samples: int, window_type, overlap_p
 def _stft(x, fs_hz: int, window_length_samples: int, window_type, overlap_percent: float,
           fft_length_samples, detrend: bool, padding: bool, scaling: SpectrumScaling):
     """-> (time_s (F,), freqs_hz (B,), stft (B', F, C))."""
+    xa = np.asarray(x)
+    if _fusable(xa):
+        # float64 on both sides: threaded cast into pinned upload chunks, widened back from pinned
+        # download chunks (power scalings keep only the real part: numpy path below)
+        pl = _stft_plan(xa, fs_hz, window_length_samples, window_type, overlap_percent, fft_length_samples,
+                        padding, scaling, planar=False)
+        if not pl["power"]:
+            out = np.empty((pl["B"], pl["n_frames"], pl["n_ch"]), dtype=np.complex128)
+            ctx = get_context()
+            ctx.check(ctx.lib.ds_stft_r2c_f64(ctx.handle, _ptr(xa), pl["n"], pl["n_ch"], pl["W"], pl["hop"],
+                                              pl["nfft"], pl["pad_front"], pl["n_frames"], _ptr(pl["w32"]),
+                                              int(bool(detrend)), pl["scale"], pl["edge"], pl["power"],
+                                              _ptr(out)), "ds_stft_r2c_f64")
+            return pl["time_s"], pl["freqs_hz"], out
     pl = _stft_plan(x, fs_hz, window_length_samples, window_type, overlap_percent, fft_length_samples,
                     padding, scaling)
     out = np.empty((pl["B"], pl["n_frames"], pl["n_ch"]), dtype=np.complex64)
@@ -485,11 +503,19 @@ def regularized_inverse(denum_spectrum, eps=None):
 def fir_filter_bank(x, taps_list, mode: int):
     """x (N, C); taps_list K arrays of equal length T.  Parallel -> (K, N, C);
     Sequential / Summed -> (N, C).  float64."""
-    xp = _planar_f32(x)
-    n_ch, n = xp.shape
     taps = np.ascontiguousarray(np.stack([np.asarray(t, dtype=np.float64) for t in taps_list]),
                                 dtype=np.float32)
     k, t = taps.shape
+    xa = np.asarray(x)
+    if _fusable(xa):  # float64 on both sides through the pinned chunk pipelines
+        n, n_ch = xa.shape
+        res = np.empty(((k if mode == DS_FB_PARALLEL else 1), n, n_ch), dtype=np.float64)
+        ctx = get_context()
+        ctx.check(ctx.lib.ds_fir_ola_f64(ctx.handle, _ptr(xa), n_ch, n, _ptr(taps), k, t, int(mode), _ptr(res)),
+                  "ds_fir_ola_f64")
+        return res if mode == DS_FB_PARALLEL else res[0]
+    xp = _planar_f32(x)
+    n_ch, n = xp.shape
     out = np.empty(((k if mode == DS_FB_PARALLEL else 1), n_ch, n), dtype=np.float32)
     ctx = get_context()
     ctx.check(ctx.lib.ds_fir_ola(ctx.handle, _ptr(xp), n_ch, n, _ptr(taps), k, t, int(mode),

@@ -1742,6 +1742,127 @@ static int upload_planar_f64(ds_ctx* c, const double* src, int64_t n_samples, in
     return DS_OK;
 }
 
+// The way back: device float32 -> host float64, chunk by chunk through the two pinned buffers, the
+// asynchronous copy of chunk k+1 running while host threads widen chunk k.
+// (a) contiguous: dst[i] = (double)src[i] (complex64 -> complex128 is the same on 2 n floats)
+static int download_widen(ds_ctx* c, const float* src_dev, int64_t n, double* dst) {
+    for (int i = 0; i < 2; ++i) {
+        if (!c->pin[i]) {
+            HIPCHK(c, hipHostMalloc(&c->pin[i], kPinBytes, hipHostMallocDefault));
+            HIPCHK(c, hipEventCreateWithFlags(&c->pin_ev[i], hipEventDisableTiming));
+        }
+        if (c->pin_busy[i]) HIPCHK(c, hipEventSynchronize(c->pin_ev[i]));
+        c->pin_busy[i] = false;
+    }
+    const int64_t cs = (int64_t)(kPinBytes / sizeof(float));
+    const int64_t n_chunks = (n + cs - 1) / cs;
+    auto issue = [&](int64_t k) -> hipError_t {
+        const int64_t s0 = k * cs, cn = std::min(cs, n - s0);
+        hipError_t e = hipMemcpyAsync(c->pin[k & 1], src_dev + s0, (size_t)cn * sizeof(float), hipMemcpyDeviceToHost,
+                                      c->stream);
+        if (e != hipSuccess) return e;
+        return hipEventRecord(c->pin_ev[k & 1], c->stream);
+    };
+    if (n_chunks > 0) HIPCHK(c, issue(0));
+    for (int64_t k = 0; k < n_chunks; ++k) {
+        if (k + 1 < n_chunks) HIPCHK(c, issue(k + 1));
+        HIPCHK(c, hipEventSynchronize(c->pin_ev[k & 1]));
+        const int64_t s0 = k * cs, cn = std::min(cs, n - s0);
+        const float* pin = (const float*)c->pin[k & 1];
+        double* d = dst + s0;
+        host_parallel(host_threads(0, cn), cn, [=](int64_t lo, int64_t hi) {
+            for (int64_t i = lo; i < hi; ++i) d[i] = (double)pin[i];
+        });
+    }
+    return DS_OK;
+}
+// (b) planar device rows src[ch*ld + n] -> (samples, channels) float64 dst[n*n_ch + ch]
+static int download_interleave(ds_ctx* c, const float* src_dev, int64_t n_samples, int n_ch, int64_t ld,
+                               double* dst) {
+    for (int i = 0; i < 2; ++i) {
+        if (!c->pin[i]) {
+            HIPCHK(c, hipHostMalloc(&c->pin[i], kPinBytes, hipHostMallocDefault));
+            HIPCHK(c, hipEventCreateWithFlags(&c->pin_ev[i], hipEventDisableTiming));
+        }
+        if (c->pin_busy[i]) HIPCHK(c, hipEventSynchronize(c->pin_ev[i]));
+        c->pin_busy[i] = false;
+    }
+    const int64_t cs = (int64_t)(kPinBytes / ((size_t)n_ch * sizeof(float))) & ~(int64_t)255;
+    if (cs < 256) return fail(c, DS_ERR_UNSUP, "download_interleave: too many channels for the staging chunk");
+    const int64_t n_chunks = (n_samples + cs - 1) / cs;
+    auto issue = [&](int64_t k) -> hipError_t {
+        const int64_t s0 = k * cs, cn = std::min(cs, n_samples - s0);
+        hipError_t e = hipMemcpy2DAsync(c->pin[k & 1], (size_t)cn * sizeof(float), src_dev + s0,
+                                        (size_t)ld * sizeof(float), (size_t)cn * sizeof(float), (size_t)n_ch,
+                                        hipMemcpyDeviceToHost, c->stream);
+        if (e != hipSuccess) return e;
+        return hipEventRecord(c->pin_ev[k & 1], c->stream);
+    };
+    if (n_chunks > 0) HIPCHK(c, issue(0));
+    for (int64_t k = 0; k < n_chunks; ++k) {
+        if (k + 1 < n_chunks) HIPCHK(c, issue(k + 1));
+        HIPCHK(c, hipEventSynchronize(c->pin_ev[k & 1]));
+        const int64_t s0 = k * cs, cn = std::min(cs, n_samples - s0);
+        const float* pin = (const float*)c->pin[k & 1];
+        double* d0 = dst + s0 * n_ch;
+        host_parallel(host_threads(0, cn * n_ch), cn, [=](int64_t lo, int64_t hi) {
+            constexpr int64_t TILE = 256;
+            for (int64_t t0 = lo; t0 < hi; t0 += TILE) {
+                const int64_t t1 = std::min(hi, t0 + TILE);
+                for (int ch = 0; ch < n_ch; ++ch) {
+                    const float* __restrict__ q = pin + (int64_t)ch * cn;
+                    double* __restrict__ d = d0 + ch;
+                    for (int64_t i = t0; i < t1; ++i) d[i * n_ch] = (double)q[i];
+                }
+            }
+        });
+    }
+    return DS_OK;
+}
+
+// ds_stft_r2c with the reference's layouts on both sides: x (n_samples, n_ch) float64 C-order in,
+// (bins, frames, channels) complex128 out.
+extern "C" int ds_stft_r2c_f64(ds_ctx* c, const double* x, int64_t n_samples, int n_ch, int W, int hop,
+                               int nfft, int64_t pad_front, int n_frames, const float* window, int detrend,
+                               float scale, float edge_scale, int power, double* out_c128) {
+    if (!c || !x || !window || !out_c128) return fail(c, DS_ERR_ARG, "ds_stft_r2c_f64: null argument");
+    if (n_ch <= 0 || n_samples <= 0 || W <= 0 || n_frames <= 0 || nfft <= 0)
+        return fail(c, DS_ERR_ARG, "ds_stft_r2c_f64: bad shape");
+    size_t nx = (size_t)n_ch * n_samples, no = (size_t)(nfft / 2 + 1) * n_frames * n_ch;
+    CHK(stage_reserve(c, Carver::pad(nx * 4) + Carver::pad((size_t)W * 4) + Carver::pad(no * 8)));
+    Carver cv(c->io);
+    float* dx = cv.take<float>(nx);
+    float* dw = cv.take<float>(W);
+    float2* dout = cv.take<float2>(no);
+    CHK(upload_planar_f64(c, x, n_samples, n_ch, dx, n_samples));
+    CHK(ds_upload(c, dw, window, (size_t)W * 4));
+    CHK(ds_stft_r2c_dev(c, dx, n_samples, n_ch, n_samples, W, hop, nfft, pad_front, n_frames, dw, detrend,
+                        scale, edge_scale, power, (ds_c32*)dout));
+    return download_widen(c, (const float*)dout, (int64_t)no * 2, out_c128);
+}
+
+// ds_fir_ola with the reference's layouts on both sides: x (n_samples, n_ch) float64 in,
+// y (bands or 1, n_samples, n_ch) float64 out.
+extern "C" int ds_fir_ola_f64(ds_ctx* c, const double* x, int n_ch, int64_t n_samples, const float* taps,
+                              int n_filt, int n_taps, int mode, double* y) {
+    if (!c || !x || !taps || !y) return fail(c, DS_ERR_ARG, "ds_fir_ola_f64: null argument");
+    if (n_ch <= 0 || n_samples <= 0 || n_filt <= 0 || n_taps <= 0) return fail(c, DS_ERR_ARG, "ds_fir_ola_f64: bad shape");
+    const int n_out = mode == DS_FB_PARALLEL ? n_filt : 1;
+    size_t nx = (size_t)n_ch * n_samples, nt = (size_t)n_filt * n_taps, no = (size_t)n_out * n_ch * n_samples;
+    CHK(stage_reserve(c, Carver::pad(nx * 4) + Carver::pad(nt * 4) + Carver::pad(no * 4)));
+    Carver cv(c->io);
+    float* dx = cv.take<float>(nx);
+    float* dt = cv.take<float>(nt);
+    float* dy = cv.take<float>(no);
+    CHK(upload_planar_f64(c, x, n_samples, n_ch, dx, n_samples));
+    CHK(ds_upload(c, dt, taps, nt * 4));
+    CHK(ds_fir_ola_dev(c, dx, n_ch, n_samples, n_samples, dt, n_filt, n_taps, mode, dy, n_samples));
+    for (int k = 0; k < n_out; ++k)
+        CHK(download_interleave(c, dy + (size_t)k * n_ch * n_samples, n_samples, n_ch, n_samples,
+                                y + (size_t)k * n_samples * n_ch));
+    return DS_OK;
+}
+
 // ds_welch_tf with the reference's own array layout at the boundary: x (n_samples, n_cx) and
 // y (n_samples, n_cy) float64 C-order (classes/signal.py:222-301), outputs as ds_welch_tf.
 extern "C" int ds_welch_tf_f64(ds_ctx* c, const double* x, int n_cx, const double* y, int n_cy,

@@ -121,7 +121,7 @@ def _spectrogram_axes(signal: Signal):
     par = signal._spectrogram_parameters
     pl = backend._stft_plan(signal.time_data, signal.sampling_rate_hz, par["window_length_samples"],
                             par["window_type"], par["overlap_percent"], par["fft_length_samples"],
-                            par["padding"], par["scaling"])
+                            par["padding"], par["scaling"], planar=False)  # axes only: no cast of the data
     return pl["time_s"], pl["freqs_hz"], pl["B"]
 
 

@@ -125,6 +125,14 @@ int ds_welch_tf(ds_ctx* ctx, const float* x, int n_cx, const float* y, int n_cy,
 /* the same with the reference's array layout at the boundary: x (n_samples, n_cx), y (n_samples,
  * n_cy) float64 C-order (classes/signal.py:222-301).  The cast + transpose to planar float32 runs
  * on host threads straight into pinned chunks whose DMA overlaps the next chunk's cast.        */
+/* float64 on both sides (the copy back runs through the same pinned chunks, widened / interleaved by
+ * host threads while the next chunk's DMA is in flight): STFT (bins, frames, channels) complex128
+ * as interleaved doubles; FIR y (bands or 1, n_samples, n_ch) float64.                            */
+int ds_stft_r2c_f64(ds_ctx* ctx, const double* x, int64_t n_samples, int n_ch, int W, int hop,
+                    int nfft, int64_t pad_front, int n_frames, const float* window, int detrend,
+                    float scale, float edge_scale, int power, double* out_c128);
+int ds_fir_ola_f64(ds_ctx* ctx, const double* x, int n_ch, int64_t n_samples, const float* taps,
+                   int n_filt, int n_taps, int mode, double* y);
 int ds_welch_psd_f64(ds_ctx* ctx, const double* x, int n_cx, int64_t n_samples, int W, int hop,
                      int n_frames, const float* window, int detrend, int average, int amp_sqrt,
                      double norm_scale, double factor, int halve_edges, float* psd);

@@ -741,6 +741,15 @@ def test_fused_float64_upload_is_the_same_computation():
         psd_b = backend._welch(yf, None, 48000, Window.Hann, 1024, 50, True, "mean", SpectrumScaling.FFTBackward)
         assert np.array_equal(psd_a, psd_b, equal_nan=True), (n, c)
         if c <= 8:
+            for sc in (SpectrumScaling.FFTBackward, SpectrumScaling.AmplitudeSpectrum, SpectrumScaling.PowerSpectrum):
+                t_a, f_a, st_a = backend._stft(y, 48000, 1024, Window.Hann, 50, None, False, True, sc)
+                t_b, f_b, st_b = backend._stft(yf, 48000, 1024, Window.Hann, 50, None, False, True, sc)
+                assert st_a.dtype == st_b.dtype and np.array_equal(st_a, st_b), (n, c, sc)
+            taps = [rng.standard_normal(301) * 0.05, rng.standard_normal(301) * 0.05]
+            for mode in (backend.DS_FB_PARALLEL, backend.DS_FB_SUMMED, backend.DS_FB_SEQUENTIAL):
+                fa = backend.fir_filter_bank(y, taps, mode)
+                fb = backend.fir_filter_bank(yf, taps, mode)
+                assert fa.shape == fb.shape and fa.dtype == np.float64 and np.array_equal(fa, fb), (n, c, mode)
             _, csm_a = backend._csm_welch(y, 48000, 1024, Window.Hann, 50, True, "mean", SpectrumScaling.FFTBackward)
             _, csm_b = backend._csm_welch(yf, 48000, 1024, Window.Hann, 50, True, "mean", SpectrumScaling.FFTBackward)
             assert np.array_equal(csm_a, csm_b, equal_nan=True), (n, c)

@@ -25,3 +25,21 @@ t0 = time.perf_counter()
 yp = backend._planar_f32(y)
 t1 = time.perf_counter()
 print(f"  host (N, C) float64 -> planar float32: {(t1 - t0) * 1e3:8.1f} ms for {y.nbytes / 1e6:.0f} MB")
+
+# STFT of the CSM shape and a 4-band FIR bank, float64 in and out
+rng = np.random.default_rng(1)
+mic = rng.standard_normal((512000, 64)) * 0.1
+S = dsp.Signal(None, mic, 48000)
+for it in range(3):
+    S = dsp.Signal(None, mic, 48000)
+    t0 = time.perf_counter()
+    t, f, st = S.get_spectrogram()
+    t1 = time.perf_counter()
+    print(f"get_spectrogram 64 ch x 512 000 (-> {st.nbytes / 1e6:.0f} MB complex128): {(t1 - t0) * 1e3:8.1f} ms")
+sig = rng.standard_normal((2**22, 8)) * 0.1
+taps = [rng.standard_normal(4097) * 0.01 for _ in range(4)]
+for it in range(3):
+    t0 = time.perf_counter()
+    out = backend.fir_filter_bank(sig, taps, backend.DS_FB_PARALLEL)
+    t1 = time.perf_counter()
+    print(f"fir_filter_bank 4 x 4097 taps, 8 ch x 2^22 (-> {out.nbytes / 1e6:.0f} MB float64): {(t1 - t0) * 1e3:8.1f} ms")
