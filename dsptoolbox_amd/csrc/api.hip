@@ -39,7 +39,7 @@ struct ds_ctx {
     float2* fir16k_tables = nullptr;  // fir16k::host_tables()
     float2* deconv8k_tables = nullptr;  // deconv8k::host_tables()
     float2* stft1k_tables = nullptr;  // stft1k::host_tables<1024>()
-    float2* stft_wave_tables[2] = {nullptr, nullptr};  // stft1k::host_tables<512>(), <256>()
+    float2* stft_wave_tables[3] = {nullptr, nullptr, nullptr};  // stft1k::host_tables<512>(), <256>(), <2048>()
     void* ws = nullptr;         // kernel workspace (spectra, partials)
     size_t ws_bytes = 0;
     void* io = nullptr;  // staging for the host-pointer entry points
@@ -785,7 +785,7 @@ static int welch4096_psd_run(ds_ctx* c, const float* x, int n_cx, int64_t ldx, i
 // twiddle tables of the wave-level transforms (stft1k::host_tables<N>), cached per context
 template <int NN>
 static int wave_tables(ds_ctx* c, const float2** out) {
-    float2** tab = NN == 1024 ? &c->stft1k_tables : &c->stft_wave_tables[NN == 512 ? 0 : 1];
+    float2** tab = NN == 1024 ? &c->stft1k_tables : &c->stft_wave_tables[NN == 512 ? 0 : (NN == 256 ? 1 : 2)];
     if (!*tab) {
         std::vector<float2> h;
         stft1k::host_tables<NN>(h);
@@ -878,8 +878,9 @@ extern "C" int ds_welch_tf_dev(ds_ctx* c, const float* x, int n_cx, int64_t ldx,
         return welch4096_run(c, x, ldx, y, n_cy, ldy, n_samples, hop, n_frames, window, detrend, mode,
                              amp_sqrt, norm_scale, factor, halve_edges, (float2*)tf, coh);
     static const bool no1k = getenv("DSPTOOLBOX_AMD_WELCH_GENERIC") != nullptr;
-    if (c && (W == 1024 || W == 512 || W == 256) && n_cx == 1 && average == DS_AVG_MEAN && !no1k) {
-        auto run = W == 1024 ? welch_wave_run<1024> : (W == 512 ? welch_wave_run<512> : welch_wave_run<256>);
+    if (c && (W == 2048 || W == 1024 || W == 512 || W == 256) && n_cx == 1 && average == DS_AVG_MEAN && !no1k) {
+        auto run = W == 2048 ? welch_wave_run<2048>
+                             : (W == 1024 ? welch_wave_run<1024> : (W == 512 ? welch_wave_run<512> : welch_wave_run<256>));
         return run(c, x, ldx, y, n_cy, ldy, n_samples, hop, n_frames, window, detrend, mode, amp_sqrt,
                    norm_scale, factor, halve_edges, (float2*)tf, coh);
     }
@@ -895,9 +896,10 @@ extern "C" int ds_welch_psd_dev(ds_ctx* c, const float* x, int n_cx, int64_t ldx
     if (c && W == 4096 && average == DS_AVG_MEAN && welch4096::enabled() && !no1k)
         return welch4096_psd_run(c, x, n_cx, ldx, n_samples, hop, n_frames, window, detrend, amp_sqrt,
                                  norm_scale, factor, halve_edges, psd);
-    if (c && (W == 1024 || W == 512 || W == 256) && average == DS_AVG_MEAN && !no1k) {
-        auto run = W == 1024 ? welch_wave_psd_run<1024>
-                             : (W == 512 ? welch_wave_psd_run<512> : welch_wave_psd_run<256>);
+    if (c && (W == 2048 || W == 1024 || W == 512 || W == 256) && average == DS_AVG_MEAN && !no1k) {
+        auto run = W == 2048 ? welch_wave_psd_run<2048>
+                             : (W == 1024 ? welch_wave_psd_run<1024>
+                                          : (W == 512 ? welch_wave_psd_run<512> : welch_wave_psd_run<256>));
         return run(c, x, n_cx, ldx, n_samples, hop, n_frames, window, detrend, amp_sqrt, norm_scale, factor,
                    halve_edges, psd);
     }

@@ -41,7 +41,8 @@ using w4::pos16;
 // L = N/16 lanes (1, 2 or 4 transforms per wave), 16 complex values per lane.
 template <int NN>
 struct Geo {
-    static_assert(NN == 256 || NN == 512 || NN == 1024, "wave-level transform: 256, 512 or 1024 points");
+    static_assert(NN == 256 || NN == 512 || NN == 1024 || NN == 2048,
+                  "team-level transform: 256, 512, 1024 points (one wave or less) or 2048 (two waves)");
     static constexpr int N = NN, L = NN / 16, R3 = NN / 256;
     static constexpr int S1 = L + R3;   // exchange-1 row stride (the R3-lane groups of pass 2 spread over the banks)
     static constexpr int REGION = ((16 * S1 > NN + 2 ? 16 * S1 : NN + 2) + 31) / 32 * 32;  // complex per image
@@ -83,12 +84,44 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// synchronise the lanes of one transform: up to 64 lanes are (part of) one wave; a 128-lane team
+// (2048 points) spans two waves and takes the workgroup barrier -- every team of the workgroup then
+// has to walk through the transform together
+template <int NN>
+__device__ __forceinline__ void team_sync() {
+    if constexpr (NN / 16 <= 64)
+        wave_sync();
+    else
+        __syncthreads();
+}
+
+// 8-point DFT in registers, natural order in and out (forward)
+__device__ __forceinline__ void dft8(float2 (&x)[8]) {
+    constexpr float R2 = 0.70710678118654752440f;
+    w4::r4(x[0], x[2], x[4], x[6]);  // even samples -> E[0..3] in x[0], x[2], x[4], x[6]
+    w4::r4(x[1], x[3], x[5], x[7]);  // odd samples  -> O[0..3] in x[1], x[3], x[5], x[7]
+    // O[k] W8^k
+    const float2 o0 = x[1];
+    const float2 o1 = make_float2((x[3].x + x[3].y) * R2, (x[3].y - x[3].x) * R2);    // (1 - i)/sqrt2
+    const float2 o2 = make_float2(x[5].y, -x[5].x);                                    // -i
+    const float2 o3 = make_float2((x[7].y - x[7].x) * R2, -(x[7].x + x[7].y) * R2);   // (-1 - i)/sqrt2
+    const float2 e0 = x[0], e1 = x[2], e2 = x[4], e3 = x[6];
+    x[0] = make_float2(e0.x + o0.x, e0.y + o0.y);
+    x[4] = make_float2(e0.x - o0.x, e0.y - o0.y);
+    x[1] = make_float2(e1.x + o1.x, e1.y + o1.y);
+    x[5] = make_float2(e1.x - o1.x, e1.y - o1.y);
+    x[2] = make_float2(e2.x + o2.x, e2.y + o2.y);
+    x[6] = make_float2(e2.x - o2.x, e2.y - o2.y);
+    x[3] = make_float2(e3.x + o3.x, e3.y + o3.y);
+    x[7] = make_float2(e3.x - o3.x, e3.y - o3.y);
+}
+
 struct NoHook {
     __device__ __forceinline__ void operator()() const {}
 };
 // The transform of one team of L lanes: v[n1] = z[t + L n1] (consumed) -> zo[m] = Z[t + L m].
 // `buf`: the team's LDS region (>= Geo::REGION complex, 16-byte aligned), tw1/tw2 the tables of
-// host_tables<N>() in LDS.  Every lane of the wave must call it (wave-level ordering).  Ends with
+// host_tables<N>() in LDS.  Every lane of the wave (2048 points: of the workgroup) must call it.  Ends with
 // buf free for reuse.  `behind_ex2` runs after the second exchange image has been written (v is
 // dead there): global loads issued from it overlap the LDS round trip and the last pass.
 template <int NN, typename Hook = NoHook>
@@ -104,10 +137,10 @@ __device__ __forceinline__ void fft_wave(float2 (&v)[16], float2 (&z)[16], float
     for (int k1 = 1; k1 < 16; ++k1) v[pos16(k1)] = cmul(v[pos16(k1)], tw1[(k1 - 1) * L + t]);
 #pragma unroll
     for (int k1 = 0; k1 < 16; ++k1) buf[k1 * S1 + t] = v[pos16(k1)];
-    wave_sync();
+    team_sync<NN>();
 #pragma unroll
     for (int n2 = 0; n2 < 16; ++n2) v[n2] = buf[k1u * S1 + R3 * n2 + n3];
-    wave_sync();
+    team_sync<NN>();
     // ---- pass 2
     w4::dft16(v);
     if constexpr (R3 == 1) {
@@ -121,7 +154,7 @@ __device__ __forceinline__ void fft_wave(float2 (&v)[16], float2 (&z)[16], float
 #pragma unroll
         for (int k2 = 0; k2 < 16; ++k2) buf[L * k2 + t] = v[pos16(k2)];  // [(k1 + 16 k2)][n3]
         behind_ex2();
-        wave_sync();
+        team_sync<NN>();
         // ---- pass 3: pair (k1,k2) = t + L j, radix R3 over n3 -> Z[t + L (j + (16/R3) k3)]
         if constexpr (R3 == 4) {
 #pragma unroll
@@ -136,6 +169,21 @@ __device__ __forceinline__ void fft_wave(float2 (&v)[16], float2 (&z)[16], float
                 z[j + 8] = x2;
                 z[j + 12] = x3;
             }
+        } else if constexpr (R3 == 8) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const float4* q = reinterpret_cast<const float4*>(buf + 8 * (t + L * j));
+                float2 x[8];
+#pragma unroll
+                for (int h = 0; h < 4; ++h) {
+                    const float4 r = q[h];
+                    x[2 * h] = make_float2(r.x, r.y);
+                    x[2 * h + 1] = make_float2(r.z, r.w);
+                }
+                dft8(x);
+#pragma unroll
+                for (int k3 = 0; k3 < 8; ++k3) z[j + 2 * k3] = x[k3];
+            }
         } else {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
@@ -144,7 +192,7 @@ __device__ __forceinline__ void fft_wave(float2 (&v)[16], float2 (&z)[16], float
                 z[j + 8] = make_float2(q.x - q.z, q.y - q.w);
             }
         }
-        wave_sync();
+        team_sync<NN>();
     }
 }
 template <typename Hook = NoHook>

@@ -26,6 +26,7 @@
 namespace welch1k {
 
 using stft1k::fft_wave;
+using stft1k::team_sync;
 using stft1k::wave_sync;
 constexpr int NTB = 256;  // threads per workgroup
 template <int NN>
@@ -129,22 +130,29 @@ __global__ __launch_bounds__(NTB) void k_x(Args p) {
     float* winl = reinterpret_cast<float*>(tw1 + W::G::TW_LEN);
     load_tables<NN>(tw1, winl, p);
     __syncthreads();
-    if (!live) return;
+    if (!live) {
+        if constexpr (L <= 64) return;  // (a team of two waves stays: the transform takes workgroup barriers)
+#pragma unroll
+        for (int m = 0; m < (HALF_HOP ? 24 : 32); ++m) raw.s[m] = 0.f;
+    }
     float2 v[16], z[16];
     window_pair<NN, HALF_HOP>(v, raw, winl, t);
-    if (needs_drop(p, pr)) {
+    if (live && needs_drop(p, pr)) {
 #pragma unroll
         for (int n1 = 0; n1 < 16; ++n1) v[n1].y = 0.f;
     }
     fft_wave<NN>(v, z, buf, tw1, tw2, t);
     if (p.detrend && t == 0) z[0] = make_float2(0.f, 0.f);
-    float4* xo = p.xs + (int64_t)pr * (NN / 2) + t;
+    if (live) {
+        float4* xo = p.xs + (int64_t)pr * (NN / 2) + t;
 #pragma unroll
-    for (int g = 0; g < 8; ++g) xo[L * g] = make_float4(z[2 * g].x, z[2 * g].y, z[2 * g + 1].x, z[2 * g + 1].y);
+        for (int g = 0; g < 8; ++g) xo[L * g] = make_float4(z[2 * g].x, z[2 * g].y, z[2 * g + 1].x, z[2 * g + 1].y);
+    }
     float* pw = reinterpret_cast<float*>(buf);
 #pragma unroll
     for (int m = 0; m < 16; ++m) pw[t + L * m] = z[m].x * z[m].x + z[m].y * z[m].y;
-    wave_sync();
+    team_sync<NN>();
+    if (!live) return;
     float* po = p.px + (int64_t)pr * NB;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -202,7 +210,9 @@ __global__ __launch_bounds__(NTB, 3) void k_y(Args p) {
     }
     __syncthreads();  // tables in LDS; the only workgroup barrier
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): keep the pre-loop loads out of the loop's wait counts
-    if (!live) return;
+    if (!live) {
+        if constexpr (L <= 64) return;  // a two-wave team stays (workgroup barriers ahead) and only skips its stores
+    }
     float2 T[16];
     float P[16];
 #pragma unroll
@@ -249,24 +259,27 @@ __global__ __launch_bounds__(NTB, 3) void k_y(Args p) {
     }
     if (p.detrend && t == 0) P[0] = 0.f;  // xs bin 0 is already 0 -> T[0] = 0
     // fold k <-> N-k once per chunk through this team's LDS region
-    const int64_t so = ((int64_t)q * p.n_ch + c) * NB;
+    const int64_t so = ((int64_t)q * p.n_ch + (live ? c : 0)) * NB;
     if (!AUTO) {
 #pragma unroll
         for (int m = 0; m < 16; ++m) buf[t + L * m] = T[m];
-        wave_sync();
+        team_sync<NN>();
+        if (live) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int k = t + L * j;
-            const float2 a = buf[k], b = buf[(NN - k) & (NN - 1)];
-            p.pxy[so + k] = make_float2(0.5f * (a.x + b.x), 0.5f * (a.y - b.y));
+            for (int j = 0; j < 8; ++j) {
+                const int k = t + L * j;
+                const float2 a = buf[k], b = buf[(NN - k) & (NN - 1)];
+                p.pxy[so + k] = make_float2(0.5f * (a.x + b.x), 0.5f * (a.y - b.y));
+            }
+            if (t == 0) p.pxy[so + NN / 2] = make_float2(buf[NN / 2].x, 0.f);
         }
-        if (t == 0) p.pxy[so + NN / 2] = make_float2(buf[NN / 2].x, 0.f);
-        wave_sync();
+        team_sync<NN>();
     }
     float* pw = reinterpret_cast<float*>(buf);
 #pragma unroll
     for (int m = 0; m < 16; ++m) pw[t + L * m] = P[m];
-    wave_sync();
+    team_sync<NN>();
+    if (!live) return;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const int k = t + L * j;
