@@ -440,12 +440,14 @@ extern "C" int ds_stft_r2c_dev(ds_ctx* c, const float* x, int64_t n_samples, int
     // 256-, 512- and 1024-point transforms (1024 = the reference's default frame): wave-level
     // register transforms, one frame pair per team of nfft/16 lanes (kernels_stft1024.hpp)
     static const bool stft_generic = getenv("DSPTOOLBOX_AMD_STFT_GENERIC") != nullptr;
-    if ((nfft == 1024 || nfft == 512 || nfft == 256) && (W == nfft || (W < nfft && !detrend)) && !stft_generic) {
-        const int slot = nfft == 1024 ? 0 : (nfft == 512 ? 1 : 2);
+    if ((nfft == 2048 || nfft == 1024 || nfft == 512 || nfft == 256) && (W == nfft || (W < nfft && !detrend)) &&
+        !stft_generic) {
+        const int slot = nfft == 1024 ? 0 : (nfft == 512 ? 1 : (nfft == 256 ? 2 : 3));
         float2** tab = slot == 0 ? &c->stft1k_tables : &c->stft_wave_tables[slot - 1];
         if (!*tab) {
             std::vector<float2> h;
-            if (nfft == 1024) stft1k::host_tables<1024>(h);
+            if (nfft == 2048) stft1k::host_tables<2048>(h);
+            else if (nfft == 1024) stft1k::host_tables<1024>(h);
             else if (nfft == 512) stft1k::host_tables<512>(h);
             else stft1k::host_tables<256>(h);
             CHK(upload_table_fwd(c, tab, h));
@@ -453,13 +455,14 @@ extern "C" int ds_stft_r2c_dev(ds_ctx* c, const float* x, int64_t n_samples, int
         // channels per workgroup: 8 x 64 lanes (64-byte runs of the output, 70 KB of LDS) at 1024
         // points, 16 teams (128-byte runs) of 32 / 16 lanes at 512 / 256
         const int lanes = nfft / 16;
-        int ct = std::min(nfft == 1024 ? 8 : 16, n_ch);
+        int ct = std::min(nfft >= 1024 ? 8 : 16, n_ch);  // 2048: 8 x 17 KB images, one 1024-thread workgroup per CU
+                                                        // (4 channels = 32-byte runs, two per CU: 0.20 ms against 0.16)
         if (const char* e = getenv("DSPTOOLBOX_AMD_STFT_CT")) {
             int v = atoi(e);
-            if (v >= 1 && v <= 16) ct = std::min(v, n_ch);
+            if (v >= 1 && v <= 16 && v * lanes <= 1024) ct = std::min(v, n_ch);
         }
         while (ct & (ct - 1)) ct &= ct - 1;
-        const size_t lds = nfft == 1024 ? stft1k::lds_bytes<1024>(ct)
+        const size_t lds = nfft == 2048 ? stft1k::lds_bytes<2048>(ct) : nfft == 1024 ? stft1k::lds_bytes<1024>(ct)
                                         : (nfft == 512 ? stft1k::lds_bytes<512>(ct) : stft1k::lds_bytes<256>(ct));
         const int threads = lanes * ct;
         // frame pairs per workgroup: as few as keep the whole grid resident at once, at most 16
@@ -471,6 +474,9 @@ extern "C" int ds_stft_r2c_dev(ds_ctx* c, const float* x, int64_t n_samples, int
         StftArgs a{x, n_samples, ld, pad_front, n_ch, W, hop, n_frames, detrend, power, ct, fpw, window,
                    *tab, scale, edge_scale, (float2*)out};
         dim3 grid((unsigned)((n_fp + fpw - 1) / fpw), (unsigned)n_ct);
+        if (nfft == 2048)
+            return power ? launch(c, "stft", stft1k::k_stft_wave<2048, true>, grid, threads, lds, a)
+                         : launch(c, "stft", stft1k::k_stft_wave<2048, false>, grid, threads, lds, a);
         if (nfft == 1024)
             return power ? launch(c, "stft", stft1k::k_stft_wave<1024, true>, grid, threads, lds, a)
                          : launch(c, "stft", stft1k::k_stft_wave<1024, false>, grid, threads, lds, a);

@@ -267,12 +267,12 @@ __global__ __launch_bounds__(1024) void k_stft_wave(StftArgs p) {
         // ---- separation: bins k = t + L j (j < 8) against Z[N - k], which sits in the upper half
 #pragma unroll
         for (int m = 8; m < 16; ++m) buf[t + L * m] = z[m];
-        wave_sync();
+        team_sync<NN>();
         float2 qc[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) qc[j] = buf[(NN - (t + L * j)) & (NN - 1)];
         if (t == 0) qc[0] = z[0];  // bin 0 pairs with itself
-        wave_sync();
+        team_sync<NN>();
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const float2 P = z[j], Q = qc[j];

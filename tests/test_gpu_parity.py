@@ -796,7 +796,7 @@ def test_stft_default_frame_kernel_vs_oracle():
             (2, 1024, 50, True, False, SpectrumScaling.FFTOrthogonal),
             (64, 8192, 50, True, False, SpectrumScaling.FFTBackward)):
         x = rng.standard_normal((n, n_ch)) * 0.3 + 0.05
-        for W in (1024, 512, 256):   # 64, 32, 16 lanes per transform: 1, 2, 4 frame pairs per wave
+        for W in (2048, 1024, 512, 256):   # 128 (two waves), 64, 32, 16 lanes per transform
             t, f, st = backend._stft(x, 48000, W, Window.Hann, ov, None, det, pad, sc)
             rt, rf, rs = orc.stft(x, 48000, W, "hann", ov, None, det, pad, sc.name)
             assert st.shape == rs.shape and np.allclose(t, rt) and np.array_equal(f, rf)
