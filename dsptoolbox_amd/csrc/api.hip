@@ -21,6 +21,7 @@
 #include "kernels_deconv8k.hpp"
 #include "kernels_stft1024.hpp"
 #include "kernels_welch1024.hpp"
+#include "kernels_welch8192.hpp"
 
 using namespace dsk;
 
@@ -759,6 +760,55 @@ static int welch4096_run(ds_ctx* c, const float* x, int64_t ldx, const float* y,
     return DS_OK;
 }
 
+// window 8192, one input channel: two 4096-point register transforms per frame pair
+// (kernels_welch8192.hpp)
+static int welch8192_run(ds_ctx* c, const float* x, int64_t ldx, const float* y, int n_cy, int64_t ldy,
+                         int64_t n_samples, int hop, int n_frames, const float* window, int detrend,
+                         int mode, int amp_sqrt, double norm_scale, double factor, int halve_edges,
+                         float2* tf, float* coh) {
+    namespace w8 = welch8k;
+    if (!x || !y || !window) return fail(c, DS_ERR_ARG, "ds_welch_tf: null argument");
+    if (n_cy <= 0 || n_samples <= 0 || hop <= 0 || hop > 8192 || n_frames <= 0 || ldx < n_samples ||
+        ldy < n_samples)
+        return fail(c, DS_ERR_ARG, "ds_welch_tf: bad shape");
+    if (mode < DS_TF_H1 || mode > DS_TF_H3) return fail(c, DS_ERR_ARG, "welch: unsupported transfer function type");
+    if (!c->w4_tables) {
+        std::vector<float2> h;
+        welch4096::host_tables(h);
+        CHK(upload_table_fwd(c, &c->w4_tables, h));
+    }
+    if (!c->deconv8k_tables) {
+        std::vector<float2> h;
+        deconv8k::host_tables(h);
+        CHK(upload_table_fwd(c, &c->deconv8k_tables, h));
+    }
+    w8::Plan pl = w8::plan(n_frames, n_cy);
+    CHK(reserve(c, &c->ws, &c->ws_bytes, pl.bytes));
+    Carver cv(c->ws);
+    float2* xs = cv.take<float2>((size_t)pl.n_pairs * w8::N);
+    float* px = cv.take<float>((size_t)pl.n_pairs * w8::NB);
+    float* psx = cv.take<float>((size_t)pl.n_chunks * w8::NB);
+    float2* pxy = cv.take<float2>((size_t)pl.n_chunks * n_cy * w8::NB);
+    float* pyy = cv.take<float>((size_t)pl.n_chunks * n_cy * w8::NB);
+    const bool half = hop == 4096;
+    w8::Args ax{x, n_samples, ldx, 1, hop, n_frames, pl.n_pairs, detrend, pl.n_chunks, window,
+                c->w4_tables, c->deconv8k_tables, (float4*)xs, px, pxy, pyy, psx};
+    auto kx = half ? w8::k_x<true> : w8::k_x<false>;
+    auto ky = half ? w8::k_y<true> : w8::k_y<false>;
+    CHK(launch(c, "welch8192_x", kx, dim3(pl.n_pairs), w8::NTB, w8::LDS_BYTES, ax));
+    w8::Args ay = ax;
+    ay.sig = y;
+    ay.ld = ldy;
+    ay.n_ch = n_cy;
+    CHK(launch(c, "welch8192_main", ky, dim3(pl.n_chunks * n_cy), w8::NTB, w8::LDS_BYTES, ay));
+    WelchFinArgs f{psx, pxy, pyy, pl.n_chunks, pl.n_chunks, 1, n_cy, 0, mode,
+                   FinishPar{norm_scale / (double)n_frames, factor, halve_edges, amp_sqrt, w8::NB},
+                   tf, coh};
+    int64_t total = (int64_t)w8::NB * n_cy;
+    CHK(launch(c, "welch_finish", k_welch_finish, dim3((unsigned)((total + 63) / 64)), 256, 0, f));
+    return DS_OK;
+}
+
 // auto spectra of every channel with a 4096-sample window on the headline kernel (AUTO variant)
 static int welch4096_psd_run(ds_ctx* c, const float* x, int n_cx, int64_t ldx, int64_t n_samples, int hop,
                              int n_frames, const float* window, int detrend, int amp_sqrt, double norm_scale,
@@ -884,6 +934,9 @@ extern "C" int ds_welch_tf_dev(ds_ctx* c, const float* x, int n_cx, int64_t ldx,
         return welch4096_run(c, x, ldx, y, n_cy, ldy, n_samples, hop, n_frames, window, detrend, mode,
                              amp_sqrt, norm_scale, factor, halve_edges, (float2*)tf, coh);
     static const bool no1k = getenv("DSPTOOLBOX_AMD_WELCH_GENERIC") != nullptr;
+    if (c && W == 8192 && n_cx == 1 && average == DS_AVG_MEAN && !no1k)
+        return welch8192_run(c, x, ldx, y, n_cy, ldy, n_samples, hop, n_frames, window, detrend, mode,
+                             amp_sqrt, norm_scale, factor, halve_edges, (float2*)tf, coh);
     if (c && (W == 2048 || W == 1024 || W == 512 || W == 256) && n_cx == 1 && average == DS_AVG_MEAN && !no1k) {
         auto run = W == 2048 ? welch_wave_run<2048>
                              : (W == 1024 ? welch_wave_run<1024> : (W == 512 ? welch_wave_run<512> : welch_wave_run<256>));

@@ -757,12 +757,38 @@ def test_fused_float64_upload_is_the_same_computation():
             assert np.array_equal(csm_a, csm_b, equal_nan=True), (n, c)
 
 
+def test_welch_8192_window_kernel_vs_oracle():
+    """Welch H1/H2/H3 with an 8192-sample window (kernels_welch8192.hpp: two 4096-point register
+    transforms per frame pair, radix-2 decimation in frequency in front): overlaps 0 / 50 / 75 %,
+    odd frame counts, ragged tails, detrend, estimators, scalings."""
+    rng = np.random.default_rng(8192)
+    worst = 0.0
+    for n_cy, n, ov, det, mode, sc in (
+            (3, 400000, 50, True, "H1", SpectrumScaling.FFTBackward),
+            (5, 300001, 75, False, "H2", SpectrumScaling.PowerSpectralDensity),
+            (2, 500000, 0, True, "H3", SpectrumScaling.AmplitudeSpectrum),
+            (64, 2**19, 50, True, "H1", SpectrumScaling.FFTBackward)):
+        x = rng.standard_normal((n, 1)) * 0.4 + 0.1
+        h = rng.standard_normal((64, n_cy)) * np.exp(-np.arange(64) / 10.0)[:, None]
+        y = np.stack([np.convolve(x[:, 0], h[:, c])[:n] for c in range(n_cy)], axis=1)
+        y += 0.05 * rng.standard_normal(y.shape) + 0.02
+        tf, coh = backend.welch_transfer_function(y, x, 48000, 8192, mode, overlap_percent=ov, detrend=det,
+                                                  scaling=sc)
+        rt, rc = orc.compute_transfer_function_batched(y, x, 48000, 8192, mode, overlap_percent=ov,
+                                                       detrend=det, scaling=sc.name)
+        sl = slice(1, None) if det else slice(None)
+        e = max(relmax(tf[sl], rt[sl]), relmax(coh[sl], rc[sl]))
+        worst = max(worst, e)
+        assert e < TOL, (n_cy, n, ov, det, mode, sc, e)
+    print("welch 8192-window kernel worst rel-max", worst)
+
+
 def test_register_kernels_tiny_and_ragged_signals():
     """Signals shorter than one window, exactly one / two windows, one sample more: single frames,
     frame pairs without a second frame, frames that are mostly zero padding -- on every window length
     that has a register-resident kernel (auto spectra, H1 and the STFT)."""
     rng = np.random.default_rng(123)
-    for W in (256, 512, 1024, 2048, 4096):
+    for W in (256, 512, 1024, 2048, 4096, 8192):
         for n in (W // 4, W, W + 1, 3 * W // 2, 2 * W, 5 * W + 17):
             x = rng.standard_normal((n, 3)) * 0.3 + 0.1
             psd = backend._welch(x, None, 48000, Window.Hann, W, 50, False, "mean", SpectrumScaling.PowerSpectralDensity)
