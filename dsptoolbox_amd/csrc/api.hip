@@ -800,7 +800,15 @@ static int welch8192_run(ds_ctx* c, const float* x, int64_t ldx, const float* y,
     ay.sig = y;
     ay.ld = ldy;
     ay.n_ch = n_cy;
-    CHK(launch(c, "welch8192_main", ky, dim3(pl.n_chunks * n_cy), w8::NTB, w8::LDS_BYTES, ay));
+    // window in LDS + one exchange buffer per group (0.226 ms) unless the global-window / two-buffer
+    // variant (0.280 ms) is asked for
+    static const bool winlds = getenv("DSPTOOLBOX_AMD_W8_WINGLOBAL") == nullptr;
+    if (winlds) {
+        auto kyw = half ? w8::k_y<true, true> : w8::k_y<false, true>;
+        CHK(launch(c, "welch8192_main", kyw, dim3(pl.n_chunks * n_cy), w8::NTB, w8::LDS_BYTES_WINLDS, ay));
+    } else {
+        CHK(launch(c, "welch8192_main", ky, dim3(pl.n_chunks * n_cy), w8::NTB, w8::LDS_BYTES, ay));
+    }
     WelchFinArgs f{psx, pxy, pyy, pl.n_chunks, pl.n_chunks, 1, n_cy, 0, mode,
                    FinishPar{norm_scale / (double)n_frames, factor, halve_edges, amp_sqrt, w8::NB},
                    tf, coh};

@@ -25,6 +25,7 @@ using w4::cmul;
 using w4::pos16;
 constexpr int N = 8192, M = 4096, NB = N / 2 + 1, NTB = 512;
 constexpr int LDS_BYTES = (4 * w4::BUF_C + 256) * 8;  // 149 504 B
+constexpr int LDS_BYTES_WINLDS = (2 * w4::BUF_C + 256) * 8 + N * 4;  // 108 544 B
 
 struct Args {
     const float* sig;  // x (k_x) or y (k_y), planar
@@ -150,13 +151,21 @@ __global__ __launch_bounds__(NTB) void k_x(Args p) {
 }
 
 // ---- output channels: grid = n_chunks * n_ch ----------------------------------------
-template <bool HALF_HOP>
+// WINLDS: the window lives in LDS (32 KB) and each group has ONE exchange buffer (two more barriers
+// per transform) -- 108 KB instead of 150 KB; otherwise the window is read from global memory at
+// every pair and each group has two buffers.
+template <bool HALF_HOP, bool WINLDS = false>
 __global__ __launch_bounds__(NTB, 1) void k_y(Args p) {
     extern __shared__ __align__(16) float2 lds[];
     const int tid = threadIdx.x, t = tid & 255;
     const int q = __builtin_amdgcn_readfirstlane(tid >> 8);
-    float2* buf = lds + q * 2 * w4::BUF_C;
-    float2* tw2 = lds + 4 * w4::BUF_C;
+    constexpr int NBUF = WINLDS ? 1 : 2;
+    float2* buf = lds + q * NBUF * w4::BUF_C;
+    float2* tw2 = lds + 2 * NBUF * w4::BUF_C;
+    float* winl = reinterpret_cast<float*>(tw2 + 256);
+    if (WINLDS)
+        for (int i = tid; i < N; i += NTB) winl[i] = p.window[i];
+    const float* wsrc = WINLDS ? winl : p.window;
     // XCD-aware decode: whole chunks per XCD (the input spectra a chunk re-reads stay in its L2)
     int cq, c;
     {
@@ -201,7 +210,7 @@ __global__ __launch_bounds__(NTB, 1) void k_y(Args p) {
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): keep the pre-loop loads out of the loop's wait counts
     for (int pr = p0; pr < p1; ++pr) {
         float2 v[16];
-        front<HALF_HOP>(v, raw, p.window, q, wt, c32, needs_drop(p, pr), t);
+        front<HALF_HOP>(v, raw, wsrc, q, wt, c32, needs_drop(p, pr), t);
         float2 xw[16];
         auto issue_loads = [&]() {
             __builtin_amdgcn_sched_barrier(0);
@@ -221,9 +230,9 @@ __global__ __launch_bounds__(NTB, 1) void k_y(Args p) {
         };
 #if W4_TIMING
         unsigned long long ph[12] = {}, prev = 0;
-        w4::fft4096<true>(v, tw, buf, tw2, t, ph, prev, issue_loads, issue_xs);
+        w4::fft4096<!WINLDS>(v, tw, buf, tw2, t, ph, prev, issue_loads, issue_xs);
 #else
-        w4::fft4096<true>(v, tw, buf, tw2, t, issue_loads, issue_xs);
+        w4::fft4096<!WINLDS>(v, tw, buf, tw2, t, issue_loads, issue_xs);
 #endif
 #pragma unroll
         for (int k3 = 0; k3 < 16; ++k3) {
