@@ -817,6 +817,40 @@ static int welch8192_run(ds_ctx* c, const float* x, int64_t ldx, const float* y,
     return DS_OK;
 }
 
+// auto spectra of every channel with an 8192-sample window (AUTO variant of welch8k::k_y)
+static int welch8192_psd_run(ds_ctx* c, const float* x, int n_cx, int64_t ldx, int64_t n_samples, int hop,
+                             int n_frames, const float* window, int detrend, int amp_sqrt, double norm_scale,
+                             double factor, int halve_edges, float* psd) {
+    namespace w8 = welch8k;
+    if (!x || !window) return fail(c, DS_ERR_ARG, "ds_welch_psd: null argument");
+    if (n_cx <= 0 || n_samples <= 0 || hop <= 0 || hop > 8192 || n_frames <= 0 || ldx < n_samples)
+        return fail(c, DS_ERR_ARG, "ds_welch_psd: bad shape");
+    if (!c->w4_tables) {
+        std::vector<float2> h;
+        welch4096::host_tables(h);
+        CHK(upload_table_fwd(c, &c->w4_tables, h));
+    }
+    if (!c->deconv8k_tables) {
+        std::vector<float2> h;
+        deconv8k::host_tables(h);
+        CHK(upload_table_fwd(c, &c->deconv8k_tables, h));
+    }
+    w8::Plan pl = w8::plan(n_frames, n_cx);
+    CHK(reserve(c, &c->ws, &c->ws_bytes, Carver::pad(sizeof(float) * (size_t)pl.n_chunks * n_cx * w8::NB)));
+    Carver cv(c->ws);
+    float* pyy = cv.take<float>((size_t)pl.n_chunks * n_cx * w8::NB);
+    w8::Args a{x, n_samples, ldx, n_cx, hop, n_frames, pl.n_pairs, detrend, pl.n_chunks, window,
+               c->w4_tables, c->deconv8k_tables, nullptr, nullptr, nullptr, pyy, nullptr};
+    auto ky = hop == 4096 ? w8::k_y<true, true, true> : w8::k_y<false, true, true>;
+    CHK(launch(c, "welch8192_main", ky, dim3(pl.n_chunks * n_cx), w8::NTB, w8::LDS_BYTES_WINLDS, a));
+    WelchFinArgs f{pyy, nullptr, nullptr, pl.n_chunks, pl.n_chunks, n_cx, 0, 1, 0,
+                   FinishPar{norm_scale / (double)n_frames, factor, halve_edges, amp_sqrt, w8::NB},
+                   nullptr, psd};
+    int64_t total = (int64_t)w8::NB * n_cx;
+    CHK(launch(c, "welch_finish", k_welch_finish, dim3((unsigned)((total + 63) / 64)), 256, 0, f));
+    return DS_OK;
+}
+
 // auto spectra of every channel with a 4096-sample window on the headline kernel (AUTO variant)
 static int welch4096_psd_run(ds_ctx* c, const float* x, int n_cx, int64_t ldx, int64_t n_samples, int hop,
                              int n_frames, const float* window, int detrend, int amp_sqrt, double norm_scale,
@@ -960,6 +994,9 @@ extern "C" int ds_welch_psd_dev(ds_ctx* c, const float* x, int n_cx, int64_t ldx
                                 int halve_edges, float* psd) {
     if (!psd) return fail(c, DS_ERR_ARG, "ds_welch_psd: null output");
     static const bool no1k = getenv("DSPTOOLBOX_AMD_WELCH_GENERIC") != nullptr;
+    if (c && W == 8192 && average == DS_AVG_MEAN && !no1k)
+        return welch8192_psd_run(c, x, n_cx, ldx, n_samples, hop, n_frames, window, detrend, amp_sqrt,
+                                 norm_scale, factor, halve_edges, psd);
     if (c && W == 4096 && average == DS_AVG_MEAN && welch4096::enabled() && !no1k)
         return welch4096_psd_run(c, x, n_cx, ldx, n_samples, hop, n_frames, window, detrend, amp_sqrt,
                                  norm_scale, factor, halve_edges, psd);

@@ -154,7 +154,8 @@ __global__ __launch_bounds__(NTB) void k_x(Args p) {
 // WINLDS: the window lives in LDS (32 KB) and each group has ONE exchange buffer (two more barriers
 // per transform) -- 108 KB instead of 150 KB; otherwise the window is read from global memory at
 // every pair and each group has two buffers.
-template <bool HALF_HOP, bool WINLDS = false>
+// AUTO: auto spectra only (ds_welch_psd): no input spectra, no cross sums, no psx.
+template <bool HALF_HOP, bool WINLDS = false, bool AUTO = false>
 __global__ __launch_bounds__(NTB, 1) void k_y(Args p) {
     extern __shared__ __align__(16) float2 lds[];
     const int tid = threadIdx.x, t = tid & 255;
@@ -187,7 +188,7 @@ __global__ __launch_bounds__(NTB, 1) void k_y(Args p) {
     const float2* c32 = p.twn + 256;
     const float* ch = p.sig + (int64_t)c * p.ld;
     const int p0 = (int)((int64_t)cq * p.n_pairs / p.n_chunks), p1 = (int)((int64_t)(cq + 1) * p.n_pairs / p.n_chunks);
-    {
+    if (!AUTO) {
         // input auto-spectrum of this chunk: this workgroup's slice of the bins, px rows summed in fp64
         const int bpc = (NB + p.n_ch - 1) / p.n_ch;
         const int b0 = c * bpc, b1 = min(b0 + bpc, NB);
@@ -218,6 +219,7 @@ __global__ __launch_bounds__(NTB, 1) void k_y(Args p) {
             __builtin_amdgcn_sched_barrier(0);
         };
         auto issue_xs = [&]() {
+            if (AUTO) return;
             __builtin_amdgcn_sched_barrier(0);
             const float4* __restrict__ xp = p.xs + ((int64_t)pr * 2 + q) * (M / 2) + t;
 #pragma unroll
@@ -236,24 +238,29 @@ __global__ __launch_bounds__(NTB, 1) void k_y(Args p) {
 #endif
 #pragma unroll
         for (int k3 = 0; k3 < 16; ++k3) {
-            const float2 w = xw[k3], z = v[pos16(k3)];
-            T[k3].x = fmaf(w.x, z.x, fmaf(w.y, z.y, T[k3].x));  // conj(w) z
-            T[k3].y = fmaf(w.x, z.y, fmaf(-w.y, z.x, T[k3].y));
+            const float2 z = v[pos16(k3)];
+            if (!AUTO) {
+                const float2 w = xw[k3];
+                T[k3].x = fmaf(w.x, z.x, fmaf(w.y, z.y, T[k3].x));  // conj(w) z
+                T[k3].y = fmaf(w.x, z.y, fmaf(-w.y, z.x, T[k3].y));
+            }
             P[k3] = fmaf(z.x, z.x, fmaf(z.y, z.y, P[k3]));
         }
     }
     if (p.detrend && tid == 0) P[0] = 0.f;  // class 0, k' = 0: xs bin 0 is already 0 -> T[0] = 0
     // fold k <-> N-k once per chunk, inside each class, through the group's LDS buffer
     __syncthreads();
-#pragma unroll
-    for (int k3 = 0; k3 < 16; ++k3) buf[t + 256 * k3] = T[k3];
-    __syncthreads();
     const int64_t so = ((int64_t)cq * p.n_ch + c) * NB;
-    for (int kp = t; kp < fold_count(q); kp += 256) {
-        const float2 a = buf[kp], b = buf[fold_partner(q, kp)];
-        p.pxy[so + 2 * kp + q] = make_float2(0.5f * (a.x + b.x), 0.5f * (a.y - b.y));
+    if (!AUTO) {
+#pragma unroll
+        for (int k3 = 0; k3 < 16; ++k3) buf[t + 256 * k3] = T[k3];
+        __syncthreads();
+        for (int kp = t; kp < fold_count(q); kp += 256) {
+            const float2 a = buf[kp], b = buf[fold_partner(q, kp)];
+            p.pxy[so + 2 * kp + q] = make_float2(0.5f * (a.x + b.x), 0.5f * (a.y - b.y));
+        }
+        __syncthreads();
     }
-    __syncthreads();
     float* pw = reinterpret_cast<float*>(buf);
 #pragma unroll
     for (int k3 = 0; k3 < 16; ++k3) pw[t + 256 * k3] = P[k3];
