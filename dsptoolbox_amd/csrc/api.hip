@@ -1614,7 +1614,7 @@ static int fir_once(ds_ctx* c, const float* x, int n_ch, int64_t ldx, int64_t n_
         fir16k::Args a{x, n_samples, ldx, ld_y, n_ch, n_filt, n_taps, c->w4_tables, c->fir16k_tables, hperm, y, 0};
         // interior blocks of a 4097-tap filter with 16-byte aligned rows: the store-everything variant
         int64_t n_plain = 0;
-        if (n_taps - 1 == fir16k::M && (ld_y & 3) == 0 && (((uintptr_t)y) & 15) == 0) n_plain = n_samples / L;
+        if (((n_taps - 1) & 3) == 0 && (ld_y & 3) == 0 && (((uintptr_t)y) & 15) == 0) n_plain = n_samples / L;
         // The few ragged blocks go to the side stream so they run beside the main grid's last,
         // partly filled round instead of after it (fork after the tap spectra, join at the end).
         const bool ragged = n_blocks > n_plain;

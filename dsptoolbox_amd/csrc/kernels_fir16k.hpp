@@ -152,8 +152,9 @@ struct Args {
 };
 
 // grid = (n_blocks, ceil(n_ch/2), filter slices); block j covers outputs [j L, (j+1) L), L = 16384 - (n_taps-1).
-// PLAIN: exactly 4096 discarded samples (4097 taps), whole block inside the signal, 16-byte aligned
-// rows: quarters 1..3 are stored whole with 16-byte stores and no test per store (the host launches
+// PLAIN: the number of discarded samples T1 = n_taps - 1 is a multiple of 4, whole block inside the
+// signal, 16-byte aligned rows: every kept group of four samples is stored with one 16-byte store
+// behind one compare per quarter (4097 taps: quarters 1..3 whole), no test per element (the host launches
 // the interior blocks with PLAIN and the rest without: keeping both store paths in one kernel costs
 // registers the 128-VGPR budget does not have).
 template <bool PLAIN>
@@ -269,11 +270,15 @@ __global__ __launch_bounds__(NTB) void k_fir(Args p) {
             return make_float2(u0.x + u1.y - u2.x - u3.y, u0.y - u1.x - u2.y + u3.x);  // u0 - i u1 - u2 + i u3
         };
         if (PLAIN) {
+            // T1 is a multiple of 4: a thread's four consecutive samples of a quarter are kept or
+            // discarded together (one compare per quarter, no test per element, no bounds test)
 #pragma unroll
-            for (int j = 1; j < 4; ++j) {
-                const float2 y0 = quarter(j, 0), y1 = quarter(j, 1), y2 = quarter(j, 2), y3 = quarter(j, 3);
-                *reinterpret_cast<float4*>(oa + n0 + M * j) = make_float4(y0.x, y1.x, y2.x, y3.x);
-                if (vb) *reinterpret_cast<float4*>(ob + n0 + M * j) = make_float4(y0.y, y1.y, y2.y, y3.y);
+            for (int j = 0; j < 4; ++j) {
+                if (n0 + M * j >= T1) {
+                    const float2 y0 = quarter(j, 0), y1 = quarter(j, 1), y2 = quarter(j, 2), y3 = quarter(j, 3);
+                    *reinterpret_cast<float4*>(oa + n0 + M * j) = make_float4(y0.x, y1.x, y2.x, y3.x);
+                    if (vb) *reinterpret_cast<float4*>(ob + n0 + M * j) = make_float4(y0.y, y1.y, y2.y, y3.y);
+                }
             }
         } else {
 #pragma unroll

@@ -321,10 +321,13 @@ def test_fir_state_zero_phase_long_golden():
 
 
 @pytest.mark.parametrize("n_taps,n,n_ch", [(2049, 50001, 3), (3000, 70000, 2), (8193, 40000, 1), (4097, 12288 * 3, 2),
-                                            (4097, 5000, 5)])
+                                            (4097, 5000, 5), (3001, 100000, 2), (2049, 14336 * 4, 4),
+                                            (6145, 90000, 3)])
 def test_fir_16k_blocks_vs_oracle(n_taps, n, n_ch):
-    """The 16384-point block kernel (2049 .. 8193 taps): other tap counts than 4097 (element-wise
-    tested stores), odd channel counts, lengths that are / are not whole blocks, one short block."""
+    """The 16384-point block kernel (2049 .. 8193 taps): tap counts whose discarded length is a
+    multiple of 4 (interior blocks store whole groups of four behind one compare per quarter) and
+    others (element-wise tested stores), odd channel counts, lengths that are / are not whole
+    blocks, one short block."""
     rng = np.random.default_rng(n_taps + n)
     x = rng.standard_normal((n, n_ch)) * 0.1
     taps = [rng.standard_normal(n_taps) * np.exp(-np.arange(n_taps) / (n_taps / 5.0)) * 0.05 for _ in range(2)]
