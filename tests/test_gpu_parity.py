@@ -322,7 +322,7 @@ def test_fir_state_zero_phase_long_golden():
 
 @pytest.mark.parametrize("n_taps,n,n_ch", [(2049, 50001, 3), (3000, 70000, 2), (8193, 40000, 1), (4097, 12288 * 3, 2),
                                             (4097, 5000, 5), (3001, 100000, 2), (2049, 14336 * 4, 4),
-                                            (6145, 90000, 3)])
+                                            (6145, 90000, 3), (1025, 80000, 3), (1501, 50000, 2), (1100, 60000, 2)])
 def test_fir_16k_blocks_vs_oracle(n_taps, n, n_ch):
     """The 16384-point block kernel (2049 .. 8193 taps): tap counts whose discarded length is a
     multiple of 4 (interior blocks store whole groups of four behind one compare per quarter) and
