@@ -1,0 +1,82 @@
+"""Dev tool: randomized shapes through the register kernels (Welch tf / psd, STFT, CSM) against
+the oracle.  usage: python tools/fuzz_parity.py [n_cases] [seed]"""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from dsptoolbox_amd import backend  # noqa: E402
+from dsptoolbox_amd.standard.enums import SpectrumScaling, Window  # noqa: E402
+from oracle import dsp_oracle as orc  # noqa: E402
+
+n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+scalings = list(SpectrumScaling)
+worst = {}
+fails = []
+
+
+def relmax(a, b, skip_dc=False):
+    a, b = np.asarray(a), np.asarray(b)
+    if skip_dc:
+        a, b = a[1:], b[1:]
+    return float(np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-300))
+
+
+for it in range(n_cases):
+    kind = rng.choice(["tf", "psd", "stft", "csm"])
+    W = int(rng.choice([256, 512, 1024, 2048, 4096, 8192] if kind in ("tf", "psd") else [256, 512, 1024, 2048]))
+    ov = float(rng.choice([0, 25, 50, 50, 50, 75]))
+    hop = W - int(ov / 100 * W)
+    frames = int(rng.integers(45, 140)) if kind in ("tf", "csm") else int(rng.integers(1, 60))
+    n = max(8, frames * hop + int(rng.integers(-hop + 1, hop)))
+    n_ch = int(rng.choice([1, 2, 3, 4, 5, 7, 8, 9, 16, 17, 20, 33]))
+    if kind == "csm":
+        n_ch = int(rng.choice([2, 3, 5, 8]))
+    det = bool(rng.integers(0, 2))
+    sc = scalings[int(rng.integers(0, len(scalings)))]
+    x = rng.standard_normal((n, 1)) * 0.3 + 0.05
+    h = rng.standard_normal((32, n_ch)) * np.exp(-np.arange(32) / 6.0)[:, None]
+    y = np.stack([np.convolve(x[:, 0], h[:, c])[:n] for c in range(n_ch)], axis=1) + 0.05 * rng.standard_normal((n, n_ch))
+    try:
+        if kind == "tf":
+            mode = str(rng.choice(["H1", "H2", "H3"]))
+            tf, coh = backend.welch_transfer_function(y, x, 48000, W, mode, overlap_percent=ov, detrend=det, scaling=sc)
+            rt, rc = orc.compute_transfer_function_batched(y, x, 48000, W, mode, overlap_percent=ov, detrend=det,
+                                                           scaling=sc.name)
+            if mode == "H2":  # Gyy / Gyx: dividing by a nearly cancelled cross spectrum where the coherence
+                good = rc > 0.05  # vanishes (nulls of the random test responses) is noise in float64 too
+                tf = np.where(good, tf, rt)
+            e_tf, e_coh = relmax(tf, rt, det), relmax(coh, rc, det)
+            e = max(e_tf, e_coh)
+            if e > 1e-6:
+                d = np.abs(np.asarray(tf) - rt)[1 if det else 0:]
+                b, c_ = np.unravel_index(np.argmax(d), d.shape)
+                print(f"  tf case W={W} n={n} ch={n_ch} ov={ov} det={det} {sc.name} mode={mode}: e_tf={e_tf:.2e} e_coh={e_coh:.2e} "
+                      f"worst bin {b + (1 if det else 0)} ch {c_} |ref|={abs(rt[b + (1 if det else 0), c_]):.3e} max|ref|={np.max(np.abs(rt)):.3e} "
+                      f"coh_ref there={rc[b + (1 if det else 0), c_]:.6f}")
+        elif kind == "psd":
+            a = backend._welch(y, None, 48000, Window.Hann, W, ov, det, "mean", sc)
+            r = orc.welch(y, None, 48000, "hann", W, ov, det, "mean", sc.name)
+            e = relmax(a, r, det)
+        elif kind == "stft":
+            pad = bool(rng.integers(0, 2))
+            t, f, st = backend._stft(y, 48000, W, Window.Hann, ov, None, det, pad, sc)
+            rt_, rf_, rs = orc.stft(y, 48000, W, "hann", ov, None, det, pad, sc.name)
+            assert st.shape == rs.shape
+            e = relmax(st, rs)
+        else:
+            f, c = backend._csm_welch(y, 48000, W, Window.Hann, ov, det, "mean", sc)
+            rf, rcm = orc.csm_welch(y, 48000, W, "hann", ov, det, "mean", sc.name)
+            e = relmax(c, rcm)
+    except Exception as ex:  # noqa: BLE001
+        fails.append((kind, W, n, n_ch, ov, det, sc.name, repr(ex)[:200]))
+        continue
+    worst[kind] = max(worst.get(kind, 0.0), e)
+    if not np.isfinite(e) or e > 1e-6:
+        fails.append((kind, W, n, n_ch, ov, det, sc.name, e))
+print("worst", worst)
+print("failures", len(fails))
+for f in fails[:20]:
+    print("  ", f)
