@@ -111,8 +111,22 @@ def spectral_deconvolve(output: Signal, input: Signal, apply_regularization: boo
         ids = find_nearest_points_index_in_vector(start_stop_hz, freqs_hz)
         eps = _inverse_hann_band(ids, len(freqs_hz)) * 10 ** (30 / 20)
     inverse = backend.regularized_inverse(denum_fft, eps)  # (B, Cx)
-    new_time_data = backend.spectral_division(
-        output.time_data, n_fft, inverse[:, 0] if multichannel else inverse, n_time)
+    if n_fft == n_time:
+        new_time_data = backend.spectral_division(
+            output.time_data, n_fft, inverse[:, 0] if multichannel else inverse, n_time)
+    else:
+        # The signal length is not a fast length: the reference transforms with n_fft =
+        # next_fast_len(n_time) points but inverts with np.fft.irfft(..., n=n_time)
+        # (_transfer_functions.py:37-41), and numpy then CROPS the spectrum to n_time//2 + 1 bins
+        # and runs an n_time-point inverse (the bins keep their values but not their spacing).
+        # Reproduced literally: forward spectrum on the device, the cropped product as a
+        # per-channel "inverse spectrum" against a unit impulse (whose rfft is 1): the device
+        # computes irfft_{n_time}(1 * product).
+        num_fft = backend.rfft_spectrum(output.time_data, n_fft)               # (n_fft//2 + 1, C)
+        prod = (num_fft * (inverse[:, :1] if multichannel else inverse))[: n_time // 2 + 1]
+        delta = np.zeros((n_time, prod.shape[1]))
+        delta[0, :] = 1.0
+        new_time_data = backend.spectral_division(delta, n_time, prod, n_time)
     new_sig = ImpulseResponse(None, new_time_data, fs_hz, constrain_amplitude=False)
     if padding and keep_original_length:
         new_sig.time_data = new_sig.time_data[:original_length].copy()

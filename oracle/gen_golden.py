@@ -294,8 +294,39 @@ def gen_fir_stream(dsp):
     save("fir_stream", dict(cases=cases, fs=fs), arrs)
 
 
+def gen_deconv_nonfast(dsp):
+    """spectral_deconvolve for signal lengths that are NOT fast FFT lengths: get_spectrum pads to
+    next_fast_len(N) but _spectral_deconvolve inverts with np.fft.irfft(..., n=N)
+    (transfer_functions/_transfer_functions.py:37-41), i.e. numpy crops the spectrum to N//2 + 1
+    bins before an N-point inverse."""
+    fs = 48000
+    rng = np.random.default_rng(66)
+    cases, arrs = [], {}
+    i = 0
+    for n, c, reg, pad, keep in ((5918, 2, True, False, False), (5918, 2, True, True, True), (26075, 1, True, True, False),
+                                 (5940, 3, False, False, False), (12345, 2, True, False, False)):
+        t = np.arange(n) / fs
+        if reg:
+            x = (0.5 * np.sin(2 * np.pi * (20 * t + (8000 - 20) / (2 * t[-1]) * t * t)))[:, None]
+        else:
+            x = rng.standard_normal((n, 1)) * 0.3
+        h = rng.standard_normal((200, c)) * np.exp(-np.arange(200) / 30.0)[:, None]
+        y = np.stack([np.convolve(x[:, 0], h[:, j])[:n] for j in range(c)], axis=1) + 1e-3 * rng.standard_normal((n, c))
+        ir = dsp.transfer_functions.spectral_deconvolve(dsp.Signal(None, y.copy(), fs), dsp.Signal(None, x.copy(), fs),
+                                                        apply_regularization=reg, padding=pad,
+                                                        keep_original_length=keep)
+        arrs[f"x_{i}"], arrs[f"y_{i}"], arrs[f"ir_{i}"] = x, y, ir.time_data
+        cases.append(dict(n=n, n_ch=c, regularized=reg, padding=pad, keep_original_length=keep))
+        i += 1
+    save("deconv_nonfast", dict(cases=cases, fs=fs), arrs)
+
+
 def main():
     dsp = import_reference()
+    if "--only-deconv-nonfast" in sys.argv:
+        import warnings
+        warnings.simplefilter("ignore")
+        return gen_deconv_nonfast(dsp)
     if "--only-chroma" in sys.argv:
         import warnings
         warnings.simplefilter("ignore")

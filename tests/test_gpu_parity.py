@@ -729,6 +729,21 @@ def test_welch_default_window_kernel_vs_oracle():
     print("welch 1024-window kernel worst rel-max", worst)
 
 
+def test_deconvolve_non_fast_lengths_golden():
+    """spectral_deconvolve when the signal length is not a fast FFT length (found by
+    tools/fuzz_misc.py): the reference's irfft(n=N) of a next_fast_len(N)-point spectrum crops the
+    spectrum; the device path reproduces that (forward spectrum, cropped product, N-point inverse)."""
+    meta, z = load_golden("deconv_nonfast")
+    for i, c in enumerate(meta["cases"]):
+        ir = dsp.transfer_functions.spectral_deconvolve(
+            dsp.Signal(None, z[f"y_{i}"].copy(), meta["fs"]), dsp.Signal(None, z[f"x_{i}"].copy(), meta["fs"]),
+            apply_regularization=c["regularized"], padding=c["padding"],
+            keep_original_length=c["keep_original_length"])
+        assert ir.time_data.shape == z[f"ir_{i}"].shape
+        lim = TOL if c["regularized"] else 20 * TOL  # plain Y/X: white-noise |X| dips to ~1e-2 of its mean
+        assert relmax(ir.time_data, z[f"ir_{i}"]) < lim, (c, relmax(ir.time_data, z[f"ir_{i}"]))
+
+
 def test_fused_float64_upload_is_the_same_computation():
     """welch_transfer_function hands large float64 C-order arrays to ds_welch_tf_f64 (threaded cast
     + transpose into pinned chunks, asynchronous 2-D copies); the result must be bit-identical to

@@ -269,6 +269,16 @@ def test_fir_streaming_classes():
     assert n_conv >= 4
 
 
+def test_deconvolve_non_fast_lengths():
+    """Signal lengths that are not fast FFT lengths: the reference transforms with next_fast_len(N)
+    points and inverts with irfft(n=N) -- numpy crops the spectrum (_transfer_functions.py:37-41)."""
+    meta, z = load_golden("deconv_nonfast")
+    for i, c in enumerate(meta["cases"]):
+        ir = orc.spectral_deconvolve(z[f"y_{i}"], z[f"x_{i}"], meta["fs"], apply_regularization=c["regularized"],
+                                     padding=c["padding"], keep_original_length=c["keep_original_length"])
+        close(ir, z[f"ir_{i}"], tol=1e-9)
+
+
 def test_chirp_pair_config1():
     """BASELINE.json configs[0]: the reference's own example chirps (16-bit PCM fixtures)."""
     meta, z = load_golden("chirp_pair")

@@ -1,0 +1,70 @@
+"""Dev tool: randomized spectral deconvolutions (power-of-two and other lengths, padding, with and
+without regularisation, mono / per-channel denominators), whole-signal spectra and median-averaged
+Welch estimates against the oracle."""
+import os
+import sys
+import warnings
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import dsptoolbox_amd as dsp  # noqa: E402
+from dsptoolbox_amd import backend  # noqa: E402
+from dsptoolbox_amd.standard.enums import SpectrumScaling, Window  # noqa: E402
+from oracle import dsp_oracle as orc  # noqa: E402
+
+warnings.simplefilter("ignore")
+n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+worst, fails = {}, []
+fs = 48000
+for it in range(n_cases):
+    kind = str(rng.choice(["deconv", "median", "spectrum"]))
+    try:
+        if kind == "deconv":
+            n = int(rng.choice([4096, 8192, 16384, 65536, rng.integers(3000, 70000), 48000, 192000]))
+            c = int(rng.integers(1, 4))
+            t = np.arange(n) / fs
+            x = (0.5 * np.sin(2 * np.pi * (20 * t + (8000 - 20) / (2 * t[-1]) * t * t)))[:, None]
+            xin = x if rng.integers(0, 2) else np.repeat(x, c, axis=1) * (1 + 0.1 * np.arange(c))
+            h = rng.standard_normal((200, c)) * np.exp(-np.arange(200) / 30.0)[:, None]
+            y = np.stack([np.convolve(x[:, 0], h[:, j])[:n] for j in range(c)], axis=1) + 1e-3 * rng.standard_normal((n, c))
+            reg, pad, keep = bool(rng.integers(0, 2)), bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+            if not reg:  # plain Y/X needs a denominator without empty bands: white noise instead of the sweep
+                x = rng.standard_normal((n, 1)) * 0.3
+                xin = x if xin.shape[1] == 1 else np.repeat(x, c, axis=1) * (1 + 0.1 * np.arange(c))
+                y = np.stack([np.convolve(x[:, 0], h[:, j])[:n] for j in range(c)], axis=1)
+            ir = dsp.transfer_functions.spectral_deconvolve(dsp.Signal(None, y, fs), dsp.Signal(None, xin, fs),
+                                                            apply_regularization=reg, padding=pad,
+                                                            keep_original_length=keep)
+            ref = orc.spectral_deconvolve(y, xin, fs, apply_regularization=reg, padding=pad, keep_original_length=keep)
+            e = orc.rel_max(ir.time_data, ref)
+            lim = 1e-6 if reg else 1e-4  # unregularised: |X| of white noise still dips to ~1e-2 of its mean
+        elif kind == "median":
+            W = int(rng.choice([64, 256, 1024, 4096]))
+            n = int(rng.integers(40 * W // 2, 200 * W // 2))
+            c = int(rng.integers(1, 4))
+            y = rng.standard_normal((n, c)) * 0.3 + 0.1
+            a = backend._welch(y, None, fs, Window.Hann, W, 50, True, "median", SpectrumScaling.FFTBackward)
+            r = orc.welch(y, None, fs, "hann", W, 50, True, "median", "FFTBackward")
+            e = orc.rel_max(a[1:], r[1:])
+            lim = 2e-6
+        else:
+            n = int(rng.choice([rng.integers(100, 5000), rng.integers(5000, 300000), 2**int(rng.integers(8, 19))]))
+            c = int(rng.integers(1, 4))
+            y = rng.standard_normal((n, c)) * 0.3
+            s = dsp.Signal(None, y, fs)
+            s.set_spectrum_parameters(method=dsp.SpectrumMethod.FFT)
+            f, sp = s.get_spectrum()
+            rf, rs = orc.spectrum_fft(y, fs)
+            e = orc.rel_max(sp, rs)
+            lim = 1e-6
+    except Exception as ex:  # noqa: BLE001
+        fails.append((kind, repr(ex)[:200]))
+        continue
+    worst[kind] = max(worst.get(kind, 0.0), e)
+    if not np.isfinite(e) or e > lim:
+        fails.append((kind, n, c, e, locals().get("reg")))
+print("worst", worst, "failures", len(fails))
+for f in fails[:20]:
+    print("  ", f)
