@@ -87,7 +87,10 @@ for it in range(n_cases):
             # neighbour and keep ~1e-7 of its amplitude: compare the frames within
             # 30 dB of the loudest one
             level = ref.max(axis=0, keepdims=True)
-            ok = (ref > -1000.0) & (level > level.max() - 30.0)
+            with np.errstate(invalid="ignore"):
+                ok = (ref > -1000.0) & (level > np.nanmax(level) - 30.0)
+            if not ok.any():  # 24 bands over too few bins give NaN filters in the reference too
+                continue
             e = orc.rel_max(lm[ok], ref[ok])
             lim = 1e-6
     except Exception as ex:  # noqa: BLE001
