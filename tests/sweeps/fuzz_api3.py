@@ -6,7 +6,7 @@ import warnings
 
 import numpy as np
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import dsptoolbox_amd as dsp  # noqa: E402
 from dsptoolbox_amd import backend  # noqa: E402
 from dsptoolbox_amd.standard.enums import SpectrumScaling, Window  # noqa: E402

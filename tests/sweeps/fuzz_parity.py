@@ -1,11 +1,11 @@
 """Dev tool: randomized shapes through the register kernels (Welch tf / psd, STFT, CSM) against
-the oracle.  usage: python tools/fuzz_parity.py [n_cases] [seed]"""
+the oracle.  usage: python tests/sweeps/fuzz_parity.py [n_cases] [seed]"""
 import os
 import sys
 
 import numpy as np
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from dsptoolbox_amd import backend  # noqa: E402
 from dsptoolbox_amd.standard.enums import SpectrumScaling, Window  # noqa: E402
 from oracle import dsp_oracle as orc  # noqa: E402

@@ -731,7 +731,7 @@ def test_welch_default_window_kernel_vs_oracle():
 
 def test_deconvolve_non_fast_lengths_golden():
     """spectral_deconvolve when the signal length is not a fast FFT length (found by
-    tools/fuzz_misc.py): the reference's irfft(n=N) of a next_fast_len(N)-point spectrum crops the
+    tests/sweeps/fuzz_misc.py): the reference's irfft(n=N) of a next_fast_len(N)-point spectrum crops the
     spectrum; the device path reproduces that (forward spectrum, cropped product, N-point inverse)."""
     meta, z = load_golden("deconv_nonfast")
     for i, c in enumerate(meta["cases"]):
