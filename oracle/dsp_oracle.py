@@ -534,7 +534,10 @@ def spectral_deconvolve(y, x, fs_hz: int, apply_regularization: bool = True,
 def lfilter_fir(b, x, zi=None):
     """filter_helpers.py:454-503: oaconvolve(...)[:N]; with zi (T-1, C) the state is added to
     the head of the full convolution and the new state is its tail (:493-500)."""
-    b = np.asarray(b, dtype=np.float64).squeeze()
+    b = np.asarray(b, dtype=np.float64)
+    if b.ndim != 1:  # :475-477 (a one-tap filter is already 1-D and stays so)
+        b = np.squeeze(b)
+        assert b.ndim == 1, "FIR Filters for audio must be 1D-arrays"
     x = np.asarray(x, dtype=np.float64)
     if x.ndim < 2:
         x = x[:, None]

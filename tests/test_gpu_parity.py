@@ -336,6 +336,22 @@ def test_fir_16k_blocks_vs_oracle(n_taps, n, n_ch):
     assert relmax(y, r) < TOL, relmax(y, r)
 
 
+def test_fir_one_and_two_tap_filters():
+    """Degenerate banks (found by tests/sweeps/fuzz_fir.py on the oracle side): gains and two-tap
+    filters in the three bank modes."""
+    rng = np.random.default_rng(17)
+    x = rng.standard_normal((12287, 2)) * 0.2
+    for T in (1, 2):
+        taps = [rng.standard_normal(T) * 0.5 for _ in range(3)]
+        for mode, name in ((backend.DS_FB_PARALLEL, "Parallel"), (backend.DS_FB_SUMMED, "Summed"),
+                           (backend.DS_FB_SEQUENTIAL, "Sequential")):
+            y = backend.fir_filter_bank(x, taps, mode)
+            r = orc.filterbank_fir(taps, x, name)
+            if name == "Parallel":
+                r = np.transpose(r, (2, 0, 1))
+            assert y.shape == r.shape and relmax(y, r) < TOL, (T, name, relmax(y, r))
+
+
 def test_fir_long_filters_vs_oracle():
     """> 8193 taps: overlap-save on the four-step FFT, several blocks, bank modes."""
     rng = np.random.default_rng(91)
