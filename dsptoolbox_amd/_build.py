@@ -13,6 +13,17 @@ SOURCES = [os.path.join(CSRC, "api.hip")]
 # together with ~270 v_mov per FFT; scalar fp32 VALU code is 25 % faster here (measured on
 # MI355X, profiles/).
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-shared", "-fPIC"]
+# per-kernel registers / scratch / LDS as the compiler reports them (parsed into RES_PATH)
+REMARK_FLAGS = ["-Rpass-analysis=kernel-resource-usage"]
+RES_PATH = os.path.join(LIB_DIR, "kernel_resources.json")
+# Kernels whose pair / block loops must not touch scratch memory: the build FAILS if one of them
+# is compiled with ScratchSize > 0 (a spill inside a register-resident transform costs more than
+# the occupancy it buys).  Matched as substrings of the demangled-ish mangled names.
+NO_SCRATCH = [
+    "welch40964k_y3", "welch40964k_x3", "welch40963k_y", "welch40963k_x",
+    "stft1k11k_stft_wave", "welch1k3k_y", "welch1k3k_x", "welch8k3k_y", "welch8k3k_x",
+    "fir16k5k_fir", "deconv8k8k_deconv", "k_csm_gemm64",
+]
 
 
 HASH_PATH = os.path.join(LIB_DIR, "libdsptoolbox_amd.srchash")
@@ -45,6 +56,38 @@ def _up_to_date() -> bool:
         return fh.read().strip() == _source_hash()
 
 
+def _parse_resources(text: str) -> dict:
+    """{mangled kernel name: {vgpr, agpr, sgpr, scratch, lds, occupancy}} from the compiler's
+    -Rpass-analysis=kernel-resource-usage remarks."""
+    import re
+    out, cur = {}, None
+    keys = {"VGPRs": "vgpr", "AGPRs": "agpr", "TotalSGPRs": "sgpr", "ScratchSize [bytes/lane]": "scratch",
+            "LDS Size [bytes/block]": "lds", "Occupancy [waves/SIMD]": "occupancy", "VGPRs Spill": "vgpr_spill"}
+    for line in text.splitlines():
+        m = re.search(r"remark: (?:.*: )?Function Name: (\S+)", line)
+        if m:
+            cur = out.setdefault(m.group(1), {})
+            continue
+        m = re.search(r"remark:\s+(?:.*?:\s+)?([A-Za-z][A-Za-z \[\]/]+): (\d+)", line)
+        if m and cur is not None and m.group(1).strip() in keys:
+            cur[keys[m.group(1).strip()]] = int(m.group(2))
+    return out
+
+
+def _without_remarks(text: str) -> str:
+    keep, skip = [], 0
+    for line in text.splitlines(True):
+        if "-Rpass-analysis=kernel-resource-usage" in line:
+            skip = 2  # the remark is followed by a source line and a caret line
+            continue
+        if skip and (line.lstrip().startswith("|") or line.strip().startswith("^") or "|" in line[:8]):
+            skip -= 1
+            continue
+        skip = 0
+        keep.append(line)
+    return "".join(keep)
+
+
 def build_library(force: bool = False, verbose: bool = True) -> str:
     """hipcc --offload-arch=gfx950 -> dsptoolbox_amd/lib/libdsptoolbox_amd.so
 
@@ -61,11 +104,22 @@ def build_library(force: bool = False, verbose: bool = True) -> str:
                 return LIB_PATH
             hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
             tmp = LIB_PATH + f".tmp{os.getpid()}"
-            cmd = [hipcc] + FLAGS + ["-o", tmp] + SOURCES + ["-ldl", "-pthread"]
+            cmd = [hipcc] + FLAGS + REMARK_FLAGS + ["-o", tmp] + SOURCES + ["-ldl", "-pthread"]
             if verbose:
                 print(" ".join(cmd), file=sys.stderr, flush=True)
             try:
-                subprocess.check_call(cmd, stdout=sys.stderr)
+                proc = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+                res = _parse_resources(proc.stderr)
+                if proc.returncode != 0:
+                    sys.stderr.write(_without_remarks(proc.stderr))
+                    raise subprocess.CalledProcessError(proc.returncode, cmd)
+                bad = {k: v["scratch"] for k, v in res.items()
+                       if v.get("scratch", 0) > 0 and any(t in k for t in NO_SCRATCH)}
+                if bad and not os.environ.get("DSPTOOLBOX_AMD_ALLOW_SCRATCH"):
+                    raise RuntimeError("hot kernels compiled with scratch (register spills), bytes/lane: %r" % bad)
+                import json
+                with open(RES_PATH, "w") as fh:
+                    json.dump(res, fh, indent=1, sort_keys=True)
                 os.replace(tmp, LIB_PATH)
                 with open(HASH_PATH, "w") as fh:
                     fh.write(_source_hash() + "\n")

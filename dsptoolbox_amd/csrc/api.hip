@@ -17,6 +17,7 @@
 #include "kernels_finish.hpp"
 #include "kernels_generic.hpp"
 #include "kernels_welch4096.hpp"
+#include "kernels_welch4096w.hpp"
 #include "kernels_fir16k.hpp"
 #include "kernels_deconv8k.hpp"
 #include "kernels_stft1024.hpp"
@@ -715,6 +716,15 @@ static int welch_common(ds_ctx* c, int kind, const float* x, int n_cx, int64_t l
     return DS_OK;
 }
 
+// Frames the kernels have to visit: a frame that starts at or past the end of the signal is all
+// zeros (include/dsptoolbox_amd.h: "zero padded") and adds nothing to any sum, so the pair loops
+// stop at the last pair that still overlaps the signal -- no loader ever forms an address from a
+// start beyond the data.  The normalisation keeps the caller's frame count.
+static int frames_to_visit(int64_t n_samples, int hop, int n_frames) {
+    const int64_t pairs = (n_samples + 2 * (int64_t)hop - 1) / (2 * (int64_t)hop);
+    return (int)std::min<int64_t>(n_frames, 2 * pairs);
+}
+
 // nfft 4096, one input channel: register-resident radix-16 FFT path (kernels_welch4096.hpp)
 static int welch4096_run(ds_ctx* c, const float* x, int64_t ldx, const float* y, int n_cy, int64_t ldy,
                          int64_t n_samples, int hop, int n_frames, const float* window, int detrend,
@@ -733,7 +743,11 @@ static int welch4096_run(ds_ctx* c, const float* x, int64_t ldx, const float* y,
         HIPCHK(c, hipMemcpyAsync(c->w4_tables, h.data(), sizeof(float2) * h.size(), hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
     }
-    w4::Plan pl = w4::plan(n_frames, n_cy);
+    const int nf = frames_to_visit(n_samples, hop, n_frames);
+    // 50 % overlap: three workgroups per CU (kernels_welch4096w.hpp); any other hop: two
+    const bool half = hop == 2048;
+    const bool three = half && w4::enabled3() && w4::fits3(n_samples, nf);
+    w4::Plan pl = three ? w4::plan3(nf, n_cy) : w4::plan(nf, n_cy);
     CHK(reserve(c, &c->ws, &c->ws_bytes, pl.bytes));
     Carver cv(c->ws);
     float2* xs = cv.take<float2>((size_t)pl.n_pairs * w4::N);
@@ -741,17 +755,21 @@ static int welch4096_run(ds_ctx* c, const float* x, int64_t ldx, const float* y,
     float* psx = cv.take<float>((size_t)pl.n_chunks * w4::NB);
     float2* pxy = cv.take<float2>((size_t)pl.n_chunks * n_cy * w4::NB);
     float* pyy = cv.take<float>((size_t)pl.n_chunks * n_cy * w4::NB);
-    const bool half = hop == 2048;
-    w4::Args ax{x, n_samples, ldx, 1, hop, n_frames, pl.n_pairs, detrend, pl.n_chunks, pl.ppc, window,
+    w4::Args ax{x, n_samples, ldx, 1, hop, nf, pl.n_pairs, detrend, pl.n_chunks, pl.ppc, window,
                 c->w4_tables, xs, px, pxy, pyy, psx};
-    auto kx = half ? w4::k_x<true> : w4::k_x<false>;
-    auto ky = half ? w4::k_y<true> : w4::k_y<false>;
-    CHK(launch(c, "welch4096_x", kx, dim3(pl.n_pairs), w4::NT, w4::LDS_BYTES, ax));
     w4::Args ay = ax;
     ay.sig = y;
     ay.ld = ldy;
     ay.n_ch = n_cy;
-    CHK(launch(c, "welch4096_main", ky, dim3(pl.n_chunks * n_cy), w4::NT, w4::LDS_BYTES_2, ay));
+    if (three) {
+        CHK(launch(c, "welch4096_x", w4::k_x3, dim3(pl.n_pairs), w4::NT, w4::LDS3_BYTES, ax));
+        CHK(launch(c, "welch4096_main", w4::k_y3<false>, dim3(pl.n_chunks * n_cy), w4::NT, w4::LDS3_BYTES, ay));
+    } else {
+        auto kx = half ? w4::k_x<true> : w4::k_x<false>;
+        auto ky = half ? w4::k_y<true> : w4::k_y<false>;
+        CHK(launch(c, "welch4096_x", kx, dim3(pl.n_pairs), w4::NT, w4::LDS_BYTES, ax));
+        CHK(launch(c, "welch4096_main", ky, dim3(pl.n_chunks * n_cy), w4::NT, w4::LDS_BYTES_2, ay));
+    }
     WelchFinArgs f{psx, pxy, pyy, pl.n_chunks, pl.n_chunks, 1, n_cy, 0, mode,
                    FinishPar{norm_scale / (double)n_frames, factor, halve_edges, amp_sqrt, w4::NB},
                    tf, coh};
@@ -782,7 +800,8 @@ static int welch8192_run(ds_ctx* c, const float* x, int64_t ldx, const float* y,
         deconv8k::host_tables(h);
         CHK(upload_table_fwd(c, &c->deconv8k_tables, h));
     }
-    w8::Plan pl = w8::plan(n_frames, n_cy);
+    const int nf = frames_to_visit(n_samples, hop, n_frames);
+    w8::Plan pl = w8::plan(nf, n_cy);
     CHK(reserve(c, &c->ws, &c->ws_bytes, pl.bytes));
     Carver cv(c->ws);
     float2* xs = cv.take<float2>((size_t)pl.n_pairs * w8::N);
@@ -791,7 +810,7 @@ static int welch8192_run(ds_ctx* c, const float* x, int64_t ldx, const float* y,
     float2* pxy = cv.take<float2>((size_t)pl.n_chunks * n_cy * w8::NB);
     float* pyy = cv.take<float>((size_t)pl.n_chunks * n_cy * w8::NB);
     const bool half = hop == 4096;
-    w8::Args ax{x, n_samples, ldx, 1, hop, n_frames, pl.n_pairs, detrend, pl.n_chunks, window,
+    w8::Args ax{x, n_samples, ldx, 1, hop, nf, pl.n_pairs, detrend, pl.n_chunks, window,
                 c->w4_tables, c->deconv8k_tables, (float4*)xs, px, pxy, pyy, psx};
     auto kx = half ? w8::k_x<true> : w8::k_x<false>;
     auto ky = half ? w8::k_y<true> : w8::k_y<false>;
@@ -835,11 +854,12 @@ static int welch8192_psd_run(ds_ctx* c, const float* x, int n_cx, int64_t ldx, i
         deconv8k::host_tables(h);
         CHK(upload_table_fwd(c, &c->deconv8k_tables, h));
     }
-    w8::Plan pl = w8::plan(n_frames, n_cx);
+    const int nf = frames_to_visit(n_samples, hop, n_frames);
+    w8::Plan pl = w8::plan(nf, n_cx);
     CHK(reserve(c, &c->ws, &c->ws_bytes, Carver::pad(sizeof(float) * (size_t)pl.n_chunks * n_cx * w8::NB)));
     Carver cv(c->ws);
     float* pyy = cv.take<float>((size_t)pl.n_chunks * n_cx * w8::NB);
-    w8::Args a{x, n_samples, ldx, n_cx, hop, n_frames, pl.n_pairs, detrend, pl.n_chunks, window,
+    w8::Args a{x, n_samples, ldx, n_cx, hop, nf, pl.n_pairs, detrend, pl.n_chunks, window,
                c->w4_tables, c->deconv8k_tables, nullptr, nullptr, nullptr, pyy, nullptr};
     auto ky = hop == 4096 ? w8::k_y<true, true, true> : w8::k_y<false, true, true>;
     CHK(launch(c, "welch8192_main", ky, dim3(pl.n_chunks * n_cx), w8::NTB, w8::LDS_BYTES_WINLDS, a));
@@ -864,14 +884,20 @@ static int welch4096_psd_run(ds_ctx* c, const float* x, int n_cx, int64_t ldx, i
         w4::host_tables(h);
         CHK(upload_table_fwd(c, &c->w4_tables, h));
     }
-    w4::Plan pl = w4::plan(n_frames, n_cx);
+    const int nf = frames_to_visit(n_samples, hop, n_frames);
+    const bool three = hop == 2048 && w4::enabled3() && w4::fits3(n_samples, nf);
+    w4::Plan pl = three ? w4::plan3(nf, n_cx) : w4::plan(nf, n_cx);
     CHK(reserve(c, &c->ws, &c->ws_bytes, Carver::pad(sizeof(float) * (size_t)pl.n_chunks * n_cx * w4::NB)));
     Carver cv(c->ws);
     float* pyy = cv.take<float>((size_t)pl.n_chunks * n_cx * w4::NB);
-    w4::Args a{x, n_samples, ldx, n_cx, hop, n_frames, pl.n_pairs, detrend, pl.n_chunks, pl.ppc, window,
+    w4::Args a{x, n_samples, ldx, n_cx, hop, nf, pl.n_pairs, detrend, pl.n_chunks, pl.ppc, window,
                c->w4_tables, nullptr, nullptr, nullptr, pyy, nullptr};
-    auto ky = hop == 2048 ? w4::k_y<true, true> : w4::k_y<false, true>;
-    CHK(launch(c, "welch4096_main", ky, dim3(pl.n_chunks * n_cx), w4::NT, w4::LDS_BYTES_2, a));
+    if (three) {
+        CHK(launch(c, "welch4096_main", w4::k_y3<true>, dim3(pl.n_chunks * n_cx), w4::NT, w4::LDS3_BYTES, a));
+    } else {
+        auto ky = hop == 2048 ? w4::k_y<true, true> : w4::k_y<false, true>;
+        CHK(launch(c, "welch4096_main", ky, dim3(pl.n_chunks * n_cx), w4::NT, w4::LDS_BYTES_2, a));
+    }
     WelchFinArgs f{pyy, nullptr, nullptr, pl.n_chunks, pl.n_chunks, n_cx, 0, 1, 0,
                    FinishPar{norm_scale / (double)n_frames, factor, halve_edges, amp_sqrt, w4::NB},
                    nullptr, psd};
@@ -909,7 +935,8 @@ static int welch_wave_run(ds_ctx* c, const float* x, int64_t ldx, const float* y
     if (mode < DS_TF_H1 || mode > DS_TF_H3) return fail(c, DS_ERR_ARG, "welch: unsupported transfer function type");
     const float2* tab;
     CHK(wave_tables<NN>(c, &tab));
-    w1::Plan pl = w1::plan<NN>(n_frames, n_cy);
+    const int nf = frames_to_visit(n_samples, hop, n_frames);
+    w1::Plan pl = w1::plan<NN>(nf, n_cy);
     CHK(reserve(c, &c->ws, &c->ws_bytes, pl.bytes));
     Carver cv(c->ws);
     float2* xs = cv.take<float2>((size_t)pl.n_pairs * NN);
@@ -918,7 +945,7 @@ static int welch_wave_run(ds_ctx* c, const float* x, int64_t ldx, const float* y
     float2* pxy = cv.take<float2>((size_t)pl.n_chunks * n_cy * W::NB);
     float* pyy = cv.take<float>((size_t)pl.n_chunks * n_cy * W::NB);
     const bool half = hop == NN / 2;
-    w1::Args ax{x, n_samples, ldx, 1, hop, n_frames, pl.n_pairs, detrend, pl.n_chunks, pl.ppc, window,
+    w1::Args ax{x, n_samples, ldx, 1, hop, nf, pl.n_pairs, detrend, pl.n_chunks, pl.ppc, window,
                 tab, (float4*)xs, px, pxy, pyy, psx};
     auto kx = half ? w1::k_x<NN, true> : w1::k_x<NN, false>;
     auto ky = half ? w1::k_y<NN, true> : w1::k_y<NN, false>;
@@ -949,11 +976,12 @@ static int welch_wave_psd_run(ds_ctx* c, const float* x, int n_cx, int64_t ldx, 
         return fail(c, DS_ERR_ARG, "ds_welch_psd: bad shape");
     const float2* tab;
     CHK(wave_tables<NN>(c, &tab));
-    w1::Plan pl = w1::plan<NN>(n_frames, n_cx);
+    const int nf = frames_to_visit(n_samples, hop, n_frames);
+    w1::Plan pl = w1::plan<NN>(nf, n_cx);
     CHK(reserve(c, &c->ws, &c->ws_bytes, Carver::pad(sizeof(float) * (size_t)pl.n_chunks * n_cx * W::NB)));
     Carver cv(c->ws);
     float* pyy = cv.take<float>((size_t)pl.n_chunks * n_cx * W::NB);
-    w1::Args a{x, n_samples, ldx, n_cx, hop, n_frames, pl.n_pairs, detrend, pl.n_chunks, pl.ppc, window,
+    w1::Args a{x, n_samples, ldx, n_cx, hop, nf, pl.n_pairs, detrend, pl.n_chunks, pl.ppc, window,
                tab, nullptr, nullptr, nullptr, pyy, nullptr};
     auto ky = hop == NN / 2 ? w1::k_y<NN, true, true> : w1::k_y<NN, false, true>;
     const int n_grp = (n_cx + W::TPB - 1) / W::TPB;
