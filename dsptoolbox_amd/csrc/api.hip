@@ -762,6 +762,7 @@ static int welch4096_run(ds_ctx* c, const float* x, int64_t ldx, const float* y,
     ay.ld = ldy;
     ay.n_ch = n_cy;
     if (three) {
+        w4::place_remainder(ay, n_cy);
         CHK(launch(c, "welch4096_x", w4::k_x3, dim3(pl.n_pairs), w4::NT, w4::LDS3_BYTES, ax));
         CHK(launch(c, "welch4096_main", w4::k_y3<false>, dim3(pl.n_chunks * n_cy), w4::NT, w4::LDS3_BYTES, ay));
     } else {
@@ -893,6 +894,7 @@ static int welch4096_psd_run(ds_ctx* c, const float* x, int n_cx, int64_t ldx, i
     w4::Args a{x, n_samples, ldx, n_cx, hop, nf, pl.n_pairs, detrend, pl.n_chunks, pl.ppc, window,
                c->w4_tables, nullptr, nullptr, nullptr, pyy, nullptr};
     if (three) {
+        w4::place_remainder(a, n_cx);
         CHK(launch(c, "welch4096_main", w4::k_y3<true>, dim3(pl.n_chunks * n_cx), w4::NT, w4::LDS3_BYTES, a));
     } else {
         auto ky = hop == 2048 ? w4::k_y<true, true> : w4::k_y<false, true>;

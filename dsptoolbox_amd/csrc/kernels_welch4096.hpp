@@ -200,6 +200,10 @@ struct Args {
     float2* pxy;        // [n_chunks][n_ch][NB]
     float* pyy;         // [n_chunks][n_ch][NB]
     float* psx;         // [n_chunks][NB]: px summed over the pairs of a chunk (k_y)
+    // k_y3 only: chunk q holds n_pairs / n_chunks pairs, plus one if bit q of `plus` is set (the
+    // host places the remainder so that every XCD gets the same number of transforms); 0 = even split
+    int use_plus;
+    uint32_t plus[24];
 };
 
 // twt: fp64-computed tables, [15][256] W4096^(t k1) (k1 = 1..15) then [16][16] W256^(n3 k2)

@@ -54,8 +54,14 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+#ifndef W4_OCC
+#define W4_OCC 3  // workgroups per CU the kernel is built for (2: twiddles and window in registers)
+#endif
+#ifndef W4_WIN_ROT
+#define W4_WIN_ROT 1
+#endif
 #ifndef W4_TW6
-#define W4_TW6 1
+#define W4_TW6 (W4_OCC == 3)
 #endif
 #ifndef W4_NO_READ2
 #define W4_NO_READ2 1
@@ -182,8 +188,8 @@ __device__ __forceinline__ void fft4096_w(float2 (&v)[16], const Tw6& tw, float2
 // the three workgroups of a CU wins every conflict, finishes its chunk at 57 us and leaves the CU
 // under-occupied while the youngest needs 92 us (per-workgroup s_memrealtime stamps).  Here a
 // workgroup's priority falls as its own work gets done (16 levels: 4 hardware levels, dithered
-// over the four segments of an iteration), so whoever is behind wins the arbitration and the three
-// finish together.
+// over consecutive iterations), so whoever is behind wins the arbitration and the three
+// finish together.  One update per iteration (the immediate operand costs a scalar branch chain).
 #ifndef W4_PRIO
 #define W4_PRIO 1
 #endif
@@ -197,9 +203,9 @@ __device__ __forceinline__ void fft4096_w(float2 (&v)[16], const Tw6& tw, float2
     do {                                   \
         if (!(W4_AB & 8)) __syncthreads(); \
     } while (0)
-__device__ __forceinline__ void set_prio(int level16, int seg) {
+__device__ __forceinline__ void set_prio(int level16, int dither) {
 #if W4_PRIO
-    const int pr = min(3, (level16 + seg) >> 2);
+    const int pr = min(3, (level16 + dither) >> 2);
     if (pr == 0)
         __builtin_amdgcn_s_setprio(0);
     else if (pr == 1)
@@ -302,7 +308,6 @@ __device__ __forceinline__ void fft4096_wi(float2 (&v)[16], const Tw6& tw, float
     ts(2);
     W4_SYNC();
     ts(3);
-    set_prio(level16, 1);
     float2* __restrict__ row = buf + k1u * L1S;
     const uint32_t a_row = lds_addr(row + n3), a_tw2 = lds_addr(tw2 + n3);
     // pass-2 inputs v[n2] = row[16 n2 + n3], requested in the order the butterflies consume them
@@ -363,7 +368,6 @@ __device__ __forceinline__ void fft4096_wi(float2 (&v)[16], const Tw6& tw, float
 #endif
         });
     ts(6);
-    set_prio(level16, 2);
     wave_sync();
     W4_PIN();
     static_for<16>([&](auto ic) {  // lane now plays k2 = n3
@@ -384,7 +388,6 @@ __device__ __forceinline__ void fft4096_wi(float2 (&v)[16], const Tw6& tw, float
                 ts(8);
                 W4_SYNC();
                 ts(9);
-                set_prio(level16, 3);
             }
         },
         NoHookI(), NoHookI());
@@ -435,7 +438,7 @@ __global__ __launch_bounds__(NT) void k_x3(Args p) {
 
 // ---- output channels ---------------------------------------------------------
 template <bool AUTO = false>
-__global__ __launch_bounds__(NT, 3) void k_y3(Args p) {
+__global__ __launch_bounds__(NT, W4_OCC) void k_y3(Args p) {
     extern __shared__ __align__(16) float2 lds[];
     float2* buf = lds;
     float2* tw2 = lds + 16 * L1S;
@@ -457,26 +460,50 @@ __global__ __launch_bounds__(NT, 3) void k_y3(Args p) {
     Tw6 tw;
     load_tw6(tw, p.twt, tid);
     tw2[tid] = p.twt[15 * 256 + tid];
+#if W4_OCC == 3
 #pragma unroll
     for (int n1 = 0; n1 < 16; ++n1) winl[tid + 256 * n1] = p.window[tid + 256 * n1];
+#else
+    float winr[16];
+#pragma unroll
+    for (int n1 = 0; n1 < 16; ++n1) winr[n1] = p.window[tid + 256 * n1];
+#endif
     const float* ch = p.sig + (int64_t)c * p.ld;
-    const int p0 = (int)((int64_t)q * p.n_pairs / p.n_chunks), p1 = (int)((int64_t)(q + 1) * p.n_pairs / p.n_chunks);
+    int p0, p1;
+    if (p.use_plus) {
+        auto below = [&](int qq) {  // number of set bits of p.plus below bit qq
+            int n = 0;
+            for (int w = 0; w < (qq >> 5); ++w) n += __popc(p.plus[w]);
+            if (qq & 31) n += __popc(p.plus[qq >> 5] & ((1u << (qq & 31)) - 1u));
+            return n;
+        };
+        const int base = p.n_pairs / p.n_chunks, bq = below(q);
+        p0 = q * base + bq;
+        p1 = p0 + base + (int)((p.plus[q >> 5] >> (q & 31)) & 1u);
+    } else {
+        p0 = (int)((int64_t)q * p.n_pairs / p.n_chunks);
+        p1 = (int)((int64_t)(q + 1) * p.n_pairs / p.n_chunks);
+    }
     if (!AUTO) {
-        double* red = reinterpret_cast<double*>(lds);  // [8][32], before the first transform
+        // Input auto-spectrum of this chunk: every workgroup of the chunk sums a slice of the bins
+        // over the chunk's px rows (fp64).  The slice (33 bins for 64 channels) is covered in ONE
+        // sweep -- `width` bins x 256 / width row groups -- so the loads of a workgroup are one
+        // round trip, not two.
+        double* red = reinterpret_cast<double*>(lds);  // [256 / width][width], before the first transform
         const int bpc = (NB + p.n_ch - 1) / p.n_ch;
         const int b0 = c * bpc, b1 = min(b0 + bpc, NB);
-        const int rg = tid >> 5, kl = tid & 31;
-        for (int kb = b0; kb < b1; kb += 32) {
+        const int lw = bpc <= 32 ? 5 : (bpc <= 64 ? 6 : (bpc <= 128 ? 7 : 8)), width = 1 << lw, rows = NT >> lw;
+        const int rg = tid >> lw, kl = tid & (width - 1);
+        for (int kb = b0; kb < b1; kb += width) {
             const int k = kb + kl;
             double sum = 0.0;
             if (k < b1)
-                for (int pr = p0 + rg; pr < p1; pr += 8) sum += (double)p.px[(int64_t)pr * NB + k];
-            red[rg * 32 + kl] = sum;
+                for (int pr = p0 + rg; pr < p1; pr += rows) sum += (double)p.px[(int64_t)pr * NB + k];
+            red[rg * width + kl] = sum;
             __syncthreads();
             if (rg == 0 && k < b1) {
                 double t = 0.0;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) t += red[j * 32 + kl];
+                for (int j = 0; j < rows; ++j) t += red[j * width + kl];
                 p.psx[(int64_t)q * NB + k] = (float)t;
             }
             __syncthreads();
@@ -493,6 +520,11 @@ __global__ __launch_bounds__(NT, 3) void k_y3(Args p) {
     // blocks 1, 2 (s[m] = ch[start + tid + 256 m], m = 8..23)
     float carry[8], nx[16];
     const __amdgpu_buffer_rsrc_t rs = channel_rsrc(ch, p.n_samples);
+    // the chunk's input spectra as a raw buffer (32-bit offsets, one address register)
+    const __amdgpu_buffer_rsrc_t xrs =
+        AUTO ? rs
+             : __builtin_amdgcn_make_buffer_rsrc(const_cast<float2*>(p.xs + (int64_t)p0 * N), 0,
+                                                 (int)(uint32_t)((p1 - p0) * (N * 8)), 0x00020000);
     if (p0 < p1) {
         const int off0 = 4 * (2 * p0 * 2048 + tid);
 #pragma unroll
@@ -504,14 +536,25 @@ __global__ __launch_bounds__(NT, 3) void k_y3(Args p) {
 #if W4_TIMING
     const unsigned long long life_r1 = __builtin_amdgcn_s_memrealtime();
 #endif
+#if W4_OCC == 3 && W4_WIN_ROT
+    // the window values of an iteration are requested from LDS at the end of the previous one (into
+    // registers the accumulation has just freed) instead of in front of their first use
+    float winr[16];
+#pragma unroll
+    for (int n1 = 0; n1 < 16; ++n1) winr[n1] = winl[tid + 256 * n1];
+#endif
     for (int pr = p0; pr < p1; ++pr) {
         float2 v[16];
         ts(0);
         const int level16 = ((p1 - pr - 1) * 16) / (p1 - p0);  // 15 ... 0 as the chunk gets done
-        set_prio(level16, 0);
+        set_prio(level16, (pr * 5) & 3);
 #pragma unroll
         for (int n1 = 0; n1 < 16; ++n1) {
+#if W4_OCC == 3 && !W4_WIN_ROT
             const float w = winl[tid + 256 * n1];
+#else
+            const float w = winr[n1];
+#endif
             const float a = n1 < 8 ? carry[n1] : nx[n1 - 8];
             v[n1] = make_float2(a * w, nx[n1] * w);
         }
@@ -521,7 +564,7 @@ __global__ __launch_bounds__(NT, 3) void k_y3(Args p) {
         ts(1);
         float2 xw[16];
         const int off1 = 4 * ((2 * pr + 2) * 2048 + tid) + 1024 * 8;
-        const float4* __restrict__ xp = reinterpret_cast<const float4*>(p.xs + (int64_t)pr * N) + tid;
+        const int xoff = (pr - p0) * (N * 8) + tid * 16;  // bytes into this chunk's input spectra
         fft4096_wi(
             v, tw, buf, tw2, tid,
             [&](int g) {  // samples of the next pair, four per call-out (past the chunk's last pair
@@ -542,7 +585,7 @@ __global__ __launch_bounds__(NT, 3) void k_y3(Args p) {
                         if (W4_AB & 1)
                             asm volatile("" : "=v"(q4.x), "=v"(q4.y), "=v"(q4.z), "=v"(q4.w));
                         else
-                            q4 = xp[256 * (2 * g + j)];
+                            q4 = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xrs, xoff + 4096 * (2 * g + j), 0, 0));
                         xw[2 * (2 * g + j)] = make_float2(q4.x, q4.y);
                         xw[2 * (2 * g + j) + 1] = make_float2(q4.z, q4.w);
                     }
@@ -560,6 +603,12 @@ __global__ __launch_bounds__(NT, 3) void k_y3(Args p) {
             }
             P[k3] = fmaf(z.x, z.x, fmaf(z.y, z.y, P[k3]));
         }
+#if W4_OCC == 3 && W4_WIN_ROT
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int n1 = 0; n1 < 16; ++n1) winr[n1] = winl[tid + 256 * n1];
+        __builtin_amdgcn_sched_barrier(0);
+#endif
         ts(11);
     }
 #if W4_TIMING
@@ -634,6 +683,49 @@ inline Plan plan3(int n_frames, int n_cy) {
                pad(sizeof(float) * (size_t)pl.n_chunks * n_cy * NB);
     return pl;
 }
+// Where the n_pairs % n_chunks longer chunks go.  k_y3 hands XCD x the units [x U, (x + 1) U) of
+// the chunk-major (chunk, channel) list, U = n_chunks n_ch / 8; with 12 chunks of 64 channels an
+// XCD owns one whole chunk and half of a shared one, and an even split (21, 21, 22, 21, ...) gives
+// the XCDs 2016 or 2080 transforms (3 % apart, seen as 89 vs 93 us mean workgroup lifetime).
+// Greedy: each extra pair goes to the chunk that keeps the busiest XCD lowest.
+inline void place_remainder(Args& a, int n_ch) {
+    a.use_plus = 0;
+    for (auto& w : a.plus) w = 0;
+    const int nc = a.n_chunks, total = nc * n_ch;
+    if (nc > 24 * 32 || (total & 7) != 0 || nc <= 0) return;
+    const int base = a.n_pairs / nc, rem = a.n_pairs - base * nc;
+    a.use_plus = 1;
+    if (rem == 0) return;
+    const int U = total / 8;
+    std::vector<int> ov((size_t)8 * nc, 0);  // units of chunk q on XCD x
+    for (int u = 0; u < total; ++u) ov[(size_t)(u / U) * nc + u / n_ch] += 1;
+    std::vector<int64_t> load(8, 0);
+    for (int x = 0; x < 8; ++x)
+        for (int q = 0; q < nc; ++q) load[x] += (int64_t)ov[(size_t)x * nc + q] * base;
+    std::vector<char> taken(nc, 0);
+    for (int r = 0; r < rem; ++r) {
+        int best = -1;
+        int64_t best_max = 0, best_aff = 0;
+        for (int q = 0; q < nc; ++q) {
+            if (taken[q]) continue;
+            int64_t mx = 0, aff = 0;
+            for (int x = 0; x < 8; ++x) {
+                const int64_t l = load[x] + ov[(size_t)x * nc + q];
+                mx = std::max(mx, l);
+                if (ov[(size_t)x * nc + q]) aff = std::max(aff, l);
+            }
+            if (best < 0 || mx < best_max || (mx == best_max && aff < best_aff)) {
+                best = q;
+                best_max = mx;
+                best_aff = aff;
+            }
+        }
+        taken[best] = 1;
+        a.plus[best >> 5] |= 1u << (best & 31);
+        for (int x = 0; x < 8; ++x) load[x] += ov[(size_t)x * nc + best];
+    }
+}
+
 // the raw-buffer loads carry byte offsets in 32 bits
 inline bool fits3(int64_t n_samples, int n_frames) {
     return n_samples < ((int64_t)1 << 30) - 8192 && (int64_t)(n_frames + 2) * 2048 < ((int64_t)1 << 30) - 8192;

@@ -45,7 +45,7 @@ int main(int argc, char** argv) {
     const int hop = 2048;
     const int n_frames = (int)((n + hop - 1) / hop);
     w4::Plan pl = w4::plan(n_frames, n_ch);
-    const int new_chunks = getenv("NEWCHUNKS") ? atoi(getenv("NEWCHUNKS")) : std::max(1, std::min(pl.n_pairs, 768 / n_ch));
+    const int new_chunks = getenv("NEWCHUNKS") ? atoi(getenv("NEWCHUNKS")) : std::max(1, std::min(pl.n_pairs, (W4_OCC * 256) / n_ch));
     const int max_chunks = std::max(pl.n_chunks, new_chunks);
     printf("n %lld ch %d frames %d pairs %d chunks %d new_chunks %d\n", (long long)n, n_ch, n_frames, pl.n_pairs, pl.n_chunks, new_chunks);
     std::mt19937 rng(1);
@@ -74,6 +74,8 @@ int main(int argc, char** argv) {
     ay.n_ch = n_ch;
     w4::Args ay3 = ay;
     ay3.n_chunks = new_chunks;
+    if (!getenv("EVEN_SPLIT")) w4::place_remainder(ay3, n_ch);
+    printf("use_plus %d mask %08x\n", ay3.use_plus, ay3.plus[0]);
     CK(hipFuncSetAttribute((const void*)w4::k_y<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, w4::LDS_BYTES_2));
     hipStream_t st;
     CK(hipStreamCreate(&st));
