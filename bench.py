@@ -7,9 +7,15 @@ Default workload (BASELINE.json configs[1], the one the metric is quoted on):
 64-channel Welch H1 transfer-function estimation, one sweep input channel,
 2^20 samples per channel, nfft 4096, Hann, 50 % overlap.  One step = one
 ds_welch_tf_dev call over inputs that are already resident in HBM.
-N > 1: one process per GPU (torch.distributed.run), every rank owns an
-independent 64-channel batch (weak scaling, no data-path collective); the
-shared sweep channel is broadcast once over RCCL/xGMI before the timed region.
+N > 1: one process per GPU (torch.distributed.run).
+  --scaling weak   (default) every rank owns an independent 64-channel batch, no data-path
+                   collective; the shared sweep channel is broadcast once over RCCL/xGMI
+                   before the timed region;
+  --scaling strong the ONE 64-channel job is split: output channels /
+                   bands / items / bins by shard_range, the shared input by ds_bcast, and every
+                   step ends with the RCCL all-gather of the result slices (ds_allgather).
+At N = 1 the per-rank shard shape of an 8-GPU strong-scaling job is timed as well and the
+implied speed-up T(full) / T(shard) is printed ("shard_prediction").
 
 Prints ONE JSON line on rank 0.
 """
@@ -38,8 +44,11 @@ FS = 48000
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)   # timed region of tens of ms
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
+    ap.add_argument("--predict-ranks", type=int, default=8,
+                    help="N = 1: world size whose per-rank shard is timed for shard_prediction (0: off)")
     ap.add_argument("--workload", default="welch_h1",
                     choices=["welch_h1", "welch_h1_1024", "fir_bank", "csm", "deconv"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -95,8 +104,6 @@ class Dist:
         self.dist.broadcast_object_list(box, src=0)
         return box[0]
 
-    comm_hung = False
-
     def finish(self):
         if self.world > 1:
             try:
@@ -104,9 +111,6 @@ class Dist:
                 self.dist.destroy_process_group()
             except Exception:  # pragma: no cover - teardown only
                 pass
-        if self.comm_hung:  # a daemon thread is stuck inside the communicator set-up
-            sys.stdout.flush()
-            os._exit(0)
 
     def all_ok(self, ok: bool) -> bool:
         if self.world == 1:
@@ -118,14 +122,16 @@ class Dist:
 
 
 def setup_rccl(ctx, dist: Dist):
-    """Library-level RCCL communicator (ds_comm_*) used for the sweep broadcast.  Returns
-    False (-> host broadcast + upload) for one rank, or if RCCL cannot be set up, e.g. a
-    gloo rehearsal with several ranks on one GPU."""
+    """Library-level RCCL communicator (ds_comm_*) for the broadcast of the shared input and the
+    gather of sharded results.  Returns False only where RCCL is not asked for: one rank, a gloo
+    rehearsal with several ranks on one GPU, or BENCH_BCAST=host (explicit opt-out: host
+    broadcast + upload).  A communicator that cannot be set up is a FAILURE of the run: the
+    diagnosis goes to stderr and the process exits non-zero (never a silent fallback)."""
     if dist.world == 1:
         return False
     if dist.backend != "nccl":
         return False
-    if os.environ.get("BENCH_BCAST", "rccl") != "rccl":  # BENCH_BCAST=torch: torch.distributed broadcast
+    if os.environ.get("BENCH_BCAST", "rccl") != "rccl":
         return False
     ident = C.create_string_buffer(128)
     ok = True
@@ -133,9 +139,10 @@ def setup_rccl(ctx, dist: Dist):
         ok = ctx.lib.ds_comm_unique_id(ident) == 0
     raw = dist.bcast_bytes(ident.raw, 128)
     if not dist.all_ok(ok):
-        return False
-    # ncclCommInitRank is collective: guard it with a watchdog so that a rendezvous problem
-    # degrades to the host broadcast instead of hanging the whole multi-GPU run
+        print(f"[bench] rank {dist.rank}: ds_comm_unique_id failed: {ctx.last_error()}", file=sys.stderr, flush=True)
+        sys.exit(3)
+    # ncclCommInitRank is collective; a rank that never returns from it would hang the whole
+    # run, so it runs under a watchdog -- which reports and exits non-zero, it does not continue
     import threading
     res = {}
 
@@ -144,36 +151,65 @@ def setup_rccl(ctx, dist: Dist):
 
     th = threading.Thread(target=init, daemon=True)
     th.start()
-    th.join(timeout=float(os.environ.get("BENCH_RCCL_TIMEOUT", "90")))
+    limit = float(os.environ.get("BENCH_RCCL_TIMEOUT", "120"))
+    th.join(timeout=limit)
     if th.is_alive():
-        dist.comm_hung = True  # leave through os._exit at the end
-        print(f"[bench] rank {dist.rank}: ds_comm_init did not return; using torch.distributed", file=sys.stderr,
-              flush=True)
-    return dist.all_ok(res.get("rc", -1) == 0)
+        print(f"[bench] rank {dist.rank}/{dist.world}: ds_comm_init (ncclCommInitRank) has not returned after "
+              f"{limit:.0f} s -- rendezvous over MASTER_ADDR={os.environ.get('MASTER_ADDR')} "
+              f"NCCL_SOCKET_IFNAME={os.environ.get('NCCL_SOCKET_IFNAME')} "
+              f"HSA_ENABLE_IPC_MODE_LEGACY={os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY')}; "
+              "set NCCL_DEBUG=INFO for the transport log, or BENCH_BCAST=host to run without RCCL. "
+              "Exiting with status 3.", file=sys.stderr, flush=True)
+        sys.stdout.flush()
+        os._exit(3)
+    if res.get("rc", -1) != 0:
+        print(f"[bench] rank {dist.rank}: ds_comm_init failed: {ctx.last_error()}", file=sys.stderr, flush=True)
+        sys.exit(3)
+    return True
+
+
+def shard_of(n_units: int, shard):
+    from dsptoolbox_amd.distributed import shard_range
+    if shard is None:
+        return 0, n_units
+    return shard_range(n_units, shard[1], shard[0])
+
+
+def gather_result(ctx, rccl: bool, shard, d_local, d_all, bytes_per_rank: int):
+    """Strong scaling: all-gather the result slices of one step (padded to the largest shard)."""
+    if rccl and shard is not None and shard[1] > 1:
+        ctx.check(ctx.lib.ds_allgather(ctx.handle, C.c_void_p(d_local.ptr), C.c_void_p(d_all.ptr),
+                                       bytes_per_rank), "ds_allgather")
 
 
 # ---------------------------------------------------------------------------
-def welch_h1(args, ctx, dist, W=4096):
+# Every workload maker builds the step of ONE rank: `shard` = None (the whole job, also each
+# rank's independent batch under weak scaling) or (rank, world) for that rank's part of the one
+# job under strong scaling.  Returns (step, units, algorithmic bytes or flops, bound, info,
+# cpu_baselines, bcast_ms, dominant kernel names); units / bytes are those of the WHOLE job.
+def welch_h1(args, ctx, dist, shard, rccl, W=4096):
     from dsptoolbox_amd import backend
     from dsptoolbox_amd._lib import DeviceBuffer
-    from dsptoolbox_amd.generators import exponential_sweep, sweep_and_responses
+    from dsptoolbox_amd.generators import sweep_and_responses
     from dsptoolbox_amd.standard.enums import SpectrumScaling, Window
 
     n, n_cy = 2**20, 64
-    # per-rank independent batch (different response / noise seeds), shared sweep
     x, y = sweep_and_responses(n, n_cy, FS)
-    if dist.rank > 0:
+    if shard is None and dist.rank > 0:  # weak scaling: another batch per rank
         rng = np.random.default_rng(9000 + dist.rank)
         y = y[:, rng.permutation(n_cy)] * (1.0 + 0.01 * dist.rank)
+    a, b = shard_of(n_cy, shard)
+    n_loc = b - a
+    n_max = -(-n_cy // (shard[1] if shard else 1))
     window = backend._window_array(Window.Hann, W)
     hop, n_frames = backend._welch_framing(n, W, 50, window)
     amp, norm_scale, factor, phys = backend._finish_params(SpectrumScaling.FFTBackward, W, FS, window)
-    d_y = DeviceBuffer.from_array(ctx, backend._planar_f32(y))
+    d_y = DeviceBuffer.from_array(ctx, backend._planar_f32(y[:, a:b])) if n_loc else None
     d_w = DeviceBuffer.from_array(ctx, window.astype(np.float32))
     xp = backend._planar_f32(x)
     d_x = DeviceBuffer(ctx, xp.nbytes)
     bcast_ms = None
-    if setup_rccl(ctx, dist):
+    if rccl:
         if dist.rank == 0:
             ctx.upload(d_x.ptr, xp)
         dist.barrier_sync(ctx)
@@ -182,34 +218,39 @@ def welch_h1(args, ctx, dist, W=4096):
         ctx.sync()
         bcast_ms = (time.perf_counter() - t0) * 1e3
     else:
-        if dist.world > 1:  # no RCCL: broadcast on the host, then upload
+        if dist.world > 1:  # BENCH_BCAST=host / gloo rehearsal: broadcast on the host, then upload
             from dsptoolbox_amd.distributed import broadcast_array
             xp = broadcast_array(xp if dist.rank == 0 else None, src=0)
         ctx.upload(d_x.ptr, xp)
     B = W // 2 + 1
-    d_tf = DeviceBuffer(ctx, B * n_cy * 8)
-    d_coh = DeviceBuffer(ctx, B * n_cy * 4)
+    # result slice of this rank: tf (B, n_loc) complex64 then coh (B, n_loc) float32, one buffer
+    slot = B * n_max * 12
+    d_res = DeviceBuffer(ctx, max(slot, 16))
+    d_all = DeviceBuffer(ctx, slot * shard[1]) if (shard and shard[1] > 1) else None
 
     def step():
-        ctx.check(ctx.lib.ds_welch_tf_dev(
-            ctx.handle, C.c_void_p(d_x.ptr), 1, n, C.c_void_p(d_y.ptr), n_cy, n, n, W, hop, n_frames,
-            C.c_void_p(d_w.ptr), int(args.detrend), 0, 1, amp, norm_scale, factor, phys,
-            C.c_void_p(d_tf.ptr), C.c_void_p(d_coh.ptr)), "ds_welch_tf_dev")
+        if n_loc:
+            ctx.check(ctx.lib.ds_welch_tf_dev(
+                ctx.handle, C.c_void_p(d_x.ptr), 1, n, C.c_void_p(d_y.ptr), n_loc, n, n, W, hop, n_frames,
+                C.c_void_p(d_w.ptr), int(args.detrend), 0, 1, amp, norm_scale, factor, phys,
+                C.c_void_p(d_res.ptr), C.c_void_p(d_res.ptr + B * n_loc * 8)), "ds_welch_tf_dev")
+        gather_result(ctx, rccl, shard, d_res, d_all, slot)
 
     samples_per_step = (n_cy + 1) * n
     alg_bytes = (n_cy + 1) * n * 4 + B * n_cy * 8 + B * n_cy * 4
     info = dict(
         workload=f"welch_h1: 64 output ch + 1 sweep input ch x 2^20 samples, nfft {W}, Hann, 50% overlap"
                  + (", detrend" if args.detrend else ""),
-        channels=n_cy, samples_per_channel=n, nfft=W, overlap_percent=50, frames=n_frames,
-        parallelism=f"channel-batch x{dist.world}")
+        channels=n_cy, samples_per_channel=n, nfft=W, overlap_percent=50, frames=n_frames)
 
     def verify():
-        tf = d_tf.to_array((B, n_cy), np.complex64)
+        raw = d_res.to_array((B * n_loc * 12,), np.uint8)
+        tf = raw[:B * n_loc * 8].view(np.complex64).reshape(B, n_loc)
+        coh = raw[B * n_loc * 8:].view(np.float32).reshape(B, n_loc)
         assert np.all(np.isfinite(tf[1:]))
-        return tf, d_coh.to_array((B, n_cy), np.float32)
+        return tf, coh
 
-    def cpu_baseline():
+    def cpu_reference_loop():
         from oracle import dsp_oracle as orc
         cc = min(args.cpu_channels, n_cy)
         reps = 2  # ~14 s of single-core work for the full 64 channels
@@ -227,43 +268,57 @@ def welch_h1(args, ctx, dist, W=4096):
                            f"{n_cy} output channels x 2^20, {reps} passes of {dt:.1f} s",
                     parity_rel_max_vs_gpu=err)
 
-    return step, samples_per_step, alg_bytes, "hbm", info, cpu_baseline, bcast_ms, \
+    def cpu_batched():
+        from oracle import dsp_oracle as orc
+        reps = 3
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            rt, rc = orc.compute_transfer_function_batched(y, x, FS, W, "H1", detrend=bool(args.detrend),
+                                                           workers=-1)
+        dt = (time.perf_counter() - t0) / reps
+        return dict(value=(n_cy + 1) * n / dt / 1e6, unit="Msamples/s", cores=os.cpu_count(), kind="port",
+                    sample=f"oracle.compute_transfer_function_batched (one framing + one rFFT batch per signal, "
+                           f"scipy.fft workers=-1), all {n_cy} channels, {reps} passes of {dt:.1f} s")
+
+    return step, samples_per_step, alg_bytes, "hbm", info, (cpu_reference_loop, cpu_batched), bcast_ms, \
         ("welch4096_main", "welch1024_main", "welch_yacc")
 
 
-def fir_bank(args, ctx, dist):
+def fir_bank(args, ctx, dist, shard, rccl):
     from dsptoolbox_amd import backend
     from dsptoolbox_amd._lib import DeviceBuffer
     from dsptoolbox_amd.generators import fir_bank_taps
 
     n, n_ch, K, T = 2**22, 8, 32, 4097
-    x = np.random.default_rng(3 + dist.rank).standard_normal((n, n_ch)) * 0.1
+    seed = 3 + (dist.rank if shard is None else 0)
+    x = np.random.default_rng(seed).standard_normal((n, n_ch)) * 0.1
     taps = fir_bank_taps(K, T, FS).astype(np.float32)
+    a, b = shard_of(K, shard)  # Parallel mode shards by bands
+    k_loc = b - a
     d_x = DeviceBuffer.from_array(ctx, backend._planar_f32(x))
-    d_t = DeviceBuffer.from_array(ctx, taps)
-    d_y = DeviceBuffer(ctx, K * n_ch * n * 4)
+    d_t = DeviceBuffer.from_array(ctx, np.ascontiguousarray(taps[a:b])) if k_loc else None
+    d_y = DeviceBuffer(ctx, max(k_loc, 1) * n_ch * n * 4)
 
-    def step():
-        ctx.check(ctx.lib.ds_fir_ola_dev(ctx.handle, C.c_void_p(d_x.ptr), n_ch, n, n,
-                                         C.c_void_p(d_t.ptr), K, T, backend.DS_FB_PARALLEL,
-                                         C.c_void_p(d_y.ptr), n), "ds_fir_ola_dev")
+    def step():  # the 4 GiB result stays sharded (band-major): no gather in the reference either
+        if k_loc:
+            ctx.check(ctx.lib.ds_fir_ola_dev(ctx.handle, C.c_void_p(d_x.ptr), n_ch, n, n,
+                                             C.c_void_p(d_t.ptr), k_loc, T, backend.DS_FB_PARALLEL,
+                                             C.c_void_p(d_y.ptr), n), "ds_fir_ola_dev")
 
     alg_bytes = n_ch * n * 4 + K * T * 4 + K * n_ch * n * 4
     info = dict(workload="fir_bank: FilterBank Parallel, 32 x 4097-tap FIR over 8 ch x 2^22",
-                channels=n_ch, samples_per_channel=n, bands=K, taps=T,
-                parallelism=f"signal-batch x{dist.world}")
+                channels=n_ch, samples_per_channel=n, bands=K, taps=T)
 
     def cpu_baseline():
         from oracle import dsp_oracle as orc
-        nb = K  # the reference loop: one oaconvolve per band (~0.5 s each)
         err = 0.0
         t0 = time.perf_counter()
-        for k in range(nb):
+        for k in range(a, b):  # the reference loop: one oaconvolve per band (~0.5 s each)
             ref = orc.lfilter_fir(taps[k].astype(np.float64), x)
             if k % 8 == 0:  # parity on every 8th band (the download is outside what is measured)
                 t1 = time.perf_counter()
                 got = np.empty((n_ch, n), dtype=np.float32)
-                ctx.download(d_y.ptr + 4 * k * n_ch * n, got)
+                ctx.download(d_y.ptr + 4 * (k - a) * n_ch * n, got)
                 err = max(err, orc.rel_max(got.T, ref))
                 t0 += time.perf_counter() - t1
         dt = time.perf_counter() - t0
@@ -271,35 +326,44 @@ def fir_bank(args, ctx, dist):
                     sample=f"oracle.lfilter_fir (scipy oaconvolve), all {K} bands, {dt:.1f} s",
                     parity_rel_max_vs_gpu=err)
 
-    return step, n_ch * n, alg_bytes, "hbm", info, cpu_baseline, None, ("fir",)
+    return step, n_ch * n, alg_bytes, "hbm", info, (cpu_baseline,), None, ("fir",)
 
 
-def csm(args, ctx, dist):
+def csm(args, ctx, dist, shard, rccl):
     from dsptoolbox_amd import backend
     from dsptoolbox_amd._lib import DeviceBuffer
     from dsptoolbox_amd.generators import mic_array_noise
     from dsptoolbox_amd.standard.enums import SpectrumScaling, Window
 
     n, n_ch, W = 512000, 64, 1024
-    x = mic_array_noise(n, n_ch, 4 + dist.rank)
+    x = mic_array_noise(n, n_ch, 4 + (dist.rank if shard is None else 0))
     window = backend._window_array(Window.Hann, W)
     hop, n_frames = backend._welch_framing(n, W, 50, window)
     amp, norm_scale, factor, phys = backend._finish_params(SpectrumScaling.FFTBackward, W, FS, window)
     d_x = DeviceBuffer.from_array(ctx, backend._planar_f32(x))
     d_w = DeviceBuffer.from_array(ctx, window.astype(np.float32))
     B = W // 2 + 1
-    d_c = DeviceBuffer(ctx, B * n_ch * n_ch * 8)
+    a, b = shard_of(B, shard)  # the matrix shards by frequency bins (all channel pairs are needed)
+    b_max = -(-B // (shard[1] if shard else 1))
+    slot = b_max * n_ch * n_ch * 8
+    d_c = DeviceBuffer(ctx, slot)
+    d_all = DeviceBuffer(ctx, slot * shard[1]) if (shard and shard[1] > 1) else None
 
     def step():
-        ctx.check(ctx.lib.ds_csm_dev(ctx.handle, C.c_void_p(d_x.ptr), n_ch, n, n, W, hop, n_frames,
-                                     C.c_void_p(d_w.ptr), 1, 0, amp, norm_scale, factor, phys,
-                                     C.c_void_p(d_c.ptr)), "ds_csm_dev")
+        if shard is None:
+            ctx.check(ctx.lib.ds_csm_dev(ctx.handle, C.c_void_p(d_x.ptr), n_ch, n, n, W, hop, n_frames,
+                                         C.c_void_p(d_w.ptr), 1, 0, amp, norm_scale, factor, phys,
+                                         C.c_void_p(d_c.ptr)), "ds_csm_dev")
+        elif b > a:
+            ctx.check(ctx.lib.ds_csm_bins_dev(ctx.handle, C.c_void_p(d_x.ptr), n_ch, n, n, W, hop, n_frames,
+                                              C.c_void_p(d_w.ptr), 1, amp, norm_scale, factor, phys, a, b - a,
+                                              C.c_void_p(d_c.ptr)), "ds_csm_bins_dev")
+        gather_result(ctx, rccl, shard, d_c, d_all, slot)
 
     flops = B * n_ch * n_ch * n_frames * 8.0
     info = dict(workload="csm: 64-mic Welch cross-spectral matrix, nfft 1024, 1000 frames",
                 channels=n_ch, samples_per_channel=n, nfft=W, frames=n_frames,
-                gemm_flops="513*64*64*1000*8 (full Hermitian count)",
-                parallelism=f"signal-batch x{dist.world}")
+                gemm_flops="513*64*64*1000*8 (full Hermitian count)")
 
     def cpu_baseline():
         from oracle import dsp_oracle as orc
@@ -308,38 +372,40 @@ def csm(args, ctx, dist):
         for _ in range(reps):
             f, ref = orc.csm_welch_batched(x, FS, W, "hann", 50, True, "FFTBackward", workers=-1)
         dt = (time.perf_counter() - t0) / reps
-        got = d_c.to_array((B, n_ch, n_ch), np.complex64)
+        got = d_c.to_array((b - a, n_ch, n_ch), np.complex64)
+        lo = max(a, 1)
         return dict(value=n_ch * n / dt / 1e6, unit="Msamples/s", cores=os.cpu_count(), kind="port",
                     sample=f"oracle.csm_welch_batched (batched restatement, scipy.fft workers=-1), all 64 "
                            f"mics, {reps} passes of {dt:.1f} s; the reference's 2080-pair loop takes ~100 s",
-                    parity_rel_max_vs_gpu=orc.rel_max(got[1:], ref[1:]))
+                    parity_rel_max_vs_gpu=orc.rel_max(got[lo - a:], ref[lo:b]))
 
-    return step, n_ch * n, flops, "mfma", info, cpu_baseline, None, ("csm_gemm",)
+    return step, n_ch * n, flops, "mfma", info, (cpu_baseline,), None, ("csm_gemm",)
 
 
-def deconv(args, ctx, dist):
-    from dsptoolbox_amd import backend
+def deconv(args, ctx, dist, shard, rccl):
     from dsptoolbox_amd._lib import DeviceBuffer
-    from dsptoolbox_amd.generators import exponential_sweep
 
-    n, items, n_ch = 8192, 1024 // max(dist.world, 1) * 1, 2
-    x = exponential_sweep(n, FS)
-    rng = np.random.default_rng(5000 + dist.rank)
-    y = rng.standard_normal((items, n_ch, n)).astype(np.float32) * 0.1
+    n, items_all, n_ch = 8192, 1024, 2
+    rng = np.random.default_rng(5000 + (dist.rank if shard is None else 0))
+    y = rng.standard_normal((items_all, n_ch, n)).astype(np.float32) * 0.1
     r = (rng.standard_normal(n // 2 + 1) + 1j * rng.standard_normal(n // 2 + 1)).astype(np.complex64)
-    d_y = DeviceBuffer.from_array(ctx, y)
+    a, b = shard_of(items_all, shard)  # independent items shard
+    items = b - a
+    y = y[a:b]
+    d_y = DeviceBuffer.from_array(ctx, y) if items else None
     d_r = DeviceBuffer.from_array(ctx, r)
-    d_o = DeviceBuffer(ctx, y.nbytes)
+    d_o = DeviceBuffer(ctx, max(y.nbytes, 16))
 
-    def step():
-        ctx.check(ctx.lib.ds_deconv_dev(ctx.handle, C.c_void_p(d_y.ptr), items, n_ch, n, n, n,
-                                        C.c_void_p(d_r.ptr), 0, n, n, C.c_void_p(d_o.ptr)),
-                  "ds_deconv_dev")
+    def step():  # the impulse responses stay with the rank that owns the items
+        if items:
+            ctx.check(ctx.lib.ds_deconv_dev(ctx.handle, C.c_void_p(d_y.ptr), items, n_ch, n, n, n,
+                                            C.c_void_p(d_r.ptr), 0, n, n, C.c_void_p(d_o.ptr)),
+                      "ds_deconv_dev")
 
-    alg_bytes = 2 * y.nbytes + r.nbytes
+    alg_bytes = 2 * items_all * n_ch * n * 4 + r.nbytes
     info = dict(workload="deconv: stereo spectral deconvolutions n=8192 against a shared inverse sweep",
-                items=items, channels=n_ch, samples_per_channel=n,
-                parallelism=f"item-shard x{dist.world}")
+                items=items_all, channels=n_ch, samples_per_channel=n)
+
     def cpu_baseline():
         # the reference's per-item path (_transfer_functions.py:19-42): rfft, multiply, irfft
         yy = y.astype(np.float64)
@@ -357,34 +423,53 @@ def deconv(args, ctx, dist):
                            f"{reps} passes of {dt:.1f} s",
                     parity_rel_max_vs_gpu=float(np.max(np.abs(got - ref))) / den)
 
-    return step, items * n_ch * n, alg_bytes, "hbm", info, cpu_baseline, None, ("deconv",)
+    return step, items_all * n_ch * n, alg_bytes, "hbm", info, (cpu_baseline,), None, ("deconv",)
 
 
-def pmc_traffic(workload: str, kernel_hint: str):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary of
-    this same command (profiles/rNN_<workload>_rocprofv3_summary.txt; FETCH_SIZE and WRITE_SIZE
-    are KiB, collected in separate --pmc passes; on gfx950 FETCH_SIZE counts half of a coalesced
-    streaming read -- MI355X_MICROARCH.md, HBM section -- hence the factor 2).  None if absent."""
+def pmc_summary(workload: str, kernel_hints):
+    """Counters of the dominant kernel from the committed rocprofv3 PMC summary of this same
+    command (profiles/rNN_<workload>_rocprofv3_summary.txt, latest round) -> ({counter: per-launch
+    average}, file name) or ({}, None)."""
     import glob
     import re
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_{workload}_rocprofv3_summary.txt")))
     if not files:
-        return None, None
+        return {}, None
     text = open(files[-1]).read()
-    sect = text.split("== PMC", 1)[-1]
+    sect = text.split("== PMC", 1)[-1].split("== bench line", 1)[0]
     blocks = re.split(r"\n(?=\S)", sect)
-    for blk in blocks:
-        head = blk.splitlines()[0] if blk.strip() else ""
-        if kernel_hint not in head:
-            continue
-        f = re.search(r"FETCH_SIZE\s+([0-9.]+)", blk)
-        w = re.search(r"WRITE_SIZE\s+([0-9.]+)", blk)
-        if f and w:
-            return (2.0 * float(f.group(1)) + float(w.group(1))) * 1024.0, os.path.basename(files[-1])
-    return None, None
+    for hint in kernel_hints:
+        for blk in blocks:
+            head = blk.splitlines()[0] if blk.strip() else ""
+            if hint not in head:
+                continue
+            vals = {m.group(1): float(m.group(2)) for m in re.finditer(r"^\s+(\w+)\s+([0-9.]+)", blk, re.M)}
+            if vals:
+                return vals, os.path.basename(files[-1])
+    return {}, None
 
 
 # ---------------------------------------------------------------------------
+def timed_steps(ctx, dist, step, steps: int, events: bool, dominant):
+    """W. warm-up done by the caller.  Times exactly `steps` steps between two
+    barrier + synchronize brackets; only the dominant kernel is event-bracketed inside."""
+    dist.barrier_sync(ctx)
+    ctx.profile_only(dominant)  # None (no instrumented warm-up step): every kernel
+    ctx.profile_enable(events)
+    ctx.profile_report()
+    t0 = time.perf_counter()
+    ctx.timer_start()
+    for _ in range(steps):
+        step()
+    ev_ms = ctx.timer_stop()
+    dist.barrier_sync(ctx)
+    wall = time.perf_counter() - t0
+    prof = ctx.profile_report()
+    ctx.profile_enable(False)
+    ctx.profile_only(None)
+    return wall, ev_ms, prof
+
+
 def main():
     args = parse_args()
     from dsptoolbox_amd._build import build_library
@@ -393,9 +478,17 @@ def main():
     build_library()
     dist = Dist(args.gpus)
     ctx = Context(None)  # device = LOCAL_RANK (modulo the visible device count)
-    maker = dict(welch_h1=welch_h1, welch_h1_1024=lambda a, c, d: welch_h1(a, c, d, W=1024),
+    if dist.world > 1:
+        from dsptoolbox_amd import distributed as dd
+        dd.init()  # host exchange of the package (TCP star from the launcher's environment)
+    rccl = setup_rccl(ctx, dist)
+    strong = args.scaling == "strong" and dist.world > 1
+    shard = (dist.rank, dist.world) if strong else None
+    maker = dict(welch_h1=welch_h1, welch_h1_1024=lambda a, c, d, sh, r: welch_h1(a, c, d, sh, r, W=1024),
                  fir_bank=fir_bank, csm=csm, deconv=deconv)[args.workload]
-    step, units, alg, bound, info, cpu_baseline, bcast_ms, dominant = maker(args, ctx, dist)
+    step, units, alg, bound, info, cpu_legs, bcast_ms, dominant = maker(args, ctx, dist, shard, rccl)
+    info["parallelism"] = (f"strong: one job sharded x{dist.world}" if strong
+                           else f"weak: independent batch x{dist.world}")
 
     # Warm-up; its last step is bracketed kernel by kernel (HIP events on the library's stream) to
     # find the dominant kernel and the per-kernel breakdown.  An event pair costs ~3 us of stream
@@ -415,27 +508,15 @@ def main():
     dom = next((k for k in dominant if k in prof_all), None)
     if dom is None and prof_all:
         dom = max(prof_all, key=lambda k: prof_all[k][0])
-    dist.barrier_sync(ctx)
-    ctx.profile_only(dom)  # None (no instrumented warm-up step): every kernel
-    ctx.profile_enable(events)
-    ctx.profile_report()
-    t0 = time.perf_counter()
-    ctx.timer_start()
-    for _ in range(args.steps):
-        step()
-    ev_ms = ctx.timer_stop()
-    dist.barrier_sync(ctx)
-    wall = time.perf_counter() - t0
-    prof = ctx.profile_report()
-    ctx.profile_enable(False)
-    ctx.profile_only(None)
+    wall, ev_ms, prof = timed_steps(ctx, dist, step, args.steps, events, dom)
     wall = dist.max_over_ranks(wall)
 
     if dist.rank != 0:
         dist.finish()
         return
     ms_per_step = wall * 1e3 / args.steps
-    value = units * dist.world / (wall / args.steps) / 1e6
+    # weak: every rank ran the whole job's units; strong: the ranks shared them
+    value = units * (1 if strong else dist.world) / (wall / args.steps) / 1e6
     if not prof:  # BENCH_NO_KERNEL_EVENTS=1: step time without the per-kernel event markers (dev)
         print(json.dumps({"value": value, "ms_per_step": ms_per_step, "step_event_ms": ev_ms / args.steps,
                           "note": "no per-kernel events: no roofline"}), flush=True)
@@ -445,46 +526,81 @@ def main():
         dom = next((k for k in dominant if k in prof), max(prof, key=lambda k: prof[k][0]))
     dom_ms = prof[dom][0] / prof[dom][1]
     launches_per_step = prof[dom][1] / args.steps
+    # algorithmic work of ONE launch on THIS rank (strong scaling: its share of the job)
+    alg_launch = alg / launches_per_step / (dist.world if strong else 1)
     if bound == "hbm":
-        achieved = alg / launches_per_step / (dom_ms * 1e-3) / 1e9
+        achieved = alg_launch / (dom_ms * 1e-3) / 1e9
         roof = dict(bound="hbm", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
                     frac=achieved / HBM_PEAK_GBS, traffic=None)
+        # the second denominator SURVEY 8(d) asks for: what a plain copy reaches on THIS GPU
+        gbs = C.c_double(0.0)
+        if ctx.lib.ds_measure_copy(ctx.handle, 1 << 30, 10, C.byref(gbs)) == 0 and gbs.value > 0:
+            roof["measured_copy_gbs"] = gbs.value
+            roof["frac_of_measured_copy"] = achieved / gbs.value
     else:
-        achieved = alg / launches_per_step / (dom_ms * 1e-3) / 1e12
+        achieved = alg_launch / (dom_ms * 1e-3) / 1e12
         roof = dict(bound="mfma", achieved=achieved, peak=MFMA_F32_PEAK_TFLOPS, unit="TFLOP/s",
                     frac=achieved / MFMA_F32_PEAK_TFLOPS, traffic=None)
-    hints = {"welch4096_main": ("welch4096::k_y<",), "welch1024_main": ("welch1k::k_y<",), "welch_yacc": ("k_yacc",), "fir": ("fir16k::k_fir<true>", "fir16k::k_fir", "k_fir<"),
-             "csm_gemm": ("k_csm_gemm",), "deconv": ("k_deconv",)}.get(dom, (dom,))
-    traffic, src = None, None
-    for hint in hints:
-        traffic, src = pmc_traffic(args.workload, hint)
-        if traffic is not None:
-            break
-    roof["traffic"] = traffic
-    if src:
+    hints = {"welch4096_main": ("welch4096::k_y3<", "welch4096::k_y<"), "welch1024_main": ("welch1k::k_y<",),
+             "welch_yacc": ("k_yacc",), "fir": ("fir16k::k_fir<true>", "fir16k::k_fir", "k_fir<"),
+             "csm_gemm": ("k_csm_fused", "k_csm_gemm"), "deconv": ("k_deconv",)}.get(dom, (dom,))
+    pmc, src = pmc_summary(args.workload, hints)
+    if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
+        # KiB, separate --pmc passes; on gfx950 FETCH_SIZE counts half of a coalesced streaming
+        # read (MI355X_MICROARCH.md, HBM section), hence the factor 2
+        roof["traffic"] = (2.0 * pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024.0
         roof["traffic_source"] = src + " (2*FETCH_SIZE + WRITE_SIZE) KiB"
+    if "SQ_INSTS_VALU" in pmc:
+        # the ceiling the vector pipe puts on this kernel: wave-level VALU instructions of one
+        # launch x 2 cycles (wave64 on a SIMD-32) over 1024 SIMDs; at the 2.4 GHz maximum clock --
+        # under load the chip holds 1.9-2.1 GHz (s_memtime / s_memrealtime in the kernel)
+        floor_ms = pmc["SQ_INSTS_VALU"] * 2.0 / 1024.0 / 2.4e9 * 1e3
+        roof["valu_issue"] = dict(insts_per_launch=pmc["SQ_INSTS_VALU"], floor_ms_at_2p4_ghz=floor_ms,
+                                  valu_issue_frac=floor_ms / dom_ms, source=src)
     roof["kernel"] = dom
     roof["kernel_avg_ms"] = dom_ms
-    roof["algorithmic_per_launch"] = alg / launches_per_step
+    roof["algorithmic_per_launch"] = alg_launch
     out = {
         "metric": "Msamples/s + GB/s vs HBM roofline, 64ch Welch H1 nfft=4096 @1/2/4/8 GPU"
                   if args.workload == "welch_h1" else f"Msamples/s ({args.workload})",
         "value": value, "unit": "Msamples/s", "n_gpus": dist.world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": info, "roofline": roof,
         "step_event_ms": ev_ms / args.steps,
         "kernels_ms_per_step": ({k: v[0] for k, v in prof_all.items()} if prof_all
                                 else {k: v[0] / args.steps for k, v in prof.items()}),
         "kernels_ms_per_step_source": ("last warm-up step, every kernel bracketed" if prof_all
                                        else "timed region"),
-        "whole_step_gbs": (alg / (ev_ms / args.steps * 1e-3) / 1e9) if bound == "hbm" else None,
+        "whole_step_gbs": (alg / (dist.world if strong else 1) / (ev_ms / args.steps * 1e-3) / 1e9)
+        if bound == "hbm" else None,
     }
+    if dist.world > 1:
+        out["bcast"] = "rccl" if rccl else "host"
+        if strong:
+            out["result_gather"] = "rccl all-gather per step" if rccl else "none"
     if bcast_ms is not None:
         out["rccl_bcast_ms"] = bcast_ms
-    if cpu_baseline is not None and not args.no_cpu_baseline and dist.world == 1:
-        out["cpu_baseline"] = cpu_baseline()
+    if dist.world == 1 and args.predict_ranks > 1:
+        # what one rank of an N-GPU strong-scaling job would run, timed on this GPU (no collective
+        # here: the all-gather of 24 KB result slices and the one-off broadcast are extra)
+        R = args.predict_ranks
+        s_step = maker(args, ctx, dist, (0, R), False)[0]
+        for _ in range(max(3, args.warmup // 2)):
+            s_step()
+        s_wall, s_ev, _ = timed_steps(ctx, dist, s_step, args.steps, False, None)
+        out["shard_prediction"] = dict(
+            ranks=R, shard="rank 0 of shard_range over " + {"welch_h1": "64 output channels (+ the sweep)",
+                                                            "welch_h1_1024": "64 output channels (+ the sweep)",
+                                                            "fir_bank": "32 bands", "csm": "513 bins",
+                                                            "deconv": "1024 items"}[args.workload],
+            ms_full=ms_per_step, ms_shard=s_wall * 1e3 / args.steps, implied_speedup=wall / s_wall,
+            note="single-GPU timing of the per-rank shape; excludes the per-step all-gather")
+    if cpu_legs and not args.no_cpu_baseline and dist.world == 1:
+        out["cpu_baseline"] = cpu_legs[0]()
         out["cpu_baseline"]["host_cpus"] = os.cpu_count()
+        if len(cpu_legs) > 1:
+            out["cpu_baseline_batched"] = cpu_legs[1]()
     print(json.dumps(out), flush=True)
     dist.finish()
 

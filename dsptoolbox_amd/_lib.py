@@ -96,7 +96,10 @@ SIGNATURES = {
     "ds_comm_unique_id": (C.c_int, [C.c_char_p]),
     "ds_comm_init": (C.c_int, [ctx_p, C.c_int, C.c_int, C.c_char_p]),
     "ds_bcast": (C.c_int, [ctx_p, C.c_void_p, C.c_size_t, C.c_int]),
+    "ds_allgather": (C.c_int, [ctx_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "ds_comm_destroy": (C.c_int, [ctx_p]),
+    "ds_measure_copy": (C.c_int, [ctx_p, C.c_size_t, C.c_int, C.POINTER(C.c_double)]),
+    "ds_mem_info": (C.c_int, [ctx_p, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
 }
 
 _lib = None
@@ -158,6 +161,10 @@ class Context:
         raise DeviceError(text)
 
     # ---- raw device memory -------------------------------------------------
+    def last_error(self) -> str:
+        msg = self.lib.ds_last_error(self.handle)
+        return msg.decode() if msg else ""
+
     def malloc(self, nbytes: int) -> int:
         p = C.c_void_p()
         self.check(self.lib.ds_malloc(self.handle, C.byref(p), nbytes), "ds_malloc")
@@ -222,15 +229,18 @@ class Context:
             pass
 
 
-_default_ctx = None
+_tls = threading.local()
 
 
 def get_context() -> Context:
-    """Process-wide default context (device = LOCAL_RANK, one process per GPU)."""
-    global _default_ctx
-    if _default_ctx is None:
-        _default_ctx = Context()
-    return _default_ctx
+    """Default context of the CALLING THREAD (device = LOCAL_RANK, one process per GPU).
+    A ds_ctx is bound to one stream and one scratch workspace and is not re-entrant
+    (INTEGRATION.md section 5), while ctypes releases the GIL during a call -- so every Python
+    thread gets its own context, like the thread-safe numpy reference it stands in for."""
+    ctx = getattr(_tls, "ctx", None)
+    if ctx is None:
+        ctx = _tls.ctx = Context()
+    return ctx
 
 
 class DeviceBuffer:

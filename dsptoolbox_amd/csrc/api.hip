@@ -36,7 +36,16 @@ struct ds_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::string err;
     std::map<int, float2*> tw;  // twiddle tables by length
-    std::map<std::pair<int64_t, int64_t>, float2*> blue;  // Bluestein chirp-filter spectra by (L, M)
+    // Bluestein chirp-filter spectra by (L, M): a least-recently-used cache under a byte cap (a
+    // table is M float2, up to 128 MB; recordings of ever-changing lengths must not pin one each)
+    struct BlueEntry {
+        float2* ptr;
+        size_t bytes;
+        uint64_t stamp;
+    };
+    std::map<std::pair<int64_t, int64_t>, BlueEntry> blue;
+    size_t blue_bytes = 0;
+    uint64_t blue_clock = 0;
     float2* w4_tables = nullptr;  // welch4096::host_tables()
     float2* fir16k_tables = nullptr;  // fir16k::host_tables()
     float2* deconv8k_tables = nullptr;  // deconv8k::host_tables()
@@ -199,7 +208,7 @@ extern "C" void ds_destroy(ds_ctx* c) {
     if (c->stft1k_tables) (void)hipFree(c->stft1k_tables);
     for (float2* t : c->stft_wave_tables)
         if (t) (void)hipFree(t);
-    for (auto& kv : c->blue) (void)hipFree(kv.second);
+    for (auto& kv : c->blue) (void)hipFree(kv.second.ptr);
     for (auto& r : c->prof_recs) {
         (void)hipEventDestroy(r.a);
         (void)hipEventDestroy(r.b);
@@ -1368,23 +1377,55 @@ static int64_t blue_len(int64_t L) {
     return m;
 }
 
+static size_t blue_cache_cap() {
+    static size_t cap = 0;
+    if (!cap) {
+        cap = (size_t)256 << 20;  // two of the largest tables, or dozens of audio-length ones
+        if (const char* e = getenv("DSPTOOLBOX_AMD_BLUESTEIN_CACHE_MB")) cap = (size_t)std::max(1, atoi(e)) << 20;
+    }
+    return cap;
+}
+
 static int blue_filter(ds_ctx* c, int64_t L, int64_t M, const float2** out) {
     auto key = std::make_pair(L, M);
     auto it = c->blue.find(key);
     if (it != c->blue.end()) {
-        *out = it->second;
+        it->second.stamp = ++c->blue_clock;
+        *out = it->second.ptr;
         return DS_OK;
     }
+    const size_t bytes = sizeof(float2) * (size_t)M;
+    // make room: drop the least recently used tables (hipFree waits for the device, so a table
+    // still referenced by queued kernels of an earlier call is never pulled from under them)
+    while (!c->blue.empty() && c->blue_bytes + bytes > blue_cache_cap()) {
+        auto lru = c->blue.begin();
+        for (auto jt = c->blue.begin(); jt != c->blue.end(); ++jt)
+            if (jt->second.stamp < lru->second.stamp) lru = jt;
+        HIPCHK(c, hipFree(lru->second.ptr));
+        c->blue_bytes -= lru->second.bytes;
+        c->blue.erase(lru);
+    }
     float2 *bt = nullptr, *bf = nullptr;
-    HIPCHK(c, hipMalloc((void**)&bt, sizeof(float2) * M));
-    HIPCHK(c, hipMalloc((void**)&bf, sizeof(float2) * M));
-    hipLaunchKernelGGL(dsblue::k_filter, dim3(1024), dim3(256), 0, c->stream, bt, L, M);
-    HIPCHK(c, hipGetLastError());
-    CHK(big_cols(c, bt, nullptr, 0, 0, 0, bt, M, 1));
-    CHK(big_rows(c, bt, bf, M, 1));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    HIPCHK(c, hipFree(bt));
-    c->blue[key] = bf;
+    HIPCHK(c, hipMalloc((void**)&bt, bytes));
+    if (hipMalloc((void**)&bf, bytes) != hipSuccess) {
+        (void)hipFree(bt);
+        return fail(c, DS_ERR_NOMEM, "Bluestein filter table: hipMalloc failed");
+    }
+    int rc = DS_OK;
+    do {
+        hipLaunchKernelGGL(dsblue::k_filter, dim3(1024), dim3(256), 0, c->stream, bt, L, M);
+        if (hipGetLastError() != hipSuccess) { rc = fail(c, DS_ERR_HIP, "Bluestein filter kernel launch failed"); break; }
+        if ((rc = big_cols(c, bt, nullptr, 0, 0, 0, bt, M, 1)) != DS_OK) break;
+        if ((rc = big_rows(c, bt, bf, M, 1)) != DS_OK) break;
+        if (hipStreamSynchronize(c->stream) != hipSuccess) { rc = fail(c, DS_ERR_HIP, "Bluestein filter: stream sync failed"); break; }
+    } while (0);
+    (void)hipFree(bt);
+    if (rc != DS_OK) {
+        (void)hipFree(bf);
+        return rc;
+    }
+    c->blue[key] = ds_ctx::BlueEntry{bf, bytes, ++c->blue_clock};
+    c->blue_bytes += bytes;
     *out = bf;
     return DS_OK;
 }
@@ -2198,6 +2239,7 @@ struct uid128 {
 };
 typedef int (*nccl_init_rank_t)(void**, int, uid128, int);
 typedef int (*nccl_bcast_t)(const void*, void*, size_t, int, int, void*, hipStream_t);
+typedef int (*nccl_allgather_t)(const void*, void*, size_t, int, void*, hipStream_t);
 typedef int (*nccl_destroy_t)(void*);
 typedef const char* (*nccl_errstr_t)(int);
 
@@ -2246,6 +2288,73 @@ extern "C" int ds_bcast(ds_ctx* c, void* buf, size_t bytes, int root) {
     if (!f) return fail(c, DS_ERR_COMM, "ncclBroadcast missing");
     int r = f(buf, buf, bytes, /*ncclChar*/ 0, root, c->comm, c->stream);
     if (r != 0) return fail(c, DS_ERR_COMM, "ncclBroadcast failed");
+    return DS_OK;
+}
+
+extern "C" int ds_allgather(ds_ctx* c, const void* send, void* recv, size_t bytes_per_rank) {
+    if (!c || !send || !recv) return fail(c, DS_ERR_ARG, "ds_allgather: null argument");
+    if (!c->comm) return fail(c, DS_ERR_COMM, "ds_allgather: communicator not initialised");
+    auto f = (nccl_allgather_t)dlsym(c->rccl, "ncclAllGather");
+    if (!f) return fail(c, DS_ERR_COMM, "ncclAllGather missing");
+    int r = f(send, recv, bytes_per_rank, /*ncclChar*/ 0, c->comm, c->stream);
+    if (r != 0) return fail(c, DS_ERR_COMM, "ncclAllGather failed");
+    return DS_OK;
+}
+
+// ---- measured copy bandwidth (the roofline's second denominator) --------------
+__global__ __launch_bounds__(256) void k_copy16(const float4* __restrict__ src, float4* __restrict__ dst, size_t n16) {
+    // four independent 16-byte loads per lane in flight before the first store
+    const size_t stride = (size_t)gridDim.x * 1024;
+    size_t i = (size_t)blockIdx.x * 1024 + threadIdx.x;
+    for (; i + 768 < n16; i += stride) {
+        const float4 a = src[i], b = src[i + 256], c = src[i + 512], d = src[i + 768];
+        dst[i] = a;
+        dst[i + 256] = b;
+        dst[i + 512] = c;
+        dst[i + 768] = d;
+    }
+    if (i < n16) {  // the last, partly filled tile
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (i + 256 * k < n16) dst[i + 256 * k] = src[i + 256 * k];
+    }
+}
+extern "C" int ds_measure_copy(ds_ctx* c, size_t bytes, int reps, double* gb_per_s) {
+    if (!c || !gb_per_s || bytes < 16 || reps <= 0) return fail(c, DS_ERR_ARG, "ds_measure_copy: bad argument");
+    HIPCHK(c, hipSetDevice(c->device));
+    float4 *a = nullptr, *b = nullptr;
+    const size_t n16 = bytes / 16;
+    if (hipMalloc((void**)&a, n16 * 16) != hipSuccess) return fail(c, DS_ERR_NOMEM, "ds_measure_copy: hipMalloc");
+    if (hipMalloc((void**)&b, n16 * 16) != hipSuccess) {
+        (void)hipFree(a);
+        return fail(c, DS_ERR_NOMEM, "ds_measure_copy: hipMalloc");
+    }
+    int rc = DS_OK;
+    float ms = 0.f;
+    const unsigned grid = (unsigned)std::min<size_t>((n16 + 1023) / 1024, 256 * 8);  // 8 workgroups per CU
+    do {
+        if (hipMemsetAsync(a, 1, n16 * 16, c->stream) != hipSuccess) { rc = fail(c, DS_ERR_HIP, "ds_measure_copy: memset"); break; }
+        hipLaunchKernelGGL(k_copy16, dim3(grid), dim3(256), 0, c->stream, a, b, n16);
+        if (hipEventRecord(c->ev0, c->stream) != hipSuccess) { rc = fail(c, DS_ERR_HIP, "ds_measure_copy: event"); break; }
+        for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(k_copy16, dim3(grid), dim3(256), 0, c->stream, a, b, n16);
+        if (hipEventRecord(c->ev1, c->stream) != hipSuccess || hipEventSynchronize(c->ev1) != hipSuccess ||
+            hipEventElapsedTime(&ms, c->ev0, c->ev1) != hipSuccess || hipGetLastError() != hipSuccess) {
+            rc = fail(c, DS_ERR_HIP, "ds_measure_copy: timing");
+            break;
+        }
+        *gb_per_s = 2.0 * (double)(n16 * 16) * reps / ((double)ms * 1e-3) / 1e9;
+    } while (0);
+    (void)hipStreamSynchronize(c->stream);
+    (void)hipFree(a);
+    (void)hipFree(b);
+    return rc;
+}
+
+extern "C" int ds_mem_info(ds_ctx* c, size_t* free_bytes, size_t* total_bytes) {
+    if (!c || !free_bytes || !total_bytes) return fail(c, DS_ERR_ARG, "ds_mem_info: null argument");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemGetInfo(free_bytes, total_bytes));
     return DS_OK;
 }
 

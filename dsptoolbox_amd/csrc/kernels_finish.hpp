@@ -219,8 +219,8 @@ __global__ __launch_bounds__(256) void k_welch_median(MedianArgs p) {
     }
     if (p.kind == 0) {  // |Y|^2 series
         __syncthreads();
-        for (int i = tid; i < 8 * F; i += 256) {
-            const int bl = i & 7, f = i >> 3, b = b0 + bl;
+        for (int i = tid; i < BP * F; i += 256) {  // BP bins per workgroup here too (LDS holds BP series)
+            const int bl = i & (BP - 1), f = i >> lb, b = b0 + bl;
             float2 yv = b < nb ? Y[(size_t)f * nb + b] : make_float2(0.f, 0.f);
             ser[(bl * 3 + 0) * F + f] = yv.x * yv.x + yv.y * yv.y;
         }

@@ -2,20 +2,44 @@
 
 The hot path has no exchange step: output channels
 (Welch / H1, FIR), items (deconvolution batch) or frequency bins are independent,
-so every rank runs the single-GPU path on its contiguous shard.  The only
-collective is a broadcast of the shared input (sweep channel, FIR taps, inverse
-spectrum) -- RCCL over xGMI through the library's ds_bcast on device buffers, or
-torch.distributed (gloo) for host arrays -- plus an optional gather of the
-small results to every rank.  torch.distributed is plumbing only (rendezvous,
-barrier, host-side gather); it never touches the signal data path on the GPU.
+so every rank runs the single-GPU path on its contiguous shard.  The collectives
+are a broadcast of the shared input (sweep channel, FIR taps, inverse spectrum)
+and an optional gather of the results -- on device buffers both go over RCCL /
+xGMI through the library's own communicator (ds_bcast, ds_allgather).  What the
+ranks exchange on the HOST (the 128-byte RCCL id, shapes, small result arrays) goes
+through `rendezvous.Exchange` -- a standard-library TCP star by default; the package
+imports no torch.
 """
 
 from __future__ import annotations
 
 import ctypes as C
 import os
+import struct
 
 import numpy as np
+
+from . import rendezvous
+
+_EX: rendezvous.Exchange | None = None
+
+
+def init(exchange: rendezvous.Exchange | None = None) -> rendezvous.Exchange:
+    """Install the host-side exchange of this process (default: the launcher's environment,
+    rendezvous.from_environment).  Idempotent without arguments."""
+    global _EX
+    if exchange is not None:
+        _EX = exchange
+    elif _EX is None:
+        _EX = rendezvous.from_environment()
+    return _EX
+
+
+def shutdown() -> None:
+    global _EX
+    if _EX is not None:
+        _EX.close()
+    _EX = None
 
 
 def shard_range(n_units: int, world_size: int, rank: int) -> tuple[int, int]:
@@ -27,50 +51,42 @@ def shard_range(n_units: int, world_size: int, rank: int) -> tuple[int, int]:
     return start, start + base + (1 if rank < extra else 0)
 
 
-def _dist():
-    import torch.distributed as dist
-    return dist
-
-
 def world() -> tuple[int, int]:
-    """(rank, world_size) from torch.distributed if initialised, else the launcher's env."""
-    try:
-        dist = _dist()
-        if dist.is_available() and dist.is_initialized():
-            return dist.get_rank(), dist.get_world_size()
-    except Exception:
-        pass
+    """(rank, world_size): the installed exchange, else the launcher's environment."""
+    if _EX is not None:
+        return _EX.rank, _EX.world
     return int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
 
 
+def _pack(arr: np.ndarray) -> bytes:
+    a = np.ascontiguousarray(arr)
+    head = repr((a.shape, a.dtype.str)).encode()
+    return struct.pack("<I", len(head)) + head + a.tobytes()
+
+
+def _unpack(b: bytes) -> np.ndarray:
+    (n,) = struct.unpack_from("<I", b, 0)
+    shape, dtype = eval(b[4:4 + n].decode(), {"__builtins__": {}})  # a tuple of ints and a dtype string
+    return np.frombuffer(b, dtype=np.dtype(dtype), offset=4 + n).reshape(shape).copy()
+
+
 def broadcast_array(arr: np.ndarray | None, src: int = 0) -> np.ndarray:
-    """Host-array broadcast through torch.distributed (gloo or nccl)."""
-    import torch
-    dist = _dist()
+    """Host-array broadcast through the host exchange (small shared inputs; a device buffer
+    travels with broadcast_device over xGMI instead)."""
     rank, ws = world()
     if ws == 1:
         return arr
-    meta = [None]
-    if rank == src:
-        meta = [(arr.shape, str(arr.dtype))]
-    dist.broadcast_object_list(meta, src=src)
-    shape, dtype = meta[0]
-    t = torch.from_numpy(np.ascontiguousarray(arr)) if rank == src else torch.empty(shape, dtype=getattr(torch, str(np.dtype(dtype))))
-    if dist.get_backend() == "nccl":
-        t = t.cuda()
-    dist.broadcast(t, src=src)
-    return t.cpu().numpy()
+    ex = init()
+    return _unpack(ex.broadcast_bytes(_pack(arr) if rank == src else None, src=src))
 
 
 def gather_channel_shards(local: np.ndarray, n_total: int, axis: int = -1) -> np.ndarray:
-    """All-gather per-rank result slices (split by shard_range along `axis`) into the full
-    array on every rank."""
+    """All-gather per-rank host result slices (split by shard_range along `axis`) into the full
+    array on every rank.  Results that live on the device are gathered there: allgather_device."""
     rank, ws = world()
     if ws == 1:
         return local
-    dist = _dist()
-    parts = [None] * ws
-    dist.all_gather_object(parts, np.ascontiguousarray(local))
+    parts = [_unpack(b) for b in init().allgather_bytes(_pack(local))]
     out = np.concatenate([p for p in parts if p.shape[axis] > 0], axis=axis)
     assert out.shape[axis] == n_total, (out.shape, n_total)
     return out
@@ -160,22 +176,16 @@ def spectral_division_sharded(num_td, n_fft: int, inverse_spectrum, n_out: int, 
     return gather_channel_shards(local, m, axis=0) if gather else local
 
 
-def init_library_comm(ctx, exchange=None) -> bool:
-    """Create the library's RCCL communicator (ds_comm_*): rank 0 makes the 128-byte id,
-    `exchange(bytes) -> bytes` hands it to every rank (default: torch.distributed
-    broadcast_object_list).  Returns False for a single-rank world."""
+def init_library_comm(ctx) -> bool:
+    """Create the library's RCCL communicator (ds_comm_*): rank 0 makes the 128-byte id, the
+    host exchange hands it to every rank.  Returns False for a single-rank world."""
     rank, ws = world()
     if ws == 1:
         return False
     ident = C.create_string_buffer(128)
     if rank == 0:
         ctx.check(ctx.lib.ds_comm_unique_id(ident), "ds_comm_unique_id")
-    if exchange is None:
-        box = [ident.raw if rank == 0 else None]
-        _dist().broadcast_object_list(box, src=0)
-        raw = box[0]
-    else:
-        raw = exchange(ident.raw)
+    raw = init().broadcast_bytes(ident.raw if rank == 0 else None, src=0)
     ctx.check(ctx.lib.ds_comm_init(ctx.handle, ws, rank, raw), "ds_comm_init")
     return True
 
@@ -183,3 +193,11 @@ def init_library_comm(ctx, exchange=None) -> bool:
 def broadcast_device(ctx, dptr: int, nbytes: int, root: int = 0):
     """RCCL broadcast of a device buffer on the context's stream (xGMI)."""
     ctx.check(ctx.lib.ds_bcast(ctx.handle, C.c_void_p(dptr), nbytes, root), "ds_bcast")
+
+
+def allgather_device(ctx, send_ptr: int, recv_ptr: int, nbytes_per_rank: int):
+    """RCCL all-gather of equal-sized device shards on the context's stream: rank r's
+    `nbytes_per_rank` bytes land at recv + r * nbytes_per_rank on every rank.  Uneven shards
+    (shard_range) are padded to the largest by the caller."""
+    ctx.check(ctx.lib.ds_allgather(ctx.handle, C.c_void_p(send_ptr), C.c_void_p(recv_ptr), nbytes_per_rank),
+              "ds_allgather")

@@ -280,13 +280,26 @@ int ds_host_interleave_f64(const float* src, int64_t n_samples, int n_ch, int64_
                            int threads); /* dst[n*n_ch + c] = (double)src[c*ld + n] */
 int ds_host_widen_f64(const float* src, int64_t n, double* dst, int threads); /* dst[i] = (double)src[i] */
 
-/* ---- multi-GPU: RCCL broadcast of shared inputs (sweep / taps / inverse) --
- * one process per GPU; rank 0 creates the id, the launcher (torch.distributed
- * store, file, MPI ...) hands the 128 bytes to every rank.                   */
+/* ---- multi-GPU: RCCL over xGMI, one process per GPU -----------------------
+ * The hot path has no exchange step: the only collectives are the
+ * broadcast of a shared input (sweep / taps / inverse spectrum) and the gather of sharded
+ * results.  Rank 0 creates the id, the host exchange (dsptoolbox_amd/rendezvous.py: a TCP
+ * star; or a file, MPI, a torch.distributed store ...) hands the 128 bytes to every rank.
+ * ds_allgather: rank r's bytes_per_rank bytes at send_dev land at recv_dev + r * bytes_per_rank
+ * on every rank (ncclAllGather on the context's stream; send may alias its own slot).  */
 int ds_comm_unique_id(char id_out[128]);
 int ds_comm_init(ds_ctx* ctx, int n_ranks, int rank, const char id[128]);
 int ds_bcast(ds_ctx* ctx, void* buf_dev, size_t bytes, int root);
+int ds_allgather(ds_ctx* ctx, const void* send_dev, void* recv_dev, size_t bytes_per_rank);
 int ds_comm_destroy(ds_ctx* ctx);
+
+/* ---- measurement: device-to-device copy bandwidth of THIS GPU (a 16-byte-per-lane streaming
+ * copy kernel over `bytes` bytes, `reps` timed launches after one warm-up; GB/s counts read +
+ * written bytes) -- the measured denominator bench.py reports next to the nominal 8 TB/s
+ * (SURVEY.md section 8(d)).                                                                  */
+int ds_measure_copy(ds_ctx* ctx, size_t bytes, int reps, double* gb_per_s);
+/* free / total device memory of the context's GPU (hipMemGetInfo), for leak checks */
+int ds_mem_info(ds_ctx* ctx, size_t* free_bytes, size_t* total_bytes);
 
 #ifdef __cplusplus
 }

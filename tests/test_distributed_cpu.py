@@ -1,6 +1,8 @@
-"""world_size-2 gloo tests (CPU): the sharding / broadcast / gather logic of the N > 1
-path.  The per-shard compute is injected (the oracle stands in for the device call, which
-needs a GPU); equality with the unsharded result proves the decomposition is exact."""
+"""world_size-2 tests (CPU): the sharding / broadcast / gather logic of the N > 1 path over
+both host transports -- the package's own TCP rendezvous (what the launcher's environment
+selects) and a torch.distributed gloo group wrapped as a rendezvous.Exchange.  The per-shard
+compute is injected (the oracle stands in for the device call, which needs a GPU); equality
+with the unsharded result proves the decomposition is exact."""
 
 import os
 import socket
@@ -20,14 +22,47 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, q):
+def _gloo_exchange(rank, world):
+    """torch.distributed (gloo) as the host transport: lives in the TEST, the package has no torch."""
+    import torch.distributed as dist
+    from dsptoolbox_amd.rendezvous import Exchange
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    class Gloo(Exchange):
+        def __init__(self):
+            self.rank, self.world = rank, world
+
+        def broadcast_bytes(self, data, src=0):
+            box = [data if rank == src else None]
+            dist.broadcast_object_list(box, src=src)
+            return box[0]
+
+        def allgather_bytes(self, data):
+            parts = [None] * world
+            dist.all_gather_object(parts, data)
+            return parts
+
+        def barrier(self):
+            dist.barrier()
+
+        def close(self):
+            dist.destroy_process_group()
+
+    return Gloo()
+
+
+def _worker(rank, world, port, q, transport="tcp"):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
                       WORLD_SIZE=str(world))
-    import torch.distributed as dist
     from dsptoolbox_amd import distributed as dd
     from oracle import dsp_oracle as orc
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    if transport == "gloo":
+        dd.init(_gloo_exchange(rank, world))
+    else:
+        dd.init()  # rendezvous.from_environment: TCP star on MASTER_PORT + 23
+    assert dd.world() == (rank, world)
+    assert "torch" not in sys.modules or transport == "gloo"
     try:
         rng = np.random.default_rng(42)
         n, n_cy = 6000, 5  # 5 channels over 2 ranks: 3 + 2
@@ -85,7 +120,7 @@ def _worker(rank, world, port, q):
         ok = ok and cs.shape == (65, 3, 3) and np.array_equal(cs, csm_bins(xs, 48000, 128, 0, 65))
         q.put((rank, bool(ok), dd.shard_range(n_cy, world, rank)))
     finally:
-        dist.destroy_process_group()
+        dd.shutdown()
 
 
 def test_shard_range_properties():
@@ -100,13 +135,21 @@ def test_shard_range_properties():
     assert shard_range(64, 8, 3) == (24, 32) and shard_range(1024, 8, 7) == (896, 1024)
 
 
+def test_package_imports_no_torch():
+    import subprocess
+    code = ("import sys; sys.path.insert(0, %r); import dsptoolbox_amd, dsptoolbox_amd.distributed, "
+            "dsptoolbox_amd.rendezvous; assert 'torch' not in sys.modules" % ROOT)
+    subprocess.run([sys.executable, "-c", code], check=True, timeout=120)
+
+
 @pytest.mark.timeout(120)
-def test_sharded_transfer_function_gloo_world2():
-    import torch.multiprocessing as mp
+@pytest.mark.parametrize("transport", ["tcp", "gloo"])
+def test_sharded_transfer_function_world2(transport):
+    import multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, transport)) for r in range(2)]
     for p in procs:
         p.start()
     res = [q.get(timeout=100) for _ in procs]

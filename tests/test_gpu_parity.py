@@ -19,6 +19,7 @@ from conftest import load_golden
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-6
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 WIN = {"hann": Window.Hann, "hamming": Window.Hamming, "blackman": Window.Blackman,
        "boxcar": Window.Boxcar}
 
@@ -428,12 +429,60 @@ def test_library_rccl_communicator_single_rank():
         ctx.check(ctx.lib.ds_bcast(ctx.handle, C.c_void_p(buf.ptr), data.nbytes, 0), "ds_bcast")
         ctx.sync()
         assert np.array_equal(buf.to_array(data.shape, np.float32), data)
+        # all-gather of result slices (one rank: its slot is the whole receive buffer)
+        out = DeviceBuffer(ctx, data.nbytes)
+        ctx.check(ctx.lib.ds_allgather(ctx.handle, C.c_void_p(buf.ptr), C.c_void_p(out.ptr), data.nbytes),
+                  "ds_allgather")
+        ctx.sync()
+        assert np.array_equal(out.to_array(data.shape, np.float32), data)
         ctx.check(ctx.lib.ds_comm_destroy(ctx.handle), "ds_comm_destroy")
-        # a broadcast without a communicator is an error, not a crash
+        # collectives without a communicator are errors, not crashes
         assert ctx.lib.ds_bcast(ctx.handle, C.c_void_p(buf.ptr), data.nbytes, 0) != 0
+        assert ctx.lib.ds_allgather(ctx.handle, C.c_void_p(buf.ptr), C.c_void_p(out.ptr), data.nbytes) != 0
         buf.free()
+        out.free()
     finally:
         ctx.close()
+
+
+def test_measured_copy_bandwidth():
+    """ds_measure_copy: the measured denominator bench.py prints next to the nominal 8 TB/s."""
+    import ctypes as C
+    from dsptoolbox_amd._lib import Context
+    ctx = Context(0)
+    try:
+        gbs = C.c_double(0.0)
+        ctx.check(ctx.lib.ds_measure_copy(ctx.handle, 1 << 28, 5, C.byref(gbs)), "ds_measure_copy")
+        assert 1000.0 < gbs.value < 8000.0, gbs.value
+        assert ctx.lib.ds_measure_copy(ctx.handle, 0, 5, C.byref(gbs)) != 0
+    finally:
+        ctx.close()
+
+
+@pytest.mark.timeout(600)
+def test_bench_two_ranks_strong_scaling_rehearsal():
+    """bench.py --gpus 2 --scaling strong as the driver launches it, with gloo as torch's backend so
+    that both ranks can share this one GPU (RCCL refuses two ranks on a device): the per-rank
+    shards, the host broadcast of the sweep and the JSON contract of the strong-scaling line."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, BENCH_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+           "--gpus", "2", "--steps", "5", "--warmup", "2", "--scaling", "strong", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=500)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["bcast"] == "host"
+    assert out["value"] > 0 and out["roofline"]["frac"] > 0
 
 
 def test_das_map_golden_and_large():
@@ -564,6 +613,59 @@ def test_median_many_frames_vs_oracle():
     f, csm = backend._csm_welch(x, 48000, 64, Window.Hann, 50, True, "median", SpectrumScaling.FFTBackward)
     rf, rcsm = orc.csm_welch(x, 48000, 64, "hann", 50, True, "median", "FFTBackward")   # 3125 frames
     assert relmax(csm, rcsm) < 10 * TOL and orc.rel_l2(csm, rcsm) < TOL
+
+
+def test_bluestein_table_cache_is_bounded():
+    """Whole-signal spectra of ever-changing, non-fast lengths (variable-length recordings): the
+    chirp-filter tables are a least-recently-used cache under a byte cap (256 MB), so device
+    memory stays flat -- 30 lengths x 16 MB tables would otherwise pin 480 MB for good."""
+    import ctypes as C
+    from dsptoolbox_amd._lib import get_context
+    ctx = get_context()
+
+    def free_bytes():
+        f, t = C.c_size_t(0), C.c_size_t(0)
+        ctx.check(ctx.lib.ds_mem_info(ctx.handle, C.byref(f), C.byref(t)), "ds_mem_info")
+        return f.value
+
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((700001, 1)) * 0.1
+    lengths = [600011 + 2 * 1013 * i for i in range(30)]  # odd, mostly with large prime factors -> M = 2^21
+    backend.rfft_spectrum(x[:lengths[0]], lengths[0])
+    free0 = free_bytes()
+    for L in lengths:
+        sp = backend.rfft_spectrum(x[:L], L)
+    ref = np.fft.rfft(x[:L, 0])
+    assert relmax(sp[:, 0], ref) < TOL
+    free1 = free_bytes()
+    assert free0 - free1 < 300 * 2**20, (free0 - free1) / 2**20
+
+
+def test_default_context_is_per_thread():
+    """Two Python threads through the default context at once (ctypes drops the GIL in a call): each
+    thread owns a ds_ctx -- stream, workspace -- so concurrent calls do not corrupt each other."""
+    import threading
+    from dsptoolbox_amd._lib import get_context
+    rng = np.random.default_rng(6)
+    xs = [rng.standard_normal((40000 + 5000 * i, 3)) * 0.3 for i in range(2)]
+    refs = [orc.welch(x, None, 48000, "hann", 1024, 50, True, "mean", "FFTBackward") for x in xs]
+    errs, ctxs = [None, None], [None, None]
+
+    def work(i):
+        ctxs[i] = get_context().handle.value if hasattr(get_context().handle, "value") else id(get_context())
+        worst = 0.0
+        for _ in range(20):
+            psd = backend._welch(xs[i], None, 48000, Window.Hann, 1024, 50, True, "mean", SpectrumScaling.FFTBackward)
+            worst = max(worst, relmax(psd, refs[i], True))
+        errs[i] = worst
+
+    th = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert ctxs[0] != ctxs[1]
+    assert errs[0] < TOL and errs[1] < TOL, errs
 
 
 def test_csm_median_vs_oracle():
