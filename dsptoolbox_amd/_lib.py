@@ -93,6 +93,9 @@ SIGNATURES = {
     "ds_fir_ola_dev": (C.c_int, [ctx_p, f32_p, C.c_int, i64, i64, f32_p, C.c_int, C.c_int, C.c_int,
                                  f32_p, i64]),
     "ds_fir_ola": (C.c_int, [ctx_p, f32_p, C.c_int, i64, f32_p, C.c_int, C.c_int, C.c_int, f32_p]),
+    "ds_welch_tf_x64": (C.c_int, [ctx_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, i64, C.c_int, C.c_int, C.c_int,
+                                  C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int,
+                                  C.c_void_p, C.c_void_p]),
     "ds_comm_unique_id": (C.c_int, [C.c_char_p]),
     "ds_comm_init": (C.c_int, [ctx_p, C.c_int, C.c_int, C.c_char_p]),
     "ds_bcast": (C.c_int, [ctx_p, C.c_void_p, C.c_size_t, C.c_int]),

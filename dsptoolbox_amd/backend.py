@@ -20,6 +20,7 @@ NotImplementedError -- nothing is silently computed on the CPU.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from warnings import warn
 
 import numpy as np
@@ -162,13 +163,36 @@ def _welch(x, y, fs_hz: int, window_type, window_length_samples: int, overlap_pe
     return res if multi else res[:, 0]
 
 
+# Arithmetic of the transfer-function estimate behind the reference-shaped API
+# (transfer_functions.compute_transfer_function): "auto" takes the float64 route
+# (ds_welch_tf_x64: float64 transforms, sums and finish, the reference's own precision) when the
+# problem is small -- frame spectra of all channels <= 64 MB, window <= 8192, mean averaging --
+# and the fp32 kernels otherwise; "f32" / "f64" force one.  Environment:
+# DSPTOOLBOX_AMD_TF_PRECISION.  backend.welch_transfer_function itself defaults to "f32".
+TF_PRECISION = os.environ.get("DSPTOOLBOX_AMD_TF_PRECISION", "auto")
+_X64_AUTO_BYTES = 64 << 20
+
+
+def _tf_x64_applies(precision, n_cx: int, n_cy: int, n_frames: int, W: int, average: str) -> bool:
+    if precision == "f64":
+        if average != "mean" or W > 8192:
+            raise NotImplementedError("the float64 route covers mean averaging and windows up to 8192")
+        return True
+    if precision == "auto":
+        return (average == "mean" and W <= 8192
+                and (n_cx + n_cy) * n_frames * (W // 2 + 1) * 16 <= _X64_AUTO_BYTES)
+    assert precision in (None, "f32"), "precision: 'f32', 'f64' or 'auto'"
+    return False
+
+
 def welch_transfer_function(output_td, input_td, fs_hz: int, window_length_samples: int, mode: str,
                             window_type=Window.Hann, overlap_percent: float = 50.0,
                             detrend: bool = True, average: str = "mean",
-                            scaling: SpectrumScaling = SpectrumScaling.FFTBackward):
+                            scaling: SpectrumScaling = SpectrumScaling.FFTBackward,
+                            precision: str | None = None):
     """H1/H2/H3 + coherence for every output channel in one device call.
     output_td (N, Cy); input_td (N, 1) or (N, Cy).  -> (tf complex128 (B, Cy),
-    coherence float64 (B, Cy))."""
+    coherence float64 (B, Cy)).  precision: "f32" (default), "f64" or "auto" (see TF_PRECISION)."""
     _welch_checks(window_length_samples, overlap_percent, average)
     if mode not in DS_TF:
         raise ValueError("Unsupported transfer function type")
@@ -179,6 +203,23 @@ def welch_transfer_function(output_td, input_td, fs_hz: int, window_length_sampl
         yo = yo[:, None]
     if xi.ndim == 1:
         xi = xi[:, None]
+    if precision not in (None, "f32"):
+        n = yo.shape[0]
+        assert xi.shape[0] == n, "Signal lengths do not match"
+        hop, n_frames = _welch_framing(n, W, overlap_percent, window)
+        if _tf_x64_applies(precision, xi.shape[1], yo.shape[1], n_frames, W, average):
+            amp, norm_scale, factor, phys = _finish_params(scaling, W, fs_hz, window)
+            y64 = np.ascontiguousarray(yo, dtype=np.float64)
+            x64 = np.ascontiguousarray(xi, dtype=np.float64)
+            w64 = np.ascontiguousarray(window, dtype=np.float64)
+            B = W // 2 + 1
+            tf = np.empty((B, yo.shape[1]), dtype=np.complex128)
+            coh = np.empty((B, yo.shape[1]), dtype=np.float64)
+            ctx = get_context()
+            ctx.check(ctx.lib.ds_welch_tf_x64(ctx.handle, _ptr(x64), x64.shape[1], _ptr(y64), y64.shape[1], n, W,
+                                              hop, n_frames, _ptr(w64), int(bool(detrend)), DS_TF[mode], amp,
+                                              norm_scale, factor, phys, _ptr(tf), _ptr(coh)), "ds_welch_tf_x64")
+            return tf, coh
     # large float64 C-order arrays (the reference's own layout) cross the boundary as they are: the
     # library casts + transposes them in threads straight into pinned upload chunks
     fused = _fusable(yo) and xi.ndim == 2 and xi.dtype == np.float64 and xi.flags.c_contiguous
@@ -219,8 +260,10 @@ def _stft_plan(x, fs_hz: int, window_length_samples: int, window_type, overlap_p
         "overlap_percent should be between 0 and 100"
     W = int(window_length_samples)
     nfft = W if fft_length_samples is None else int(fft_length_samples)
-    if nfft & (nfft - 1) or nfft < 8:
-        raise NotImplementedError("fft_length_samples must be a power of two >= 8 on the GPU path")
+    # any positive length, as numpy's rfft(n=...) (_spectral_methods.py:268): frames are cropped to
+    # nfft or zero-padded; powers of two >= 8 take the fused kernels, everything else the general
+    # route of the library (kernels_stft_any.hpp)
+    assert nfft >= 2, "fft_length_samples must be at least 2"
     window = _window_array(window_type, W)
     overlap = int(overlap_percent / 100 * W + 0.5)  # rounding, _spectral_methods.py:247
     hop = W - overlap

@@ -23,6 +23,8 @@
 #include "kernels_stft1024.hpp"
 #include "kernels_welch1024.hpp"
 #include "kernels_welch8192.hpp"
+#include "kernels_welch_f64.hpp"
+#include "kernels_stft_any.hpp"
 
 using namespace dsk;
 
@@ -433,6 +435,43 @@ static int welch_big(ds_ctx* c, int kind, const float* x, int n_cx, int64_t ldx,
                      const float* window, int detrend, int average, int mode, int amp_sqrt,
                      double norm_scale, double factor, int halve_edges, float2* out_c, float* out_r);
 
+extern "C" int ds_rfft_dev(ds_ctx* c, const float* x, int n_ch, int64_t ld, int64_t n_samples,
+                           int n_fft, float scale, ds_c32* spec);
+
+// any fft length (kernels_stft_any.hpp): rows = windowed frames -> ds_rfft_dev -> scaling pass
+static int stft_any(ds_ctx* c, const float* x, int64_t n_samples, int n_ch, int64_t ld, int W, int hop,
+                    int nfft, int64_t pad_front, int n_frames, const float* window, int detrend, float scale,
+                    float edge_scale, int power, float2* out) {
+    if (nfft < 2) return fail(c, DS_ERR_ARG, "ds_stft_r2c: fft length must be >= 2");
+    const int keep = std::min(W, nfft), B = nfft / 2 + 1;
+    const int64_t total_rows = (int64_t)n_frames * n_ch;
+    // rows per group: the transform's scratch grows with the (padded) length; keep a group's
+    // rows + spectra near 256 MB (Bluestein lengths count with their convolution length)
+    int64_t conv = nfft;
+    if (!is_pow2(nfft)) {
+        conv = (int64_t)1 << 15;
+        while (conv < 2 * (int64_t)nfft - 1) conv <<= 1;
+    }
+    int64_t group = std::max<int64_t>(2, ((int64_t)256 << 20) / (conv * 16));
+    group = std::min<int64_t>(total_rows, group & ~(int64_t)1);
+    if (group < 1) group = 1;
+    CHK(reserve(c, &c->aux, &c->aux_bytes,
+                Carver::pad(sizeof(float) * (size_t)group * keep) + Carver::pad(sizeof(float2) * (size_t)group * B)));
+    Carver cv(c->aux);
+    float* rows = cv.take<float>((size_t)group * keep);
+    float2* tmp = cv.take<float2>((size_t)group * B);
+    for (int64_t r0 = 0; r0 < total_rows; r0 += group) {
+        const int nr = (int)std::min<int64_t>(group, total_rows - r0);
+        stftany::PrepArgs pa{x, n_samples, ld, pad_front, n_ch, W, hop, detrend, window, keep, (int)r0, rows};
+        CHK(launch(c, "stft_any_prepare", stftany::k_prepare, dim3(nr), 256, 0, pa));
+        CHK(ds_rfft_dev(c, rows, nr, keep, keep, nfft, 1.0f, (ds_c32*)tmp));
+        stftany::PostArgs po{tmp, out, B, nr, (int)r0, (int)total_rows, scale, edge_scale, (nfft % 2) == 0, power};
+        const int64_t tot = (int64_t)B * nr;
+        CHK(launch(c, "stft_any_post", stftany::k_post, dim3((unsigned)((tot + 255) / 256)), 256, 0, po));
+    }
+    return DS_OK;
+}
+
 // ---- STFT ------------------------------------------------------------------
 extern "C" int ds_stft_r2c_dev(ds_ctx* c, const float* x, int64_t n_samples, int n_ch, int64_t ld,
                                int W, int hop, int nfft, int64_t pad_front, int n_frames,
@@ -441,6 +480,9 @@ extern "C" int ds_stft_r2c_dev(ds_ctx* c, const float* x, int64_t n_samples, int
     if (!c || !x || !out || !window) return fail(c, DS_ERR_ARG, "ds_stft_r2c: null argument");
     if (n_ch <= 0 || n_samples <= 0 || W <= 0 || hop <= 0 || n_frames <= 0 || ld < n_samples)
         return fail(c, DS_ERR_ARG, "ds_stft_r2c: bad shape");
+    if (!is_pow2(nfft) || nfft < kMinFft)  // numpy's rfft(n=...) takes any n: crop or pad
+        return stft_any(c, x, n_samples, n_ch, ld, W, hop, nfft, pad_front, n_frames, window, detrend, scale,
+                        edge_scale, power, (float2*)out);
     if (nfft > kMaxFft && is_pow2(nfft)) {  // four-step transform per frame pair
         CHK(reserve(c, &c->ws, &c->ws_bytes, stft_big_ws(n_ch, n_frames, nfft)));
         Carver cv(c->ws);
@@ -1027,6 +1069,57 @@ extern "C" int ds_welch_tf_dev(ds_ctx* c, const float* x, int n_cx, int64_t ldx,
     return welch_common(c, 0, x, n_cx, ldx, y, n_cy, ldy, n_samples, W, hop, n_frames, window, detrend,
                         average, mode, amp_sqrt, norm_scale, factor, halve_edges, (float2*)tf, coh);
 }
+// float64 end to end (kernels_welch_f64.hpp): host arrays in the reference's own layout
+extern "C" int ds_welch_tf_x64(ds_ctx* c, const double* x, int n_cx, const double* y, int n_cy,
+                               int64_t n_samples, int W, int hop, int n_frames, const double* window,
+                               int detrend, int mode, int amp_sqrt, double norm_scale, double factor,
+                               int halve_edges, double* tf, double* coh) {
+    if (!c || !x || !y || !window || !tf || !coh) return fail(c, DS_ERR_ARG, "ds_welch_tf_x64: null argument");
+    if (n_cy <= 0 || (n_cx != 1 && n_cx != n_cy) || n_samples <= 0 || hop <= 0 || hop > W || n_frames <= 0)
+        return fail(c, DS_ERR_ARG, "ds_welch_tf_x64: bad shape");
+    if (!is_pow2(W) || W < 8 || W > 8192)
+        return fail(c, DS_ERR_UNSUP, "ds_welch_tf_x64: window length must be a power of two in [8, 8192]");
+    if (mode < DS_TF_H1 || mode > DS_TF_H3) return fail(c, DS_ERR_ARG, "welch: unsupported transfer function type");
+    const int nb = W / 2 + 1;
+    const size_t spec_x = (size_t)n_cx * n_frames * nb, spec_y = (size_t)n_cy * n_frames * nb;
+    if ((spec_x + spec_y) * sizeof(double2) > ((size_t)2 << 30))
+        return fail(c, DS_ERR_UNSUP, "ds_welch_tf_x64: problem too large for the float64 route (use ds_welch_tf)");
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t bx = (size_t)n_samples * n_cx * 8, by = (size_t)n_samples * n_cy * 8;
+    const size_t bout = (size_t)nb * n_cy;
+    CHK(reserve(c, &c->io, &c->io_bytes,
+                Carver::pad(bx) + Carver::pad(by) + Carver::pad((size_t)W * 8) + Carver::pad((size_t)W * 8) +
+                    Carver::pad((spec_x + spec_y) * 16) + Carver::pad(bout * 16) + Carver::pad(bout * 8)));
+    Carver cv(c->io);
+    double* dx = cv.take<double>((size_t)n_samples * n_cx);
+    double* dy = cv.take<double>((size_t)n_samples * n_cy);
+    double* dw = cv.take<double>(W);
+    double2* tw = cv.take<double2>(W / 2);
+    double2* xs = cv.take<double2>(spec_x);
+    double2* ys = cv.take<double2>(spec_y);
+    double2* dtf = cv.take<double2>(bout);
+    double* dcoh = cv.take<double>(bout);
+    HIPCHK(c, hipMemcpyAsync(dx, x, bx, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(dy, y, by, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(dw, window, (size_t)W * 8, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(w64::k_twiddles, dim3((W / 2 + 255) / 256), dim3(256), 0, c->stream, tw, W / 2);
+    HIPCHK(c, hipGetLastError());
+    int lg = 0;
+    while ((1 << lg) < W) ++lg;
+    const size_t lds = (size_t)W * 16 + 256 * 8;
+    w64::FrameArgs fx{dx, n_samples, n_cx, W, lg, hop, n_frames, detrend, dw, tw, xs};
+    CHK(launch(c, "welch_f64_frames", w64::k_frames, dim3(n_frames, n_cx), 256, lds, fx));
+    w64::FrameArgs fy{dy, n_samples, n_cy, W, lg, hop, n_frames, detrend, dw, tw, ys};
+    CHK(launch(c, "welch_f64_frames", w64::k_frames, dim3(n_frames, n_cy), 256, lds, fy));
+    w64::TfArgs ta{xs, ys, n_cx, n_cy, n_frames, mode,
+                   FinishPar{norm_scale / (double)n_frames, factor, halve_edges, amp_sqrt, nb}, dtf, dcoh};
+    CHK(launch(c, "welch_f64_tf", w64::k_tf, dim3((nb + 255) / 256, n_cy), 256, 0, ta));
+    HIPCHK(c, hipMemcpyAsync(tf, dtf, bout * 16, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(coh, dcoh, bout * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return DS_OK;
+}
+
 extern "C" int ds_welch_psd_dev(ds_ctx* c, const float* x, int n_cx, int64_t ldx, int64_t n_samples,
                                 int W, int hop, int n_frames, const float* window, int detrend,
                                 int average, int amp_sqrt, double norm_scale, double factor,

@@ -1,0 +1,127 @@
+// Welch transfer functions in float64 end to end: the precise route for small or ill-conditioned
+// problems (reference: _welch, standard/_spectral_methods.py:10-173, and compute_transfer_function,
+// transfer_functions/transfer_functions.py:476-534, which are float64 throughout).  gfx950.
+//
+// Why it exists: with fp32 transforms every frame's rounding floor (1e-7 of the frame's PEAK)
+// lands on all of its bins, so bins 80 dB below the peak -- the high end of a fast pink sweep,
+// BASELINE config 1 -- are only good to 1e-4 (single-precision pocketfft gives the same).  MI355X
+// has a 78 TFLOP/s fp64 vector pipe and such problems are a few hundred transforms: one
+// workgroup per (frame, channel) runs a plain radix-2 transform in LDS on double2 values
+// (W <= 8192: 128 KB), the frame spectra go to HBM as complex128, and a second kernel sums them
+// per (bin, channel) in fp64 and applies the same finish() as the fp32 path.
+//   inputs: float64 (samples, channels) C-order arrays exactly as the reference holds them
+//   (the stride between samples is n_ch), float64 window, mean averaging.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "kernels_finish.hpp"
+
+namespace w64 {
+
+using dsk::cd;
+
+struct FrameArgs {
+    const double* sig;  // (n_samples, n_ch) C order
+    int64_t n_samples;
+    int n_ch, W, lgW, hop, n_frames, detrend;
+    const double* window;  // [W]
+    const double2* tw;     // [W / 2]: exp(-2 pi i k / W)
+    double2* spec;         // [n_ch][n_frames][W / 2 + 1]
+};
+
+__global__ __launch_bounds__(256) void k_twiddles(double2* tw, int half) {
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= half) return;
+    double s, c;
+    sincospi(-(double)k / (double)half, &s, &c);  // exp(-2 pi i k / W), W = 2 half
+    tw[k] = make_double2(c, s);
+}
+
+// grid = (n_frames, n_ch); dynamic LDS = W * 16 bytes (+ 256 * 8 for the mean)
+__global__ __launch_bounds__(256) void k_frames(FrameArgs p) {
+    extern __shared__ __align__(16) double2 buf[];
+    double* red = reinterpret_cast<double*>(buf + p.W);
+    const int tid = threadIdx.x, f = blockIdx.x, c = blockIdx.y;
+    const int W = p.W, lg = p.lgW;
+    const int64_t start = (int64_t)f * p.hop;
+    // windowed frame, zero past the end of the signal (helpers/other.py:207-209)
+    double part = 0.0;
+    for (int n = tid; n < W; n += 256) {
+        const int64_t s = start + n;
+        const double v = s < p.n_samples ? p.sig[s * p.n_ch + c] * p.window[n] : 0.0;
+        part += v;
+        buf[__brev((unsigned)n) >> (32 - lg)] = make_double2(v, 0.0);  // bit-reversed order in
+    }
+    if (p.detrend) {  // mean of the WINDOWED frame (_spectral_methods.py:136-139)
+        red[tid] = part;
+        __syncthreads();
+        for (int s = 128; s > 0; s >>= 1) {
+            if (tid < s) red[tid] += red[tid + s];
+            __syncthreads();
+        }
+        const double mean = red[0] / (double)W;
+        __syncthreads();
+        for (int n = tid; n < W; n += 256) buf[n].x -= mean;  // every slot holds one sample
+    }
+    __syncthreads();
+    // radix-2 decimation in time, natural order out
+    for (int s = 0; s < lg; ++s) {
+        const int half = 1 << s;
+        for (int i = tid; i < W / 2; i += 256) {
+            const int j = i & (half - 1), a = ((i >> s) << (s + 1)) + j, b = a + half;
+            const double2 w = p.tw[(size_t)j << (lg - 1 - s)];
+            const double2 u = buf[a], v = buf[b];
+            const double2 t = make_double2(v.x * w.x - v.y * w.y, v.x * w.y + v.y * w.x);
+            buf[a] = make_double2(u.x + t.x, u.y + t.y);
+            buf[b] = make_double2(u.x - t.x, u.y - t.y);
+        }
+        __syncthreads();
+    }
+    double2* out = p.spec + ((size_t)c * p.n_frames + f) * (W / 2 + 1);
+    for (int k = tid; k <= W / 2; k += 256) out[k] = buf[k];
+}
+
+struct TfArgs {
+    const double2* xs;  // [n_cx][F][nb]
+    const double2* ys;  // [n_cy][F][nb]
+    int n_cx, n_cy, n_frames, mode;
+    dsk::FinishPar fin;
+    double2* tf;  // [nb][n_cy]
+    double* coh;  // [nb][n_cy]
+};
+
+// grid = (ceil(nb / 256), n_cy)
+__global__ __launch_bounds__(256) void k_tf(TfArgs p) {
+    const int b = blockIdx.x * 256 + threadIdx.x, c = blockIdx.y, nb = p.fin.nb;
+    if (b >= nb) return;
+    const int cx = p.n_cx == 1 ? 0 : c;
+    const double2* X = p.xs + (size_t)cx * p.n_frames * nb + b;
+    const double2* Y = p.ys + (size_t)c * p.n_frames * nb + b;
+    double sxx = 0.0, syy = 0.0;
+    cd sxy{0.0, 0.0};
+    for (int f = 0; f < p.n_frames; ++f) {
+        const double2 x = X[(size_t)f * nb], y = Y[(size_t)f * nb];
+        sxx += x.x * x.x + x.y * x.y;
+        syy += y.x * y.x + y.y * y.y;
+        sxy.x += x.x * y.x + x.y * y.y;  // conj(x) y
+        sxy.y += x.x * y.y - x.y * y.x;
+    }
+    const cd gxy = dsk::finish_cplx(sxy, b, p.fin);
+    const double gxx = dsk::finish_real(sxx, b, p.fin), gyy = dsk::finish_real(syy, b, p.fin);
+    const double axy2 = gxy.x * gxy.x + gxy.y * gxy.y;
+    cd h;
+    if (p.mode == 1) {
+        h = cd{gxy.x / gxx, gxy.y / gxx};
+    } else if (p.mode == 2) {  // see tf_from_sums (kernels_finish.hpp) for the real-negative case
+        const cd gyx = (sxy.y == 0.0) ? gxy : cd{gxy.x, -gxy.y};
+        h = cd{gyy * gyx.x / axy2, -gyy * gyx.y / axy2};
+    } else {
+        const double s = sqrt(gyy / gxx) / sqrt(axy2);
+        h = cd{gxy.x * s, gxy.y * s};
+    }
+    p.tf[(size_t)b * p.n_cy + c] = make_double2(h.x, h.y);
+    p.coh[(size_t)b * p.n_cy + c] = axy2 / gxx / gyy;
+}
+
+}  // namespace w64

@@ -31,9 +31,10 @@ def compute_transfer_function(output: Signal, input: Signal, window_length_sampl
         par.pop(k)
     if not isinstance(mode, TransferFunctionType):
         raise ValueError("Unsupported transfer function type")
+    # small problems run in float64 end to end like the reference (backend.TF_PRECISION)
     tf, coherence = backend.welch_transfer_function(
         output.time_data, input.time_data, input.sampling_rate_hz, window_length_samples,
-        mode.name, **par)
+        mode.name, precision=backend.TF_PRECISION, **par)
     spec = Spectrum(np.fft.rfftfreq(window_length_samples, 1 / input.sampling_rate_hz), tf)
     spec.set_coherence(coherence)
     return spec

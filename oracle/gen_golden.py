@@ -57,6 +57,35 @@ def save(name, meta, arrays):
     print(f"{name}: {os.path.getsize(path) / 1024:.1f} KiB, {len(meta['cases'])} cases")
 
 
+def gen_stft_anylen(dsp):
+    """Signal.get_spectrogram with fft_length_samples that are not powers of two, or shorter than
+    the window (standard/_spectral_methods.py:268: np.fft.rfft(..., n=fft_length_samples) crops or
+    zero-pads each frame; the edge-bin division by sqrt 2 touches the last bin only for even n)."""
+    from dsptoolbox.standard.enums import SpectrumScaling as S, Window
+    fs = 48000
+    rng = np.random.default_rng(41)
+    xs = rng.standard_normal((1500, 2)) * 0.4 + 0.1
+    cases, arrs = [], {"x": xs}
+    combos = [
+        (256, 50, 255, True, False, S.FFTBackward),              # W - 1: crop, odd
+        (256, 50, 384, True, True, S.FFTBackward),               # 3 * 2^7: zero-pad
+        (256, 50, 1000, False, False, S.AmplitudeSpectrum),      # 2^3 5^3
+        (512, 50, 1023, True, False, S.PowerSpectralDensity),    # odd: no Nyquist bin
+        (128, 0, 96, True, True, S.PowerSpectrum),               # 3 * 2^5 < W: crop
+        (1024, 50, 100, False, False, S.FFTOrthogonal),          # far below W
+        (64, 33, 600, True, False, S.AmplitudeSpectralDensity),
+        (256, 50, 257, True, False, S.FFTForward),               # prime
+    ]
+    for i, (W, ov, nfft, det, pad, sc) in enumerate(combos):
+        s = dsp.Signal(None, xs.copy(), fs)
+        s.set_spectrogram_parameters(window_length_samples=W, window_type=Window.Hann, overlap_percent=ov,
+                                     fft_length_samples=nfft, detrend=det, padding=pad, scaling=sc)
+        t, f, st = s.get_spectrogram()
+        cases.append(dict(W=W, overlap=ov, fft_length=nfft, detrend=det, padding=pad, scaling=sc.name))
+        arrs[f"t_{i}"], arrs[f"f_{i}"], arrs[f"stft_{i}"] = t, f, st
+    save("stft_anylen", dict(cases=cases, fs=fs), arrs)
+
+
 def gen_fir_state(dsp):
     """Filter state (zi), zero-phase and long FIR filters: Filter / FilterBank.filter_signal with
     activate_zi / zero_phase (classes/filter.py:648-743, filter_helpers.py:288-382, 454-503)."""
@@ -347,6 +376,10 @@ def main():
         import warnings
         warnings.simplefilter("ignore")
         return gen_rir(dsp)
+    if "--only-stft-anylen" in sys.argv:
+        import warnings
+        warnings.simplefilter("ignore")
+        return gen_stft_anylen(dsp)
     if "--only-istft" in sys.argv:
         import warnings
         warnings.simplefilter("ignore")
@@ -625,6 +658,7 @@ def main():
               ir_peak=np.array([np.max(np.abs(ir.time_data))])))
     gen_fir_state(dsp)
     gen_istft(dsp)
+    gen_stft_anylen(dsp)
     gen_rir(dsp)
     gen_das(dsp)
     gen_mel(dsp)

@@ -167,6 +167,17 @@ def test_fir_state_zero_phase_long():
             close(y, z["y_long"], tol=1e-6)  # stored as float32
 
 
+def test_stft_any_fft_length():
+    meta, z = load_golden("stft_anylen")
+    for i, c in enumerate(meta["cases"]):
+        t, f, s = orc.stft(z["x"], meta["fs"], c["W"], "hann", c["overlap"], c["fft_length"],
+                           c["detrend"], c["padding"], c["scaling"])
+        close(t, z[f"t_{i}"])
+        close(f, z[f"f_{i}"])
+        close(s, z[f"stft_{i}"])
+        assert s.dtype == z[f"stft_{i}"].dtype
+
+
 def test_istft():
     """transforms.istft incl. its quirks (step from the un-rounded overlap, empty edge frames)."""
     meta, z = load_golden("istft")
