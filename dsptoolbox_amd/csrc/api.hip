@@ -25,6 +25,7 @@
 #include "kernels_welch8192.hpp"
 #include "kernels_welch_f64.hpp"
 #include "kernels_stft_any.hpp"
+#include "kernels_fir_stream.hpp"
 
 using namespace dsk;
 
@@ -2323,6 +2324,80 @@ extern "C" int ds_fir_ola(ds_ctx* c, const float* x, int n_ch, int64_t n_samples
     CHK(ds_upload(c, dt, taps, nt * 4));
     CHK(ds_fir_ola_dev(c, dx, n_ch, n_samples, n_samples, dt, n_filt, n_taps, mode, dy, n_samples));
     return ds_download(c, y, dy, no * 4);
+}
+
+// ---- block-streaming FIR classes, state on the device (kernels_fir_stream.hpp) ----------
+static int stream_ones(ds_ctx* c, float* dst, int n) {  // n_call unit impulses of length 1
+    std::vector<float> h((size_t)n, 1.0f);
+    HIPCHK(c, hipMemcpyAsync(dst, h.data(), sizeof(float) * (size_t)n, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));  // h goes out of scope
+    return DS_OK;
+}
+
+extern "C" int ds_fir_part_step_dev(ds_ctx* c, float* inbuf, const float* block, int bs, int n_ch, int ch0,
+                                    int n_call, const ds_c32* h, int n_part, int n_fir_ch, ds_c32* delay,
+                                    int ind, float* out) {
+    if (!c || !inbuf || !block || !h || !delay || !out) return fail(c, DS_ERR_ARG, "ds_fir_part_step: null argument");
+    if (bs < 1 || n_ch < 1 || ch0 < 0 || n_call < 1 || ch0 + n_call > n_ch || n_part < 1 || ind < 0 || ind >= n_part ||
+        (n_fir_ch != 1 && n_fir_ch != n_ch))
+        return fail(c, DS_ERR_ARG, "ds_fir_part_step: bad shape");
+    const int n_fft = 2 * bs, B = bs + 1;
+    CHK(reserve(c, &c->aux, &c->aux_bytes,
+                2 * Carver::pad(sizeof(float2) * (size_t)B * n_call) + Carver::pad(sizeof(float) * (size_t)n_call * n_fft) +
+                    Carver::pad(sizeof(float) * (size_t)n_call)));
+    Carver cv(c->aux);
+    float2* X = cv.take<float2>((size_t)B * n_call);
+    float2* Y = cv.take<float2>((size_t)B * n_call);
+    float* full = cv.take<float>((size_t)n_call * n_fft);
+    float* ones = cv.take<float>(n_call);
+    CHK(stream_ones(c, ones, n_call));
+    const int64_t nb = (int64_t)n_call * bs;
+    hipLaunchKernelGGL(firstream::k_shift_in, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, c->stream, inbuf, block,
+                       bs, ch0, n_call);
+    HIPCHK(c, hipGetLastError());
+    CHK(ds_rfft_dev(c, inbuf + (int64_t)ch0 * n_fft, n_call, n_fft, n_fft, n_fft, 1.0f, (ds_c32*)X));
+    firstream::AccArgs aa{X, (float2*)delay, (const float2*)h, Y, B, n_part, n_ch, n_fir_ch, ch0, n_call, ind};
+    const int64_t na = (int64_t)B * n_call;
+    CHK(launch(c, "fir_part_acc", firstream::k_part_acc, dim3((unsigned)((na + 255) / 256)), 256, 0, aa));
+    // numpy's irfft of bs + 1 bins without a length: 2 bs points
+    CHK(ds_deconv_dev(c, ones, 1, n_call, 1, 1, n_fft, (const ds_c32*)Y, 1, n_fft, n_fft, full));
+    hipLaunchKernelGGL(firstream::k_tail, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, c->stream,
+                       (const float*)full, (int64_t)n_fft, bs, n_call, out);
+    HIPCHK(c, hipGetLastError());
+    return DS_OK;
+}
+
+extern "C" int ds_fir_ols_step_dev(ds_ctx* c, float* row, const float* block, int bs, int64_t L,
+                                   const ds_c32* h, float* out) {
+    if (!c || !row || !block || !h || !out) return fail(c, DS_ERR_ARG, "ds_fir_ols_step: null argument");
+    if (bs < 1 || L < 2 || bs > L || L > ((int64_t)1 << 22)) return fail(c, DS_ERR_ARG, "ds_fir_ols_step: bad shape");
+    const int B = (int)(L / 2 + 1);
+    const int64_t n_inv = 2 * (int64_t)(B - 1);  // L for even L, L - 1 for odd L: irfft without a length
+    if (bs > n_inv) return fail(c, DS_ERR_ARG, "ds_fir_ols_step: block longer than the inverse transform");
+    CHK(reserve(c, &c->aux, &c->aux_bytes,
+                2 * Carver::pad(sizeof(float2) * (size_t)B) + 2 * Carver::pad(sizeof(float) * (size_t)L) +
+                    Carver::pad(sizeof(float))));
+    Carver cv(c->aux);
+    float2* X = cv.take<float2>(B);
+    float2* Y = cv.take<float2>(B);
+    float* full = cv.take<float>((size_t)L);
+    float* roll = cv.take<float>((size_t)L);
+    float* one = cv.take<float>(1);
+    CHK(stream_ones(c, one, 1));
+    hipLaunchKernelGGL(firstream::k_ols_put, dim3((bs + 255) / 256), dim3(256), 0, c->stream, row, block, L, bs);
+    HIPCHK(c, hipGetLastError());
+    CHK(ds_rfft_dev(c, row, 1, L, L, (int)L, 1.0f, (ds_c32*)X));
+    hipLaunchKernelGGL(firstream::k_cmul, dim3((B + 255) / 256), dim3(256), 0, c->stream, (const float2*)X,
+                       (const float2*)h, Y, B);
+    HIPCHK(c, hipGetLastError());
+    CHK(ds_deconv_dev(c, one, 1, 1, 1, 1, (int)n_inv, (const ds_c32*)Y, 0, n_inv, n_inv, full));
+    hipLaunchKernelGGL(firstream::k_tail, dim3((bs + 255) / 256), dim3(256), 0, c->stream, (const float*)full, n_inv, bs,
+                       1, out);
+    hipLaunchKernelGGL(firstream::k_ols_roll, dim3((unsigned)((L + 255) / 256)), dim3(256), 0, c->stream,
+                       (const float*)row, roll, L, bs);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(row, roll, sizeof(float) * (size_t)L, hipMemcpyDeviceToDevice, c->stream));
+    return DS_OK;
 }
 
 // ---- RCCL (resolved at run time so the library loads on machines without it) ----

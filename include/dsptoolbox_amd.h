@@ -280,6 +280,26 @@ int ds_fir_ola_dev(ds_ctx* ctx, const float* x_dev, int n_ch, int64_t ldx,
 int ds_fir_ola(ds_ctx* ctx, const float* x, int n_ch, int64_t n_samples,
                const float* taps, int n_filt, int n_taps, int mode, float* y);
 
+/* ---- block-streaming FIR classes with device-resident state ------------------------------
+ * One process_block of the reference's real-time classes (classes/fir_filter_realtime.py:75-335),
+ * executed literally on buffers that stay on the device between calls; per call only the block
+ * goes up and the filtered block comes back.
+ * ds_fir_part_step_dev: FIRUniformPartitioned (:206-240) / FIRUniformPartitionedMultichannel
+ *   (:296-335) for the channels [ch0, ch0 + n_call): shift the 2*bs input buffers, transform,
+ *   store the spectra at slot `ind` of the delay line S[b][P][C], accumulate
+ *   sum_p H[b][p][ch or 0] * S[b][(ind - p) mod P][ch], inverse transform, return the last bs
+ *   samples.  inbuf [C][2 bs], block [n_call][bs], H [bs + 1][P][Cf] (Cf = 1: one impulse
+ *   response for all channels, else Cf = C), out [n_call][bs].  The caller advances `ind`.
+ * ds_fir_ols_step_dev: FIRFilterOverlapSave.process_block (:120-142) for ONE channel: buffer row
+ *   [L] (L = next_fast_len(T + bs), any length), H [L / 2 + 1]; the inverse transform has the
+ *   length numpy's irfft picks without an argument, 2 (L / 2) -- so for odd L the block is NOT
+ *   the convolution, exactly as in the reference; the buffer is rolled by bs afterwards.     */
+int ds_fir_part_step_dev(ds_ctx* ctx, float* inbuf_dev, const float* block_dev, int bs, int n_ch,
+                         int ch0, int n_call, const ds_c32* h_dev, int n_part, int n_fir_ch,
+                         ds_c32* delay_dev, int ind, float* out_dev);
+int ds_fir_ols_step_dev(ds_ctx* ctx, float* buffer_row_dev, const float* block_dev, int bs,
+                        int64_t total_length, const ds_c32* h_dev, float* out_dev);
+
 /* ---- host marshalling (no device work): the reference hands (samples, channels) float64
  * C-order arrays (classes/signal.py:222-301) and expects the same back; the kernels take planar
  * float32.  Multi-threaded cast + transpose on the host (numpy's strided cast takes 0.2 s for the
