@@ -495,7 +495,7 @@ extern "C" int ds_stft_r2c_dev(ds_ctx* c, const float* x, int64_t n_samples, int
     // register transforms, one frame pair per team of nfft/16 lanes (kernels_stft1024.hpp)
     static const bool stft_generic = getenv("DSPTOOLBOX_AMD_STFT_GENERIC") != nullptr;
     if ((nfft == 2048 || nfft == 1024 || nfft == 512 || nfft == 256) && (W == nfft || (W < nfft && !detrend)) &&
-        !stft_generic) {
+        !stft_generic && stft1k::stft_wave_fits(n_samples, n_ch, ld, pad_front, nfft)) {
         const int slot = nfft == 1024 ? 0 : (nfft == 512 ? 1 : (nfft == 256 ? 2 : 3));
         float2** tab = slot == 0 ? &c->stft1k_tables : &c->stft_wave_tables[slot - 1];
         if (!*tab) {
@@ -550,10 +550,10 @@ extern "C" int ds_stft_r2c_dev(ds_ctx* c, const float* x, int64_t n_samples, int
     int threads = 0;
     DISPATCH_N(nfft, {
         const size_t per = (size_t)stft_ch_stride<NN>() * sizeof(float2);
-        ct = std::min<int>({16, 1024 / Cfg<NN>::NT, std::max<int>(1, (int)((74 * 1024) / per)), n_ch});
-        if (const char* e = getenv("DSPTOOLBOX_AMD_STFT_CT")) {
+        ct = std::min<int>(stft_max_teams<NN>(), n_ch);
+        if (const char* e = getenv("DSPTOOLBOX_AMD_STFT_CT")) {  // fewer teams only: the kernel is compiled for the maximum
             int v = atoi(e);
-            if (v >= 1 && v <= 1024 / Cfg<NN>::NT && (size_t)v * per <= 150 * 1024) ct = std::min(v, std::max(1, n_ch));
+            if (v >= 1 && v <= stft_max_teams<NN>()) ct = std::min(v, std::max(1, n_ch));
         }
         while (ct & (ct - 1)) ct &= ct - 1;  // power of two (shift-only index math in the kernel)
         lds = per * ct;
@@ -866,20 +866,16 @@ static int welch8192_run(ds_ctx* c, const float* x, int64_t ldx, const float* y,
     w8::Args ax{x, n_samples, ldx, 1, hop, nf, pl.n_pairs, detrend, pl.n_chunks, window,
                 c->w4_tables, c->deconv8k_tables, (float4*)xs, px, pxy, pyy, psx};
     auto kx = half ? w8::k_x<true> : w8::k_x<false>;
-    auto ky = half ? w8::k_y<true> : w8::k_y<false>;
     CHK(launch(c, "welch8192_x", kx, dim3(pl.n_pairs), w8::NTB, w8::LDS_BYTES, ax));
     w8::Args ay = ax;
     ay.sig = y;
     ay.ld = ldy;
     ay.n_ch = n_cy;
-    // window in LDS + one exchange buffer per group (0.226 ms) unless the global-window / two-buffer
-    // variant (0.280 ms) is asked for
-    static const bool winlds = getenv("DSPTOOLBOX_AMD_W8_WINGLOBAL") == nullptr;
-    if (winlds) {
+    // window in LDS + one exchange buffer per group (0.226 ms; the global-window / two-buffer
+    // variant measured 0.280 ms and spilled: removed)
+    {
         auto kyw = half ? w8::k_y<true, true> : w8::k_y<false, true>;
         CHK(launch(c, "welch8192_main", kyw, dim3(pl.n_chunks * n_cy), w8::NTB, w8::LDS_BYTES_WINLDS, ay));
-    } else {
-        CHK(launch(c, "welch8192_main", ky, dim3(pl.n_chunks * n_cy), w8::NTB, w8::LDS_BYTES, ay));
     }
     WelchFinArgs f{psx, pxy, pyy, pl.n_chunks, pl.n_chunks, 1, n_cy, 0, mode,
                    FinishPar{norm_scale / (double)n_frames, factor, halve_edges, amp_sqrt, w8::NB},
@@ -1058,10 +1054,11 @@ extern "C" int ds_welch_tf_dev(ds_ctx* c, const float* x, int n_cx, int64_t ldx,
         return welch4096_run(c, x, ldx, y, n_cy, ldy, n_samples, hop, n_frames, window, detrend, mode,
                              amp_sqrt, norm_scale, factor, halve_edges, (float2*)tf, coh);
     static const bool no1k = getenv("DSPTOOLBOX_AMD_WELCH_GENERIC") != nullptr;
-    if (c && W == 8192 && n_cx == 1 && average == DS_AVG_MEAN && !no1k)
+    if (c && W == 8192 && n_cx == 1 && average == DS_AVG_MEAN && !no1k && welch8k::buf_fits(n_samples, n_frames, hop))
         return welch8192_run(c, x, ldx, y, n_cy, ldy, n_samples, hop, n_frames, window, detrend, mode,
                              amp_sqrt, norm_scale, factor, halve_edges, (float2*)tf, coh);
-    if (c && (W == 2048 || W == 1024 || W == 512 || W == 256) && n_cx == 1 && average == DS_AVG_MEAN && !no1k) {
+    if (c && (W == 2048 || W == 1024 || W == 512 || W == 256) && n_cx == 1 && average == DS_AVG_MEAN && !no1k &&
+        welch1k::buf_fits(n_samples, n_cy, ldy)) {
         auto run = W == 2048 ? welch_wave_run<2048>
                              : (W == 1024 ? welch_wave_run<1024> : (W == 512 ? welch_wave_run<512> : welch_wave_run<256>));
         return run(c, x, ldx, y, n_cy, ldy, n_samples, hop, n_frames, window, detrend, mode, amp_sqrt,
@@ -1127,13 +1124,14 @@ extern "C" int ds_welch_psd_dev(ds_ctx* c, const float* x, int n_cx, int64_t ldx
                                 int halve_edges, float* psd) {
     if (!psd) return fail(c, DS_ERR_ARG, "ds_welch_psd: null output");
     static const bool no1k = getenv("DSPTOOLBOX_AMD_WELCH_GENERIC") != nullptr;
-    if (c && W == 8192 && average == DS_AVG_MEAN && !no1k)
+    if (c && W == 8192 && average == DS_AVG_MEAN && !no1k && welch8k::buf_fits(n_samples, n_frames, hop))
         return welch8192_psd_run(c, x, n_cx, ldx, n_samples, hop, n_frames, window, detrend, amp_sqrt,
                                  norm_scale, factor, halve_edges, psd);
     if (c && W == 4096 && average == DS_AVG_MEAN && welch4096::enabled() && !no1k)
         return welch4096_psd_run(c, x, n_cx, ldx, n_samples, hop, n_frames, window, detrend, amp_sqrt,
                                  norm_scale, factor, halve_edges, psd);
-    if (c && (W == 2048 || W == 1024 || W == 512 || W == 256) && average == DS_AVG_MEAN && !no1k) {
+    if (c && (W == 2048 || W == 1024 || W == 512 || W == 256) && average == DS_AVG_MEAN && !no1k &&
+        welch1k::buf_fits(n_samples, n_cx, ldx)) {
         auto run = W == 2048 ? welch_wave_psd_run<2048>
                              : (W == 1024 ? welch_wave_psd_run<1024>
                                           : (W == 512 ? welch_wave_psd_run<512> : welch_wave_psd_run<256>));

@@ -177,8 +177,21 @@ struct StftArgs {
 template <int N>
 __host__ __device__ constexpr int stft_ch_stride() { return ((lds_len<N>() + 2 + 30) / 32) * 32 + 1; }
 
+// channel teams per workgroup the host may ask for: <= 16, <= 1024 threads, <= 74 KB of LDS (two
+// workgroups per CU), a power of two -- and the thread count the kernel is compiled for (a blanket
+// __launch_bounds__(1024) capped every length at 128 registers: 4096 points spilled 268 bytes)
 template <int N>
-__global__ __launch_bounds__(1024) void k_stft(StftArgs p) {
+__host__ __device__ constexpr int stft_max_teams() {
+    int ct = 16;
+    if (1024 / Cfg<N>::NT < ct) ct = 1024 / Cfg<N>::NT;
+    const int by_lds = (int)((74 * 1024) / ((size_t)stft_ch_stride<N>() * sizeof(float2)));
+    if (by_lds < ct) ct = by_lds < 1 ? 1 : by_lds;
+    int p2 = 1;
+    while (2 * p2 <= ct) p2 *= 2;
+    return p2;
+}
+template <int N>
+__global__ __launch_bounds__(stft_max_teams<N>() * Cfg<N>::NT) void k_stft(StftArgs p) {
     using C = Cfg<N>;
     constexpr int NB = N / 2 + 1, CHS = stft_ch_stride<N>();
     extern __shared__ __align__(16) float2 lds[];

@@ -55,8 +55,15 @@ constexpr int S1 = Geo<1024>::S1, REGION = Geo<1024>::REGION, TW1 = Geo<1024>::T
 // channel-fastest read-out fall on distinct banks; even (float4-aligned images): ct <= 16
 template <int NN>
 __host__ __device__ constexpr int ch_stride(int ct) { return Geo<NN>::REGION + (ct > 1 ? 32 / ct : 0); }
+// images + twiddle tables (+ the window, NN floats, zero beyond the caller's window length, for the
+// lengths whose images leave room: at 2048 points eight 17 KB images fill the CU)
 template <int NN>
-inline size_t lds_bytes(int ct) { return ((size_t)ct * ch_stride<NN>(ct) + Geo<NN>::TW_LEN) * sizeof(float2); }
+__host__ __device__ constexpr bool win_in_lds() { return NN <= 1024; }
+template <int NN>
+inline size_t lds_bytes(int ct) {
+    return ((size_t)ct * ch_stride<NN>(ct) + Geo<NN>::TW_LEN) * sizeof(float2) +
+           (win_in_lds<NN>() ? (size_t)NN * sizeof(float) : 0);
+}
 
 // [15][L] W_N^(t k1) (k1 = 1..15), then [16][R3] W_(16 R3)^(n3 k2); fp64-computed
 template <int NN>
@@ -202,6 +209,49 @@ __device__ __forceinline__ void fft1024(float2 (&v)[16], float2 (&z)[16], float2
     fft_wave<1024, Hook>(v, z, buf, tw1, tw2, t, behind_ex2);
 }
 
+// Raw samples of a frame pair through ONE raw-buffer descriptor over the whole planar signal
+// (32-bit byte offsets in a single register per frame).  The generic loader keeps a 64-bit
+// address per group of loads; at the 128 registers two 512-thread workgroups per CU allow those
+// addresses were spilled and every reload carried an `s_waitcnt vmcnt(0)` that drained the previous
+// pair's output stores.  Interior pairs load unconditionally; for a pair that touches the front
+// padding, the end of the signal or a missing second frame each offset is replaced by an
+// out-of-range one where the sample does not exist, and the hardware range check returns 0.
+struct Raw16 {
+    float a[16], b[16];
+};
+__device__ __forceinline__ float ld_f32(__amdgpu_buffer_rsrc_t r, uint32_t byte_off) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)byte_off, 0, 0));
+}
+template <int L>
+__device__ __forceinline__ void load_pair_buf(Raw16& r, __amdgpu_buffer_rsrc_t rs, uint32_t chan_samples, bool live,
+                                              int start_a, int start_b, bool have_b, int n_samples, int t) {
+    constexpr uint32_t OOB = 0xFFFFFFF0u;
+    constexpr int NN = 16 * L;
+    const bool interior = live && start_a >= 0 && (have_b ? start_b : start_a) + NN <= n_samples;
+    if (interior) {
+        const uint32_t oa = (chan_samples + (uint32_t)(start_a + t)) * 4u;
+        const uint32_t ob = have_b ? (chan_samples + (uint32_t)(start_b + t)) * 4u : OOB - 64u * L;
+#pragma unroll
+        for (int n1 = 0; n1 < 16; ++n1) {
+            r.a[n1] = ld_f32(rs, oa + 4u * L * n1);
+            r.b[n1] = ld_f32(rs, have_b ? ob + 4u * L * n1 : OOB);
+        }
+    } else {
+        const uint32_t ns = live ? (uint32_t)n_samples : 0u;
+#pragma unroll
+        for (int n1 = 0; n1 < 16; ++n1) {
+            const int sa = start_a + t + L * n1, sb = start_b + t + L * n1;
+            r.a[n1] = ld_f32(rs, (uint32_t)sa < ns ? (chan_samples + (uint32_t)sa) * 4u : OOB);
+            r.b[n1] = ld_f32(rs, (have_b && (uint32_t)sb < ns) ? (chan_samples + (uint32_t)sb) * 4u : OOB);
+        }
+    }
+}
+// the host takes this kernel only when the byte offsets fit (stft_wave_fits)
+inline bool stft_wave_fits(int64_t n_samples, int n_ch, int64_t ld, int64_t pad_front, int nfft) {
+    return ((int64_t)(n_ch - 1) * ld + n_samples) * 4 < ((int64_t)1 << 32) - ((int64_t)1 << 20) &&
+           n_samples + pad_front + 4 * (int64_t)nfft < ((int64_t)1 << 30);
+}
+
 // grid = (ceil(ceil(n_frames/2)/fpw), ceil(n_ch/ct)); block = ct teams of L lanes; p.tw =
 // host_tables<NN>(); p.W <= NN (shorter windows are zero-padded); detrend requires p.W == NN, where
 // removing the frame mean only clears bin 0 (a constant has no other bin).
@@ -218,29 +268,36 @@ __global__ __launch_bounds__(1024) void k_stft_wave(StftArgs p) {
     float2* tw1 = lds + p.ct * CHS;
     const float2* tw2 = tw1 + G::TW1;
     for (int i = threadIdx.x; i < G::TW_LEN; i += blockDim.x) tw1[i] = p.tw[i];
+    // the window lives in LDS (16 registers less per lane: with them the kernel spilled 19 dwords
+    // at the 128 registers that two 512-thread workgroups per CU allow)
+    float* winl = reinterpret_cast<float*>(tw1 + G::TW_LEN);
+    float winr[win_in_lds<NN>() ? 1 : 16];
+    if constexpr (win_in_lds<NN>()) {
+        for (int i = threadIdx.x; i < NN; i += blockDim.x) winl[i] = i < p.W ? p.window[i] : 0.f;
+    } else {
+#pragma unroll
+        for (int n1 = 0; n1 < 16; ++n1)
+            winr[n1] = p.window[min(t + L * n1, p.W - 1)] * (t + L * n1 < p.W ? 1.f : 0.f);
+    }
     const int c0 = blockIdx.y * p.ct;
     const int ctv = min(p.ct, p.n_ch - c0);
     const int c = c0 + team;
-    const float* xc = c < p.n_ch ? p.x + (int64_t)c * p.ld : nullptr;  // idle teams transform zeros
+    const bool live = c < p.n_ch;  // idle teams transform zeros
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.x), 0, (int)(uint32_t)(((int64_t)(p.n_ch - 1) * p.ld + p.n_samples) * 4), 0x00020000);
+    const uint32_t chan = live ? (uint32_t)((int64_t)c * p.ld) : 0u;
     const int64_t F = p.n_frames, Cn = p.n_ch;
     const int lct = __ffs(p.ct) - 1;
     const int cl = threadIdx.x & (p.ct - 1), r0 = threadIdx.x >> lct;  // read-out: channel, first row (< L)
     const int n_fp = (p.n_frames + 1) >> 1;
     const int fp0 = blockIdx.x * p.fpw, fp1 = min(fp0 + p.fpw, n_fp);
-    auto src = [&](int fp, FrameSrc& a, FrameSrc& b) {
-        const int f0 = 2 * fp, f1 = f0 + 1;
-        a = FrameSrc{xc, (int64_t)f0 * p.hop - p.pad_front};
-        b = FrameSrc{f1 < p.n_frames ? xc : nullptr, (int64_t)f1 * p.hop - p.pad_front};
+    Raw16 raw;
+    auto load = [&](int fp) {
+        const int f0 = 2 * fp;
+        const int sa = (int)((int64_t)f0 * p.hop - p.pad_front);
+        load_pair_buf<L>(raw, rs, chan, live, sa, sa + p.hop, f0 + 1 < p.n_frames, (int)p.n_samples, t);
     };
-    RawPair<NN> raw;
-    FrameSrc a, b;
-    if (fp0 < fp1) {
-        src(fp0, a, b);
-        dsk::load_raw_pair<NN>(raw, a, b, p.n_samples, p.W, t);
-    }
-    float win[16];
-#pragma unroll
-    for (int n1 = 0; n1 < 16; ++n1) win[n1] = p.window[min(t + L * n1, p.W - 1)] * (t + L * n1 < p.W ? 1.f : 0.f);
+    if (fp0 < fp1) load(fp0);
     // Drain the loads above before the loop: otherwise the wait for them is merged into the loop body
     // (vmcnt is a FIFO count) and stalls every iteration on the prefetch it has just issued.
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
@@ -256,12 +313,11 @@ __global__ __launch_bounds__(1024) void k_stft_wave(StftArgs p) {
         float2 v[16];
         __syncthreads();  // tables written / the previous pair has been streamed out
 #pragma unroll
-        for (int n1 = 0; n1 < 16; ++n1) v[n1] = make_float2(raw.a[n1] * win[n1], raw.b[n1] * win[n1]);
-        if (fp + 1 < fp1) {
-            FrameSrc na, nb;
-            src(fp + 1, na, nb);
-            dsk::load_raw_pair<NN>(raw, na, nb, p.n_samples, p.W, t);
+        for (int n1 = 0; n1 < 16; ++n1) {
+            const float w = win_in_lds<NN>() ? winl[t + L * n1] : winr[win_in_lds<NN>() ? 0 : n1];
+            v[n1] = make_float2(raw.a[n1] * w, raw.b[n1] * w);
         }
+        if (fp + 1 < fp1) load(fp + 1);
         float2 z[16];
         fft_wave<NN>(v, z, buf, tw1, tw2, t);
         // ---- separation: bins k = t + L j (j < 8) against Z[N - k], which sits in the upper half

@@ -88,6 +88,47 @@ __device__ __forceinline__ void load_raw(Raw<HALF_HOP>& r, const float* __restri
         }
     }
 }
+// The same samples through ONE raw-buffer descriptor over the whole planar signal: a 32-bit byte
+// offset per load instead of 64-bit addresses (which the register cap of three workgroups per CU
+// pushed into scratch: 120 bytes per lane for the 1024-point kernel, each reload behind an
+// `s_waitcnt vmcnt(0)`).  Samples past the end come back as 0 from the hardware range check: a
+// pair that reaches past n_samples gets out-of-range offsets where the sample does not exist.
+template <int NN, bool HALF_HOP>
+__device__ __forceinline__ void load_raw_buf(Raw<HALF_HOP>& r, __amdgpu_buffer_rsrc_t rs, uint32_t chan_samples,
+                                             bool live, int64_t start0, int hop, int64_t n_samples, int t) {
+    constexpr int L = NN / 16;
+    constexpr int CNT = HALF_HOP ? 24 : 32;
+    constexpr uint32_t OOB = 0xFFFFFFF0u;
+    const int span = HALF_HOP ? 3 * (NN / 2) : hop + NN;
+    if (live && start0 + span <= n_samples) {
+        const uint32_t o = (chan_samples + (uint32_t)start0 + (uint32_t)t) * 4u;
+#pragma unroll
+        for (int m = 0; m < CNT; ++m) {
+            const uint32_t i = HALF_HOP ? L * m : (m < 16 ? L * m : hop + L * (m - 16));
+            r.s[m] = stft1k::ld_f32(rs, o + 4u * i);
+        }
+    } else {
+        // samples of this pair that exist (32-bit: the pair spans at most hop + NN samples)
+        const int64_t rem = n_samples - start0;
+        const int left = !live || rem <= 0 ? 0 : (rem > (int64_t)(1 << 20) ? (1 << 20) : (int)rem);
+        // lane index against a SCALAR limit per load (a per-load lane value would be hoisted out of
+        // the pair loop into 24 more registers)
+        // (the lane index is laundered so that the per-load lane values of this rare path are
+        // computed here and not hoisted out of the pair loop into registers the hot path needs)
+        int tt = t;
+        asm volatile("" : "+v"(tt));
+        const uint32_t ot = (chan_samples + (uint32_t)start0 + (uint32_t)tt) * 4u;
+#pragma unroll
+        for (int m = 0; m < CNT; ++m) {
+            const int im = HALF_HOP ? L * m : (m < 16 ? L * m : hop + L * (m - 16));  // wave-uniform
+            r.s[m] = stft1k::ld_f32(rs, tt < left - im ? ot + 4u * (uint32_t)im : OOB);
+        }
+    }
+}
+inline bool buf_fits(int64_t n_samples, int n_ch, int64_t ld) {
+    return ((int64_t)(n_ch - 1) * ld + n_samples) * 4 < ((int64_t)1 << 32) - ((int64_t)1 << 20);
+}
+
 template <int NN, bool HALF_HOP>
 __device__ __forceinline__ void window_pair(float2 (&v)[16], const Raw<HALF_HOP>& r, const float* winl, int t) {
     constexpr int L = NN / 16;
@@ -193,9 +234,11 @@ __global__ __launch_bounds__(NTB, 3) void k_y(Args p) {
     const bool live = c < p.n_ch;
     // balanced split of the pairs over the chunks (n_chunks stays a multiple of 8 for the XCD mapping)
     const int p0 = (int)((int64_t)q * p.n_pairs / p.n_chunks), p1 = (int)((int64_t)(q + 1) * p.n_pairs / p.n_chunks);
-    const float* ch = p.sig + (int64_t)(live ? c : 0) * p.ld;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.sig), 0, (int)(uint32_t)(((int64_t)(p.n_ch - 1) * p.ld + p.n_samples) * 4), 0x00020000);
+    const uint32_t chan = live ? (uint32_t)((int64_t)c * p.ld) : 0u;
     Raw<HALF_HOP> raw;
-    if (p0 < p1) load_raw<NN, HALF_HOP>(raw, ch, p.n_samples, (int64_t)(2 * p0) * p.hop, p.hop, t);
+    if (p0 < p1) load_raw_buf<NN, HALF_HOP>(raw, rs, chan, live, (int64_t)(2 * p0) * p.hop, p.hop, p.n_samples, t);
     float* winl = reinterpret_cast<float*>(tw1 + W::G::TW_LEN);
     load_tables<NN>(tw1, winl, p);
     if (!AUTO) {
@@ -227,7 +270,8 @@ __global__ __launch_bounds__(NTB, 3) void k_y(Args p) {
 #pragma unroll
             for (int n1 = 0; n1 < 16; ++n1) v[n1].y = 0.f;
         }
-        if (pr + 1 < p1) load_raw<NN, HALF_HOP>(raw, ch, p.n_samples, (int64_t)(2 * pr + 2) * p.hop, p.hop, t);
+        if (pr + 1 < p1)
+            load_raw_buf<NN, HALF_HOP>(raw, rs, chan, live, (int64_t)(2 * pr + 2) * p.hop, p.hop, p.n_samples, t);
         if constexpr (AUTO) {
             fft_wave<NN>(v, z, buf, tw1, tw2, t);
 #pragma unroll

@@ -78,6 +78,26 @@ __device__ __forceinline__ void load_raw(Raw<HALF_HOP>& r, const float* __restri
     }
 }
 
+// The same samples through a raw-buffer descriptor of the channel: 32-bit offsets, and samples at
+// or past n_samples come back as 0 from the hardware range check -- no ragged-tail path, no 64-bit
+// address registers (the kernel sits at the 256-register limit; they were spilled).
+template <bool HALF_HOP>
+__device__ __forceinline__ void load_raw_buf(Raw<HALF_HOP>& r, __amdgpu_buffer_rsrc_t rs, int64_t start0, int hop, int t) {
+    constexpr int SEG = HALF_HOP ? 3 : 4;
+    const uint32_t o = ((uint32_t)start0 + (uint32_t)t) * 4u;
+#pragma unroll
+    for (int j = 0; j < SEG; ++j) {
+        const uint32_t off = HALF_HOP ? (uint32_t)(M * j) : (uint32_t)(j < 2 ? M * j : hop + M * (j - 2));
+#pragma unroll
+        for (int n1 = 0; n1 < 16; ++n1)
+            r.s[16 * j + n1] = __builtin_bit_cast(
+                float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)(o + 4u * (off + 256u * n1)), 0, 0));
+    }
+}
+inline bool buf_fits(int64_t n_samples, int n_frames, int hop) {
+    return n_samples < ((int64_t)1 << 30) - 4 * N && (int64_t)(n_frames + 2) * hop < ((int64_t)1 << 30) - 4 * N;
+}
+
 // window, pack the two frames and run the radix-2 front end of class q:
 // v[n1] = (z[n'] + (-1)^q z[n' + 4096]) W8192^(n' q), n' = t + 256 n1
 template <bool HALF_HOP>
@@ -207,7 +227,9 @@ __global__ __launch_bounds__(NTB, 1) void k_y(Args p) {
         P[j] = 0.f;
     }
     Raw<HALF_HOP> raw;
-    if (p0 < p1) load_raw<HALF_HOP>(raw, ch, p.n_samples, (int64_t)(2 * p0) * p.hop, p.hop, t);
+    const __amdgpu_buffer_rsrc_t rs =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ch), 0, (int)(uint32_t)(p.n_samples * 4), 0x00020000);
+    if (p0 < p1) load_raw_buf<HALF_HOP>(raw, rs, (int64_t)(2 * p0) * p.hop, p.hop, t);
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): keep the pre-loop loads out of the loop's wait counts
     for (int pr = p0; pr < p1; ++pr) {
         float2 v[16];
@@ -215,7 +237,7 @@ __global__ __launch_bounds__(NTB, 1) void k_y(Args p) {
         float2 xw[16];
         auto issue_loads = [&]() {
             __builtin_amdgcn_sched_barrier(0);
-            if (pr + 1 < p1) load_raw<HALF_HOP>(raw, ch, p.n_samples, (int64_t)(2 * pr + 2) * p.hop, p.hop, t);
+            if (pr + 1 < p1) load_raw_buf<HALF_HOP>(raw, rs, (int64_t)(2 * pr + 2) * p.hop, p.hop, t);
             __builtin_amdgcn_sched_barrier(0);
         };
         auto issue_xs = [&]() {
