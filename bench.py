@@ -14,8 +14,9 @@ N > 1: one process per GPU (torch.distributed.run).
   --scaling strong the ONE 64-channel job is split: output channels /
                    bands / items / bins by shard_range, the shared input by ds_bcast, and every
                    step ends with the RCCL all-gather of the result slices (ds_allgather).
-At N = 1 the per-rank shard shape of an 8-GPU strong-scaling job is timed as well and the
-implied speed-up T(full) / T(shard) is printed ("shard_prediction").
+At N = 1, `--predict-ranks 8` also times the per-rank shard shape of an 8-GPU strong-scaling
+job and prints the implied speed-up T(full) / T(shard) ("shard_prediction"; results of this
+round: profiles/r02_shard_prediction.jsonl).
 
 Prints ONE JSON line on rank 0.
 """
@@ -47,8 +48,10 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=200)   # timed region of tens of ms
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
-    ap.add_argument("--predict-ranks", type=int, default=8,
-                    help="N = 1: world size whose per-rank shard is timed for shard_prediction (0: off)")
+    ap.add_argument("--predict-ranks", type=int, default=0,
+                    help="N = 1: also time the per-rank shard of a strong-scaling job over this many GPUs and "
+                         "print shard_prediction (off by default: those launches reuse the dominant kernel with a "
+                         "smaller grid and would dilute its average in a rocprofv3 trace of this command)")
     ap.add_argument("--workload", default="welch_h1",
                     choices=["welch_h1", "welch_h1_1024", "fir_bank", "csm", "deconv"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -557,6 +560,14 @@ def main():
         floor_ms = pmc["SQ_INSTS_VALU"] * 2.0 / 1024.0 / 2.4e9 * 1e3
         roof["valu_issue"] = dict(insts_per_launch=pmc["SQ_INSTS_VALU"], floor_ms_at_2p4_ghz=floor_ms,
                                   valu_issue_frac=floor_ms / dom_ms, source=src)
+    if bound == "mfma" and pmc.get("SQ_INSTS_MFMA"):
+        # the flops the matrix pipe really executes (v_mfma_f32_32x32x2_f32 = 4096 flop): the Hermitian
+        # structure lets the kernel skip 6 of the 16 tile products the full count charges
+        ex = pmc["SQ_INSTS_MFMA"] * 4096.0
+        roof["executed"] = dict(mfma_insts_per_launch=pmc["SQ_INSTS_MFMA"], flops_per_launch=ex,
+                                achieved_tflops=ex / (dom_ms * 1e-3) / 1e12,
+                                frac=ex / (dom_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, source=src)
+        roof["flop_count"] = "full Hermitian count 513*64*64*1000*8; 'executed' = issued matrix instructions"
     roof["kernel"] = dom
     roof["kernel_avg_ms"] = dom_ms
     roof["algorithmic_per_launch"] = alg_launch

@@ -316,6 +316,10 @@ struct CsmArgs {
 
 // Combine the four waves' partial 32x32 tiles (fp64, through LDS), apply the Welch finish and
 // store the tile and its conjugate mirror.  All 256 threads call this together.
+// DIAG_M (diagonal tiles, I == J, of k_csm_gemm64): `im` holds only M = Xi Xr^T; the imaginary
+// part of the Hermitian tile is M - M^T (Im = Xi Xr^T - Xr Xi^T), formed here from the element
+// and its mirror -- one matrix instruction per k-step less than accumulating both products.
+template <bool DIAG_M = false>
 __device__ __forceinline__ void csm_tile_epilogue(float (&red)[4][2][16][64], const f32x16& re, const f32x16& im,
                                                   int I, int J, int b, const CsmArgs& p) {
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
@@ -336,6 +340,13 @@ __device__ __forceinline__ void csm_tile_epilogue(float (&red)[4][2][16][64], co
             g.y += (double)red[ww][1][r][l];
         }
         const int i = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), j = l & 31;
+        if (DIAG_M) {  // element (j, i) of the tile sits in register rm, lane lm
+            const int rm = (j & 3) + 4 * (j >> 3), lm = i + 32 * ((j >> 2) & 1);
+            double m = 0.0;
+#pragma unroll
+            for (int ww = 0; ww < 4; ++ww) m += (double)red[ww][1][rm][lm];
+            g.y -= m;
+        }
         const int gi = 32 * I + i, gj = 32 * J + j;
         if (gi < C && gj < C && gi >= gj) {
             float2* out = p.csm + (int64_t)(b - p.b0) * C * C;
@@ -420,7 +431,8 @@ __device__ __forceinline__ void csm64_bin(float (&red)[4][2][16][64], int b, con
     const int c0 = l & 31, c1 = 32 + (l & 31);
     const float2* Xb = p.X + (int64_t)b * F * C;
     f32x16 re00 = {0}, im00 = {0}, re10 = {0}, im10 = {0}, re11 = {0}, im11 = {0};
-    constexpr int U = 8;  // 96 MFMAs per batch: 4 -> 8 k-steps ahead measured -2 %
+    constexpr int U = 4;  // 40 MFMAs per batch; with 8 the kernel needs 376 registers (one workgroup per CU,
+                          // its three fp64 epilogues exposed); 4 fits 256 -> two per CU, epilogues overlap
     const int fo = l >> 5;
     // operands of U k-steps (2 frames each; this wave takes k-steps w, w+4, ...) are fetched one
     // whole iteration (12 U MFMAs) ahead of their use.  No branch per load (hipcc would drain
@@ -454,14 +466,12 @@ __device__ __forceinline__ void csm64_bin(float (&red)[4][2][16][64], int b, con
             re11 = __builtin_amdgcn_mfma_f32_32x32x2f32(x1[u].x, x1[u].x, re11, 0, 0, 0);
             if (!REAL_BIN) {
                 re00 = __builtin_amdgcn_mfma_f32_32x32x2f32(x0[u].y, x0[u].y, re00, 0, 0, 0);
-                im00 = __builtin_amdgcn_mfma_f32_32x32x2f32(x0[u].y, x0[u].x, im00, 0, 0, 0);
-                im00 = __builtin_amdgcn_mfma_f32_32x32x2f32(-x0[u].x, x0[u].y, im00, 0, 0, 0);
+                im00 = __builtin_amdgcn_mfma_f32_32x32x2f32(x0[u].y, x0[u].x, im00, 0, 0, 0);  // M only (DIAG_M)
                 re10 = __builtin_amdgcn_mfma_f32_32x32x2f32(x1[u].y, x0[u].y, re10, 0, 0, 0);
                 im10 = __builtin_amdgcn_mfma_f32_32x32x2f32(x1[u].y, x0[u].x, im10, 0, 0, 0);
                 im10 = __builtin_amdgcn_mfma_f32_32x32x2f32(-x1[u].x, x0[u].y, im10, 0, 0, 0);
                 re11 = __builtin_amdgcn_mfma_f32_32x32x2f32(x1[u].y, x1[u].y, re11, 0, 0, 0);
-                im11 = __builtin_amdgcn_mfma_f32_32x32x2f32(x1[u].y, x1[u].x, im11, 0, 0, 0);
-                im11 = __builtin_amdgcn_mfma_f32_32x32x2f32(-x1[u].x, x1[u].y, im11, 0, 0, 0);
+                im11 = __builtin_amdgcn_mfma_f32_32x32x2f32(x1[u].y, x1[u].x, im11, 0, 0, 0);  // M only (DIAG_M)
             }
         }
     };
@@ -477,16 +487,16 @@ __device__ __forceinline__ void csm64_bin(float (&red)[4][2][16][64], int b, con
         __builtin_amdgcn_sched_barrier(0);
         consume(s0 + 4 * U, b0, b1);
     }
-    csm_tile_epilogue(red, re00, im00, 0, 0, b, p);
+    csm_tile_epilogue<!REAL_BIN>(red, re00, im00, 0, 0, b, p);
     if (C > 32) {
         __syncthreads();  // red is reused
         csm_tile_epilogue(red, re10, im10, 1, 0, b, p);
         __syncthreads();
-        csm_tile_epilogue(red, re11, im11, 1, 1, b, p);
+        csm_tile_epilogue<!REAL_BIN>(red, re11, im11, 1, 1, b, p);
     }
 }
 
-__global__ __launch_bounds__(256) void k_csm_gemm64(CsmArgs p) {
+__global__ __launch_bounds__(256, 2) void k_csm_gemm64(CsmArgs p) {
     __shared__ float red[4][2][16][64];
     const int nb = p.fin.nb;
     if ((int)blockIdx.x < nb - 2) {
