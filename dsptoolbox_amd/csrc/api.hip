@@ -778,12 +778,13 @@ static int frames_to_visit(int64_t n_samples, int hop, int n_frames) {
 }
 
 // nfft 4096, one input channel: register-resident radix-16 FFT path (kernels_welch4096.hpp)
-static int welch4096_run(ds_ctx* c, const float* x, int64_t ldx, const float* y, int n_cy, int64_t ldy,
+static int welch4096_run(ds_ctx* c, const float* x, int n_cx, int64_t ldx, const float* y, int n_cy, int64_t ldy,
                          int64_t n_samples, int hop, int n_frames, const float* window, int detrend,
                          int mode, int amp_sqrt, double norm_scale, double factor, int halve_edges,
                          float2* tf, float* coh) {
     namespace w4 = welch4096;
     if (!x || !y || !window) return fail(c, DS_ERR_ARG, "ds_welch_tf: null argument");
+    if (n_cx != 1 && n_cx != n_cy) return fail(c, DS_ERR_ARG, "ds_welch_tf: one input channel, or one per output channel");
     if (n_cy <= 0 || n_samples <= 0 || hop <= 0 || hop > 4096 || n_frames <= 0 || ldx < n_samples ||
         ldy < n_samples)
         return fail(c, DS_ERR_ARG, "ds_welch_tf: bad shape");
@@ -800,22 +801,27 @@ static int welch4096_run(ds_ctx* c, const float* x, int64_t ldx, const float* y,
     const bool half = hop == 2048;
     const bool three = half && w4::enabled3() && w4::fits3(n_samples, nf);
     w4::Plan pl = three ? w4::plan3(nf, n_cy) : w4::plan(nf, n_cy);
-    CHK(reserve(c, &c->ws, &c->ws_bytes, pl.bytes));
+    // (paired inputs -- one input channel per output channel -- exist on the three-per-CU kernels only)
+    CHK(reserve(c, &c->ws, &c->ws_bytes, pl.bytes + (size_t)(n_cx - 1) * (Carver::pad(sizeof(float2) * (size_t)pl.n_pairs * w4::N) +
+                                                                  Carver::pad(sizeof(float) * (size_t)pl.n_pairs * w4::NB) +
+                                                                  Carver::pad(sizeof(float) * (size_t)pl.n_chunks * w4::NB)) + 4096));
     Carver cv(c->ws);
-    float2* xs = cv.take<float2>((size_t)pl.n_pairs * w4::N);
-    float* px = cv.take<float>((size_t)pl.n_pairs * w4::NB);
-    float* psx = cv.take<float>((size_t)pl.n_chunks * w4::NB);
+    float2* xs = cv.take<float2>((size_t)n_cx * pl.n_pairs * w4::N);
+    float* px = cv.take<float>((size_t)n_cx * pl.n_pairs * w4::NB);
+    float* psx = cv.take<float>((size_t)pl.n_chunks * n_cx * w4::NB);
     float2* pxy = cv.take<float2>((size_t)pl.n_chunks * n_cy * w4::NB);
     float* pyy = cv.take<float>((size_t)pl.n_chunks * n_cy * w4::NB);
     w4::Args ax{x, n_samples, ldx, 1, hop, nf, pl.n_pairs, detrend, pl.n_chunks, pl.ppc, window,
                 c->w4_tables, xs, px, pxy, pyy, psx};
+    ax.n_cx = n_cx;
     w4::Args ay = ax;
     ay.sig = y;
     ay.ld = ldy;
     ay.n_ch = n_cy;
     if (three) {
         w4::place_remainder(ay, n_cy);
-        CHK(launch(c, "welch4096_x", w4::k_x3, dim3(pl.n_pairs), w4::NT, w4::LDS3_BYTES, ax));
+        CHK(launch(c, "welch4096_x", w4::k_x3, dim3(pl.n_pairs * n_cx), w4::NT, w4::LDS3_BYTES, ax));
+        if (n_cx > 1) CHK(launch(c, "welch4096_pxsum", w4::k_px_sum, dim3(pl.n_chunks, n_cx), 256, 0, ay));
         CHK(launch(c, "welch4096_main", w4::k_y3<false>, dim3(pl.n_chunks * n_cy), w4::NT, w4::LDS3_BYTES, ay));
     } else {
         auto kx = half ? w4::k_x<true> : w4::k_x<false>;
@@ -823,7 +829,7 @@ static int welch4096_run(ds_ctx* c, const float* x, int64_t ldx, const float* y,
         CHK(launch(c, "welch4096_x", kx, dim3(pl.n_pairs), w4::NT, w4::LDS_BYTES, ax));
         CHK(launch(c, "welch4096_main", ky, dim3(pl.n_chunks * n_cy), w4::NT, w4::LDS_BYTES_2, ay));
     }
-    WelchFinArgs f{psx, pxy, pyy, pl.n_chunks, pl.n_chunks, 1, n_cy, 0, mode,
+    WelchFinArgs f{psx, pxy, pyy, pl.n_chunks, pl.n_chunks, n_cx, n_cy, 0, mode,
                    FinishPar{norm_scale / (double)n_frames, factor, halve_edges, amp_sqrt, w4::NB},
                    tf, coh};
     int64_t total = (int64_t)w4::NB * n_cy;
@@ -1050,8 +1056,11 @@ extern "C" int ds_welch_tf_dev(ds_ctx* c, const float* x, int n_cx, int64_t ldx,
                                double norm_scale, double factor, int halve_edges, ds_c32* tf,
                                float* coh) {
     if (!tf || !coh) return fail(c, DS_ERR_ARG, "ds_welch_tf: null output");
-    if (c && W == 4096 && n_cx == 1 && average == DS_AVG_MEAN && welch4096::enabled())
-        return welch4096_run(c, x, ldx, y, n_cy, ldy, n_samples, hop, n_frames, window, detrend, mode,
+    // one input channel, or -- on the three-per-CU kernels (50 % overlap) -- one per output channel
+    if (c && W == 4096 && average == DS_AVG_MEAN && welch4096::enabled() &&
+        (n_cx == 1 || (n_cx == n_cy && hop == 2048 && welch4096::enabled3() &&
+                       welch4096::fits3(n_samples, frames_to_visit(n_samples, hop, n_frames)))))
+        return welch4096_run(c, x, n_cx, ldx, y, n_cy, ldy, n_samples, hop, n_frames, window, detrend, mode,
                              amp_sqrt, norm_scale, factor, halve_edges, (float2*)tf, coh);
     static const bool no1k = getenv("DSPTOOLBOX_AMD_WELCH_GENERIC") != nullptr;
     if (c && W == 8192 && n_cx == 1 && average == DS_AVG_MEAN && !no1k && welch8k::buf_fits(n_samples, n_frames, hop))

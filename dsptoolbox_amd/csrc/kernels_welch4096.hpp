@@ -204,6 +204,9 @@ struct Args {
     // host places the remainder so that every XCD gets the same number of transforms); 0 = even split
     int use_plus;
     uint32_t plus[24];
+    // k_x3 / k_y3 only: number of input channels (0 or 1: one input for every output channel; else
+    // one per output channel: xs[cx][pair][...], px[cx][pair][NB], psx[chunk][cx][NB])
+    int n_cx;
 };
 
 // twt: fp64-computed tables, [15][256] W4096^(t k1) (k1 = 1..15) then [16][16] W256^(n3 k2)

@@ -398,12 +398,13 @@ __global__ __launch_bounds__(NT) void k_x3(Args p) {
     extern __shared__ __align__(16) float2 lds[];
     float2* buf = lds;
     float2* tw2 = lds + 16 * L1S;
-    const int tid = threadIdx.x, pr = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int cx = (int)blockIdx.x / p.n_pairs, pr = (int)blockIdx.x - cx * p.n_pairs;  // one input channel: cx = 0
     Tw6 tw;
     float2 v[16];
     {
         Raw<true> raw;
-        const __amdgpu_buffer_rsrc_t rs = channel_rsrc(p.sig, p.n_samples);
+        const __amdgpu_buffer_rsrc_t rs = channel_rsrc(p.sig + (int64_t)cx * p.ld, p.n_samples);
         const int off0 = 4 * (2 * pr * 2048 + tid);
 #pragma unroll
         for (int m = 0; m < 24; ++m) raw.s[m] = ld_sample(rs, off0 + 1024 * m);
@@ -417,7 +418,7 @@ __global__ __launch_bounds__(NT) void k_x3(Args p) {
     }
     fft4096_w(v, tw, buf, tw2, tid);
     if (p.detrend && tid == 0) v[pos16(0)] = make_float2(0.f, 0.f);
-    float4* xo = reinterpret_cast<float4*>(p.xs + (int64_t)pr * N) + tid;
+    float4* xo = reinterpret_cast<float4*>(p.xs + ((int64_t)cx * p.n_pairs + pr) * N) + tid;
 #pragma unroll
     for (int g = 0; g < 8; ++g) {
         float2 z0 = v[pos16(2 * g)], z1 = v[pos16(2 * g + 1)];
@@ -432,8 +433,40 @@ __global__ __launch_bounds__(NT) void k_x3(Args p) {
         pw[fold_pos(bt + 256 * k3)] = z.x * z.x + z.y * z.y;
     }
     __syncthreads();
-    float* po = p.px + (int64_t)pr * NB;
+    float* po = p.px + ((int64_t)cx * p.n_pairs + pr) * NB;
     for (int k = tid; k < NB; k += NT) po[k] = 0.5f * (pw[fold_pos(k)] + pw[fold_pos((N - k) & (N - 1))]);
+}
+
+// pairs [p0, p1) of chunk q: n_pairs / n_chunks each, one more where the host set the chunk's bit
+// (place_remainder), else the even split
+__device__ __forceinline__ void chunk_range(const Args& p, int q, int& p0, int& p1) {
+    if (p.use_plus) {
+        auto below = [&](int qq) {  // number of set bits of p.plus below bit qq
+            int n = 0;
+            for (int w = 0; w < (qq >> 5); ++w) n += __popc(p.plus[w]);
+            if (qq & 31) n += __popc(p.plus[qq >> 5] & ((1u << (qq & 31)) - 1u));
+            return n;
+        };
+        const int base = p.n_pairs / p.n_chunks;
+        p0 = q * base + below(q);
+        p1 = p0 + base + (int)((p.plus[q >> 5] >> (q & 31)) & 1u);
+    } else {
+        p0 = (int)((int64_t)q * p.n_pairs / p.n_chunks);
+        p1 = (int)((int64_t)(q + 1) * p.n_pairs / p.n_chunks);
+    }
+}
+
+// paired inputs: px rows of every input channel summed over the pairs of each chunk (fp64);
+// grid = (n_chunks, n_cx).  (With ONE input channel k_y3's workgroups share this sum instead.)
+__global__ __launch_bounds__(256) void k_px_sum(Args p) {
+    const int q = blockIdx.x, cx = blockIdx.y;
+    int p0, p1;
+    chunk_range(p, q, p0, p1);
+    for (int k = threadIdx.x; k < NB; k += 256) {
+        double sum = 0.0;
+        for (int pr = p0; pr < p1; ++pr) sum += (double)p.px[((int64_t)cx * p.n_pairs + pr) * NB + k];
+        p.psx[((int64_t)q * p.n_cx + cx) * NB + k] = (float)sum;
+    }
 }
 
 // ---- output channels ---------------------------------------------------------
@@ -470,21 +503,9 @@ __global__ __launch_bounds__(NT, W4_OCC) void k_y3(Args p) {
 #endif
     const float* ch = p.sig + (int64_t)c * p.ld;
     int p0, p1;
-    if (p.use_plus) {
-        auto below = [&](int qq) {  // number of set bits of p.plus below bit qq
-            int n = 0;
-            for (int w = 0; w < (qq >> 5); ++w) n += __popc(p.plus[w]);
-            if (qq & 31) n += __popc(p.plus[qq >> 5] & ((1u << (qq & 31)) - 1u));
-            return n;
-        };
-        const int base = p.n_pairs / p.n_chunks, bq = below(q);
-        p0 = q * base + bq;
-        p1 = p0 + base + (int)((p.plus[q >> 5] >> (q & 31)) & 1u);
-    } else {
-        p0 = (int)((int64_t)q * p.n_pairs / p.n_chunks);
-        p1 = (int)((int64_t)(q + 1) * p.n_pairs / p.n_chunks);
-    }
-    if (!AUTO) {
+    chunk_range(p, q, p0, p1);
+    const int cx = p.n_cx > 1 ? c : 0;  // paired inputs: this channel's own input spectra
+    if (!AUTO && p.n_cx <= 1) {
         // Input auto-spectrum of this chunk: every workgroup of the chunk sums a slice of the bins
         // over the chunk's px rows (fp64).  The slice (33 bins for 64 channels) is covered in ONE
         // sweep -- `width` bins x 256 / width row groups -- so the loads of a workgroup are one
@@ -523,7 +544,7 @@ __global__ __launch_bounds__(NT, W4_OCC) void k_y3(Args p) {
     // the chunk's input spectra as a raw buffer (32-bit offsets, one address register)
     const __amdgpu_buffer_rsrc_t xrs =
         AUTO ? rs
-             : __builtin_amdgcn_make_buffer_rsrc(const_cast<float2*>(p.xs + (int64_t)p0 * N), 0,
+             : __builtin_amdgcn_make_buffer_rsrc(const_cast<float2*>(p.xs + ((int64_t)cx * p.n_pairs + p0) * N), 0,
                                                  (int)(uint32_t)((p1 - p0) * (N * 8)), 0x00020000);
     if (p0 < p1) {
         const int off0 = 4 * (2 * p0 * 2048 + tid);

@@ -254,6 +254,24 @@ def test_chirp_pair_config1():
     assert eh < TOL and et < TOL
 
 
+def test_welch4096_paired_inputs_vs_oracle():
+    """One input channel per output channel (n_cx == n_cy) with a 4096-sample window on the
+    three-per-CU register kernels (k_x3 over every input channel, k_px_sum, k_y3): H1 / H2 / H3 and
+    coherence within 1e-6 -- the shapes whose generic-kernel results touched 1.0-1.3e-6 in the
+    round-1 sweeps (about 100 frames)."""
+    rng = np.random.default_rng(23)
+    for n, C, det in ((4096 * 50 + 777, 5, True), (2**18, 3, False)):
+        x = rng.standard_normal((n, C)) * 0.3
+        y = np.stack([np.convolve(x[:, i], rng.standard_normal(12) * np.exp(-np.arange(12) / 4.0))[:n]
+                      for i in range(C)], axis=1)
+        y += 0.02 * rng.standard_normal(y.shape)
+        for mode in ("H1", "H2", "H3"):
+            tf, coh = backend.welch_transfer_function(y, x, 48000, 4096, mode, detrend=det)
+            rt, rc = orc.compute_transfer_function(y, x, 48000, 4096, mode, detrend=det)
+            e1, e2 = relmax(tf, rt, det), relmax(coh, rc, det)
+            assert e1 < TOL and e2 < TOL, (n, C, mode, e1, e2)
+
+
 def test_transfer_function_float64_route_vs_oracle():
     """ds_welch_tf_x64: float64 transforms, sums and finish -- the oracle's own precision (1e-11),
     every mode, amplitude and power scalings, one input channel or one per output, ragged tail."""
