@@ -139,6 +139,8 @@ __device__ __forceinline__ void fft_wave(float2 (&v)[16], float2 (&z)[16], float
     constexpr int L = G::L, R3 = G::R3, S1 = G::S1;
     const int k1u = t / R3, n3 = t % R3;
     // ---- pass 1
+    // (spreading the 16 image stores between the butterflies, as the 4096-point kernel does, was
+    // A/B-tested here in one process on one GPU: no difference for these wave-local exchanges)
     w4::dft16(v);
 #pragma unroll
     for (int k1 = 1; k1 < 16; ++k1) v[pos16(k1)] = cmul(v[pos16(k1)], tw1[(k1 - 1) * L + t]);

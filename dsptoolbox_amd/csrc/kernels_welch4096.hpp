@@ -33,6 +33,7 @@
 #include <stdint.h>
 
 #include <cmath>
+#include <utility>
 #include <vector>
 
 #include "kernels_finish.hpp"
@@ -103,6 +104,53 @@ __device__ __forceinline__ void dft16(float2 (&v)[16]) {
     for (int k1 = 0; k1 < 4; ++k1) r4(v[4 * k1], v[4 * k1 + 1], v[4 * k1 + 2], v[4 * k1 + 3]);
 }
 __device__ __forceinline__ constexpr int pos16(int k) { return 4 * (k & 3) + (k >> 2); }
+
+// dft16 with a call-out after each of its eight radix-4 butterflies: stage A (n0 = 0..3, its
+// three internal W16 twiddles folded in) then stage B (k1g = 0..3; afterwards v[4 k1g + j] holds
+// X[k1g + 4 j]).  The call-outs carry the LDS / global traffic of the surrounding exchange so that
+// it is issued a few operations at a time between the butterflies instead of in one burst (a burst
+// of 16 ds_write_b64 from all four waves fills the LDS command queue: rocprof SQ_WAIT_INST_LDS was
+// 20 % of the wave cycles).
+#define W4_PIN() __builtin_amdgcn_sched_barrier(0)
+template <typename PA, typename HA, typename HB>
+__device__ __forceinline__ void dft16_h(float2 (&v)[16], PA pre_a, HA after_a, HB after_b) {
+    constexpr float C8 = 0.92387953251128673848f, S8 = 0.38268343236508978178f;
+    constexpr float R2 = 0.70710678118654752440f;
+    auto mulw = [](float2 z, float c, float s) {  // z * (c - i s)
+        return make_float2(fmaf(z.x, c, z.y * s), fmaf(z.y, c, -z.x * s));
+    };
+    pre_a(std::integral_constant<int, 0>{});
+    r4(v[0], v[4], v[8], v[12]);
+    after_a(0);
+    pre_a(std::integral_constant<int, 1>{});
+    r4(v[1], v[5], v[9], v[13]);
+    v[5] = mulw(v[5], C8, S8);                                                  // W16^1
+    v[9] = make_float2((v[9].x + v[9].y) * R2, (v[9].y - v[9].x) * R2);         // W16^2
+    v[13] = mulw(v[13], S8, C8);                                                // W16^3
+    after_a(1);
+    pre_a(std::integral_constant<int, 2>{});
+    r4(v[2], v[6], v[10], v[14]);
+    v[6] = make_float2((v[6].x + v[6].y) * R2, (v[6].y - v[6].x) * R2);         // W16^2
+    v[10] = make_float2(v[10].y, -v[10].x);                                     // W16^4 = -i
+    v[14] = make_float2((v[14].y - v[14].x) * R2, -(v[14].x + v[14].y) * R2);   // W16^6
+    after_a(2);
+    pre_a(std::integral_constant<int, 3>{});
+    r4(v[3], v[7], v[11], v[15]);
+    v[7] = mulw(v[7], S8, C8);                                                  // W16^3
+    v[11] = make_float2((v[11].y - v[11].x) * R2, -(v[11].x + v[11].y) * R2);   // W16^6
+    v[15] = mulw(v[15], -C8, -S8);                                              // W16^9
+    after_a(3);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        r4(v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]);
+        after_b(g);
+    }
+}
+struct NoHookI {
+    template <typename T>
+    __device__ __forceinline__ void operator()(T) const {}
+};
+
 
 struct Tw {
     float2 w[15];  // W4096^(t k1), k1 = 1..15
