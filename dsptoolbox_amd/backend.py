@@ -166,7 +166,8 @@ def _welch(x, y, fs_hz: int, window_type, window_length_samples: int, overlap_pe
 # Arithmetic of the transfer-function estimate behind the reference-shaped API
 # (transfer_functions.compute_transfer_function): "auto" takes the float64 route
 # (ds_welch_tf_x64: float64 transforms, sums and finish, the reference's own precision) when the
-# problem is small -- frame spectra of all channels <= 64 MB, window <= 8192, mean averaging --
+# problem is small -- frame spectra of all channels <= 64 MB, window <= 8192 (median averaging: at
+# most 4096 frames) --
 # and the fp32 kernels otherwise; "f32" / "f64" force one.  Environment:
 # DSPTOOLBOX_AMD_TF_PRECISION.  backend.welch_transfer_function itself defaults to "f32".
 TF_PRECISION = os.environ.get("DSPTOOLBOX_AMD_TF_PRECISION", "auto")
@@ -174,13 +175,13 @@ _X64_AUTO_BYTES = 64 << 20
 
 
 def _tf_x64_applies(precision, n_cx: int, n_cy: int, n_frames: int, W: int, average: str) -> bool:
+    ok = W <= 8192 and (average == "mean" or n_frames <= 4096)
     if precision == "f64":
-        if average != "mean" or W > 8192:
-            raise NotImplementedError("the float64 route covers mean averaging and windows up to 8192")
+        if not ok:
+            raise NotImplementedError("the float64 route covers windows up to 8192 (median: up to 4096 frames)")
         return True
     if precision == "auto":
-        return (average == "mean" and W <= 8192
-                and (n_cx + n_cy) * n_frames * (W // 2 + 1) * 16 <= _X64_AUTO_BYTES)
+        return ok and (n_cx + n_cy) * n_frames * (W // 2 + 1) * 16 <= _X64_AUTO_BYTES
     assert precision in (None, "f32"), "precision: 'f32', 'f64' or 'auto'"
     return False
 
@@ -217,7 +218,7 @@ def welch_transfer_function(output_td, input_td, fs_hz: int, window_length_sampl
             coh = np.empty((B, yo.shape[1]), dtype=np.float64)
             ctx = get_context()
             ctx.check(ctx.lib.ds_welch_tf_x64(ctx.handle, _ptr(x64), x64.shape[1], _ptr(y64), y64.shape[1], n, W,
-                                              hop, n_frames, _ptr(w64), int(bool(detrend)), DS_TF[mode], amp,
+                                              hop, n_frames, _ptr(w64), int(bool(detrend)), DS_AVG[average], DS_TF[mode], amp,
                                               norm_scale, factor, phys, _ptr(tf), _ptr(coh)), "ds_welch_tf_x64")
             return tf, coh
     # large float64 C-order arrays (the reference's own layout) cross the boundary as they are: the

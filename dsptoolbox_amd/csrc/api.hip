@@ -1079,9 +1079,13 @@ extern "C" int ds_welch_tf_dev(ds_ctx* c, const float* x, int n_cx, int64_t ldx,
 // float64 end to end (kernels_welch_f64.hpp): host arrays in the reference's own layout
 extern "C" int ds_welch_tf_x64(ds_ctx* c, const double* x, int n_cx, const double* y, int n_cy,
                                int64_t n_samples, int W, int hop, int n_frames, const double* window,
-                               int detrend, int mode, int amp_sqrt, double norm_scale, double factor,
-                               int halve_edges, double* tf, double* coh) {
+                               int detrend, int average, int mode, int amp_sqrt, double norm_scale,
+                               double factor, int halve_edges, double* tf, double* coh) {
     if (!c || !x || !y || !window || !tf || !coh) return fail(c, DS_ERR_ARG, "ds_welch_tf_x64: null argument");
+    if (average != DS_AVG_MEAN && average != DS_AVG_MEDIAN)
+        return fail(c, DS_ERR_ARG, "welch: average must be mean (0) or median (1)");
+    if (average == DS_AVG_MEDIAN && n_frames > 4096)
+        return fail(c, DS_ERR_UNSUP, "ds_welch_tf_x64: median averaging over more than 4096 frames (use ds_welch_tf)");
     if (n_cy <= 0 || (n_cx != 1 && n_cx != n_cy) || n_samples <= 0 || hop <= 0 || hop > W || n_frames <= 0)
         return fail(c, DS_ERR_ARG, "ds_welch_tf_x64: bad shape");
     if (!is_pow2(W) || W < 8 || W > 8192)
@@ -1118,9 +1122,17 @@ extern "C" int ds_welch_tf_x64(ds_ctx* c, const double* x, int n_cx, const doubl
     CHK(launch(c, "welch_f64_frames", w64::k_frames, dim3(n_frames, n_cx), 256, lds, fx));
     w64::FrameArgs fy{dy, n_samples, n_cy, W, lg, hop, n_frames, detrend, dw, tw, ys};
     CHK(launch(c, "welch_f64_frames", w64::k_frames, dim3(n_frames, n_cy), 256, lds, fy));
-    w64::TfArgs ta{xs, ys, n_cx, n_cy, n_frames, mode,
-                   FinishPar{norm_scale / (double)n_frames, factor, halve_edges, amp_sqrt, nb}, dtf, dcoh};
-    CHK(launch(c, "welch_f64_tf", w64::k_tf, dim3((nb + 255) / 256, n_cy), 256, 0, ta));
+    if (average == DS_AVG_MEDIAN) {
+        const int nbias = (n_frames & 1) ? n_frames : n_frames - 1;
+        w64::TfArgs ta{xs, ys, n_cx, n_cy, n_frames, mode,
+                       FinishPar{norm_scale * (double)std::max(1, nbias), factor, halve_edges, amp_sqrt, nb}, dtf, dcoh};
+        CHK(launch(c, "welch_f64_tf_median", w64::k_tf_median, dim3(nb, n_cy), 256,
+                   sizeof(double) * (4 * (size_t)n_frames + 8), ta));
+    } else {
+        w64::TfArgs ta{xs, ys, n_cx, n_cy, n_frames, mode,
+                       FinishPar{norm_scale / (double)n_frames, factor, halve_edges, amp_sqrt, nb}, dtf, dcoh};
+        CHK(launch(c, "welch_f64_tf", w64::k_tf, dim3((nb + 255) / 256, n_cy), 256, 0, ta));
+    }
     HIPCHK(c, hipMemcpyAsync(tf, dtf, bout * 16, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(coh, dcoh, bout * 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));

@@ -124,4 +124,61 @@ __global__ __launch_bounds__(256) void k_tf(TfArgs p) {
     p.coh[(size_t)b * p.n_cy + c] = axy2 / gxx / gyy;
 }
 
+// average = "median" (_spectral_methods.py:153-162): per bin the median over the frames of |X|^2,
+// |Y|^2 and of the real and imaginary parts of conj(X) Y; the host folds the bias n (F or F - 1)
+// into fin.inv.  One workgroup per (bin, channel); the four series sit in LDS (4 F doubles) and
+// every element is ranked against all others (ties by index).  grid = (nb, n_cy).
+__device__ __forceinline__ double median_rank(const double* s, int F, int tid, double* out2) {
+    const int r0 = (F - 1) / 2, r1 = F / 2;
+    for (int i = tid; i < F; i += 256) {
+        const double v = s[i];
+        int rank = 0;
+        for (int j = 0; j < F; ++j) {
+            const double u = s[j];
+            rank += (u < v || (u == v && j < i)) ? 1 : 0;
+        }
+        if (rank == r0) out2[0] = v;
+        if (rank == r1) out2[1] = v;
+    }
+    return 0.0;
+}
+__global__ __launch_bounds__(256) void k_tf_median(TfArgs p) {
+    extern __shared__ __align__(16) double ser[];  // [4][F] + 8 results
+    const int b = blockIdx.x, c = blockIdx.y, nb = p.fin.nb, F = p.n_frames, tid = threadIdx.x;
+    double* res = ser + 4 * (size_t)F;
+    const int cx = p.n_cx == 1 ? 0 : c;
+    const double2* X = p.xs + (size_t)cx * F * nb + b;
+    const double2* Y = p.ys + (size_t)c * F * nb + b;
+    for (int f = tid; f < F; f += 256) {
+        const double2 x = X[(size_t)f * nb], y = Y[(size_t)f * nb];
+        ser[f] = x.x * x.x + x.y * x.y;
+        ser[F + f] = y.x * y.x + y.y * y.y;
+        ser[2 * F + f] = x.x * y.x + x.y * y.y;
+        ser[3 * F + f] = x.x * y.y - x.y * y.x;
+    }
+    __syncthreads();
+    for (int q = 0; q < 4; ++q) median_rank(ser + (size_t)q * F, F, tid, res + 2 * q);
+    __syncthreads();
+    if (tid != 0) return;
+    const double sxx = 0.5 * (res[0] + res[1]), syy = 0.5 * (res[2] + res[3]);
+    // + 0.0: the reference forms `median(real) + 1j * median(imag)`, so a -0 imaginary median becomes +0
+    // (it decides the branch of the principal square root at the purely real bins)
+    const cd sxy{0.5 * (res[4] + res[5]), 0.5 * (res[6] + res[7]) + 0.0};
+    const cd gxy = dsk::finish_cplx(sxy, b, p.fin);
+    const double gxx = dsk::finish_real(sxx, b, p.fin), gyy = dsk::finish_real(syy, b, p.fin);
+    const double axy2 = gxy.x * gxy.x + gxy.y * gxy.y;
+    cd h;
+    if (p.mode == 1) {
+        h = cd{gxy.x / gxx, gxy.y / gxx};
+    } else if (p.mode == 2) {
+        const cd gyx = (sxy.y == 0.0) ? gxy : cd{gxy.x, -gxy.y};
+        h = cd{gyy * gyx.x / axy2, -gyy * gyx.y / axy2};
+    } else {
+        const double s = sqrt(gyy / gxx) / sqrt(axy2);
+        h = cd{gxy.x * s, gxy.y * s};
+    }
+    p.tf[(size_t)b * p.n_cy + c] = make_double2(h.x, h.y);
+    p.coh[(size_t)b * p.n_cy + c] = axy2 / gxx / gyy;
+}
+
 }  // namespace w64

@@ -145,14 +145,15 @@ int ds_welch_tf_f64(ds_ctx* ctx, const double* x, int n_cx, const double* y, int
                     double factor, int halve_edges, ds_c32* tf, float* coh);
 /* The same estimate in float64 END TO END (transforms, sums, finish) for small or ill-conditioned
  * problems: x (n_samples, n_cx), y (n_samples, n_cy) float64 C-order exactly as the reference
- * holds them, float64 window, mean averaging, W a power of two <= 8192; tf[b][c] complex128
+ * holds them, float64 window, mean or median averaging (median: at most 4096 frames), W a power
+ * of two <= 8192; tf[b][c] complex128
  * (interleaved re, im), coh[b][c] float64.  With fp32 transforms every frame's rounding floor
  * (1e-7 of its peak) lands on all bins, so bins 80 dB down -- the top of a fast pink sweep,
  * BASELINE config 1 -- are only good to 1e-4; this route keeps the reference's 1e-12.        */
 int ds_welch_tf_x64(ds_ctx* ctx, const double* x, int n_cx, const double* y, int n_cy,
                     int64_t n_samples, int W, int hop, int n_frames, const double* window,
-                    int detrend, int mode, int amp_sqrt, double norm_scale, double factor,
-                    int halve_edges, double* tf, double* coh);
+                    int detrend, int average, int mode, int amp_sqrt, double norm_scale,
+                    double factor, int halve_edges, double* tf, double* coh);
 int ds_welch_psd_dev(ds_ctx* ctx, const float* x_dev, int n_cx, int64_t ldx,
                      int64_t n_samples, int W, int hop, int n_frames,
                      const float* window_dev, int detrend, int average, int amp_sqrt,

@@ -289,8 +289,26 @@ def test_transfer_function_float64_route_vs_oracle():
                                                        scaling=sc.name)
                 assert tf.dtype == np.complex128 and coh.dtype == np.float64
                 assert relmax(tf, rt, det) < 1e-9 and relmax(coh, rc, det) < 1e-9, (n, W, mode, sc)
+        # median averaging on the float64 route (single-frame values are picked, so fp32 transform
+        # noise is not averaged down: the fp32 kernels need 10 x the tolerance on the coherence)
+        for mode in ("H1", "H2"):
+            tf, coh = backend.welch_transfer_function(y, x, 48000, W, mode, overlap_percent=ov, detrend=det,
+                                                      average="median", precision="f64")
+            rt, rc = orc.compute_transfer_function(y, x, 48000, W, mode, overlap_percent=ov, detrend=det,
+                                                   average="median")
+            assert relmax(tf, rt, det) < 1e-9 and relmax(coh, rc, det) < 1e-9, (n, W, mode, "median")
+    # what the reference-shaped API does with small problems (backend.TF_PRECISION = "auto"): median
+    # averaging and one- or two-frame estimates meet the plain 1e-6, coherence included
+    x = rng.standard_normal((5000, 1)) * 0.3
+    y = np.stack([np.convolve(x[:, 0], rng.standard_normal(7))[:5000] for _ in range(2)], axis=1)
+    inp, out = dsp.Signal(None, x, 48000), dsp.Signal(None, y + 1e-3 * rng.standard_normal(y.shape), 48000)
+    for W, avg in ((256, "median"), (4096, "mean"), (2048, "median")):
+        inp.set_spectrum_parameters(window_length_samples=W, overlap_percent=50, detrend=True, average=avg)
+        sp = dsp.transfer_functions.compute_transfer_function(out, inp, W, TransferFunctionType.H1)
+        rt, rc = orc.compute_transfer_function(out.time_data, inp.time_data, 48000, W, "H1", average=avg)
+        assert relmax(sp.spectral_data, rt, True) < TOL and relmax(sp.coherence, rc, True) < TOL, (W, avg)
     with pytest.raises(NotImplementedError):
-        backend.welch_transfer_function(y, x, 48000, 64, "H1", average="median", precision="f64")
+        backend.welch_transfer_function(y, x, 48000, 16384, "H1", precision="f64")
 
 
 def test_deconvolve_golden():
