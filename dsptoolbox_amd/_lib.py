@@ -38,6 +38,7 @@ SIGNATURES = {
     "ds_profile_enable": (C.c_int, [ctx_p, C.c_int]),
     "ds_profile_report": (C.c_char_p, [ctx_p]),
     "ds_profile_only": (C.c_int, [ctx_p, C.c_char_p]),
+    "ds_profile_stride": (C.c_int, [ctx_p, C.c_int]),
     "ds_stft_r2c_dev": (C.c_int, [ctx_p, f32_p, i64, C.c_int, i64, C.c_int, C.c_int, C.c_int, i64,
                                   C.c_int, f32_p, C.c_int, C.c_float, C.c_float, C.c_int, c32_p]),
     "ds_stft_r2c": (C.c_int, [ctx_p, f32_p, i64, C.c_int, C.c_int, C.c_int, C.c_int, i64, C.c_int,
@@ -213,6 +214,10 @@ class Context:
         """Bracket only launches of this kernel name (None: all kernels)."""
         self.check(self.lib.ds_profile_only(self.handle, kernel_name.encode() if kernel_name else None),
                    "ds_profile_only")
+
+    def profile_stride(self, every: int):
+        """Bracket only every `every`-th matching launch (1: all)."""
+        self.check(self.lib.ds_profile_stride(self.handle, int(every)), "ds_profile_stride")
 
     def profile_report(self) -> dict:
         """{kernel: (total_ms, launches)} since the previous report."""

@@ -76,6 +76,8 @@ struct ds_ctx {
     std::vector<hipEvent_t> prof_pool;
     std::string prof_text;
     std::string prof_only;  // non-empty: only launches of this kernel name are bracketed
+    int prof_stride = 1;    // bracket every prof_stride-th matching launch (an event pair costs ~3 us of stream time)
+    long prof_seen = 0;
 };
 
 static int fail(ds_ctx* c, int code, const std::string& msg) {
@@ -295,6 +297,13 @@ extern "C" int ds_profile_only(ds_ctx* c, const char* kernel_name) {
     return DS_OK;
 }
 
+extern "C" int ds_profile_stride(ds_ctx* c, int every) {
+    if (!c || every < 1) return fail(c, DS_ERR_ARG, "ds_profile_stride: bad argument");
+    c->prof_stride = every;
+    c->prof_seen = 0;
+    return DS_OK;
+}
+
 // "name total_ms count\n" per kernel since the last call; synchronises the stream
 extern "C" const char* ds_profile_report(ds_ctx* c) {
     if (!c) return "";
@@ -365,7 +374,8 @@ static int launch(ds_ctx* c, const char* name, K kernel, dim3 grid, int threads,
     if (lds > 64 * 1024)
         HIPCHK(c, hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     ds_ctx::ProfRec rec{name, nullptr, nullptr};
-    const bool prof = c->prof && (c->prof_only.empty() || c->prof_only == name);
+    bool prof = c->prof && (c->prof_only.empty() || c->prof_only == name);
+    if (prof && c->prof_stride > 1 && (c->prof_seen++ % c->prof_stride) != 0) prof = false;
     if (prof) {
         CHK(prof_event(c, &rec.a));
         CHK(prof_event(c, &rec.b));

@@ -79,6 +79,8 @@ const char* ds_profile_report(ds_ctx* ctx);
 /* restrict the bracketing to one kernel name (NULL or "": all kernels): every
  * event pair costs ~3 us of stream time, which matters for 10 us kernels      */
 int         ds_profile_only(ds_ctx* ctx, const char* kernel_name);
+/* bracket only every `every`-th matching launch (1 = all): an event pair costs ~3 us of stream time */
+int         ds_profile_stride(ds_ctx* ctx, int every);
 /* max FFT length one workgroup transforms inside LDS (complex points)       */
 int         ds_max_fft_len(void);
 
