@@ -38,6 +38,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 MFMA_F32_PEAK_TFLOPS = 157.3
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense, MI355X_MICROARCH.md
 
 FS = 48000
 
@@ -364,9 +365,16 @@ def csm(args, ctx, dist, shard, rccl):
         gather_result(ctx, rccl, shard, d_c, d_all, slot)
 
     flops = B * n_ch * n_ch * n_frames * 8.0
+    # Two HBM-streaming kernels since the Gram product runs on the bf16 matrix pipe (three bf16
+    # pieces per fp32 value, kernels_csm_b3.hpp): the transform reads the samples once and writes the
+    # spectrogram X[bin][frame][mic]; the product reads X once and writes the matrices.  "step" is
+    # what SURVEY 8(d) counts for the fused ideal (samples in, matrices out).
+    x_bytes = B * n_frames * n_ch * 8.0
+    alg = {"stft": n_ch * n * 4.0 + x_bytes, "csm_gemm": x_bytes + B * n_ch * n_ch * 8.0,
+           "step": n_ch * n * 4.0 + B * n_ch * n_ch * 8.0, "gemm_flops": flops}
     info = dict(workload="csm: 64-mic Welch cross-spectral matrix, nfft 1024, 1000 frames",
                 channels=n_ch, samples_per_channel=n, nfft=W, frames=n_frames,
-                gemm_flops="513*64*64*1000*8 (full Hermitian count)")
+                gemm_flops="513*64*64*1000*8 (full Hermitian count, fp32-equivalent)")
 
     def cpu_baseline():
         from oracle import dsp_oracle as orc
@@ -382,7 +390,7 @@ def csm(args, ctx, dist, shard, rccl):
                            f"mics, {reps} passes of {dt:.1f} s; the reference's 2080-pair loop takes ~100 s",
                     parity_rel_max_vs_gpu=orc.rel_max(got[lo - a:], ref[lo:b]))
 
-    return step, n_ch * n, flops, "mfma", info, (cpu_baseline,), None, ("csm_gemm",)
+    return step, n_ch * n, alg, "hbm", info, (cpu_baseline,), None, ("stft", "csm_gemm")
 
 
 def deconv(args, ctx, dist, shard, rccl):
@@ -515,7 +523,7 @@ def main():
             ctx.profile_enable(False)
         else:
             step()
-    dom = next((k for k in dominant if k in prof_all), None)
+    dom = max((k for k in dominant if k in prof_all), key=lambda k: prof_all[k][0], default=None)
     if dom is None and prof_all:
         dom = max(prof_all, key=lambda k: prof_all[k][0])
     wall, ev_ms, prof = timed_steps(ctx, dist, step, args.steps, events, dom)
@@ -537,7 +545,12 @@ def main():
     dom_ms = prof[dom][0] / prof[dom][1]  # average over the bracketed launches
     launches_per_step = max(1, round(prof[dom][1] * EVENT_STRIDE / args.steps))
     # algorithmic work of ONE launch on THIS rank (strong scaling: its share of the job)
-    alg_launch = alg / launches_per_step / (dist.world if strong else 1)
+    alg_parts = alg if isinstance(alg, dict) else None  # per kernel (csm: two streaming kernels)
+    if alg_parts:
+        alg = alg_parts["step"]
+    alg_launch = (alg_parts[dom] if alg_parts else alg) / launches_per_step / (dist.world if strong else 1)
+    if alg_parts and dom == "stft":  # the bin shards of a strong-scaling run all transform every frame
+        alg_launch = alg_parts[dom] / launches_per_step
     if bound == "hbm":
         achieved = alg_launch / (dom_ms * 1e-3) / 1e9
         roof = dict(bound="hbm", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
@@ -567,14 +580,30 @@ def main():
         floor_ms = pmc["SQ_INSTS_VALU"] * 2.0 / 1024.0 / 2.4e9 * 1e3
         roof["valu_issue"] = dict(insts_per_launch=pmc["SQ_INSTS_VALU"], floor_ms_at_2p4_ghz=floor_ms,
                                   valu_issue_frac=floor_ms / dom_ms, source=src)
-    if bound == "mfma" and pmc.get("SQ_INSTS_MFMA"):
-        # the flops the matrix pipe really executes (v_mfma_f32_32x32x2_f32 = 4096 flop): the Hermitian
-        # structure lets the kernel skip 6 of the 16 tile products the full count charges
-        ex = pmc["SQ_INSTS_MFMA"] * 4096.0
-        roof["executed"] = dict(mfma_insts_per_launch=pmc["SQ_INSTS_MFMA"], flops_per_launch=ex,
-                                achieved_tflops=ex / (dom_ms * 1e-3) / 1e12,
-                                frac=ex / (dom_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, source=src)
-        roof["flop_count"] = "full Hermitian count 513*64*64*1000*8; 'executed' = issued matrix instructions"
+    if alg_parts and prof_all:
+        # every kernel of the step against the HBM roofline (warm-up step, every kernel bracketed), and
+        # the Gram product's matrix-pipe numbers: fp32-equivalent flops by the full Hermitian count, and
+        # the bf16 instructions really issued (v_mfma_f32_32x32x16_bf16 = 32768 flop; 60 per 16 frames
+        # and workgroup: 10 of the 16 tile products, 6 piece products each)
+        div = dist.world if strong else 1
+        roof["kernels"] = {}
+        for k in ("stft", "csm_gemm"):
+            if k in prof_all:
+                nbytes = alg_parts[k] / (1 if k == "stft" else div)
+                gbs = nbytes / (prof_all[k][0] * 1e-3) / 1e9
+                roof["kernels"][k] = dict(ms=prof_all[k][0], algorithmic_bytes=nbytes, gbs=gbs, frac=gbs / HBM_PEAK_GBS)
+        if "csm_gemm" in prof_all:
+            g_ms = prof_all["csm_gemm"][0]
+            gpmc, gsrc = pmc_summary(args.workload, ("k_csm_gemm",))
+            gemm = dict(ms=g_ms, fp32_equivalent_tflops=alg_parts["gemm_flops"] / div / (g_ms * 1e-3) / 1e12,
+                        fp32_mfma_peak_tflops=MFMA_F32_PEAK_TFLOPS,
+                        note="fp32-exact product from three bf16 pieces per value on the bf16 matrix pipe; "
+                             "bound by the operand stream from HBM, not by the pipe")
+            if gpmc.get("SQ_INSTS_MFMA"):
+                ex = gpmc["SQ_INSTS_MFMA"] * 32768.0
+                gemm.update(mfma_insts_per_launch=gpmc["SQ_INSTS_MFMA"], executed_bf16_tflops=ex / (g_ms * 1e-3) / 1e12,
+                            frac_of_bf16_peak=ex / (g_ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, source=gsrc)
+            roof["gemm"] = gemm
     roof["kernel"] = dom
     roof["kernel_event_sampling"] = f"every {EVENT_STRIDE}th launch of the timed region ({prof[dom][1]} brackets)"
     roof["kernel_avg_ms"] = dom_ms

@@ -15,6 +15,7 @@
 #include "kernels_bigfft.hpp"
 #include "kernels_bluestein.hpp"
 #include "kernels_finish.hpp"
+#include "kernels_csm_b3.hpp"
 #include "kernels_generic.hpp"
 #include "kernels_welch4096.hpp"
 #include "kernels_welch4096w.hpp"
@@ -1245,7 +1246,13 @@ static int csm_dev(ds_ctx* c, const float* x, int n_ch, int64_t ld, int64_t n_sa
     // pairs (the spectra of an even-length real transform are purely real at both edge bins,
     // which the kernel relies on)
     static const bool no64 = getenv("DSPTOOLBOX_AMD_CSM_GENERIC") != nullptr;
-    if (all_bins && n_ch <= 64 && n_frames >= 8 && nb >= 3 && !no64)
+    // even channel counts: the same product from bf16 triples on the 16 x faster bf16 matrix pipe
+    // (kernels_csm_b3.hpp; DSPTOOLBOX_AMD_CSM_F32=1 keeps the fp32 matrix instructions)
+    static const bool f32_only = getenv("DSPTOOLBOX_AMD_CSM_F32") != nullptr;
+    const bool one_wg_per_bin = all_bins && n_ch <= 64 && n_frames >= 8 && nb >= 3 && !no64;
+    if (one_wg_per_bin && !f32_only && csmb3::fits(n_ch, n_frames))
+        CHK(launch(c, "csm_gemm", csmb3::k_csm_gemm64_b3, dim3(nb - 1), 256, 0, a));
+    else if (one_wg_per_bin)
         CHK(launch(c, "csm_gemm", k_csm_gemm64, dim3(nb - 1), 256, 0, a));
     else
         CHK(launch(c, "csm_gemm", k_csm_gemm, dim3(bin_count, nt * (nt + 1) / 2), 256, 0, a));

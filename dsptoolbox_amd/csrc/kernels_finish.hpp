@@ -315,70 +315,148 @@ struct CsmArgs {
 };
 
 // Combine the four waves' partial 32x32 tiles (fp64, through LDS), apply the Welch finish and
-// store the tile and its conjugate mirror.  All 256 threads call this together.
-// DIAG_M (diagonal tiles, I == J, of k_csm_gemm64): `im` holds only M = Xi Xr^T; the imaginary
-// part of the Hermitian tile is M - M^T (Im = Xi Xr^T - Xr Xi^T), formed here from the element
-// and its mirror -- one matrix instruction per k-step less than accumulating both products.
-template <bool DIAG_M = false>
-__device__ __forceinline__ void csm_tile_epilogue(float (&red)[4][2][16][64], const f32x16& re, const f32x16& im,
-                                                  int I, int J, int b, const CsmArgs& p) {
-    const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
-    const int C = p.n_ch, F = p.n_frames;
+// store the tile and its conjugate mirror.  All 256 threads call these together.
+//   diag_m (diagonal tiles, I == J, of the one-workgroup-per-bin kernels): `im` holds only
+//   M = Xi Xr^T; the imaginary part of the Hermitian tile is M - M^T (Im = Xi Xr^T - Xr Xi^T),
+//   formed here from the element and its mirror -- one matrix product per k-step less than
+//   accumulating both.
+//   ILV (k_csm_gemm64_b3): tile T holds the channels 2 r + T (even / odd) instead of 32 T + r; the
+//   off-diagonal tile then has elements on both sides of the diagonal, and an upper one is stored
+//   as the conjugate of the lower element it mirrors (finish() is applied to the lower one, as
+//   everywhere).
+// Code size matters here: the fp64 finish (division, complex square root) is some hundred
+// instructions per element, and a kernel that inlines it per element, tile and bin kind (round 2's
+// first form: 17 000 instructions, 135 KB against a 64 KB instruction cache) spends more time
+// fetching its epilogue than running its matrix instructions.  So: tile kind as run-time
+// arguments, one call site per tile and kernel, and the finish written once, branch-free, for the
+// thread's four elements (csm_tile_reduce_store).
+// the four waves' partial tiles [wave][re / im][register][lane]; rows of 65 so that the transposed
+// reads of the diagonal tiles (register index varying across the lanes) fall into different banks
+typedef float CsmRed[4][2][16][65];
+
+__device__ __forceinline__ void csm_tile_put(CsmRed& red, const f32x16& re, const f32x16& im) {
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         red[w][0][r][l] = re[r];
         red[w][1][r][l] = im[r];
     }
-    __syncthreads();
+}
+
+// STAGED: the finished elements go into an LDS image G of the C x C matrix (row stride C + 1, so
+// that the mirror writes of a wave fall into different banks) and leave as whole rows afterwards:
+// stored straight from here, the mirror elements of a wave are 64 separate 8-byte writes C * 8 bytes
+// apart, and the 3 M such requests of the 64-channel shape keep the L2 channels busy for 16 us.
+template <bool ILV = false, bool STAGED = false>
+__device__ __forceinline__ void csm_tile_reduce_store(CsmRed& red, int I, int J, bool diag_m, int b,
+                                                      const CsmArgs& p, float2* G = nullptr) {
+    const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
+    const int C = p.n_ch, F = p.n_frames;
+    const int ldo = STAGED ? C + 1 : C;
+    float2* out = STAGED ? G : p.csm + (int64_t)(b - p.b0) * C * C;
+    // The chain LDS read -> sum -> fp64 scale -> complex square root -> store is ~800 cycles of
+    // dependent latency per element and there are only two waves per SIMD to hide it, so the four
+    // elements of a thread run side by side in branch-free code (selects instead of the branches of
+    // finish_real / finish_cplx / csqrt_principal, same expressions, same results).
+    float gx[4], gy[4];
+    int gi[4], gj[4];
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) {
         const int r = w * 4 + rr;
-        cd g{0.0, 0.0};
-#pragma unroll
-        for (int ww = 0; ww < 4; ++ww) {
-            g.x += (double)red[ww][0][r][l];
-            g.y += (double)red[ww][1][r][l];
-        }
+        // the four partial sums (250 frames each, accumulated in fp32 by the matrix instructions) are
+        // combined in fp32 as well: two more roundings of 6e-8; the finish below stays in fp64
+        gx[rr] = (red[0][0][r][l] + red[1][0][r][l]) + (red[2][0][r][l] + red[3][0][r][l]);
+        gy[rr] = (red[0][1][r][l] + red[1][1][r][l]) + (red[2][1][r][l] + red[3][1][r][l]);
         const int i = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), j = l & 31;
-        if (DIAG_M) {  // element (j, i) of the tile sits in register rm, lane lm
+        if (diag_m) {  // element (j, i) of the tile sits in register rm, lane lm (uniform branch)
             const int rm = (j & 3) + 4 * (j >> 3), lm = i + 32 * ((j >> 2) & 1);
-            double m = 0.0;
-#pragma unroll
-            for (int ww = 0; ww < 4; ++ww) m += (double)red[ww][1][rm][lm];
-            g.y -= m;
+            gy[rr] -= (red[0][1][rm][lm] + red[1][1][rm][lm]) + (red[2][1][rm][lm] + red[3][1][rm][lm]);
         }
-        const int gi = 32 * I + i, gj = 32 * J + j;
-        if (gi < C && gj < C && gi >= gj) {
-            float2* out = p.csm + (int64_t)(b - p.b0) * C * C;
-            if (gi == gj) {
-                double d = finish_real(g.x, b, p.fin);
-                out[(int64_t)gi * C + gj] = make_float2((float)d, 0.f);
-            } else {
-                bool real_bin = false;
-                if (F == 1 && g.y == 0.0) {
-                    // one frame (_csm_fft) at a purely real bin (DC / Nyquist): numpy's
-                    // `csm[[0, -1]] /= 2.0` (complex / real) turns every -0 imaginary part of
-                    // a negative real element into +0, so BOTH mirror elements take the +i
-                    // branch of the square root (the matrix is not Hermitian there).
-                    g.y = 0.0;
-                    real_bin = true;
-                }
-                cd v = finish_cplx(g, b, p.fin);
-                out[(int64_t)gi * C + gj] = make_float2((float)v.x, (float)v.y);
-                if (real_bin) {
-                    cd u = finish_cplx(cd{g.x, 0.0}, b, p.fin);
-                    out[(int64_t)gj * C + gi] = make_float2((float)u.x, (float)u.y);
-                } else {
-                    out[(int64_t)gj * C + gi] = make_float2((float)v.x, (float)-v.y);
-                }
-            }
+        const int ti = ILV ? 2 * i + I : 32 * I + i, tj = ILV ? 2 * j + J : 32 * J + j;
+        const bool up = ILV && I != J && ti < tj;  // G[ti][tj] = conj(G[tj][ti])
+        gi[rr] = up ? tj : ti;
+        gj[rr] = up ? ti : tj;
+        gy[rr] = up ? -gy[rr] : gy[rr];
+    }
+    const double e = p.fin.halve_edges ? ((b == 0 || b == p.fin.nb - 1) ? 0.5 * p.fin.factor : p.fin.factor) : 1.0;
+    double vx[4], vy[4];
+    bool keep_sign[4];
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+        const bool diag = gi[rr] == gj[rr];
+        // one frame (_csm_fft) at a purely real bin (DC / Nyquist): numpy's `csm[[0, -1]] /= 2.0`
+        // (complex / real) turns every -0 imaginary part of a negative real element into +0, so BOTH
+        // mirror elements take the +i branch of the square root (the matrix is not Hermitian there)
+        keep_sign[rr] = F == 1 && gy[rr] == 0.f;
+        const double y0 = (diag || keep_sign[rr]) ? 0.0 : (double)gy[rr];
+        vx[rr] = (double)gx[rr] * p.fin.inv * e;  // (x inv) e as in finish_cplx; e = 1 is exact
+        vy[rr] = y0 * p.fin.inv * e;
+    }
+    if (p.fin.amp_sqrt) {  // principal square root (csqrt_principal), all four at once
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const double x = vx[rr], y = vy[rr];
+            const double r = sqrt(x * x + y * y);
+            const double t = sqrt(0.5 * (r + fabs(x)));
+            const double q = fabs(y) / (2.0 * t);
+            const bool pos = x >= 0.0, zero = r == 0.0;
+            vx[rr] = zero ? 0.0 : (pos ? t : q);
+            vy[rr] = zero ? y : copysign(pos ? q : t, y);
+        }
+    }
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+        if (gi[rr] < C && gj[rr] < C && gi[rr] >= gj[rr]) {
+            const float fx = (float)vx[rr], fy = (float)vy[rr];
+            out[(int64_t)gi[rr] * ldo + gj[rr]] = make_float2(fx, fy);
+            // sqrt(x + 0i) = conj(sqrt(x - 0i)) everywhere but on the negative real axis, where
+            // keep_sign leaves the +i branch for the mirror as well
+            if (gi[rr] != gj[rr]) out[(int64_t)gj[rr] * ldo + gi[rr]] = make_float2(fx, keep_sign[rr] ? fy : -fy);
         }
     }
 }
 
+template <bool DIAG_M = false>
+__device__ __forceinline__ void csm_tile_epilogue(CsmRed& red, const f32x16& re, const f32x16& im,
+                                                  int I, int J, int b, const CsmArgs& p) {
+    csm_tile_put(red, re, im);
+    __syncthreads();
+    csm_tile_reduce_store<false>(red, I, J, DIAG_M, b, p);
+}
+
+// the three tile pairs of a one-workgroup-per-bin kernel (C <= 64), the matrix staged in G[64 * 65]
+// and written as whole rows
+constexpr int CSM64_G = 64 * 65;
+template <bool ILV>
+__device__ __forceinline__ void csm_epilogue64(CsmRed& red, float2* G, const f32x16& re00,
+                                               const f32x16& im00, const f32x16& re10, const f32x16& im10,
+                                               const f32x16& re11, const f32x16& im11, bool diag_m, int b,
+                                               const CsmArgs& p) {
+    const int C = p.n_ch;
+    // (a rolled loop over the tiles makes hipcc select the accumulators through scratch memory)
+    csm_tile_put(red, re00, im00);
+    __syncthreads();
+    csm_tile_reduce_store<ILV, true>(red, 0, 0, diag_m, b, p, G);
+    if (ILV || C > 32) {
+        __syncthreads();  // red is reused
+        csm_tile_put(red, re10, im10);
+        __syncthreads();
+        csm_tile_reduce_store<ILV, true>(red, 1, 0, false, b, p, G);
+        __syncthreads();
+        csm_tile_put(red, re11, im11);
+        __syncthreads();
+        csm_tile_reduce_store<ILV, true>(red, 1, 1, diag_m, b, p, G);
+    }
+    __syncthreads();
+    float2* out = p.csm + (int64_t)(b - p.b0) * C * C;
+    const int col = threadIdx.x & 63;
+    if (col < C)
+        for (int row = threadIdx.x >> 6; row < C; row += 4) out[row * C + col] = G[row * (C + 1) + col];
+}
+
 // generic: grid = (bins, tile pairs I >= J of 32 x 32 channels)
 __global__ __launch_bounds__(256) void k_csm_gemm(CsmArgs p) {
-    __shared__ float red[4][2][16][64];
+    __shared__ CsmRed red;
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
     const int b = blockIdx.x + p.b0;
     int I = 0;
@@ -425,12 +503,12 @@ __global__ __launch_bounds__(256) void k_csm_gemm(CsmArgs p) {
 // k-step instead of four (their imaginary parts are exactly zero and the imaginary accumulator
 // of the full form stays +0), so every workgroup has about the same amount of work.
 template <bool REAL_BIN>
-__device__ __forceinline__ void csm64_bin(float (&red)[4][2][16][64], int b, const CsmArgs& p) {
+__device__ __forceinline__ void csm64_bin(int b, const CsmArgs& p, f32x16& re00, f32x16& im00, f32x16& re10,
+                                          f32x16& im10, f32x16& re11, f32x16& im11) {
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
     const int C = p.n_ch, F = p.n_frames;
     const int c0 = l & 31, c1 = 32 + (l & 31);
     const float2* Xb = p.X + (int64_t)b * F * C;
-    f32x16 re00 = {0}, im00 = {0}, re10 = {0}, im10 = {0}, re11 = {0}, im11 = {0};
     constexpr int U = 4;  // 40 MFMAs per batch; with 8 the kernel needs 376 registers (one workgroup per CU,
                           // its three fp64 epilogues exposed); 4 fits 256 -> two per CU, epilogues overlap
     const int fo = l >> 5;
@@ -487,24 +565,26 @@ __device__ __forceinline__ void csm64_bin(float (&red)[4][2][16][64], int b, con
         __builtin_amdgcn_sched_barrier(0);
         consume(s0 + 4 * U, b0, b1);
     }
-    csm_tile_epilogue<!REAL_BIN>(red, re00, im00, 0, 0, b, p);
-    if (C > 32) {
-        __syncthreads();  // red is reused
-        csm_tile_epilogue(red, re10, im10, 1, 0, b, p);
-        __syncthreads();
-        csm_tile_epilogue<!REAL_BIN>(red, re11, im11, 1, 1, b, p);
-    }
 }
 
 __global__ __launch_bounds__(256, 2) void k_csm_gemm64(CsmArgs p) {
-    __shared__ float red[4][2][16][64];
+    __shared__ CsmRed red;
+    __shared__ float2 G[CSM64_G];
     const int nb = p.fin.nb;
     if ((int)blockIdx.x < nb - 2) {
-        csm64_bin<false>(red, (int)blockIdx.x + 1, p);
-    } else {
-        csm64_bin<true>(red, 0, p);
-        __syncthreads();
-        csm64_bin<true>(red, nb - 1, p);
+        const int b = (int)blockIdx.x + 1;
+        f32x16 re00 = {0}, im00 = {0}, re10 = {0}, im10 = {0}, re11 = {0}, im11 = {0};
+        csm64_bin<false>(b, p, re00, im00, re10, im10, re11, im11);
+        csm_epilogue64<false>(red, G, re00, im00, re10, im10, re11, im11, true, b, p);
+        return;
+    }
+#pragma unroll 1
+    for (int e = 0; e < 2; ++e) {
+        const int b = e ? nb - 1 : 0;
+        f32x16 re00 = {0}, im00 = {0}, re10 = {0}, im10 = {0}, re11 = {0}, im11 = {0};
+        csm64_bin<true>(b, p, re00, im00, re10, im10, re11, im11);
+        if (e) __syncthreads();  // red and G are reused
+        csm_epilogue64<false>(red, G, re00, im00, re10, im10, re11, im11, false, b, p);
     }
 }
 
