@@ -517,11 +517,13 @@ extern "C" int ds_stft_r2c_dev(ds_ctx* c, const float* x, int64_t n_samples, int
             else stft1k::host_tables<256>(h);
             CHK(upload_table_fwd(c, tab, h));
         }
-        // channels per workgroup: 8 x 64 lanes (64-byte runs of the output, 70 KB of LDS) at 1024
-        // points, 16 teams (128-byte runs) of 32 / 16 lanes at 512 / 256
+        // channels per workgroup: 16 teams = 128-byte runs of the output X[bin][frame][channel] (whole
+        // cache lines; at 1024 points that is one 1024-thread workgroup of 140 KB per CU instead of two
+        // of 8 channels with 64-byte runs: transform of the 64-microphone shape 105 -> 97 us);
+        // 2048 points: 8 x 17 KB images, one 1024-thread workgroup per CU (4 channels = 32-byte runs,
+        // two per CU: 0.20 ms against 0.16)
         const int lanes = nfft / 16;
-        int ct = std::min(nfft >= 1024 ? 8 : 16, n_ch);  // 2048: 8 x 17 KB images, one 1024-thread workgroup per CU
-                                                        // (4 channels = 32-byte runs, two per CU: 0.20 ms against 0.16)
+        int ct = std::min(nfft >= 2048 ? 8 : 16, n_ch);
         if (const char* e = getenv("DSPTOOLBOX_AMD_STFT_CT")) {
             int v = atoi(e);
             if (v >= 1 && v <= 16 && v * lanes <= 1024) ct = std::min(v, n_ch);
