@@ -991,7 +991,7 @@ static int wave_tables(ds_ctx* c, const float2** out) {
 // windows of 256 / 512 / 1024 samples (1024 = the reference's default), one input channel:
 // wave-level register transforms (kernels_welch1024.hpp)
 template <int NN>
-static int welch_wave_run(ds_ctx* c, const float* x, int64_t ldx, const float* y, int n_cy, int64_t ldy,
+static int welch_wave_run(ds_ctx* c, const float* x, int n_cx, int64_t ldx, const float* y, int n_cy, int64_t ldy,
                           int64_t n_samples, int hop, int n_frames, const float* window, int detrend,
                           int mode, int amp_sqrt, double norm_scale, double factor, int halve_edges,
                           float2* tf, float* coh) {
@@ -1005,27 +1005,29 @@ static int welch_wave_run(ds_ctx* c, const float* x, int64_t ldx, const float* y
     const float2* tab;
     CHK(wave_tables<NN>(c, &tab));
     const int nf = frames_to_visit(n_samples, hop, n_frames);
-    w1::Plan pl = w1::plan<NN>(nf, n_cy);
+    if (n_cx != 1 && n_cx != n_cy) return fail(c, DS_ERR_ARG, "ds_welch_tf: one input channel, or one per output channel");
+    w1::Plan pl = w1::plan<NN>(nf, n_cy, n_cx);
     CHK(reserve(c, &c->ws, &c->ws_bytes, pl.bytes));
     Carver cv(c->ws);
-    float2* xs = cv.take<float2>((size_t)pl.n_pairs * NN);
-    float* px = cv.take<float>((size_t)pl.n_pairs * W::NB);
-    float* psx = cv.take<float>((size_t)pl.n_chunks * W::NB);
+    float2* xs = cv.take<float2>((size_t)n_cx * pl.n_pairs * NN);
+    float* px = cv.take<float>((size_t)n_cx * pl.n_pairs * W::NB);
+    float* psx = cv.take<float>((size_t)pl.n_chunks * n_cx * W::NB);
     float2* pxy = cv.take<float2>((size_t)pl.n_chunks * n_cy * W::NB);
     float* pyy = cv.take<float>((size_t)pl.n_chunks * n_cy * W::NB);
     const bool half = hop == NN / 2;
-    w1::Args ax{x, n_samples, ldx, 1, hop, nf, pl.n_pairs, detrend, pl.n_chunks, pl.ppc, window,
-                tab, (float4*)xs, px, pxy, pyy, psx};
+    w1::Args ax{x, n_samples, ldx, n_cx, hop, nf, pl.n_pairs, detrend, pl.n_chunks, pl.ppc, window,
+                tab, (float4*)xs, px, pxy, pyy, psx, n_cx};
     auto kx = half ? w1::k_x<NN, true> : w1::k_x<NN, false>;
     auto ky = half ? w1::k_y<NN, true> : w1::k_y<NN, false>;
-    CHK(launch(c, "welch1024_x", kx, dim3((pl.n_pairs + W::TPB - 1) / W::TPB), w1::NTB, W::LDS_BYTES, ax));
+    CHK(launch(c, "welch1024_x", kx, dim3((pl.n_pairs + W::TPB - 1) / W::TPB, n_cx), w1::NTB, W::LDS_BYTES, ax));
+    if (n_cx > 1) CHK(launch(c, "welch1024_pxsum", w1::k_px_sum<NN>, dim3(pl.n_chunks, n_cx), 256, 0, ax));
     w1::Args ay = ax;
     ay.sig = y;
     ay.ld = ldy;
     ay.n_ch = n_cy;
     const int n_grp = (n_cy + W::TPB - 1) / W::TPB;
     CHK(launch(c, "welch1024_main", ky, dim3(pl.n_chunks * n_grp), w1::NTB, W::LDS_BYTES, ay));
-    WelchFinArgs f{psx, pxy, pyy, pl.n_chunks, pl.n_chunks, 1, n_cy, 0, mode,
+    WelchFinArgs f{psx, pxy, pyy, pl.n_chunks, pl.n_chunks, n_cx, n_cy, 0, mode,
                    FinishPar{norm_scale / (double)n_frames, factor, halve_edges, amp_sqrt, W::NB},
                    tf, coh};
     int64_t total = (int64_t)W::NB * n_cy;
@@ -1051,7 +1053,7 @@ static int welch_wave_psd_run(ds_ctx* c, const float* x, int n_cx, int64_t ldx, 
     Carver cv(c->ws);
     float* pyy = cv.take<float>((size_t)pl.n_chunks * n_cx * W::NB);
     w1::Args a{x, n_samples, ldx, n_cx, hop, nf, pl.n_pairs, detrend, pl.n_chunks, pl.ppc, window,
-               tab, nullptr, nullptr, nullptr, pyy, nullptr};
+               tab, nullptr, nullptr, nullptr, pyy, nullptr, 1};
     auto ky = hop == NN / 2 ? w1::k_y<NN, true, true> : w1::k_y<NN, false, true>;
     const int n_grp = (n_cx + W::TPB - 1) / W::TPB;
     CHK(launch(c, "welch1024_main", ky, dim3(pl.n_chunks * n_grp), w1::NTB, W::LDS_BYTES, a));
@@ -1079,11 +1081,12 @@ extern "C" int ds_welch_tf_dev(ds_ctx* c, const float* x, int n_cx, int64_t ldx,
     if (c && W == 8192 && n_cx == 1 && average == DS_AVG_MEAN && !no1k && welch8k::buf_fits(n_samples, n_frames, hop))
         return welch8192_run(c, x, ldx, y, n_cy, ldy, n_samples, hop, n_frames, window, detrend, mode,
                              amp_sqrt, norm_scale, factor, halve_edges, (float2*)tf, coh);
-    if (c && (W == 2048 || W == 1024 || W == 512 || W == 256) && n_cx == 1 && average == DS_AVG_MEAN && !no1k &&
-        welch1k::buf_fits(n_samples, n_cy, ldy)) {
+    // 256 ... 2048-sample windows (1024: the reference's default): one input channel or one per output channel
+    if (c && (W == 2048 || W == 1024 || W == 512 || W == 256) && (n_cx == 1 || n_cx == n_cy) && average == DS_AVG_MEAN &&
+        !no1k && welch1k::buf_fits(n_samples, n_cy, ldy)) {
         auto run = W == 2048 ? welch_wave_run<2048>
                              : (W == 1024 ? welch_wave_run<1024> : (W == 512 ? welch_wave_run<512> : welch_wave_run<256>));
-        return run(c, x, ldx, y, n_cy, ldy, n_samples, hop, n_frames, window, detrend, mode, amp_sqrt,
+        return run(c, x, n_cx, ldx, y, n_cy, ldy, n_samples, hop, n_frames, window, detrend, mode, amp_sqrt,
                    norm_scale, factor, halve_edges, (float2*)tf, coh);
     }
     return welch_common(c, 0, x, n_cx, ldx, y, n_cy, ldy, n_samples, W, hop, n_frames, window, detrend,

@@ -49,7 +49,9 @@ struct Args {
     float* px;          // [n_pairs][NB]
     float2* pxy;        // [n_chunks][n_ch][NB]
     float* pyy;         // [n_chunks][n_ch][NB]
-    float* psx;         // [n_chunks][NB]
+    float* psx;         // [n_chunks][n_cx][NB]
+    int n_cx;           // input channels: 1 (shared by every output channel) or n_ch (one per output channel);
+                        // then xs is [n_cx][n_pairs][8][L], px [n_cx][n_pairs][NB] and k_px_sum fills psx
 };
 
 // Raw samples of the frame pair (2p, 2p+1): HALF_HOP (hop == 512) -> 24 loads s[m] = ch[start +
@@ -166,8 +168,9 @@ __global__ __launch_bounds__(NTB) void k_x(Args p) {
     const float2* tw2 = tw1 + W::G::TW1;
     const int pr = blockIdx.x * W::TPB + w;
     const bool live = pr < p.n_pairs;
+    const int cx = blockIdx.y;  // input channel
     Raw<HALF_HOP> raw;
-    if (live) load_raw<NN, HALF_HOP>(raw, p.sig, p.n_samples, (int64_t)(2 * pr) * p.hop, p.hop, t);
+    if (live) load_raw<NN, HALF_HOP>(raw, p.sig + (int64_t)cx * p.ld, p.n_samples, (int64_t)(2 * pr) * p.hop, p.hop, t);
     float* winl = reinterpret_cast<float*>(tw1 + W::G::TW_LEN);
     load_tables<NN>(tw1, winl, p);
     __syncthreads();
@@ -185,7 +188,7 @@ __global__ __launch_bounds__(NTB) void k_x(Args p) {
     fft_wave<NN>(v, z, buf, tw1, tw2, t);
     if (p.detrend && t == 0) z[0] = make_float2(0.f, 0.f);
     if (live) {
-        float4* xo = p.xs + (int64_t)pr * (NN / 2) + t;
+        float4* xo = p.xs + ((int64_t)cx * p.n_pairs + pr) * (NN / 2) + t;
 #pragma unroll
         for (int g = 0; g < 8; ++g) xo[L * g] = make_float4(z[2 * g].x, z[2 * g].y, z[2 * g + 1].x, z[2 * g + 1].y);
     }
@@ -194,13 +197,29 @@ __global__ __launch_bounds__(NTB) void k_x(Args p) {
     for (int m = 0; m < 16; ++m) pw[t + L * m] = z[m].x * z[m].x + z[m].y * z[m].y;
     team_sync<NN>();
     if (!live) return;
-    float* po = p.px + (int64_t)pr * NB;
+    float* po = p.px + ((int64_t)cx * p.n_pairs + pr) * NB;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const int k = t + L * j;
         po[k] = 0.5f * (pw[k] + pw[(NN - k) & (NN - 1)]);
     }
     if (t == 0) po[NN / 2] = pw[NN / 2];
+}
+
+// ---- input auto spectra per chunk when every output channel has its own input channel:
+// psx[q][cx][k] = sum over the chunk's pairs of px[cx][pair][k] (fp64).  grid = (n_chunks, n_cx).
+// (With ONE input channel k_y's workgroups share this sum instead.)
+template <int NN>
+__global__ __launch_bounds__(256) void k_px_sum(Args p) {
+    constexpr int NB = WG<NN>::NB;
+    const int q = blockIdx.x, cx = blockIdx.y;
+    const int p0 = (int)((int64_t)q * p.n_pairs / p.n_chunks), p1 = (int)((int64_t)(q + 1) * p.n_pairs / p.n_chunks);
+    const float* __restrict__ px = p.px + (int64_t)cx * p.n_pairs * NB;
+    for (int k = threadIdx.x; k < NB; k += 256) {
+        double sum = 0.0;
+        for (int pr = p0; pr < p1; ++pr) sum += (double)px[(int64_t)pr * NB + k];
+        p.psx[((int64_t)q * p.n_cx + cx) * NB + k] = (float)sum;
+    }
 }
 
 // ---- output channels: grid = n_chunks * ceil(n_ch / TPB) --------------------------
@@ -241,7 +260,7 @@ __global__ __launch_bounds__(NTB, 3) void k_y(Args p) {
     if (p0 < p1) load_raw_buf<NN, HALF_HOP>(raw, rs, chan, live, (int64_t)(2 * p0) * p.hop, p.hop, p.n_samples, t);
     float* winl = reinterpret_cast<float*>(tw1 + W::G::TW_LEN);
     load_tables<NN>(tw1, winl, p);
-    if (!AUTO) {
+    if (!AUTO && p.n_cx <= 1) {
         // input auto-spectrum of this chunk: this workgroup's slice of the bins, px rows summed in fp64
         const int bpg = (NB + n_grp - 1) / n_grp;
         const int b0 = g * bpg, b1 = min(b0 + bpg, NB);
@@ -263,6 +282,8 @@ __global__ __launch_bounds__(NTB, 3) void k_y(Args p) {
         T[j] = make_float2(0.f, 0.f);
         P[j] = 0.f;
     }
+    // input spectra of this team's channel: the shared ones, or its own (an idle team reads channel 0)
+    const float4* __restrict__ xs_ch = AUTO ? nullptr : p.xs + (int64_t)((p.n_cx > 1 && live) ? c : 0) * p.n_pairs * (NN / 2) + t;
     for (int pr = p0; pr < p1; ++pr) {
         float2 v[16], z[16];
         window_pair<NN, HALF_HOP>(v, raw, winl, t);
@@ -281,7 +302,7 @@ __global__ __launch_bounds__(NTB, 3) void k_y(Args p) {
             float4 xq[8];
             auto issue_xs = [&]() {
                 __builtin_amdgcn_sched_barrier(0);
-                const float4* __restrict__ xp = p.xs + (int64_t)pr * (NN / 2) + t;
+                const float4* __restrict__ xp = xs_ch + (int64_t)pr * (NN / 2);
 #pragma unroll
                 for (int gg = 0; gg < 8; ++gg) xq[gg] = xp[L * gg];
                 __builtin_amdgcn_sched_barrier(0);
@@ -338,7 +359,7 @@ struct Plan {
     size_t bytes;
 };
 template <int NN>
-inline Plan plan(int n_frames, int n_cy) {
+inline Plan plan(int n_frames, int n_cy, int n_cx = 1) {
     using W = WG<NN>;
     Plan pl;
     pl.n_pairs = (n_frames + 1) / 2;
@@ -357,8 +378,8 @@ inline Plan plan(int n_frames, int n_cy) {
     pl.n_chunks = want;         // chunk q = pairs [q n_pairs / n_chunks, (q+1) n_pairs / n_chunks)
     pl.ppc = (pl.n_pairs + want - 1) / want;
     auto pad = [](size_t b) { return (b + 255) & ~size_t(255); };
-    pl.bytes = pad(sizeof(float2) * (size_t)pl.n_pairs * NN) + pad(sizeof(float) * (size_t)pl.n_pairs * W::NB) +
-               pad(sizeof(float) * (size_t)pl.n_chunks * W::NB) + pad(sizeof(float2) * (size_t)pl.n_chunks * n_cy * W::NB) +
+    pl.bytes = pad(sizeof(float2) * (size_t)n_cx * pl.n_pairs * NN) + pad(sizeof(float) * (size_t)n_cx * pl.n_pairs * W::NB) +
+               pad(sizeof(float) * (size_t)pl.n_chunks * n_cx * W::NB) + pad(sizeof(float2) * (size_t)pl.n_chunks * n_cy * W::NB) +
                pad(sizeof(float) * (size_t)pl.n_chunks * n_cy * W::NB);
     return pl;
 }

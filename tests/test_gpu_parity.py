@@ -272,6 +272,25 @@ def test_welch4096_paired_inputs_vs_oracle():
             assert e1 < TOL and e2 < TOL, (n, C, mode, e1, e2)
 
 
+@pytest.mark.parametrize("W", [256, 512, 1024, 2048])
+def test_welch_wave_kernels_paired_inputs_vs_oracle(W):
+    """One input channel per output channel on the wave-level register kernels (256 ... 2048-sample
+    windows, 1024 being the reference's default): k_x over every input channel, k_px_sum, k_y with
+    the team's own input spectra.  50 % overlap (carried half frame) and 75 %, ragged tails, more
+    channels than teams per workgroup."""
+    rng = np.random.default_rng(100 + W)
+    for n, C, ov, det in ((W * 40 + 333, 5, 50, True), (W * 25, 19, 75, False), (W * 9 + 1, 2, 50, True)):
+        x = rng.standard_normal((n, C)) * 0.3
+        y = np.stack([np.convolve(x[:, i], rng.standard_normal(12) * np.exp(-np.arange(12) / 4.0))[:n]
+                      for i in range(C)], axis=1)
+        y += 0.02 * rng.standard_normal(y.shape)
+        for mode in ("H1", "H2", "H3"):
+            tf, coh = backend.welch_transfer_function(y, x, 48000, W, mode, overlap_percent=ov, detrend=det)
+            rt, rc = orc.compute_transfer_function(y, x, 48000, W, mode, overlap_percent=ov, detrend=det)
+            e1, e2 = relmax(tf, rt, det), relmax(coh, rc, det)
+            assert e1 < TOL and e2 < TOL, (W, n, C, mode, e1, e2)
+
+
 def test_transfer_function_float64_route_vs_oracle():
     """ds_welch_tf_x64: float64 transforms, sums and finish -- the oracle's own precision (1e-11),
     every mode, amplitude and power scalings, one input channel or one per output, ragged tail."""
