@@ -852,7 +852,7 @@ static int welch4096_run(ds_ctx* c, const float* x, int n_cx, int64_t ldx, const
 
 // window 8192, one input channel: two 4096-point register transforms per frame pair
 // (kernels_welch8192.hpp)
-static int welch8192_run(ds_ctx* c, const float* x, int64_t ldx, const float* y, int n_cy, int64_t ldy,
+static int welch8192_run(ds_ctx* c, const float* x, int n_cx, int64_t ldx, const float* y, int n_cy, int64_t ldy,
                          int64_t n_samples, int hop, int n_frames, const float* window, int detrend,
                          int mode, int amp_sqrt, double norm_scale, double factor, int halve_edges,
                          float2* tf, float* coh) {
@@ -873,19 +873,21 @@ static int welch8192_run(ds_ctx* c, const float* x, int64_t ldx, const float* y,
         CHK(upload_table_fwd(c, &c->deconv8k_tables, h));
     }
     const int nf = frames_to_visit(n_samples, hop, n_frames);
-    w8::Plan pl = w8::plan(nf, n_cy);
+    if (n_cx != 1 && n_cx != n_cy) return fail(c, DS_ERR_ARG, "ds_welch_tf: one input channel, or one per output channel");
+    w8::Plan pl = w8::plan(nf, n_cy, n_cx);
     CHK(reserve(c, &c->ws, &c->ws_bytes, pl.bytes));
     Carver cv(c->ws);
-    float2* xs = cv.take<float2>((size_t)pl.n_pairs * w8::N);
-    float* px = cv.take<float>((size_t)pl.n_pairs * w8::NB);
-    float* psx = cv.take<float>((size_t)pl.n_chunks * w8::NB);
+    float2* xs = cv.take<float2>((size_t)n_cx * pl.n_pairs * w8::N);
+    float* px = cv.take<float>((size_t)n_cx * pl.n_pairs * w8::NB);
+    float* psx = cv.take<float>((size_t)pl.n_chunks * n_cx * w8::NB);
     float2* pxy = cv.take<float2>((size_t)pl.n_chunks * n_cy * w8::NB);
     float* pyy = cv.take<float>((size_t)pl.n_chunks * n_cy * w8::NB);
     const bool half = hop == 4096;
-    w8::Args ax{x, n_samples, ldx, 1, hop, nf, pl.n_pairs, detrend, pl.n_chunks, window,
-                c->w4_tables, c->deconv8k_tables, (float4*)xs, px, pxy, pyy, psx};
+    w8::Args ax{x, n_samples, ldx, n_cx, hop, nf, pl.n_pairs, detrend, pl.n_chunks, window,
+                c->w4_tables, c->deconv8k_tables, (float4*)xs, px, pxy, pyy, psx, n_cx};
     auto kx = half ? w8::k_x<true> : w8::k_x<false>;
-    CHK(launch(c, "welch8192_x", kx, dim3(pl.n_pairs), w8::NTB, w8::LDS_BYTES, ax));
+    CHK(launch(c, "welch8192_x", kx, dim3(pl.n_pairs, n_cx), w8::NTB, w8::LDS_BYTES, ax));
+    if (n_cx > 1) CHK(launch(c, "welch8192_pxsum", w8::k_px_sum, dim3(pl.n_chunks, n_cx), 256, 0, ax));
     w8::Args ay = ax;
     ay.sig = y;
     ay.ld = ldy;
@@ -896,7 +898,7 @@ static int welch8192_run(ds_ctx* c, const float* x, int64_t ldx, const float* y,
         auto kyw = half ? w8::k_y<true, true> : w8::k_y<false, true>;
         CHK(launch(c, "welch8192_main", kyw, dim3(pl.n_chunks * n_cy), w8::NTB, w8::LDS_BYTES_WINLDS, ay));
     }
-    WelchFinArgs f{psx, pxy, pyy, pl.n_chunks, pl.n_chunks, 1, n_cy, 0, mode,
+    WelchFinArgs f{psx, pxy, pyy, pl.n_chunks, pl.n_chunks, n_cx, n_cy, 0, mode,
                    FinishPar{norm_scale / (double)n_frames, factor, halve_edges, amp_sqrt, w8::NB},
                    tf, coh};
     int64_t total = (int64_t)w8::NB * n_cy;
@@ -1078,8 +1080,9 @@ extern "C" int ds_welch_tf_dev(ds_ctx* c, const float* x, int n_cx, int64_t ldx,
         return welch4096_run(c, x, n_cx, ldx, y, n_cy, ldy, n_samples, hop, n_frames, window, detrend, mode,
                              amp_sqrt, norm_scale, factor, halve_edges, (float2*)tf, coh);
     static const bool no1k = getenv("DSPTOOLBOX_AMD_WELCH_GENERIC") != nullptr;
-    if (c && W == 8192 && n_cx == 1 && average == DS_AVG_MEAN && !no1k && welch8k::buf_fits(n_samples, n_frames, hop))
-        return welch8192_run(c, x, ldx, y, n_cy, ldy, n_samples, hop, n_frames, window, detrend, mode,
+    if (c && W == 8192 && (n_cx == 1 || n_cx == n_cy) && average == DS_AVG_MEAN && !no1k &&
+        welch8k::buf_fits(n_samples, n_frames, hop))
+        return welch8192_run(c, x, n_cx, ldx, y, n_cy, ldy, n_samples, hop, n_frames, window, detrend, mode,
                              amp_sqrt, norm_scale, factor, halve_edges, (float2*)tf, coh);
     // 256 ... 2048-sample windows (1024: the reference's default): one input channel or one per output channel
     if (c && (W == 2048 || W == 1024 || W == 512 || W == 256) && (n_cx == 1 || n_cx == n_cy) && average == DS_AVG_MEAN &&

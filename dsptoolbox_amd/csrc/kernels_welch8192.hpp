@@ -39,7 +39,9 @@ struct Args {
     float* px;          // [n_pairs][NB]
     float2* pxy;        // [n_chunks][n_ch][NB]
     float* pyy;         // [n_chunks][n_ch][NB]
-    float* psx;         // [n_chunks][NB]
+    float* psx;         // [n_chunks][n_cx][NB]
+    int n_cx;           // input channels: 1 (shared) or n_ch (one per output channel; then xs is
+                        // [n_cx][n_pairs][2][8][256], px [n_cx][n_pairs][NB] and k_px_sum fills psx)
 };
 
 // Raw samples of the frame pair (2p, 2p+1): segment j, slot n1 = ch[start0 + off_j + t + 256 n1].
@@ -139,9 +141,9 @@ __global__ __launch_bounds__(NTB) void k_x(Args p) {
     const int q = __builtin_amdgcn_readfirstlane(tid >> 8);
     float2* buf = lds + q * 2 * w4::BUF_C;
     float2* tw2 = lds + 4 * w4::BUF_C;
-    const int pr = blockIdx.x;
+    const int pr = blockIdx.x, cx = blockIdx.y;
     Raw<HALF_HOP> raw;
-    load_raw<HALF_HOP>(raw, p.sig, p.n_samples, (int64_t)(2 * pr) * p.hop, p.hop, t);
+    load_raw<HALF_HOP>(raw, p.sig + (int64_t)cx * p.ld, p.n_samples, (int64_t)(2 * pr) * p.hop, p.hop, t);
     w4::Tw tw;
 #pragma unroll
     for (int k1 = 1; k1 < 16; ++k1) tw.w[k1 - 1] = p.twt[(k1 - 1) * 256 + t];
@@ -152,7 +154,7 @@ __global__ __launch_bounds__(NTB) void k_x(Args p) {
     front<HALF_HOP>(v, raw, p.window, q, wt, p.twn + 256, needs_drop(p, pr), t);
     w4::fft4096_plain<true>(v, tw, buf, tw2, t);
     if (p.detrend && tid == 0) v[pos16(0)] = make_float2(0.f, 0.f);  // bin 0 = class 0, k' = 0
-    float4* xo = p.xs + ((int64_t)pr * 2 + q) * (M / 2) + t;
+    float4* xo = p.xs + (((int64_t)cx * p.n_pairs + pr) * 2 + q) * (M / 2) + t;
 #pragma unroll
     for (int g = 0; g < 8; ++g) {
         const float2 z0 = v[pos16(2 * g)], z1 = v[pos16(2 * g + 1)];
@@ -166,7 +168,7 @@ __global__ __launch_bounds__(NTB) void k_x(Args p) {
         pw[t + 256 * k3] = z.x * z.x + z.y * z.y;
     }
     __syncthreads();
-    float* po = p.px + (int64_t)pr * NB;
+    float* po = p.px + ((int64_t)cx * p.n_pairs + pr) * NB;
     for (int kp = t; kp < fold_count(q); kp += 256) po[2 * kp + q] = 0.5f * (pw[kp] + pw[fold_partner(q, kp)]);
 }
 
@@ -208,7 +210,7 @@ __global__ __launch_bounds__(NTB, 1) void k_y(Args p) {
     const float2* c32 = p.twn + 256;
     const float* ch = p.sig + (int64_t)c * p.ld;
     const int p0 = (int)((int64_t)cq * p.n_pairs / p.n_chunks), p1 = (int)((int64_t)(cq + 1) * p.n_pairs / p.n_chunks);
-    if (!AUTO) {
+    if (!AUTO && p.n_cx <= 1) {
         // input auto-spectrum of this chunk: this workgroup's slice of the bins, px rows summed in fp64
         const int bpc = (NB + p.n_ch - 1) / p.n_ch;
         const int b0 = c * bpc, b1 = min(b0 + bpc, NB);
@@ -243,7 +245,7 @@ __global__ __launch_bounds__(NTB, 1) void k_y(Args p) {
         auto issue_xs = [&]() {
             if (AUTO) return;
             __builtin_amdgcn_sched_barrier(0);
-            const float4* __restrict__ xp = p.xs + ((int64_t)pr * 2 + q) * (M / 2) + t;
+            const float4* __restrict__ xp = p.xs + (((int64_t)(p.n_cx > 1 ? c : 0) * p.n_pairs + pr) * 2 + q) * (M / 2) + t;
 #pragma unroll
             for (int g = 0; g < 8; ++g) {
                 const float4 r = xp[256 * g];
@@ -291,11 +293,24 @@ __global__ __launch_bounds__(NTB, 1) void k_y(Args p) {
 }
 
 // ---- host side ------------------------------------------------------------------------
+// input auto spectra per chunk when every output channel has its own input channel:
+// psx[q][cx][k] = sum over the chunk's pairs of px[cx][pair][k] (fp64).  grid = (n_chunks, n_cx)
+__global__ __launch_bounds__(256) void k_px_sum(Args p) {
+    const int q = blockIdx.x, cx = blockIdx.y;
+    const int p0 = (int)((int64_t)q * p.n_pairs / p.n_chunks), p1 = (int)((int64_t)(q + 1) * p.n_pairs / p.n_chunks);
+    const float* __restrict__ px = p.px + (int64_t)cx * p.n_pairs * NB;
+    for (int k = threadIdx.x; k < NB; k += 256) {
+        double sum = 0.0;
+        for (int pr = p0; pr < p1; ++pr) sum += (double)px[(int64_t)pr * NB + k];
+        p.psx[((int64_t)q * p.n_cx + cx) * NB + k] = (float)sum;
+    }
+}
+
 struct Plan {
     int n_pairs, n_chunks;
     size_t bytes;
 };
-inline Plan plan(int n_frames, int n_cy) {
+inline Plan plan(int n_frames, int n_cy, int n_cx = 1) {
     Plan pl;
     pl.n_pairs = (n_frames + 1) / 2;
     // one workgroup per CU (256) resident at once when there is enough work; fp32 chains <= 64 pairs
@@ -307,8 +322,8 @@ inline Plan plan(int n_frames, int n_cy) {
     if (want >= 8) want &= ~7;
     pl.n_chunks = want;
     auto pad = [](size_t b) { return (b + 255) & ~size_t(255); };
-    pl.bytes = pad(sizeof(float2) * (size_t)pl.n_pairs * N) + pad(sizeof(float) * (size_t)pl.n_pairs * NB) +
-               pad(sizeof(float) * (size_t)pl.n_chunks * NB) + pad(sizeof(float2) * (size_t)pl.n_chunks * n_cy * NB) +
+    pl.bytes = pad(sizeof(float2) * (size_t)n_cx * pl.n_pairs * N) + pad(sizeof(float) * (size_t)n_cx * pl.n_pairs * NB) +
+               pad(sizeof(float) * (size_t)pl.n_chunks * n_cx * NB) + pad(sizeof(float2) * (size_t)pl.n_chunks * n_cy * NB) +
                pad(sizeof(float) * (size_t)pl.n_chunks * n_cy * NB);
     return pl;
 }

@@ -272,11 +272,11 @@ def test_welch4096_paired_inputs_vs_oracle():
             assert e1 < TOL and e2 < TOL, (n, C, mode, e1, e2)
 
 
-@pytest.mark.parametrize("W", [256, 512, 1024, 2048])
+@pytest.mark.parametrize("W", [256, 512, 1024, 2048, 8192])
 def test_welch_wave_kernels_paired_inputs_vs_oracle(W):
     """One input channel per output channel on the wave-level register kernels (256 ... 2048-sample
-    windows, 1024 being the reference's default): k_x over every input channel, k_px_sum, k_y with
-    the team's own input spectra.  50 % overlap (carried half frame) and 75 %, ragged tails, more
+    windows, 1024 being the reference's default) and the 8192-sample ones: k_x over every input
+    channel, k_px_sum, k_y with the team's own input spectra.  50 % overlap (carried half frame) and 75 %, ragged tails, more
     channels than teams per workgroup."""
     rng = np.random.default_rng(100 + W)
     for n, C, ov, det in ((W * 40 + 333, 5, 50, True), (W * 25, 19, 75, False), (W * 9 + 1, 2, 50, True)):
