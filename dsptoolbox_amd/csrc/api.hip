@@ -794,7 +794,7 @@ static int frames_to_visit(int64_t n_samples, int hop, int n_frames) {
 static int welch4096_run(ds_ctx* c, const float* x, int n_cx, int64_t ldx, const float* y, int n_cy, int64_t ldy,
                          int64_t n_samples, int hop, int n_frames, const float* window, int detrend,
                          int mode, int amp_sqrt, double norm_scale, double factor, int halve_edges,
-                         float2* tf, float* coh) {
+                         float2* tf, float* coh, int kind = 0) {  // kind 2: tf = cross spectra, no coh
     namespace w4 = welch4096;
     if (!x || !y || !window) return fail(c, DS_ERR_ARG, "ds_welch_tf: null argument");
     if (n_cx != 1 && n_cx != n_cy) return fail(c, DS_ERR_ARG, "ds_welch_tf: one input channel, or one per output channel");
@@ -842,7 +842,7 @@ static int welch4096_run(ds_ctx* c, const float* x, int n_cx, int64_t ldx, const
         CHK(launch(c, "welch4096_x", kx, dim3(pl.n_pairs), w4::NT, w4::LDS_BYTES, ax));
         CHK(launch(c, "welch4096_main", ky, dim3(pl.n_chunks * n_cy), w4::NT, w4::LDS_BYTES_2, ay));
     }
-    WelchFinArgs f{psx, pxy, pyy, pl.n_chunks, pl.n_chunks, n_cx, n_cy, 0, mode,
+    WelchFinArgs f{psx, pxy, pyy, pl.n_chunks, pl.n_chunks, n_cx, n_cy, kind, mode,
                    FinishPar{norm_scale / (double)n_frames, factor, halve_edges, amp_sqrt, w4::NB},
                    tf, coh};
     int64_t total = (int64_t)w4::NB * n_cy;
@@ -855,7 +855,7 @@ static int welch4096_run(ds_ctx* c, const float* x, int n_cx, int64_t ldx, const
 static int welch8192_run(ds_ctx* c, const float* x, int n_cx, int64_t ldx, const float* y, int n_cy, int64_t ldy,
                          int64_t n_samples, int hop, int n_frames, const float* window, int detrend,
                          int mode, int amp_sqrt, double norm_scale, double factor, int halve_edges,
-                         float2* tf, float* coh) {
+                         float2* tf, float* coh, int kind = 0) {  // kind 2: tf = cross spectra, no coh
     namespace w8 = welch8k;
     if (!x || !y || !window) return fail(c, DS_ERR_ARG, "ds_welch_tf: null argument");
     if (n_cy <= 0 || n_samples <= 0 || hop <= 0 || hop > 8192 || n_frames <= 0 || ldx < n_samples ||
@@ -898,7 +898,7 @@ static int welch8192_run(ds_ctx* c, const float* x, int n_cx, int64_t ldx, const
         auto kyw = half ? w8::k_y<true, true> : w8::k_y<false, true>;
         CHK(launch(c, "welch8192_main", kyw, dim3(pl.n_chunks * n_cy), w8::NTB, w8::LDS_BYTES_WINLDS, ay));
     }
-    WelchFinArgs f{psx, pxy, pyy, pl.n_chunks, pl.n_chunks, n_cx, n_cy, 0, mode,
+    WelchFinArgs f{psx, pxy, pyy, pl.n_chunks, pl.n_chunks, n_cx, n_cy, kind, mode,
                    FinishPar{norm_scale / (double)n_frames, factor, halve_edges, amp_sqrt, w8::NB},
                    tf, coh};
     int64_t total = (int64_t)w8::NB * n_cy;
@@ -996,7 +996,7 @@ template <int NN>
 static int welch_wave_run(ds_ctx* c, const float* x, int n_cx, int64_t ldx, const float* y, int n_cy, int64_t ldy,
                           int64_t n_samples, int hop, int n_frames, const float* window, int detrend,
                           int mode, int amp_sqrt, double norm_scale, double factor, int halve_edges,
-                          float2* tf, float* coh) {
+                          float2* tf, float* coh, int kind = 0) {  // kind 2: tf = cross spectra, no coh
     namespace w1 = welch1k;
     using W = w1::WG<NN>;
     if (!x || !y || !window) return fail(c, DS_ERR_ARG, "ds_welch_tf: null argument");
@@ -1029,7 +1029,7 @@ static int welch_wave_run(ds_ctx* c, const float* x, int n_cx, int64_t ldx, cons
     ay.n_ch = n_cy;
     const int n_grp = (n_cy + W::TPB - 1) / W::TPB;
     CHK(launch(c, "welch1024_main", ky, dim3(pl.n_chunks * n_grp), w1::NTB, W::LDS_BYTES, ay));
-    WelchFinArgs f{psx, pxy, pyy, pl.n_chunks, pl.n_chunks, n_cx, n_cy, 0, mode,
+    WelchFinArgs f{psx, pxy, pyy, pl.n_chunks, pl.n_chunks, n_cx, n_cy, kind, mode,
                    FinishPar{norm_scale / (double)n_frames, factor, halve_edges, amp_sqrt, W::NB},
                    tf, coh};
     int64_t total = (int64_t)W::NB * n_cy;
@@ -1090,7 +1090,7 @@ extern "C" int ds_welch_tf_dev(ds_ctx* c, const float* x, int n_cx, int64_t ldx,
         auto run = W == 2048 ? welch_wave_run<2048>
                              : (W == 1024 ? welch_wave_run<1024> : (W == 512 ? welch_wave_run<512> : welch_wave_run<256>));
         return run(c, x, n_cx, ldx, y, n_cy, ldy, n_samples, hop, n_frames, window, detrend, mode, amp_sqrt,
-                   norm_scale, factor, halve_edges, (float2*)tf, coh);
+                   norm_scale, factor, halve_edges, (float2*)tf, coh, 0);
     }
     return welch_common(c, 0, x, n_cx, ldx, y, n_cy, ldy, n_samples, W, hop, n_frames, window, detrend,
                         average, mode, amp_sqrt, norm_scale, factor, halve_edges, (float2*)tf, coh);
@@ -1185,6 +1185,25 @@ static int welch_csd_dev(ds_ctx* c, const float* x, const float* y, int n_ch, in
                          int64_t n_samples, int W, int hop, int n_frames, const float* window,
                          int detrend, int average, int amp_sqrt, double norm_scale, double factor,
                          int halve_edges, ds_c32* csd) {
+    // csd_i = mean_f conj(X_i) Y_i is the cross sum a transfer function with one input channel per
+    // output channel accumulates: the register kernels with the finish of kind 2
+    static const bool generic = getenv("DSPTOOLBOX_AMD_WELCH_GENERIC") != nullptr;
+    if (c && x && y && window && csd && average == DS_AVG_MEAN && !generic && n_ch > 0 && n_samples > 0 &&
+        n_frames > 0 && hop > 0 && hop <= W && ld >= n_samples) {
+        if (W == 4096 && hop == 2048 && welch4096::enabled() && welch4096::enabled3() &&
+            welch4096::fits3(n_samples, frames_to_visit(n_samples, hop, n_frames)))
+            return welch4096_run(c, x, n_ch, ld, y, n_ch, ld, n_samples, hop, n_frames, window, detrend, DS_TF_H1,
+                                 amp_sqrt, norm_scale, factor, halve_edges, (float2*)csd, nullptr, 2);
+        if (W == 8192 && welch8k::buf_fits(n_samples, n_frames, hop))
+            return welch8192_run(c, x, n_ch, ld, y, n_ch, ld, n_samples, hop, n_frames, window, detrend, DS_TF_H1,
+                                 amp_sqrt, norm_scale, factor, halve_edges, (float2*)csd, nullptr, 2);
+        if ((W == 2048 || W == 1024 || W == 512 || W == 256) && welch1k::buf_fits(n_samples, n_ch, ld)) {
+            auto run = W == 2048 ? welch_wave_run<2048>
+                                 : (W == 1024 ? welch_wave_run<1024> : (W == 512 ? welch_wave_run<512> : welch_wave_run<256>));
+            return run(c, x, n_ch, ld, y, n_ch, ld, n_samples, hop, n_frames, window, detrend, DS_TF_H1, amp_sqrt,
+                       norm_scale, factor, halve_edges, (float2*)csd, nullptr, 2);
+        }
+    }
     return welch_common(c, 2, x, n_ch, ld, y, n_ch, ld, n_samples, W, hop, n_frames, window, detrend,
                         average, 0, amp_sqrt, norm_scale, factor, halve_edges, (float2*)csd, nullptr);
 }

@@ -289,6 +289,31 @@ def test_welch_wave_kernels_paired_inputs_vs_oracle(W):
             rt, rc = orc.compute_transfer_function(y, x, 48000, W, mode, overlap_percent=ov, detrend=det)
             e1, e2 = relmax(tf, rt, det), relmax(coh, rc, det)
             assert e1 < TOL and e2 < TOL, (W, n, C, mode, e1, e2)
+        # the cross spectra of the same channel pairs (ds_welch_csd: the same kernels, finish of kind 2)
+        for sc in (SpectrumScaling.FFTBackward, SpectrumScaling.PowerSpectralDensity):
+            k = backend._welch(x, y, 48000, Window.Hann, W, ov, det, "mean", sc)
+            r = orc.welch(x, y, 48000, "hann", W, ov, det, "mean", sc.name)
+            assert k.shape == r.shape and relmax(k, r, det) < TOL, (W, n, C, sc, relmax(k, r, det))
+
+
+def test_welch4096_cross_spectra_on_register_kernels():
+    """ds_welch_csd with a 4096-sample window at 50 % overlap: k_x3 / k_px_sum / k_y3 + finish kind 2."""
+    rng = np.random.default_rng(4096)
+    for n, C, det in ((4096 * 30 + 55, 4, True), (2**17, 1, False)):
+        x = rng.standard_normal((n, C)) * 0.3
+        y = np.stack([np.convolve(x[:, i], rng.standard_normal(8))[:n] for i in range(C)], axis=1)
+        y += 0.05 * rng.standard_normal(y.shape)
+        for sc in (SpectrumScaling.FFTBackward, SpectrumScaling.PowerSpectralDensity):
+            from dsptoolbox_amd._lib import get_context
+            ctx = get_context()
+            ctx.profile_enable(True)
+            ctx.profile_report()
+            k = backend._welch(x, y, 48000, Window.Hann, 4096, 50, det, "mean", sc)
+            launched = ctx.profile_report()
+            ctx.profile_enable(False)
+            assert "welch4096_main" in launched and "welch_finish" in launched, sorted(launched)
+            r = orc.welch(x, y, 48000, "hann", 4096, 50, det, "mean", sc.name)
+            assert k.shape == r.shape and relmax(k, r, det) < TOL, (n, C, sc, relmax(k, r, det))
 
 
 def test_transfer_function_float64_route_vs_oracle():
