@@ -24,6 +24,7 @@
 #include "kernels_stft1024.hpp"
 #include "kernels_welch1024.hpp"
 #include "kernels_welch8192.hpp"
+#include "kernels_welch16384.hpp"
 #include "kernels_welch_f64.hpp"
 #include "kernels_stft_any.hpp"
 #include "kernels_fir_stream.hpp"
@@ -941,6 +942,88 @@ static int welch8192_psd_run(ds_ctx* c, const float* x, int n_cx, int64_t ldx, i
     return DS_OK;
 }
 
+// window 16384: four 4096-point register transforms per frame pair, two per slot of 256 threads
+// (kernels_welch16384.hpp)
+static int welch16k_tables(ds_ctx* c) {
+    if (!c->w4_tables) {
+        std::vector<float2> h;
+        welch4096::host_tables(h);
+        CHK(upload_table_fwd(c, &c->w4_tables, h));
+    }
+    if (!c->fir16k_tables) {
+        std::vector<float2> h;
+        fir16k::host_tables(h);
+        CHK(upload_table_fwd(c, &c->fir16k_tables, h));
+    }
+    return DS_OK;
+}
+static int welch16384_run(ds_ctx* c, const float* x, int n_cx, int64_t ldx, const float* y, int n_cy, int64_t ldy,
+                          int64_t n_samples, int hop, int n_frames, const float* window, int detrend,
+                          int mode, int amp_sqrt, double norm_scale, double factor, int halve_edges,
+                          float2* tf, float* coh, int kind = 0) {  // kind 2: tf = cross spectra, no coh
+    namespace w16 = welch16k;
+    if (!x || !y || !window) return fail(c, DS_ERR_ARG, "ds_welch_tf: null argument");
+    if (n_cx != 1 && n_cx != n_cy) return fail(c, DS_ERR_ARG, "ds_welch_tf: one input channel, or one per output channel");
+    if (n_cy <= 0 || n_samples <= 0 || hop <= 0 || hop > 16384 || n_frames <= 0 || ldx < n_samples ||
+        ldy < n_samples)
+        return fail(c, DS_ERR_ARG, "ds_welch_tf: bad shape");
+    if (mode < DS_TF_H1 || mode > DS_TF_H3) return fail(c, DS_ERR_ARG, "welch: unsupported transfer function type");
+    CHK(welch16k_tables(c));
+    const int nf = frames_to_visit(n_samples, hop, n_frames);
+    w16::Plan pl = w16::plan(nf, n_cy, n_cx);
+    CHK(reserve(c, &c->ws, &c->ws_bytes, pl.bytes));
+    Carver cv(c->ws);
+    float2* xs = cv.take<float2>((size_t)n_cx * pl.n_pairs * w16::N);
+    float* pxu = cv.take<float>((size_t)n_cx * pl.n_pairs * w16::N);
+    float* psx = cv.take<float>((size_t)pl.n_chunks * n_cx * w16::NB);
+    float2* pxy = cv.take<float2>((size_t)pl.n_chunks * n_cy * w16::NB);
+    float* pyy = cv.take<float>((size_t)pl.n_chunks * n_cy * w16::NB);
+    float2* tu = cv.take<float2>((size_t)pl.n_chunks * n_cy * w16::N);
+    float* pu = cv.take<float>((size_t)pl.n_chunks * n_cy * w16::N);
+    w16::Args ax{x, n_samples, ldx, n_cx, hop, nf, pl.n_pairs, detrend, pl.n_chunks, window,
+                 c->w4_tables, c->fir16k_tables, (float4*)xs, pxu, pxy, pyy, psx, n_cx, tu, pu};
+    CHK(launch(c, "welch16384_x", w16::k_x, dim3(pl.n_pairs, n_cx, 2), w16::NTB, w16::LDS_BYTES, ax));
+    CHK(launch(c, "welch16384_pxsum", w16::k_px_sum, dim3((w16::NB + 255) / 256, pl.n_chunks, n_cx), 256, 0, ax));
+    w16::Args ay = ax;
+    ay.sig = y;
+    ay.ld = ldy;
+    ay.n_ch = n_cy;
+    CHK(launch(c, "welch16384_main", w16::k_y<false>, dim3(pl.n_chunks * n_cy, 1, 2), w16::NTB, w16::LDS_BYTES, ay));
+    CHK(launch(c, "welch16384_fold", w16::k_fold<false>, dim3((w16::NB + 255) / 256, pl.n_chunks * n_cy), 256, 0, ay));
+    WelchFinArgs f{psx, pxy, pyy, pl.n_chunks, pl.n_chunks, n_cx, n_cy, kind, mode,
+                   FinishPar{norm_scale / (double)n_frames, factor, halve_edges, amp_sqrt, w16::NB},
+                   tf, coh};
+    int64_t total = (int64_t)w16::NB * n_cy;
+    CHK(launch(c, "welch_finish", k_welch_finish, dim3((unsigned)((total + 63) / 64)), 256, 0, f));
+    return DS_OK;
+}
+static int welch16384_psd_run(ds_ctx* c, const float* x, int n_cx, int64_t ldx, int64_t n_samples, int hop,
+                              int n_frames, const float* window, int detrend, int amp_sqrt, double norm_scale,
+                              double factor, int halve_edges, float* psd) {
+    namespace w16 = welch16k;
+    if (!x || !window) return fail(c, DS_ERR_ARG, "ds_welch_psd: null argument");
+    if (n_cx <= 0 || n_samples <= 0 || hop <= 0 || hop > 16384 || n_frames <= 0 || ldx < n_samples)
+        return fail(c, DS_ERR_ARG, "ds_welch_psd: bad shape");
+    CHK(welch16k_tables(c));
+    const int nf = frames_to_visit(n_samples, hop, n_frames);
+    w16::Plan pl = w16::plan(nf, n_cx);
+    CHK(reserve(c, &c->ws, &c->ws_bytes, Carver::pad(sizeof(float) * (size_t)pl.n_chunks * n_cx * w16::NB) +
+                                             Carver::pad(sizeof(float) * (size_t)pl.n_chunks * n_cx * w16::N)));
+    Carver cv(c->ws);
+    float* pyy = cv.take<float>((size_t)pl.n_chunks * n_cx * w16::NB);
+    float* pu = cv.take<float>((size_t)pl.n_chunks * n_cx * w16::N);
+    w16::Args a{x, n_samples, ldx, n_cx, hop, nf, pl.n_pairs, detrend, pl.n_chunks, window,
+                c->w4_tables, c->fir16k_tables, nullptr, nullptr, nullptr, pyy, nullptr, 1, nullptr, pu};
+    CHK(launch(c, "welch16384_main", w16::k_y<true>, dim3(pl.n_chunks * n_cx, 1, 2), w16::NTB, w16::LDS_BYTES, a));
+    CHK(launch(c, "welch16384_fold", w16::k_fold<true>, dim3((w16::NB + 255) / 256, pl.n_chunks * n_cx), 256, 0, a));
+    WelchFinArgs f{pyy, nullptr, nullptr, pl.n_chunks, pl.n_chunks, n_cx, 0, 1, 0,
+                   FinishPar{norm_scale / (double)n_frames, factor, halve_edges, amp_sqrt, w16::NB},
+                   nullptr, psd};
+    int64_t total = (int64_t)w16::NB * n_cx;
+    CHK(launch(c, "welch_finish", k_welch_finish, dim3((unsigned)((total + 63) / 64)), 256, 0, f));
+    return DS_OK;
+}
+
 // auto spectra of every channel with a 4096-sample window on the headline kernel (AUTO variant)
 static int welch4096_psd_run(ds_ctx* c, const float* x, int n_cx, int64_t ldx, int64_t n_samples, int hop,
                              int n_frames, const float* window, int detrend, int amp_sqrt, double norm_scale,
@@ -1080,6 +1163,10 @@ extern "C" int ds_welch_tf_dev(ds_ctx* c, const float* x, int n_cx, int64_t ldx,
         return welch4096_run(c, x, n_cx, ldx, y, n_cy, ldy, n_samples, hop, n_frames, window, detrend, mode,
                              amp_sqrt, norm_scale, factor, halve_edges, (float2*)tf, coh);
     static const bool no1k = getenv("DSPTOOLBOX_AMD_WELCH_GENERIC") != nullptr;
+    if (c && W == 16384 && (n_cx == 1 || n_cx == n_cy) && average == DS_AVG_MEAN && !no1k &&
+        welch16k::buf_fits(n_samples, n_frames, hop))
+        return welch16384_run(c, x, n_cx, ldx, y, n_cy, ldy, n_samples, hop, n_frames, window, detrend, mode,
+                              amp_sqrt, norm_scale, factor, halve_edges, (float2*)tf, coh);
     if (c && W == 8192 && (n_cx == 1 || n_cx == n_cy) && average == DS_AVG_MEAN && !no1k &&
         welch8k::buf_fits(n_samples, n_frames, hop))
         return welch8192_run(c, x, n_cx, ldx, y, n_cy, ldy, n_samples, hop, n_frames, window, detrend, mode,
@@ -1164,6 +1251,9 @@ extern "C" int ds_welch_psd_dev(ds_ctx* c, const float* x, int n_cx, int64_t ldx
                                 int halve_edges, float* psd) {
     if (!psd) return fail(c, DS_ERR_ARG, "ds_welch_psd: null output");
     static const bool no1k = getenv("DSPTOOLBOX_AMD_WELCH_GENERIC") != nullptr;
+    if (c && W == 16384 && average == DS_AVG_MEAN && !no1k && welch16k::buf_fits(n_samples, n_frames, hop))
+        return welch16384_psd_run(c, x, n_cx, ldx, n_samples, hop, n_frames, window, detrend, amp_sqrt,
+                                  norm_scale, factor, halve_edges, psd);
     if (c && W == 8192 && average == DS_AVG_MEAN && !no1k && welch8k::buf_fits(n_samples, n_frames, hop))
         return welch8192_psd_run(c, x, n_cx, ldx, n_samples, hop, n_frames, window, detrend, amp_sqrt,
                                  norm_scale, factor, halve_edges, psd);
@@ -1194,6 +1284,9 @@ static int welch_csd_dev(ds_ctx* c, const float* x, const float* y, int n_ch, in
             welch4096::fits3(n_samples, frames_to_visit(n_samples, hop, n_frames)))
             return welch4096_run(c, x, n_ch, ld, y, n_ch, ld, n_samples, hop, n_frames, window, detrend, DS_TF_H1,
                                  amp_sqrt, norm_scale, factor, halve_edges, (float2*)csd, nullptr, 2);
+        if (W == 16384 && welch16k::buf_fits(n_samples, n_frames, hop))
+            return welch16384_run(c, x, n_ch, ld, y, n_ch, ld, n_samples, hop, n_frames, window, detrend, DS_TF_H1,
+                                  amp_sqrt, norm_scale, factor, halve_edges, (float2*)csd, nullptr, 2);
         if (W == 8192 && welch8k::buf_fits(n_samples, n_frames, hop))
             return welch8192_run(c, x, n_ch, ld, y, n_ch, ld, n_samples, hop, n_frames, window, detrend, DS_TF_H1,
                                  amp_sqrt, norm_scale, factor, halve_edges, (float2*)csd, nullptr, 2);
