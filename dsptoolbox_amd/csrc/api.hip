@@ -1374,6 +1374,8 @@ static int csm_dev(ds_ctx* c, const float* x, int n_ch, int64_t ld, int64_t n_sa
         CHK(launch(c, "csm_gemm", csmb3::k_csm_gemm64_b3, dim3(nb - 1), 256, 0, a));
     else if (one_wg_per_bin)
         CHK(launch(c, "csm_gemm", k_csm_gemm64, dim3(nb - 1), 256, 0, a));
+    else if (!all_bins && n_ch <= 64 && n_frames >= 8 && !no64 && !f32_only && csmb3::fits(n_ch, n_frames))
+        CHK(launch(c, "csm_gemm", csmb3::k_csm_gemm64_b3_range, dim3(bin_count), 256, 0, a));
     else
         CHK(launch(c, "csm_gemm", k_csm_gemm, dim3(bin_count, nt * (nt + 1) / 2), 256, 0, a));
     return DS_OK;

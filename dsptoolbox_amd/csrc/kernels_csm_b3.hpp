@@ -231,6 +231,19 @@ __global__ __launch_bounds__(256, 2) void k_csm_gemm64_b3(CsmArgs p) {
     dsk::csm_epilogue64<true>(red, G, re00, im00, re10, im10, re11, im11, true, b, p);
 }
 
+// a range of bins (the multi-GPU split by frequency): workgroup j takes bin b0 + j; the purely real
+// edge bins go through the complex path (their imaginary pieces are zeros)
+__global__ __launch_bounds__(256, 2) void k_csm_gemm64_b3_range(CsmArgs p) {
+    __shared__ __attribute__((aligned(16))) char smem[sizeof(dsk::CsmRed) + sizeof(float2) * dsk::CSM64_G];
+    dsk::CsmRed& red = *reinterpret_cast<dsk::CsmRed*>(smem);
+    float2* G = reinterpret_cast<float2*>(smem + sizeof(dsk::CsmRed));
+    const int b = p.b0 + (int)blockIdx.x;
+    f32x16 re00 = {0}, im00 = {0}, re10 = {0}, im10 = {0}, re11 = {0}, im11 = {0};
+    bin_dma(smem, b, p, re00, im00, re10, im10, re11, im11);
+    __syncthreads();  // every wave's ring is idle
+    dsk::csm_epilogue64<true>(red, G, re00, im00, re10, im10, re11, im11, true, b, p);
+}
+
 // X of one bin must stay below 2^31 bytes for the 32-bit buffer offsets
 __host__ inline bool fits(int n_ch, int n_frames) {
     return n_ch >= 2 && n_ch <= 64 && (n_ch & 1) == 0 && (int64_t)n_frames * n_ch * 8 < (int64_t)1 << 31;
