@@ -376,7 +376,10 @@ __device__ __forceinline__ void csm_tile_reduce_store(CsmRed& red, int I, int J,
         const bool up = ILV && I != J && ti < tj;  // G[ti][tj] = conj(G[tj][ti])
         gi[rr] = up ? tj : ti;
         gj[rr] = up ? ti : tj;
-        gy[rr] = up ? -gy[rr] : gy[rr];
+        // 0 - y, not -y: at the purely real bins y is +0 and must stay +0 -- the sign of a zero imaginary
+        // part selects the branch of the square root of a negative real element (+i for the lower
+        // element, its conjugate for the mirror, as the reference's sqrt of its Hermitian matrix gives)
+        gy[rr] = up ? 0.f - gy[rr] : gy[rr];
     }
     const double e = p.fin.halve_edges ? ((b == 0 || b == p.fin.nb - 1) ? 0.5 * p.fin.factor : p.fin.factor) : 1.0;
     double vx[4], vy[4];

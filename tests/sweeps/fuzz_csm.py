@@ -28,7 +28,12 @@ for it in range(n_cases):
     det = bool(rng.integers(0, 2))
     sc = scalings[int(rng.integers(0, len(scalings)))]
     level = float(10.0 ** rng.uniform(-4, 2))
-    x = level * (0.3 * rng.standard_normal((n, C)) + 0.5 * rng.standard_normal(n)[:, None])
+    if rng.integers(0, 2):
+        x = level * (0.3 * rng.standard_normal((n, C)) + 0.5 * rng.standard_normal(n)[:, None])
+    else:  # one source through responses of either sign: negative real cross spectra at DC / Nyquist
+        src = rng.standard_normal(n) * 0.3 + 0.05
+        h = rng.standard_normal((32, C)) * np.exp(-np.arange(32) / 6.0)[:, None]
+        x = level * (np.stack([np.convolve(src, h[:, c])[:n] for c in range(C)], axis=1) + 0.05 * rng.standard_normal((n, C)))
     info = (W, C, n, ov, det, sc.name, f"{level:.1e}")
     try:
         f, csm = backend._csm_welch(x, 48000, W, Window.Hann, ov, det, "mean", sc)

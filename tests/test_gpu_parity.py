@@ -1299,6 +1299,29 @@ def test_fir_bank_full_size_properties():
         d.free()
 
 
+@pytest.mark.parametrize("n_ch", [4, 8, 16, 33, 64])
+def test_csm_negative_real_elements_at_the_real_bins(n_ch):
+    """Coherent channels with responses of either sign: at DC and Nyquist the cross spectra are real
+    and some are NEGATIVE, where the amplitude scalings take the square root on the branch cut -- the
+    lower element gets +i sqrt|x| (imaginary part +0), its mirror the conjugate.  (Found by
+    tests/sweeps/fuzz_parity.py after the interleaved-tile kernel negated a +0.)"""
+    rng = np.random.default_rng(3)
+    n, W = 7665, 256
+    x = rng.standard_normal((n, 1)) * 0.3 + 0.05
+    h = rng.standard_normal((32, n_ch)) * np.exp(-np.arange(32) / 6.0)[:, None]
+    y = np.stack([np.convolve(x[:, 0], h[:, c])[:n] for c in range(n_ch)], axis=1) + 0.05 * rng.standard_normal((n, n_ch))
+    for sc in (SpectrumScaling.FFTBackward, SpectrumScaling.AmplitudeSpectrum, SpectrumScaling.PowerSpectralDensity):
+        f, c = backend._csm_welch(y, 48000, W, Window.Hann, 50.0, False, "mean", sc)
+        rf, r = orc.csm_welch_batched(y, 48000, W, "hann", 50.0, False, sc.name)
+        if sc != SpectrumScaling.PowerSpectralDensity:  # the case is there: purely imaginary roots at DC
+            assert np.any((r[0].real == 0) & (r[0].imag != 0))
+        assert relmax(c, r) < TOL, (n_ch, sc, relmax(c, r))
+        part = backend._csm_welch_bins(y, 48000, W, Window.Hann, 50.0, False, sc, 0, 3)
+        assert relmax(part, r[:3]) < TOL
+        part = backend._csm_welch_bins(y, 48000, W, Window.Hann, 50.0, False, sc, W // 2 - 2, W // 2 + 1)
+        assert relmax(part, r[W // 2 - 2:]) < TOL
+
+
 def test_csm_bin_ranges_match_the_full_matrix():
     """ds_csm_bins_dev (one rank's share of the bins-sharded CSM) returns exactly the rows of the
     full matrix, including the edge-bin handling at DC / Nyquist."""
