@@ -25,11 +25,14 @@ def relmax(a, b, skip_dc=False):
 
 
 for it in range(n_cases):
-    kind = rng.choice(["tf", "psd", "stft", "csm"])
-    W = int(rng.choice([256, 512, 1024, 2048, 4096, 8192] if kind in ("tf", "psd") else [256, 512, 1024, 2048]))
+    kind = rng.choice(["tf", "tf_paired", "csd", "psd", "stft", "csm"])
+    W = int(rng.choice([256, 512, 1024, 2048, 4096, 8192, 16384] if kind in ("tf", "tf_paired", "csd", "psd")
+                       else [256, 512, 1024, 2048]))
     ov = float(rng.choice([0, 25, 50, 50, 50, 75]))
     hop = W - int(ov / 100 * W)
-    frames = int(rng.integers(45, 140)) if kind in ("tf", "csm") else int(rng.integers(1, 60))
+    frames = int(rng.integers(45, 140)) if kind in ("tf", "tf_paired", "csd", "csm") else int(rng.integers(1, 60))
+    if W == 16384:
+        frames = min(frames, 60)
     n = max(8, frames * hop + int(rng.integers(-hop + 1, hop)))
     n_ch = int(rng.choice([1, 2, 3, 4, 5, 7, 8, 9, 16, 17, 20, 33]))
     if kind == "csm":
@@ -56,6 +59,28 @@ for it in range(n_cases):
                 print(f"  tf case W={W} n={n} ch={n_ch} ov={ov} det={det} {sc.name} mode={mode}: e_tf={e_tf:.2e} e_coh={e_coh:.2e} "
                       f"worst bin {b + (1 if det else 0)} ch {c_} |ref|={abs(rt[b + (1 if det else 0), c_]):.3e} max|ref|={np.max(np.abs(rt)):.3e} "
                       f"coh_ref there={rc[b + (1 if det else 0), c_]:.6f}")
+        elif kind in ("tf_paired", "csd"):
+            # one input channel per output channel: y_c = h_c * x_c + noise
+            xs = rng.standard_normal((n, n_ch)) * 0.3 + 0.05
+            ys = np.stack([np.convolve(xs[:, c], h[:, c])[:n] for c in range(n_ch)], axis=1) + 0.05 * rng.standard_normal((n, n_ch))
+            if kind == "csd":
+                k = backend._welch(xs, ys, 48000, Window.Hann, W, ov, det, "mean", sc)
+                r = orc.welch(xs, ys, 48000, "hann", W, ov, det, "mean", sc.name)
+                e = relmax(k, r, det)
+            else:
+                mode = str(rng.choice(["H1", "H2", "H3"]))
+                tf, coh = backend.welch_transfer_function(ys, xs, 48000, W, mode, overlap_percent=ov, detrend=det, scaling=sc)
+                rt, rc = orc.compute_transfer_function(ys, xs, 48000, W, mode, overlap_percent=ov, detrend=det, scaling=sc.name)
+                if mode == "H2":
+                    tf = np.where(rc > 0.1, tf, rt)
+                e_tf, e_coh = relmax(tf, rt, det), relmax(coh, rc, det)
+                e = max(e_tf, e_coh)
+                if e > 1e-6:
+                    lo = 1 if det else 0
+                    d = (np.abs(np.asarray(tf) - rt) if e_tf >= e_coh else np.abs(np.asarray(coh) - rc))[lo:]
+                    b, c_ = np.unravel_index(np.argmax(d), d.shape)
+                    print(f"  tf_paired case W={W} n={n} ch={n_ch} ov={ov} det={det} {sc.name} mode={mode}: e_tf={e_tf:.2e} "
+                          f"e_coh={e_coh:.2e} worst bin {b + lo} ch {c_} coh_ref there={rc[b + lo, c_]:.6f}")
         elif kind == "psd":
             a = backend._welch(y, None, 48000, Window.Hann, W, ov, det, "mean", sc)
             r = orc.welch(y, None, 48000, "hann", W, ov, det, "mean", sc.name)
