@@ -39,6 +39,7 @@ SIGNATURES = {
     "ds_profile_report": (C.c_char_p, [ctx_p]),
     "ds_profile_only": (C.c_int, [ctx_p, C.c_char_p]),
     "ds_profile_stride": (C.c_int, [ctx_p, C.c_int]),
+    "ds_profile_overhead": (C.c_int, [ctx_p, C.c_int, C.c_int, C.POINTER(C.c_double)]),
     "ds_stft_r2c_dev": (C.c_int, [ctx_p, f32_p, i64, C.c_int, i64, C.c_int, C.c_int, C.c_int, i64,
                                   C.c_int, f32_p, C.c_int, C.c_float, C.c_float, C.c_int, c32_p]),
     "ds_stft_r2c": (C.c_int, [ctx_p, f32_p, i64, C.c_int, C.c_int, C.c_int, C.c_int, i64, C.c_int,
@@ -218,6 +219,16 @@ class Context:
     def profile_stride(self, every: int):
         """Bracket only every `every`-th matching launch (1: all)."""
         self.check(self.lib.ds_profile_stride(self.handle, int(every)), "ds_profile_stride")
+
+    def profile_overhead(self, reps: int = 100) -> float:
+        """Lower bound (ms) of what an event pair adds to the kernel it brackets: with b1 / b2 the
+        brackets of one / two empty kernels, 2 b1 - b2 (b2 - b1 is an empty kernel's cost in the stream)."""
+        b = []
+        for n in (1, 2):
+            ms = C.c_double(0.0)
+            self.check(self.lib.ds_profile_overhead(self.handle, int(reps), n, C.byref(ms)), "ds_profile_overhead")
+            b.append(ms.value)
+        return max(0.0, 2.0 * b[0] - b[1])
 
     def profile_report(self) -> dict:
         """{kernel: (total_ms, launches)} since the previous report."""

@@ -306,6 +306,35 @@ extern "C" int ds_profile_stride(ds_ctx* c, int every) {
     return DS_OK;
 }
 
+// What an event pair adds to the kernels it brackets: `n_kernels` empty kernels bracketed exactly as
+// launch() does it, behind another kernel on the same stream (the start event then waits for a
+// predecessor, as in a real step).  Average elapsed time over `reps` brackets, in ms.  With
+// b1 = one and b2 = two kernels inside, b2 - b1 is what an empty kernel costs in the stream and
+// 2 b1 - b2 a lower bound of the bracket's fixed cost.
+__global__ void k_profile_nop() {}
+static int prof_event(ds_ctx* c, hipEvent_t* ev);
+extern "C" int ds_profile_overhead(ds_ctx* c, int reps, int n_kernels, double* ms) {
+    if (!c || !ms || reps < 1 || n_kernels < 1) return fail(c, DS_ERR_ARG, "ds_profile_overhead: bad argument");
+    hipEvent_t a, b;
+    CHK(prof_event(c, &a));
+    CHK(prof_event(c, &b));
+    double sum = 0.0;
+    for (int i = 0; i < reps; ++i) {
+        hipLaunchKernelGGL(k_profile_nop, dim3(1), dim3(64), 0, c->stream);
+        HIPCHK(c, hipEventRecord(a, c->stream));
+        for (int k = 0; k < n_kernels; ++k) hipLaunchKernelGGL(k_profile_nop, dim3(1), dim3(64), 0, c->stream);
+        HIPCHK(c, hipEventRecord(b, c->stream));
+        HIPCHK(c, hipEventSynchronize(b));
+        float e = 0.f;
+        HIPCHK(c, hipEventElapsedTime(&e, a, b));
+        sum += e;
+    }
+    c->prof_pool.push_back(a);
+    c->prof_pool.push_back(b);
+    *ms = sum / reps;
+    return DS_OK;
+}
+
 // "name total_ms count\n" per kernel since the last call; synchronises the stream
 extern "C" const char* ds_profile_report(ds_ctx* c) {
     if (!c) return "";

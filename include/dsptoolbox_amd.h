@@ -81,6 +81,10 @@ const char* ds_profile_report(ds_ctx* ctx);
 int         ds_profile_only(ds_ctx* ctx, const char* kernel_name);
 /* bracket only every `every`-th matching launch (1 = all): an event pair costs ~3 us of stream time */
 int         ds_profile_stride(ds_ctx* ctx, int every);
+/* what an event pair adds to the kernels it brackets: n_kernels empty kernels bracketed the same
+ * way, average over reps, in ms.  b1 (one kernel) and b2 (two) give 2 b1 - b2, a lower bound of the
+ * bracket's fixed cost (bench.py reports kernel times with and without it) */
+int         ds_profile_overhead(ds_ctx* ctx, int reps, int n_kernels, double* ms);
 /* max FFT length one workgroup transforms inside LDS (complex points)       */
 int         ds_max_fft_len(void);
 
