@@ -125,12 +125,19 @@ class Dist:
         return bool(t.item() > 0.5)
 
 
-def setup_rccl(ctx, dist: Dist):
+RCCL_ERROR = None  # set when a weak-scaling run went on without the library communicator
+
+
+def setup_rccl(ctx, dist: Dist, required: bool = True):
     """Library-level RCCL communicator (ds_comm_*) for the broadcast of the shared input and the
-    gather of sharded results.  Returns False only where RCCL is not asked for: one rank, a gloo
+    gather of sharded results.  Returns False where RCCL is not asked for: one rank, a gloo
     rehearsal with several ranks on one GPU, or BENCH_BCAST=host (explicit opt-out: host
-    broadcast + upload).  A communicator that cannot be set up is a FAILURE of the run: the
-    diagnosis goes to stderr and the process exits non-zero (never a silent fallback)."""
+    broadcast + upload).  A communicator that HANGS in its set-up is a failure of the run: the
+    diagnosis goes to stderr and the process exits non-zero.  One that reports an error is a failure
+    too where the data path needs it (`required`: strong scaling gathers results over it); a weak-
+    scaling run has no collective in its timed region, so it goes on with the host broadcast and
+    says so in the JSON ("bcast": "host", "rccl_error": ...)."""
+    global RCCL_ERROR
     if dist.world == 1:
         return False
     if dist.backend != "nccl":
@@ -144,7 +151,10 @@ def setup_rccl(ctx, dist: Dist):
     raw = dist.bcast_bytes(ident.raw, 128)
     if not dist.all_ok(ok):
         print(f"[bench] rank {dist.rank}: ds_comm_unique_id failed: {ctx.last_error()}", file=sys.stderr, flush=True)
-        sys.exit(3)
+        if required:
+            sys.exit(3)
+        RCCL_ERROR = f"ds_comm_unique_id failed: {ctx.last_error()}"
+        return False
     # ncclCommInitRank is collective; a rank that never returns from it would hang the whole
     # run, so it runs under a watchdog -- which reports and exits non-zero, it does not continue
     import threading
@@ -166,9 +176,14 @@ def setup_rccl(ctx, dist: Dist):
               "Exiting with status 3.", file=sys.stderr, flush=True)
         sys.stdout.flush()
         os._exit(3)
-    if res.get("rc", -1) != 0:
+    ok = res.get("rc", -1) == 0
+    if not ok:
         print(f"[bench] rank {dist.rank}: ds_comm_init failed: {ctx.last_error()}", file=sys.stderr, flush=True)
-        sys.exit(3)
+    if not dist.all_ok(ok):  # every rank takes the same way
+        if required:
+            sys.exit(3)
+        RCCL_ERROR = "ds_comm_init failed on at least one rank" + ("" if ok else f": {ctx.last_error()}")
+        return False
     return True
 
 
@@ -499,7 +514,7 @@ def main():
     if dist.world > 1:
         from dsptoolbox_amd import distributed as dd
         dd.init()  # host exchange of the package (TCP star from the launcher's environment)
-    rccl = setup_rccl(ctx, dist)
+    rccl = setup_rccl(ctx, dist, required=(args.scaling == "strong"))
     strong = args.scaling == "strong" and dist.world > 1
     shard = (dist.rank, dist.world) if strong else None
     maker = dict(welch_h1=welch_h1, welch_h1_1024=lambda a, c, d, sh, r: welch_h1(a, c, d, sh, r, W=1024),
@@ -635,6 +650,8 @@ def main():
     }
     if dist.world > 1:
         out["bcast"] = "rccl" if rccl else "host"
+        if RCCL_ERROR:
+            out["rccl_error"] = RCCL_ERROR
         if strong:
             out["result_gather"] = "rccl all-gather per step" if rccl else "none"
     if bcast_ms is not None:
