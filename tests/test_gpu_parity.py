@@ -636,6 +636,39 @@ def test_bench_two_ranks_strong_scaling_rehearsal():
     assert out["value"] > 0 and out["roofline"]["frac"] > 0
 
 
+@pytest.mark.timeout(600)
+def test_bench_default_line_contract():
+    """`python bench.py` (one GPU, the headline workload, a short run with a reduced CPU leg): ONE JSON
+    line with the driver's fields, the roofline object (live kernel time, its raw bracket and the
+    bracket's measured fixed cost) and the CPU baseline with its parity against the GPU result."""
+    import json
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "40", "--warmup", "5",
+                        "--cpu-channels", "2"], cwd=ROOT, capture_output=True, text=True, timeout=500)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in out, key
+    assert out["n_gpus"] == 1 and out["steps"] == 40 and out["warmup"] == 5 and out["higher_is_better"] is True
+    assert out["vs_baseline"] is None and out["dtype"] == "f32" and out["data"] == "synthetic"
+    assert "workload" in out["config"] and "model" not in out["config"]
+    roof = out["roofline"]
+    assert roof["bound"] == "hbm" and roof["unit"] == "GB/s" and roof["peak"] == 8000.0
+    assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-12 and 0.05 < roof["frac"] < 1.0
+    assert roof["kernel"] == "welch4096_main"
+    assert 0.0 <= roof["event_bracket_overhead_ms"] < 0.5 * roof["kernel_avg_ms_raw_events"]
+    assert abs(roof["kernel_avg_ms"] + roof["event_bracket_overhead_ms"] - roof["kernel_avg_ms_raw_events"]) < 1e-9
+    assert roof["frac_raw_events"] <= roof["frac"] and roof["measured_copy_gbs"] > 1000.0
+    cpu = out["cpu_baseline"]
+    assert cpu["kind"] == "port" and cpu["cores"] == 1 and cpu["value"] > 0 and "sample" in cpu
+    assert cpu["parity_rel_max_vs_gpu"] < TOL
+    assert out["value"] > 0 and out["ms_per_step"] > 0
+
+
 def test_das_map_golden_and_large():
     """Delay-and-sum beamformer maps: the reference's outputs (4 steering formulations, with and
     without diagonal removal), and a 64-mic / 3000-point / 40-bin problem against the oracle."""
