@@ -1011,13 +1011,13 @@ static int welch16384_run(ds_ctx* c, const float* x, int n_cx, int64_t ldx, cons
     float* pu = cv.take<float>((size_t)pl.n_chunks * n_cy * w16::N);
     w16::Args ax{x, n_samples, ldx, n_cx, hop, nf, pl.n_pairs, detrend, pl.n_chunks, window,
                  c->w4_tables, c->fir16k_tables, (float4*)xs, pxu, pxy, pyy, psx, n_cx, tu, pu};
-    CHK(launch(c, "welch16384_x", w16::k_x, dim3(pl.n_pairs, n_cx, 2), w16::NTB, w16::LDS_BYTES, ax));
+    CHK(launch(c, "welch16384_x", w16::k_x, dim3(pl.n_pairs, n_cx, 4), w16::NTB, w16::LDS_BYTES, ax));
     CHK(launch(c, "welch16384_pxsum", w16::k_px_sum, dim3((w16::NB + 255) / 256, pl.n_chunks, n_cx), 256, 0, ax));
     w16::Args ay = ax;
     ay.sig = y;
     ay.ld = ldy;
     ay.n_ch = n_cy;
-    CHK(launch(c, "welch16384_main", w16::k_y<false>, dim3(pl.n_chunks * n_cy, 1, 2), w16::NTB, w16::LDS_BYTES, ay));
+    CHK(launch(c, "welch16384_main", w16::k_y<false>, dim3(pl.n_chunks * n_cy, 1, 4), w16::NTB, w16::LDS_BYTES, ay));
     CHK(launch(c, "welch16384_fold", w16::k_fold<false>, dim3((w16::NB + 255) / 256, pl.n_chunks * n_cy), 256, 0, ay));
     WelchFinArgs f{psx, pxy, pyy, pl.n_chunks, pl.n_chunks, n_cx, n_cy, kind, mode,
                    FinishPar{norm_scale / (double)n_frames, factor, halve_edges, amp_sqrt, w16::NB},
@@ -1043,7 +1043,7 @@ static int welch16384_psd_run(ds_ctx* c, const float* x, int n_cx, int64_t ldx, 
     float* pu = cv.take<float>((size_t)pl.n_chunks * n_cx * w16::N);
     w16::Args a{x, n_samples, ldx, n_cx, hop, nf, pl.n_pairs, detrend, pl.n_chunks, window,
                 c->w4_tables, c->fir16k_tables, nullptr, nullptr, nullptr, pyy, nullptr, 1, nullptr, pu};
-    CHK(launch(c, "welch16384_main", w16::k_y<true>, dim3(pl.n_chunks * n_cx, 1, 2), w16::NTB, w16::LDS_BYTES, a));
+    CHK(launch(c, "welch16384_main", w16::k_y<true>, dim3(pl.n_chunks * n_cx, 1, 4), w16::NTB, w16::LDS_BYTES, a));
     CHK(launch(c, "welch16384_fold", w16::k_fold<true>, dim3((w16::NB + 255) / 256, pl.n_chunks * n_cx), 256, 0, a));
     WelchFinArgs f{pyy, nullptr, nullptr, pl.n_chunks, pl.n_chunks, n_cx, 0, 1, 0,
                    FinishPar{norm_scale / (double)n_frames, factor, halve_edges, amp_sqrt, w16::NB},

@@ -6,8 +6,9 @@
 //   in front of the transform):
 //       b_q[n'] = ( sum_j z[n' + 4096 j] (-i)^(j q) ) W16384^(n' q) ,   Z[4k' + q] = FFT4096(b_q)[k']
 //   z = frame_2p w + i frame_2p+1 w (two real frames per complex transform).
-//   512 threads = 2 slots of 256; slot s of the workgroup with blockIdx.z = hi runs class q = s + 2 hi, so the four classes of a (chunk, channel)
-//   unit are two workgroups -- one class per slot keeps the register budget of the 8192-sample
+//   One workgroup of 256 threads per class (blockIdx.z = q), two workgroups per CU (77 KB of LDS,
+//   <= 256 registers), each with its own barriers; the four classes of a (chunk, channel) unit are
+//   four workgroups -- one class per workgroup keeps the register budget of the 8192-sample
 //   kernel (16 + 8 accumulators, 32 values, 32 input-spectrum values, 30 twiddles, a batch of loads);
 //   both classes of a slot in one workgroup spilled 300 registers.
 //   T[k] += conj(W[k]) Z[k], P[k] += |Z[k]|^2 over the 4096 bins of a class, 16 per thread, written
@@ -30,8 +31,8 @@ namespace welch16k {
 namespace w4 = welch4096;
 using w4::cmul;
 using w4::pos16;
-constexpr int N = 16384, M = 4096, NB = N / 2 + 1, NTB = 512;
-constexpr int LDS_BYTES = (4 * w4::BUF_C + 256) * 8;  // two exchange buffers per slot + W256 table: 149 504 B
+constexpr int N = 16384, M = 4096, NB = N / 2 + 1, NTB = 256;
+constexpr int LDS_BYTES = (2 * w4::BUF_C + 256) * 8;  // two exchange buffers + W256 table: 76 800 B, two workgroups per CU
 
 struct Args {
     const float* sig;  // x (k_x) or y (k_y), planar
@@ -110,14 +111,13 @@ __device__ __forceinline__ void front(float2 (&v)[16], __amdgpu_buffer_rsrc_t rs
 // fold partner of bin 4 k' + q: class of the partner and its index
 __device__ __forceinline__ int fold_index(int q, int kp) { return q == 0 ? ((M - kp) & (M - 1)) : (M - 1 - kp); }
 
-// ---- input spectra: grid = (n_pairs, n_cx, 2) ---------------------------------------
-__global__ __launch_bounds__(NTB, 1) void k_x(Args p) {
+// ---- input spectra: grid = (n_pairs, n_cx, 4) ---------------------------------------
+__global__ __launch_bounds__(NTB, 2) void k_x(Args p) {
     extern __shared__ __align__(16) float2 lds[];
-    const int tid = threadIdx.x, t = tid & 255;
-    const int s = __builtin_amdgcn_readfirstlane(tid >> 8);
-    float2* buf = lds + s * 2 * w4::BUF_C;
-    float2* tw2 = lds + 4 * w4::BUF_C;
-    const int pr = blockIdx.x, cx = blockIdx.y, hi = blockIdx.z, q = s + 2 * hi;
+    const int tid = threadIdx.x, t = tid;
+    float2* buf = lds;
+    float2* tw2 = lds + 2 * w4::BUF_C;
+    const int pr = blockIdx.x, cx = blockIdx.y, q = blockIdx.z, s = q & 1, hi = q >> 1;
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(p.sig + (int64_t)cx * p.ld), 0, (int)(uint32_t)(p.n_samples * 4), 0x00020000);
     w4::Tw tw;
@@ -130,7 +130,7 @@ __global__ __launch_bounds__(NTB, 1) void k_x(Args p) {
     front(v, rs, (uint32_t)((int64_t)(2 * pr) * p.hop), (uint32_t)p.hop, p.window, s, hi, wt, p.twn + 4 * 256 + q * 16,
           needs_drop(p, pr), t);
     w4::fft4096_plain<true>(v, tw, buf, tw2, t);
-    if (p.detrend && tid == 0 && hi == 0) v[pos16(0)] = make_float2(0.f, 0.f);  // bin 0 = class 0, k' = 0
+    if (p.detrend && tid == 0 && q == 0) v[pos16(0)] = make_float2(0.f, 0.f);  // bin 0 = class 0, k' = 0
     const int64_t unit = ((int64_t)cx * p.n_pairs + pr) * 4 + q;
     float4* xo = p.xs + unit * (M / 2) + t;
 #pragma unroll
@@ -160,16 +160,15 @@ __global__ __launch_bounds__(256) void k_px_sum(Args p) {
     p.psx[((int64_t)cq * p.n_cx + cx) * NB + k] = (float)(0.5 * sum);
 }
 
-// ---- output channels: grid = (n_chunks * n_ch, 1, 2) -----------------------------------
+// ---- output channels: grid = (n_chunks * n_ch, 1, 4) -----------------------------------
 // AUTO: auto spectra only (ds_welch_psd): no input spectra, no cross sums.
 template <bool AUTO = false>
-__global__ __launch_bounds__(NTB, 1) void k_y(Args p) {
+__global__ __launch_bounds__(NTB, 2) void k_y(Args p) {
     extern __shared__ __align__(16) float2 lds[];
-    const int tid = threadIdx.x, t = tid & 255;
-    const int s = __builtin_amdgcn_readfirstlane(tid >> 8);
-    float2* buf = lds + s * 2 * w4::BUF_C;
-    float2* tw2 = lds + 4 * w4::BUF_C;
-    const int hi = blockIdx.z, q = s + 2 * hi;
+    const int tid = threadIdx.x, t = tid;
+    float2* buf = lds;
+    float2* tw2 = lds + 2 * w4::BUF_C;
+    const int q = blockIdx.z, s = q & 1, hi = q >> 1;
     // XCD-aware decode: whole chunks per XCD (the input spectra a chunk re-reads stay in its L2)
     int cq, c;
     {
@@ -239,7 +238,7 @@ __global__ __launch_bounds__(NTB, 1) void k_y(Args p) {
             P[k3] = fmaf(z.x, z.x, fmaf(z.y, z.y, P[k3]));
         }
     }
-    if (p.detrend && tid == 0 && hi == 0) P[0] = 0.f;  // class 0, k' = 0: xs bin 0 is already 0 -> T = 0 there
+    if (p.detrend && tid == 0 && q == 0) P[0] = 0.f;  // class 0, k' = 0: xs bin 0 is already 0 -> T = 0 there
     const int64_t unit = (((int64_t)cq * p.n_ch + c) * 4 + q) * M + t;
 #pragma unroll
     for (int k3 = 0; k3 < 16; ++k3) {
@@ -271,7 +270,7 @@ struct Plan {
 inline Plan plan(int n_frames, int n_cy, int n_cx = 1) {
     Plan pl;
     pl.n_pairs = (n_frames + 1) / 2;
-    // one workgroup per CU (256 = 128 units x 2 class halves) resident at once when there is enough
+    // two workgroups per CU (512 = 128 units x 4 classes) resident at once when there is enough
     // work; fp32 chains <= 64 pairs
     int want = (128 + n_cy - 1) / n_cy;
     want = (want + 7) & ~7;
