@@ -350,8 +350,59 @@ def gen_deconv_nonfast(dsp):
     save("deconv_nonfast", dict(cases=cases, fs=fs), arrs)
 
 
+def gen_welch_long(dsp):
+    """Long windows (2048 ... 16384 samples) through the reference's _welch (auto spectra, cross spectra
+    of channel pairs) and compute_transfer_function with one input channel per output channel and
+    with one for all -- the shapes the register kernels of round 2 cover.  Inputs are stored as
+    float32 values (cast to float64 before the reference runs) to keep the fixture small."""
+    from dsptoolbox.standard._spectral_methods import _welch
+    from dsptoolbox.standard.enums import SpectrumScaling as S, Window
+    from dsptoolbox.transfer_functions.enums import TransferFunctionType
+    fs = 48000
+    rng = np.random.default_rng(2048)
+    n = 16384 * 3 + 100
+    x = (rng.standard_normal((n, 3)) * 0.3).astype(np.float32).astype(np.float64)
+    h = rng.standard_normal((3, 16)) * np.exp(-np.arange(16) / 5.0)
+    y = np.stack([np.convolve(x[:, c], h[c])[:n] for c in range(3)], axis=1) + 0.05 * rng.standard_normal((n, 3))
+    y1 = np.stack([np.convolve(x[:, 0], h[c])[:n] for c in range(3)], axis=1) + 0.05 * rng.standard_normal((n, 3))
+    y, y1 = y.astype(np.float32).astype(np.float64), y1.astype(np.float32).astype(np.float64)
+    cases, arrs = [], {"x": x.astype(np.float32), "y_multi": y.astype(np.float32), "y_single": y1.astype(np.float32)}
+    i = 0
+
+    def some(a, W):  # the edge bins and every 5th one (5 is coprime to the 2 / 4 sub-spectrum classes)
+        nb = W // 2 + 1
+        idx = np.unique(np.r_[0:8, 0:nb:5, nb - 8:nb])
+        return idx, np.asarray(a)[idx]
+    for W, ov, det, sc in ((2048, 50, True, S.FFTBackward), (8192, 50, False, S.PowerSpectralDensity),
+                           (8192, 75, True, S.AmplitudeSpectrum), (16384, 50, True, S.FFTBackward),
+                           (16384, 25, False, S.PowerSpectrum)):
+        auto = _welch(y.copy(), None, fs, Window.Hann, W, ov, det, "mean", sc)
+        cross = _welch(x.copy(), y.copy(), fs, Window.Hann, W, ov, det, "mean", sc)
+        arrs[f"bins_{i}"], arrs[f"auto_{i}"] = some(auto, W)
+        arrs[f"cross_{i}"] = some(cross, W)[1]
+        case = dict(W=W, overlap=ov, detrend=det, scaling=sc.name, tf=[])
+        for mode in TransferFunctionType:
+            for single in (True, False):
+                inp = dsp.Signal(None, x[:, :1].copy() if single else x.copy(), fs)
+                out = dsp.Signal(None, (y1 if single else y).copy(), fs)
+                inp.set_spectrum_parameters(window_length_samples=W, window_type=Window.Hann, overlap_percent=ov,
+                                            detrend=det, average="mean", scaling=sc)
+                sp = dsp.transfer_functions.compute_transfer_function(out, inp, W, mode)
+                key = f"{i}_{mode.name}_{'single' if single else 'multi'}"
+                arrs["tf_" + key] = some(sp.spectral_data, W)[1].astype(np.complex64)
+                arrs["coh_" + key] = some(sp.coherence, W)[1].astype(np.float32)
+                case["tf"].append(key)
+        cases.append(case)
+        i += 1
+    save("welch_long", dict(cases=cases, fs=fs, note="outputs at bins_<i> only; tf / coh stored as complex64 / float32 (compare at 1e-6)"), arrs)
+
+
 def main():
     dsp = import_reference()
+    if "--only-welch-long" in sys.argv:
+        import warnings
+        warnings.simplefilter("ignore")
+        return gen_welch_long(dsp)
     if "--only-deconv-nonfast" in sys.argv:
         import warnings
         warnings.simplefilter("ignore")
@@ -656,6 +707,7 @@ def main():
          dict(x_int16=xi, y_int16=yi, tf=np.asarray(sp.spectral_data), coh=np.asarray(sp.coherence),
               ir_head=ir.time_data[:48000], ir_tail=ir.time_data[-4096:],
               ir_peak=np.array([np.max(np.abs(ir.time_data))])))
+    gen_welch_long(dsp)
     gen_fir_state(dsp)
     gen_istft(dsp)
     gen_stft_anylen(dsp)

@@ -312,6 +312,34 @@ def test_welch_wave_kernels_paired_inputs_vs_oracle(W):
             assert k.shape == r.shape and relmax(k, r, det) < TOL, (W, n, C, sc, relmax(k, r, det))
 
 
+def test_welch_long_windows_golden():
+    """The reference's own outputs (tests/golden/welch_long.npz, made by oracle/gen_golden.py from
+    dsptoolbox 0.8) for windows of 2048 ... 16384 samples: auto spectra, cross spectra of channel pairs,
+    H1 / H2 / H3 with one input channel per output channel and with one for all -- the register kernels
+    of every long window against the reference itself."""
+    meta, z = load_golden("welch_long")
+    x, ym, ys = (z[k].astype(np.float64) for k in ("x", "y_multi", "y_single"))
+    for i, c in enumerate(meta["cases"]):
+        bins, dc, sc = z[f"bins_{i}"], c["detrend"], SpectrumScaling[c["scaling"]]
+        a = backend._welch(ym, None, meta["fs"], Window.Hann, c["W"], c["overlap"], c["detrend"], "mean", sc)
+        assert relmax(a[bins], z[f"auto_{i}"], dc) < TOL, (c["W"], "auto")
+        k = backend._welch(x, ym, meta["fs"], Window.Hann, c["W"], c["overlap"], c["detrend"], "mean", sc)
+        assert relmax(k[bins], z[f"cross_{i}"], dc) < TOL, (c["W"], "cross")
+        for key in c["tf"]:
+            _, mode, which = key.split("_")
+            xin, yout = (x[:, :1], ys) if which == "single" else (x, ym)
+            tf, coh = backend.welch_transfer_function(yout, xin, meta["fs"], c["W"], mode, overlap_percent=c["overlap"],
+                                                      detrend=c["detrend"], scaling=sc, precision="f32")
+            rt, rc = z["tf_" + key], z["coh_" + key]
+            if mode == "H2":  # see test_welch_wave_kernels_paired_inputs_vs_oracle
+                weak = rc < 0.1
+                tf, rt = np.where(weak, 0.0, tf[bins]), np.where(weak, 0.0, rt)
+            else:
+                tf = tf[bins]
+            # 2 TOL: the fixture holds tf / coh rounded to complex64 / float32 (6e-8 of their own)
+            assert relmax(tf, rt, dc) < 2 * TOL and relmax(coh[bins], rc, dc) < 2 * TOL, (c["W"], key)
+
+
 def test_welch4096_cross_spectra_on_register_kernels():
     """ds_welch_csd with a 4096-sample window at 50 % overlap: k_x3 / k_px_sum / k_y3 + finish kind 2."""
     rng = np.random.default_rng(4096)

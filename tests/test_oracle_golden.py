@@ -305,6 +305,28 @@ def test_chirp_pair_config1():
     assert np.max(np.abs(ir[-c["ir_tail"]:] - z["ir_tail"])) < 1e-11 * pk
 
 
+def test_welch_long_windows_paired_inputs_and_cross_spectra():
+    """Windows of 2048 ... 16384 samples: the reference's auto and cross spectra (stored in float64)
+    and its H1 / H2 / H3 with one input channel per output channel and with one for all (stored as
+    complex64 / float32, hence 1e-6) at the fixture's bins."""
+    meta, z = load_golden("welch_long")
+    x, ym, ys = (z[k].astype(np.float64) for k in ("x", "y_multi", "y_single"))
+    for i, c in enumerate(meta["cases"]):
+        bins = z[f"bins_{i}"]
+        dc = c["detrend"]
+        a = orc.welch(ym, None, meta["fs"], "hann", c["W"], c["overlap"], c["detrend"], "mean", c["scaling"])
+        close(a[bins], z[f"auto_{i}"], skip_dc=dc)
+        k = orc.welch(x, ym, meta["fs"], "hann", c["W"], c["overlap"], c["detrend"], "mean", c["scaling"])
+        close(k[bins], z[f"cross_{i}"], skip_dc=dc)
+        for key in c["tf"]:
+            _, mode, which = key.split("_")
+            xin, yout = (x[:, :1], ys) if which == "single" else (x, ym)
+            tf, coh = orc.compute_transfer_function(yout, xin, meta["fs"], c["W"], mode, overlap_percent=c["overlap"],
+                                                    detrend=c["detrend"], scaling=c["scaling"])
+            close(tf[bins], z["tf_" + key], tol=1e-6, skip_dc=dc)
+            close(coh[bins], z["coh_" + key], tol=1e-6, skip_dc=dc)
+
+
 @pytest.mark.parametrize("mode", ["H1", "H2", "H3"])
 def test_property_linearity_of_h1(mode):
     """Scaling the output by g scales H by g and leaves coherence unchanged."""
