@@ -397,8 +397,38 @@ def gen_welch_long(dsp):
     save("welch_long", dict(cases=cases, fs=fs, note="outputs at bins_<i> only; tf / coh stored as complex64 / float32 (compare at 1e-6)"), arrs)
 
 
+def gen_csm_coherent(dsp):
+    """Cross-spectral matrices of coherent channels (one source through responses of either sign): at DC
+    and Nyquist the cross spectra are real and some are negative, where the amplitude scalings take the
+    square root on its branch cut -- the reference's convention for those elements (and even channel
+    counts, which the csm fixture of round 1 does not have)."""
+    from dsptoolbox.standard.enums import SpectrumScaling as S, SpectrumMethod
+    fs = 48000
+    rng = np.random.default_rng(77)
+    n = 7665
+    src = rng.standard_normal(n) * 0.3 + 0.05
+    h = rng.standard_normal((32, 8)) * np.exp(-np.arange(32) / 6.0)[:, None]
+    x = np.stack([np.convolve(src, h[:, c])[:n] for c in range(8)], axis=1) + 0.05 * rng.standard_normal((n, 8))
+    x = x.astype(np.float32).astype(np.float64)
+    cases, arrs = [], {"x": x.astype(np.float32)}
+    for i, (C, W, ov, det, sc) in enumerate(((8, 256, 50, False, S.FFTBackward), (8, 256, 50, True, S.AmplitudeSpectrum),
+                                             (6, 512, 75, False, S.AmplitudeSpectralDensity),
+                                             (8, 256, 50, False, S.PowerSpectralDensity))):
+        s_ = dsp.Signal(None, x[:, :C].copy(), fs)
+        s_.set_spectrum_parameters(method=SpectrumMethod.WelchPeriodogram, window_length_samples=W,
+                                   overlap_percent=ov, detrend=det, scaling=sc)
+        f, csm = s_.get_csm()
+        cases.append(dict(n_ch=C, W=W, overlap=ov, detrend=det, scaling=sc.name))
+        arrs[f"csm_{i}"] = csm
+    save("csm_coherent", dict(cases=cases, fs=fs), arrs)
+
+
 def main():
     dsp = import_reference()
+    if "--only-csm-coherent" in sys.argv:
+        import warnings
+        warnings.simplefilter("ignore")
+        return gen_csm_coherent(dsp)
     if "--only-welch-long" in sys.argv:
         import warnings
         warnings.simplefilter("ignore")
@@ -708,6 +738,7 @@ def main():
               ir_head=ir.time_data[:48000], ir_tail=ir.time_data[-4096:],
               ir_peak=np.array([np.max(np.abs(ir.time_data))])))
     gen_welch_long(dsp)
+    gen_csm_coherent(dsp)
     gen_fir_state(dsp)
     gen_istft(dsp)
     gen_stft_anylen(dsp)

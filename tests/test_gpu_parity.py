@@ -1383,6 +1383,24 @@ def test_csm_negative_real_elements_at_the_real_bins(n_ch):
         assert relmax(part, r[W // 2 - 2:]) < TOL
 
 
+def test_csm_coherent_channels_golden():
+    """tests/golden/csm_coherent.npz: the reference's own matrices for coherent channels of either
+    sign, even channel counts (the bf16-triple kernel), every branch-cut element at DC / Nyquist."""
+    meta, z = load_golden("csm_coherent")
+    x = z["x"].astype(np.float64)
+    for i, c in enumerate(meta["cases"]):
+        f, csm = backend._csm_welch(x[:, :c["n_ch"]], meta["fs"], c["W"], Window.Hann, c["overlap"], c["detrend"],
+                                    "mean", SpectrumScaling[c["scaling"]])
+        ref = z[f"csm_{i}"]
+        assert csm.shape == ref.shape
+        lo = 1 if c["detrend"] else 0  # the detrended DC bin is 0 / 0-like: compared from bin 1 on
+        assert relmax(csm[lo:], ref[lo:]) < TOL, (c, relmax(csm[lo:], ref[lo:]))
+        # the branch: elements that are purely imaginary in the reference are so here, with the same sign
+        pure = (ref.real == 0) & (ref.imag != 0)
+        pure[:lo] = False
+        assert np.all(np.sign(csm.imag[pure]) == np.sign(ref.imag[pure]))
+
+
 def test_csm_bin_ranges_match_the_full_matrix():
     """ds_csm_bins_dev (one rank's share of the bins-sharded CSM) returns exactly the rows of the
     full matrix, including the edge-bin handling at DC / Nyquist."""

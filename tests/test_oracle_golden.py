@@ -305,6 +305,20 @@ def test_chirp_pair_config1():
     assert np.max(np.abs(ir[-c["ir_tail"]:] - z["ir_tail"])) < 1e-11 * pk
 
 
+def test_csm_coherent_channels_branch_cut():
+    """The reference's matrices for coherent channels of either sign (negative real cross spectra at the
+    real bins under the amplitude scalings: +i sqrt|x| below the diagonal, -i above)."""
+    meta, z = load_golden("csm_coherent")
+    x = z["x"].astype(np.float64)
+    for i, c in enumerate(meta["cases"]):
+        f, csm = orc.csm_welch(x[:, :c["n_ch"]], meta["fs"], c["W"], "hann", c["overlap"], c["detrend"], "mean",
+                               c["scaling"])
+        close(csm, z[f"csm_{i}"])
+        f, csm = orc.csm_welch_batched(x[:, :c["n_ch"]], meta["fs"], c["W"], "hann", c["overlap"], c["detrend"],
+                                       c["scaling"])
+        close(csm, z[f"csm_{i}"])
+
+
 def test_welch_long_windows_paired_inputs_and_cross_spectra():
     """Windows of 2048 ... 16384 samples: the reference's auto and cross spectra (stored in float64)
     and its H1 / H2 / H3 with one input channel per output channel and with one for all (stored as
