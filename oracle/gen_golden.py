@@ -420,6 +420,17 @@ def gen_csm_coherent(dsp):
         f, csm = s_.get_csm()
         cases.append(dict(n_ch=C, W=W, overlap=ov, detrend=det, scaling=sc.name))
         arrs[f"csm_{i}"] = csm
+    # 64 channels = the 8 stored ones through a stored 8 x 64 mixing matrix (the input itself would be
+    # 2 MB); every 8th bin and the edge bins, as complex64
+    mix = rng.standard_normal((8, 64)).astype(np.float32).astype(np.float64)
+    x64 = x @ mix
+    s_ = dsp.Signal(None, x64.copy(), fs)
+    s_.set_spectrum_parameters(method=SpectrumMethod.WelchPeriodogram, window_length_samples=256,
+                               overlap_percent=50, detrend=False, scaling=S.FFTBackward)
+    f, csm = s_.get_csm()
+    bins = np.unique(np.r_[0:3, 0:129:8, 126:129])
+    arrs["mix"], arrs["bins64"], arrs["csm64"] = mix.astype(np.float32), bins, csm[bins].astype(np.complex64)
+    cases.append(dict(n_ch=64, W=256, overlap=50, detrend=False, scaling="FFTBackward", data="x @ mix, bins64 only"))
     save("csm_coherent", dict(cases=cases, fs=fs), arrs)
 
 

@@ -311,6 +311,11 @@ def test_csm_coherent_channels_branch_cut():
     meta, z = load_golden("csm_coherent")
     x = z["x"].astype(np.float64)
     for i, c in enumerate(meta["cases"]):
+        if c["n_ch"] == 64:  # the stored channels through the stored mixing matrix; some bins, complex64
+            x64 = x @ z["mix"].astype(np.float64)
+            f, csm = orc.csm_welch_batched(x64, meta["fs"], c["W"], "hann", c["overlap"], c["detrend"], c["scaling"])
+            close(csm[z["bins64"]], z["csm64"], tol=1e-6)
+            continue
         f, csm = orc.csm_welch(x[:, :c["n_ch"]], meta["fs"], c["W"], "hann", c["overlap"], c["detrend"], "mean",
                                c["scaling"])
         close(csm, z[f"csm_{i}"])
