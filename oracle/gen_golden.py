@@ -86,6 +86,30 @@ def gen_stft_anylen(dsp):
     save("stft_anylen", dict(cases=cases, fs=fs), arrs)
 
 
+def gen_stft_manych(dsp):
+    """Signal.get_spectrogram of a 20-channel signal (more channels than one workgroup of the
+    wave-level STFT kernels takes: a full tile of 16 and a ragged one of 4) at windows 256 ... 2048;
+    every 4th bin and the edge bins, stored as complex64."""
+    from dsptoolbox.standard.enums import SpectrumScaling as S, Window
+    fs = 48000
+    rng = np.random.default_rng(43)
+    xs = (rng.standard_normal((7000, 20)) * 0.4 + 0.1).astype(np.float32)
+    cases, arrs = [], {"x": xs}
+    for i, (W, ov, det, pad, sc) in enumerate(((1024, 50, True, False, S.FFTBackward),
+                                               (512, 75, False, True, S.AmplitudeSpectrum),
+                                               (256, 50, True, True, S.PowerSpectralDensity),
+                                               (2048, 50, False, False, S.FFTBackward))):
+        s = dsp.Signal(None, xs.astype(np.float64), fs)
+        s.set_spectrogram_parameters(window_length_samples=W, window_type=Window.Hann, overlap_percent=ov,
+                                     detrend=det, padding=pad, scaling=sc)
+        t, f, st = s.get_spectrogram()
+        nb = W // 2 + 1
+        bins = np.unique(np.r_[0:3, 0:nb:4, nb - 3:nb])
+        cases.append(dict(W=W, overlap=ov, detrend=det, padding=pad, scaling=sc.name, shape=list(st.shape)))
+        arrs[f"bins_{i}"], arrs[f"stft_{i}"] = bins, st[bins].astype(np.complex64)
+    save("stft_manych", dict(cases=cases, fs=fs), arrs)
+
+
 def gen_fir_state(dsp):
     """Filter state (zi), zero-phase and long FIR filters: Filter / FilterBank.filter_signal with
     activate_zi / zero_phase (classes/filter.py:648-743, filter_helpers.py:288-382, 454-503)."""
@@ -436,6 +460,10 @@ def gen_csm_coherent(dsp):
 
 def main():
     dsp = import_reference()
+    if "--only-stft-manych" in sys.argv:
+        import warnings
+        warnings.simplefilter("ignore")
+        return gen_stft_manych(dsp)
     if "--only-csm-coherent" in sys.argv:
         import warnings
         warnings.simplefilter("ignore")
@@ -750,6 +778,7 @@ def main():
               ir_peak=np.array([np.max(np.abs(ir.time_data))])))
     gen_welch_long(dsp)
     gen_csm_coherent(dsp)
+    gen_stft_manych(dsp)
     gen_fir_state(dsp)
     gen_istft(dsp)
     gen_stft_anylen(dsp)

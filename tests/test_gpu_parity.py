@@ -1383,6 +1383,19 @@ def test_csm_negative_real_elements_at_the_real_bins(n_ch):
         assert relmax(part, r[W // 2 - 2:]) < TOL
 
 
+def test_stft_many_channels_golden():
+    """tests/golden/stft_manych.npz: the reference's spectrograms of a 20-channel signal (one full tile of
+    16 channels and a ragged one of 4 in the wave-level kernels) at windows 256 ... 2048."""
+    meta, z = load_golden("stft_manych")
+    x = z["x"].astype(np.float64)
+    for i, c in enumerate(meta["cases"]):
+        t, f, st = backend._stft(x, meta["fs"], c["W"], Window.Hann, c["overlap"], None, c["detrend"], c["padding"],
+                                 SpectrumScaling[c["scaling"]])
+        assert list(st.shape) == c["shape"]
+        e = relmax(st[z[f"bins_{i}"]], z[f"stft_{i}"])
+        assert e < 2 * TOL, (c, e)  # the reference is stored as complex64
+
+
 def test_csm_coherent_channels_golden():
     """tests/golden/csm_coherent.npz: the reference's own matrices for coherent channels of either
     sign, even channel counts (the bf16-triple kernel), every branch-cut element at DC / Nyquist."""

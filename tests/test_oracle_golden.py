@@ -178,6 +178,15 @@ def test_stft_any_fft_length():
         assert s.dtype == z[f"stft_{i}"].dtype
 
 
+def test_stft_many_channels():
+    meta, z = load_golden("stft_manych")
+    x = z["x"].astype(np.float64)
+    for i, c in enumerate(meta["cases"]):
+        t, f, s = orc.stft(x, meta["fs"], c["W"], "hann", c["overlap"], None, c["detrend"], c["padding"], c["scaling"])
+        assert list(s.shape) == c["shape"]
+        close(s[z[f"bins_{i}"]], z[f"stft_{i}"], tol=1e-6)  # stored as complex64
+
+
 def test_istft():
     """transforms.istft incl. its quirks (step from the un-rounded overlap, empty edge frames)."""
     meta, z = load_golden("istft")
