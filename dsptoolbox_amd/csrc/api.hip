@@ -844,7 +844,6 @@ static int welch4096_run(ds_ctx* c, const float* x, int n_cx, int64_t ldx, const
     const bool half = hop == 2048;
     const bool three = half && w4::enabled3() && w4::fits3(n_samples, nf);
     w4::Plan pl = three ? w4::plan3(nf, n_cy) : w4::plan(nf, n_cy);
-    // (paired inputs -- one input channel per output channel -- exist on the three-per-CU kernels only)
     CHK(reserve(c, &c->ws, &c->ws_bytes, pl.bytes + (size_t)(n_cx - 1) * (Carver::pad(sizeof(float2) * (size_t)pl.n_pairs * w4::N) +
                                                                   Carver::pad(sizeof(float) * (size_t)pl.n_pairs * w4::NB) +
                                                                   Carver::pad(sizeof(float) * (size_t)pl.n_chunks * w4::NB)) + 4096));
@@ -869,7 +868,8 @@ static int welch4096_run(ds_ctx* c, const float* x, int n_cx, int64_t ldx, const
     } else {
         auto kx = half ? w4::k_x<true> : w4::k_x<false>;
         auto ky = half ? w4::k_y<true> : w4::k_y<false>;
-        CHK(launch(c, "welch4096_x", kx, dim3(pl.n_pairs), w4::NT, w4::LDS_BYTES, ax));
+        CHK(launch(c, "welch4096_x", kx, dim3(pl.n_pairs, n_cx), w4::NT, w4::LDS_BYTES, ax));
+        if (n_cx > 1) CHK(launch(c, "welch4096_pxsum", w4::k_px_sum, dim3(pl.n_chunks, n_cx), 256, 0, ay));
         CHK(launch(c, "welch4096_main", ky, dim3(pl.n_chunks * n_cy), w4::NT, w4::LDS_BYTES_2, ay));
     }
     WelchFinArgs f{psx, pxy, pyy, pl.n_chunks, pl.n_chunks, n_cx, n_cy, kind, mode,
@@ -1185,10 +1185,8 @@ extern "C" int ds_welch_tf_dev(ds_ctx* c, const float* x, int n_cx, int64_t ldx,
                                double norm_scale, double factor, int halve_edges, ds_c32* tf,
                                float* coh) {
     if (!tf || !coh) return fail(c, DS_ERR_ARG, "ds_welch_tf: null output");
-    // one input channel, or -- on the three-per-CU kernels (50 % overlap) -- one per output channel
-    if (c && W == 4096 && average == DS_AVG_MEAN && welch4096::enabled() &&
-        (n_cx == 1 || (n_cx == n_cy && hop == 2048 && welch4096::enabled3() &&
-                       welch4096::fits3(n_samples, frames_to_visit(n_samples, hop, n_frames)))))
+    // one input channel, or one per output channel (three-per-CU kernels at 50 % overlap, two-per-CU otherwise)
+    if (c && W == 4096 && average == DS_AVG_MEAN && welch4096::enabled() && (n_cx == 1 || n_cx == n_cy))
         return welch4096_run(c, x, n_cx, ldx, y, n_cy, ldy, n_samples, hop, n_frames, window, detrend, mode,
                              amp_sqrt, norm_scale, factor, halve_edges, (float2*)tf, coh);
     static const bool no1k = getenv("DSPTOOLBOX_AMD_WELCH_GENERIC") != nullptr;
@@ -1309,8 +1307,7 @@ static int welch_csd_dev(ds_ctx* c, const float* x, const float* y, int n_ch, in
     static const bool generic = getenv("DSPTOOLBOX_AMD_WELCH_GENERIC") != nullptr;
     if (c && x && y && window && csd && average == DS_AVG_MEAN && !generic && n_ch > 0 && n_samples > 0 &&
         n_frames > 0 && hop > 0 && hop <= W && ld >= n_samples) {
-        if (W == 4096 && hop == 2048 && welch4096::enabled() && welch4096::enabled3() &&
-            welch4096::fits3(n_samples, frames_to_visit(n_samples, hop, n_frames)))
+        if (W == 4096 && welch4096::enabled())
             return welch4096_run(c, x, n_ch, ld, y, n_ch, ld, n_samples, hop, n_frames, window, detrend, DS_TF_H1,
                                  amp_sqrt, norm_scale, factor, halve_edges, (float2*)csd, nullptr, 2);
         if (W == 16384 && welch16k::buf_fits(n_samples, n_frames, hop))

@@ -350,7 +350,7 @@ __global__ __launch_bounds__(NT) void k_x(Args p) {
     extern __shared__ __align__(16) float2 lds[];
     float2* buf = lds;
     float2* tw2 = lds + BUF_C;
-    const int tid = threadIdx.x, pr = blockIdx.x;
+    const int tid = threadIdx.x, pr = blockIdx.x, cx = blockIdx.y;  // grid = (n_pairs, input channels)
     Tw tw;
     float win[16];
     float2 v[16];
@@ -358,14 +358,14 @@ __global__ __launch_bounds__(NT) void k_x(Args p) {
         // one transform per workgroup: the kernel is a latency chain, so the samples are
         // requested before the tables (whose barrier would otherwise be waited for first)
         Raw<HALF_HOP> raw;
-        load_raw<HALF_HOP>(raw, p.sig, p.n_samples, (int64_t)(2 * pr) * p.hop, p.hop, tid);
+        load_raw<HALF_HOP>(raw, p.sig + (int64_t)cx * p.ld, p.n_samples, (int64_t)(2 * pr) * p.hop, p.hop, tid);
         init_tables(tw, win, tw2, p.window, p.twt, tid);
         window_pair<HALF_HOP>(v, raw, win);
         if (needs_drop(p, pr)) drop_second(v);
     }
     fft4096_plain<false>(v, tw, buf, tw2, tid);
     if (p.detrend && tid == 0) v[pos16(0)] = make_float2(0.f, 0.f);
-    float4* xo = reinterpret_cast<float4*>(p.xs + (int64_t)pr * N) + tid;
+    float4* xo = reinterpret_cast<float4*>(p.xs + ((int64_t)cx * p.n_pairs + pr) * N) + tid;
 #pragma unroll
     for (int g = 0; g < 8; ++g) {
         float2 z0 = v[pos16(2 * g)], z1 = v[pos16(2 * g + 1)];
@@ -380,7 +380,7 @@ __global__ __launch_bounds__(NT) void k_x(Args p) {
         pw[tid + 256 * k3] = z.x * z.x + z.y * z.y;
     }
     __syncthreads();
-    float* po = p.px + (int64_t)pr * NB;
+    float* po = p.px + ((int64_t)cx * p.n_pairs + pr) * NB;
     for (int k = tid; k < NB; k += NT) po[k] = 0.5f * (pw[k] + pw[(N - k) & (N - 1)]);
 }
 
@@ -416,7 +416,7 @@ __global__ __launch_bounds__(NT, 2) void k_y(Args p) {
     const float* ch = p.sig + (int64_t)c * p.ld;
     // balanced split of the pairs over the chunks (n_chunks stays a multiple of 8 for the XCD mapping)
     const int p0 = (int)((int64_t)q * p.n_pairs / p.n_chunks), p1 = (int)((int64_t)(q + 1) * p.n_pairs / p.n_chunks);
-    if (!AUTO) {
+    if (!AUTO && p.n_cx <= 1) {  // (one input channel per output channel: welch4096::k_px_sum does it)
         // Input auto-spectrum of this chunk: the px rows k_x wrote, summed in fp64 -- instead of a
         // separate reduction kernel every workgroup of the chunk takes a slice of the bins
         // (8 row groups x 32 bins per sweep, independent loads, combined through LDS).
@@ -478,7 +478,8 @@ __global__ __launch_bounds__(NT, 2) void k_y(Args p) {
 #pragma unroll
                     for (int k3 = 0; k3 < 16; ++k3) xw[k3] = tw.w[k3 % 15];
                 } else {
-                    const float4* __restrict__ xp = reinterpret_cast<const float4*>(p.xs + (int64_t)pr * N) + tid;
+                    const float4* __restrict__ xp =
+                        reinterpret_cast<const float4*>(p.xs + ((int64_t)(p.n_cx > 1 ? c : 0) * p.n_pairs + pr) * N) + tid;
 #pragma unroll
                     for (int g = 0; g < 8; ++g) {
                         float4 q = xp[256 * g];

@@ -270,6 +270,14 @@ def test_welch4096_paired_inputs_vs_oracle():
             rt, rc = orc.compute_transfer_function(y, x, 48000, 4096, mode, detrend=det)
             e1, e2 = relmax(tf, rt, det), relmax(coh, rc, det)
             assert e1 < TOL and e2 < TOL, (n, C, mode, e1, e2)
+        # other overlaps: the two-workgroups-per-CU kernels (k_x per input channel, k_px_sum, k_y)
+        for ov in (75.0, 25.0):
+            tf, coh = backend.welch_transfer_function(y, x, 48000, 4096, "H1", overlap_percent=ov, detrend=det)
+            rt, rc = orc.compute_transfer_function(y, x, 48000, 4096, "H1", overlap_percent=ov, detrend=det)
+            assert relmax(tf, rt, det) < TOL and relmax(coh, rc, det) < TOL, (n, C, ov)
+            k = backend._welch(x, y, 48000, Window.Hann, 4096, ov, det, "mean", SpectrumScaling.FFTBackward)
+            r = orc.welch(x, y, 48000, "hann", 4096, ov, det, "mean", "FFTBackward")
+            assert relmax(k, r, det) < TOL, (n, C, ov, "csd")
 
 
 @pytest.mark.parametrize("W", [256, 512, 1024, 2048, 8192, 16384])
