@@ -78,6 +78,12 @@ __device__ __forceinline__ void idft16(float2 (&v)[16]) {
 // twt: the W4096^(t k1) table in global memory ([15][256]); this thread's 15 values are fetched
 // into the registers the data has just left, behind the second exchange barrier (keeping them
 // resident costs 30 registers the 128-register budget of a 1024-thread workgroup does not have).
+// FOLD (kernels_fir16k.hpp's own use): twt is a [16][256] table W16384^(t (4 k1 + q)) of the calling
+// group q -- the last pass's twiddle W4096^(t k1) times the group's output twiddle W16384^(t q), which
+// is the same for every output of a thread and therefore can ride on the 16 inputs of the last
+// 16-point transform (k1 = 0 included): the caller's recombination is left with the wave-uniform
+// factor W64^(n1 q) only -- 60 vector instructions less per thread and filter.
+template <bool FOLD = false>
 __device__ __forceinline__ void ifft4096(float2 (&v)[16], const float2* __restrict__ twt, float2* __restrict__ buf,
                                          const float2* __restrict__ tw2, int t) {
     idft16(v);  // v[n3]
@@ -97,21 +103,29 @@ __device__ __forceinline__ void ifft4096(float2 (&v)[16], const float2* __restri
     __syncthreads();  // every read of the row image is done before it is overwritten
 #pragma unroll
     for (int n2 = 0; n2 < 16; ++n2) buf[k1u * w4::L1S + 16 * n2 + n3] = v[n2];
-    float2 w1[15];
+    float2 w1[FOLD ? 16 : 15];
 #pragma unroll
-    for (int k1 = 1; k1 < 16; ++k1) w1[k1 - 1] = twt[(k1 - 1) * 256 + t];
+    for (int k1 = FOLD ? 0 : 1; k1 < 16; ++k1) w1[FOLD ? k1 : k1 - 1] = twt[(FOLD ? k1 : k1 - 1) * 256 + t];
     __syncthreads();
 #pragma unroll
     for (int k1 = 0; k1 < 16; ++k1) v[w4::pos16(k1)] = buf[k1 * w4::L1S + t];
 #pragma unroll
-    for (int k1 = 1; k1 < 16; ++k1) v[w4::pos16(k1)] = cmulc(v[w4::pos16(k1)], w1[k1 - 1]);
+    for (int k1 = FOLD ? 0 : 1; k1 < 16; ++k1) v[w4::pos16(k1)] = cmulc(v[w4::pos16(k1)], w1[FOLD ? k1 : k1 - 1]);
     idft16(v);  // v[n1]
 }
 
-// twn: [4][256] W16384^(t q) then [4][16] W64^(n1 q)  (fp64-computed)
-constexpr int TWN_LEN = 4 * 256 + 4 * 16;
+// twn: [4][256] W16384^(t q) then [4][16] W64^(n1 q), then the folded last-pass table
+// [4][16][256] W16384^(t (4 k1 + q))  (fp64-computed)
+constexpr int TWN_FOLD = 4 * 256 + 4 * 16;
+constexpr int TWN_LEN = TWN_FOLD + 4 * 16 * 256;
 inline void host_tables(std::vector<float2>& t) {
     t.resize(TWN_LEN);
+    for (int q = 0; q < 4; ++q)
+        for (int k1 = 0; k1 < 16; ++k1)
+            for (int tt = 0; tt < 256; ++tt) {
+                double a = -2.0 * M_PI * (double)(tt * (4 * k1 + q)) / 16384.0;
+                t[TWN_FOLD + (q * 16 + k1) * 256 + tt] = make_float2((float)std::cos(a), (float)std::sin(a));
+            }
     for (int q = 0; q < 4; ++q) {
         for (int tt = 0; tt < 256; ++tt) {
             double a = -2.0 * M_PI * (double)(tt * q) / 16384.0;
@@ -236,12 +250,12 @@ __global__ __launch_bounds__(NTB) void k_fir(Args p) {
 #pragma unroll
         for (int s = 0; s < 16; ++s) v[s] = cmul(z[s], v[s]);
         __syncthreads();  // the previous filter's recombination reads are done
-        const float2* twt = p.twt;
-        asm volatile("" : "+s"(twt));  // not loop invariant for the compiler: no hoisting into 30 live registers
-        ifft4096(v, twt, buf, tw2, t);
+        const float2* twq = p.twn + TWN_FOLD + q * 16 * 256;
+        asm volatile("" : "+s"(twq));  // not loop invariant for the compiler: no hoisting into 32 live registers
+        ifft4096<true>(v, twq, buf, tw2, t);
         __syncthreads();  // every group has read its last exchange image: the buffers become comb
 #pragma unroll
-        for (int n1 = 0; n1 < 16; ++n1) comb[q * M + t + 256 * n1] = cmulc(v[n1], cmul(wt, c64[n1]));
+        for (int n1 = 0; n1 < 16; ++n1) comb[q * M + t + 256 * n1] = cmulc(v[n1], c64[n1]);  // W16384^(-t q) is folded in
         // the registers are free: fetch the next filter's tap spectrum behind the recombination
         if (k + 1 < k1) load_taps(hq + (int64_t)(k + 1) * (NBIG / 2));
         __syncthreads();
