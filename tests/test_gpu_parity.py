@@ -673,6 +673,32 @@ def test_bench_two_ranks_strong_scaling_rehearsal():
 
 
 @pytest.mark.timeout(600)
+def test_bench_two_ranks_weak_scaling_rehearsal():
+    """bench.py --gpus 2 as the driver launches it for the scaling curve (weak scaling, the default), with
+    gloo as torch's backend so that both ranks can share this one GPU: every rank an independent batch,
+    value = 2 x units / slowest rank, one JSON line from rank 0."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, BENCH_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+           "--gpus", "2", "--steps", "10", "--warmup", "3", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=500)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["bcast"] == "host"
+    assert out["value"] > 0 and out["roofline"]["frac"] > 0 and out["steps"] == 10
+
+
+@pytest.mark.timeout(600)
 def test_bench_default_line_contract():
     """`python bench.py` (one GPU, the headline workload, a short run with a reduced CPU leg): ONE JSON
     line with the driver's fields, the roofline object (live kernel time, its raw bracket and the
