@@ -126,6 +126,7 @@ class Dist:
 
 
 RCCL_ERROR = None  # set when a weak-scaling run went on without the library communicator
+HOST_EXCHANGE_ERROR = None  # set when a weak-scaling run went on without the package's host exchange
 
 
 def setup_rccl(ctx, dist: Dist, required: bool = True):
@@ -237,7 +238,7 @@ def welch_h1(args, ctx, dist, shard, rccl, W=4096):
         ctx.sync()
         bcast_ms = (time.perf_counter() - t0) * 1e3
     else:
-        if dist.world > 1:  # BENCH_BCAST=host / gloo rehearsal: broadcast on the host, then upload
+        if dist.world > 1 and HOST_EXCHANGE_ERROR is None:  # BENCH_BCAST=host / gloo rehearsal: host broadcast, upload
             from dsptoolbox_amd.distributed import broadcast_array
             xp = broadcast_array(xp if dist.rank == 0 else None, src=0)
         ctx.upload(d_x.ptr, xp)
@@ -513,7 +514,19 @@ def main():
     ctx = Context(None)  # device = LOCAL_RANK (modulo the visible device count)
     if dist.world > 1:
         from dsptoolbox_amd import distributed as dd
-        dd.init()  # host exchange of the package (TCP star from the launcher's environment)
+        ok, err = True, None
+        try:
+            dd.init()  # host exchange of the package (TCP star from the launcher's environment)
+        except Exception as ex:  # noqa: BLE001 - e.g. the exchange's port is taken
+            ok, err = False, repr(ex)[:200]
+        if not dist.all_ok(ok):
+            # strong scaling shards ONE job and needs the exchange; the batches of a weak-scaling run are
+            # independent (every rank builds the same shared sweep from its seed), so it goes on and says so
+            print(f"[bench] rank {dist.rank}: host exchange not available: {err}", file=sys.stderr, flush=True)
+            if args.scaling == "strong":
+                sys.exit(3)
+            global HOST_EXCHANGE_ERROR
+            HOST_EXCHANGE_ERROR = err or "failed on another rank"
     rccl = setup_rccl(ctx, dist, required=(args.scaling == "strong"))
     strong = args.scaling == "strong" and dist.world > 1
     shard = (dist.rank, dist.world) if strong else None
@@ -652,6 +665,10 @@ def main():
         out["bcast"] = "rccl" if rccl else "host"
         if RCCL_ERROR:
             out["rccl_error"] = RCCL_ERROR
+        if HOST_EXCHANGE_ERROR:
+            if not rccl:
+                out["bcast"] = "none (every rank built the shared input from its seed)"
+            out["host_exchange_error"] = HOST_EXCHANGE_ERROR
         if strong:
             out["result_gather"] = "rccl all-gather per step" if rccl else "none"
     if bcast_ms is not None:
