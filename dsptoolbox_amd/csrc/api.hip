@@ -1392,7 +1392,7 @@ static int csm_dev(ds_ctx* c, const float* x, int n_ch, int64_t ld, int64_t n_sa
     // pairs (the spectra of an even-length real transform are purely real at both edge bins,
     // which the kernel relies on)
     static const bool no64 = getenv("DSPTOOLBOX_AMD_CSM_GENERIC") != nullptr;
-    // even channel counts: the same product from bf16 triples on the 16 x faster bf16 matrix pipe
+    // the same product from bf16 triples on the 16 x faster bf16 matrix pipe
     // (kernels_csm_b3.hpp; DSPTOOLBOX_AMD_CSM_F32=1 keeps the fp32 matrix instructions)
     static const bool f32_only = getenv("DSPTOOLBOX_AMD_CSM_F32") != nullptr;
     const bool one_wg_per_bin = all_bins && n_ch <= 64 && n_frames >= 8 && nb >= 3 && !no64;

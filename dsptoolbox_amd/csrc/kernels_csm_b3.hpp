@@ -10,7 +10,7 @@
 // at the rate its operand stream arrives from HBM.  (reference: _csm_welch,
 // standard/_spectral_methods.py:285-371 -- the per-bin  X^H X  over the frames.)  gfx950.
 //
-//   X[b][f][c] (the STFT layout), C even.  One workgroup per bin (the two purely real edge bins
+//   X[b][f][c] (the STFT layout), C <= 64.  One workgroup per bin (the two purely real edge bins
 //   share the last one), four waves split the k-steps of 16 frames.  Tile T (T = 0, 1) holds
 //   the channels 2 r + T, so one 16-byte load per lane and frame -- (re, im) of channels
 //   2 r and 2 r + 1 -- feeds row r of both tiles; lanes 0..31 take frames 0..7 of the k-step,
@@ -246,7 +246,10 @@ __global__ __launch_bounds__(256, 2) void k_csm_gemm64_b3_range(CsmArgs p) {
 
 // X of one bin must stay below 2^31 bytes for the 32-bit buffer offsets
 __host__ inline bool fits(int n_ch, int n_frames) {
-    return n_ch >= 2 && n_ch <= 64 && (n_ch & 1) == 0 && (int64_t)n_frames * n_ch * 8 < (int64_t)1 << 31;
+    // odd counts too: the last lane pair's second channel is then the first value of the next row (or
+    // zero past the end of the bin) and lands in tile rows / columns the epilogue does not store; the
+    // 16-byte loads are 8-byte aligned in that case, which buffer loads allow
+    return n_ch >= 2 && n_ch <= 64 && (int64_t)n_frames * n_ch * 8 < (int64_t)1 << 31;
 }
 
 }  // namespace csmb3
