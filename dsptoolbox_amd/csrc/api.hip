@@ -1402,6 +1402,15 @@ static int csm_dev(ds_ctx* c, const float* x, int n_ch, int64_t ld, int64_t n_sa
         CHK(launch(c, "csm_gemm", k_csm_gemm64, dim3(nb - 1), 256, 0, a));
     else if (!all_bins && n_ch <= 64 && n_frames >= 8 && !no64 && !f32_only && csmb3::fits(n_ch, n_frames))
         CHK(launch(c, "csm_gemm", csmb3::k_csm_gemm64_b3_range, dim3(bin_count), 256, 0, a));
+    else if (n_ch > 64 && n_frames >= 8 && !no64 && !f32_only && csmb3::fits_groups(n_ch, n_frames)) {
+        // groups of 64 channels: the diagonal blocks, then the blocks below the diagonal (two workgroups each)
+        const int ng = (n_ch + 63) / 64;
+        a.n_groups = ng;
+        a.n_groups_bins = bin_count;
+        CHK(launch(c, "csm_gemm", csmb3::k_csm_group_b3, dim3(bin_count, ng), 256, 0, a));
+        CHK(launch(c, "csm_gemm_offdiag", csmb3::k_csm_offdiag_b3, dim3(16 * ((bin_count + 7) / 8), ng * (ng - 1) / 2),
+                   256, 0, a));
+    }
     else
         CHK(launch(c, "csm_gemm", k_csm_gemm, dim3(bin_count, nt * (nt + 1) / 2), 256, 0, a));
     return DS_OK;

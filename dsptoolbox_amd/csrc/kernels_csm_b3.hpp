@@ -98,16 +98,18 @@ __device__ __forceinline__ void dma16(const v4i& rsrc, uint32_t voff, uint32_t l
         : "memory");
 }
 
+// c0, cg: the channels [c0, c0 + cg) of the rows (cg < 0: all of them)
 __device__ __forceinline__ void bin_dma(char* smem, int b, const CsmArgs& p, f32x16& re00, f32x16& im00,
-                                        f32x16& re10, f32x16& im10, f32x16& re11, f32x16& im11) {
+                                        f32x16& re10, f32x16& im10, f32x16& re11, f32x16& im11, int c0 = 0,
+                                        int cg = -1) {
     const int tid = threadIdx.x, w = __builtin_amdgcn_readfirstlane(tid >> 6), l = tid & 63;
-    const int C = p.n_ch, F = p.n_frames;
+    const int C = p.n_ch, F = p.n_frames, Cg = cg < 0 ? C : cg;
     const uint32_t row_bytes = (uint32_t)C * 8u, bin_bytes = (uint32_t)F * row_bytes;
     const uint64_t base = (uint64_t)(p.X + (int64_t)b * F * C);
     const v4i rs = {__builtin_amdgcn_readfirstlane((int)(uint32_t)base),
                     __builtin_amdgcn_readfirstlane((int)(uint32_t)(base >> 32)) & 0xffff, (int)bin_bytes, 0x00020000};
     const int r = l & 31, h = l >> 5;
-    const uint32_t lane_off = 2 * r < C ? (uint32_t)(8 * h) * row_bytes + 16u * r : bin_bytes;
+    const uint32_t lane_off = 2 * r < Cg ? (uint32_t)(8 * h) * row_bytes + 8u * (uint32_t)(c0 + 2 * r) : bin_bytes;
     const int nks = (F + 15) >> 4;
     // this wave's ring: buffers k = 0, 1 of 8 rows x 1 KB
     const uint32_t ring = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem + (uint32_t)w * 16384u;
@@ -244,7 +246,126 @@ __global__ __launch_bounds__(256, 2) void k_csm_gemm64_b3_range(CsmArgs p) {
     dsk::csm_epilogue64<true>(red, G, re00, im00, re10, im10, re11, im11, true, b, p);
 }
 
+// ---- more than 64 channels: groups of 64 -----------------------------------------------------
+// The matrix is cut into 64 x 64 blocks.  A diagonal block is the Gram matrix of its group: the
+// kernel above with a channel offset (grid = (bins, groups); every bin through the complex path).
+__global__ __launch_bounds__(256, 2) void k_csm_group_b3(CsmArgs p) {
+    __shared__ __attribute__((aligned(16))) char smem[sizeof(dsk::CsmRed) + sizeof(float2) * dsk::CSM64_G];
+    dsk::CsmRed& red = *reinterpret_cast<dsk::CsmRed*>(smem);
+    float2* G = reinterpret_cast<float2*>(smem + sizeof(dsk::CsmRed));
+    const int b = p.b0 + (int)blockIdx.x, c0 = 64 * (int)blockIdx.y, cg = min(64, p.n_ch - c0);
+    f32x16 re00 = {0}, im00 = {0}, re10 = {0}, im10 = {0}, re11 = {0}, im11 = {0};
+    bin_dma(smem, b, p, re00, im00, re10, im10, re11, im11, c0, cg);
+    __syncthreads();  // every wave's ring is idle
+    dsk::csm_epilogue64<true>(red, G, re00, im00, re10, im10, re11, im11, true, b, p, c0, cg);
+}
+
+// An off-diagonal block (group A below group B) has no symmetry: all 64 x 64 elements
+//   G[a][b] = sum_f X_a conj(X_b):  Re = Ra Rb^T + Ia Ib^T,  Im = Ia Rb^T - Ra Ib^T.
+// One workgroup takes the 32 rows of parity T of group A (channels a0 + 2 r + T, 8-byte loads) against
+// both column tiles of group B (16-byte loads): 8 products of 6 instructions per k-step, 64
+// accumulator registers (the whole block in one workgroup would need 128).  Register loads, one
+// k-step ahead.  The finished elements go straight to global memory: G[a][b] and its mirror
+// conj at [b][a].  grid = (16 ceil(bins / 8), pairs A > B).
+__global__ __launch_bounds__(256, 2) void k_csm_offdiag_b3(CsmArgs p) {
+    __shared__ dsk::CsmRed red;
+    const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
+    const int C = p.n_ch, F = p.n_frames;
+    // workgroups x and x + 8 land on the same XCD one after the other: they take the two row parities of
+    // one bin, so the second finds group B's rows in that XCD's L2 (the kernel is bound by its reads)
+    const int T = ((int)blockIdx.x >> 3) & 1, bl = ((int)blockIdx.x >> 4) * 8 + ((int)blockIdx.x & 7);
+    if (bl >= p.n_groups_bins) return;
+    const int b = p.b0 + bl;
+    int ga = 1, pair = blockIdx.y;  // pair index -> (ga, gb), ga > gb
+    while (pair >= ga) {
+        pair -= ga;
+        ++ga;
+    }
+    const int gb = pair, a0 = 64 * ga, b0c = 64 * gb, ca = min(64, C - a0);
+    const uint32_t row_bytes = (uint32_t)C * 8u, bin_bytes = (uint32_t)F * row_bytes;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float2*>(p.X + (int64_t)b * F * C), 0, (int)bin_bytes, 0x00020000);
+    const int r = l & 31, h = l >> 5;
+    const uint32_t offa = 2 * r + T < ca ? (uint32_t)(8 * h) * row_bytes + 8u * (uint32_t)(a0 + 2 * r + T) : bin_bytes;
+    const uint32_t offb = (uint32_t)(8 * h) * row_bytes + 8u * (uint32_t)(b0c + 2 * r);  // group B is a full one
+    const int nks = (F + 15) >> 4;
+    f32x16 re0 = {0}, im0 = {0}, re1 = {0}, im1 = {0};
+    float2 qa[8];
+    float4 qb[8];
+    auto fetch = [&](int s) {
+        const uint32_t oa = s < nks ? offa + (uint32_t)(16 * s) * row_bytes : bin_bytes;
+        const uint32_t ob = s < nks ? offb + (uint32_t)(16 * s) * row_bytes : bin_bytes;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            qa[j] = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(rs, oa + j * row_bytes, 0, 0));
+            qb[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, ob + j * row_bytes, 0, 0));
+        }
+    };
+    fetch(w);
+    for (int s = w; s < nks; s += 4) {
+        Pieces Ra, Ia, R0, I0, R1, I1;
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            split_pair(qa[2 * jj].x, qa[2 * jj + 1].x, jj, Ra);
+            split_pair(qa[2 * jj].y, qa[2 * jj + 1].y, jj, Ia);
+            split_pair(qb[2 * jj].x, qb[2 * jj + 1].x, jj, R0);
+            split_pair(qb[2 * jj].y, qb[2 * jj + 1].y, jj, I0);
+            split_pair(qb[2 * jj].z, qb[2 * jj + 1].z, jj, R1);
+            split_pair(qb[2 * jj].w, qb[2 * jj + 1].w, jj, I1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        fetch(s + 4);
+        __builtin_amdgcn_sched_barrier(0);
+        prod(re0, Ra, R0);
+        prod(re1, Ra, R1);
+        prod(re0, Ia, I0);
+        prod(re1, Ia, I1);
+        prod(im0, Ia, R0);
+        prod(im1, Ia, R1);
+        const Pieces Na = negated(Ra);  // last use of Ra: negated in place
+        prod(im0, Na, I0);
+        prod(im1, Na, I1);
+    }
+    // ---- epilogue: combine the four waves' partial tiles, finish, store the element and its mirror
+    const double e = p.fin.halve_edges ? ((b == 0 || b == p.fin.nb - 1) ? 0.5 * p.fin.factor : p.fin.factor) : 1.0;
+    float2* out = p.csm + (int64_t)(b - p.b0) * C * C;
+#pragma unroll  // (rolled, hipcc selects the accumulators through scratch memory)
+    for (int U = 0; U < 2; ++U) {
+        if (U) __syncthreads();  // red is reused
+        dsk::csm_tile_put(red, U ? re1 : re0, U ? im1 : im0);
+        __syncthreads();
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const int rg = w * 4 + rr;
+            const float gx = (red[0][0][rg][l] + red[1][0][rg][l]) + (red[2][0][rg][l] + red[3][0][rg][l]);
+            const float gy = (red[0][1][rg][l] + red[1][1][rg][l]) + (red[2][1][rg][l] + red[3][1][rg][l]);
+            const int i = (rg & 3) + 8 * (rg >> 2) + 4 * (l >> 5), j = l & 31;
+            const int gi = a0 + 2 * i + T, gj = b0c + 2 * j + U;
+            // one frame at a purely real bin: see csm_tile_reduce_store (keep_sign)
+            const bool keep = F == 1 && gy == 0.f;
+            double vx = (double)gx * p.fin.inv * e, vy = (keep ? 0.0 : (double)gy) * p.fin.inv * e;
+            if (p.fin.amp_sqrt) {
+                const double x = vx, y = vy;
+                const double rad = sqrt(x * x + y * y);
+                const double t = sqrt(0.5 * (rad + fabs(x)));
+                const double q = fabs(y) / (2.0 * t);
+                const bool pos = x >= 0.0, zero = rad == 0.0;
+                vx = zero ? 0.0 : (pos ? t : q);
+                vy = zero ? y : copysign(pos ? q : t, y);
+            }
+            if (2 * i + T < ca) {
+                const float fx = (float)vx, fy = (float)vy;
+                out[(int64_t)gi * C + gj] = make_float2(fx, fy);
+                out[(int64_t)gj * C + gi] = make_float2(fx, keep ? fy : -fy);
+            }
+        }
+    }
+}
+
 // X of one bin must stay below 2^31 bytes for the 32-bit buffer offsets
+__host__ inline bool fits_groups(int n_ch, int n_frames) {  // more than 64 channels: groups of 64
+    return n_ch > 64 && n_ch <= 1024 && (int64_t)n_frames * n_ch * 8 < (int64_t)1 << 31;
+}
 __host__ inline bool fits(int n_ch, int n_frames) {
     // odd counts too: the last lane pair's second channel is then the first value of the next row (or
     // zero past the end of the bin) and lands in tile rows / columns the epilogue does not store; the

@@ -312,6 +312,8 @@ struct CsmArgs {
     FinishPar fin;
     float2* csm;  // matrix of bin b0 first
     int b0;       // first bin of this call (generic kernel: a bin range for the multi-GPU split)
+    int n_groups; // k_csm_group_b3 / k_csm_offdiag_b3: groups of 64 channels (0: not used)
+    int n_groups_bins;  // k_csm_offdiag_b3: bins of this call (its grid is padded to whole XCD rounds)
 };
 
 // Combine the four waves' partial 32x32 tiles (fp64, through LDS), apply the Welch finish and
@@ -349,9 +351,9 @@ __device__ __forceinline__ void csm_tile_put(CsmRed& red, const f32x16& re, cons
 // apart, and the 3 M such requests of the 64-channel shape keep the L2 channels busy for 16 us.
 template <bool ILV = false, bool STAGED = false>
 __device__ __forceinline__ void csm_tile_reduce_store(CsmRed& red, int I, int J, bool diag_m, int b,
-                                                      const CsmArgs& p, float2* G = nullptr) {
+                                                      const CsmArgs& p, float2* G = nullptr, int c_local = -1) {
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
-    const int C = p.n_ch, F = p.n_frames;
+    const int C = c_local < 0 ? p.n_ch : c_local, F = p.n_frames;  // c_local: channels of the group staged in G
     const int ldo = STAGED ? C + 1 : C;
     float2* out = STAGED ? G : p.csm + (int64_t)(b - p.b0) * C * C;
     // The chain LDS read -> sum -> fp64 scale -> complex square root -> store is ~800 cycles of
@@ -434,27 +436,28 @@ template <bool ILV>
 __device__ __forceinline__ void csm_epilogue64(CsmRed& red, float2* G, const f32x16& re00,
                                                const f32x16& im00, const f32x16& re10, const f32x16& im10,
                                                const f32x16& re11, const f32x16& im11, bool diag_m, int b,
-                                               const CsmArgs& p) {
-    const int C = p.n_ch;
+                                               const CsmArgs& p, int c0 = 0, int c_group = -1) {
+    // c0, c_group: a group of channels [c0, c0 + c_group) of a wider matrix (k_csm_group_b3)
+    const int C = c_group < 0 ? p.n_ch : c_group, Ct = p.n_ch;
     // (a rolled loop over the tiles makes hipcc select the accumulators through scratch memory)
     csm_tile_put(red, re00, im00);
     __syncthreads();
-    csm_tile_reduce_store<ILV, true>(red, 0, 0, diag_m, b, p, G);
+    csm_tile_reduce_store<ILV, true>(red, 0, 0, diag_m, b, p, G, C);
     if (ILV || C > 32) {
         __syncthreads();  // red is reused
         csm_tile_put(red, re10, im10);
         __syncthreads();
-        csm_tile_reduce_store<ILV, true>(red, 1, 0, false, b, p, G);
+        csm_tile_reduce_store<ILV, true>(red, 1, 0, false, b, p, G, C);
         __syncthreads();
         csm_tile_put(red, re11, im11);
         __syncthreads();
-        csm_tile_reduce_store<ILV, true>(red, 1, 1, diag_m, b, p, G);
+        csm_tile_reduce_store<ILV, true>(red, 1, 1, diag_m, b, p, G, C);
     }
     __syncthreads();
-    float2* out = p.csm + (int64_t)(b - p.b0) * C * C;
+    float2* out = p.csm + (int64_t)(b - p.b0) * Ct * Ct + (int64_t)c0 * Ct + c0;
     const int col = threadIdx.x & 63;
     if (col < C)
-        for (int row = threadIdx.x >> 6; row < C; row += 4) out[row * C + col] = G[row * (C + 1) + col];
+        for (int row = threadIdx.x >> 6; row < C; row += 4) out[row * Ct + col] = G[row * (C + 1) + col];
 }
 
 // generic: grid = (bins, tile pairs I >= J of 32 x 32 channels)

@@ -1286,8 +1286,8 @@ def test_headline_full_size_properties():
 
 @pytest.mark.parametrize("n_ch", [64, 40, 33, 70])
 def test_csm_64ch_vs_oracle(n_ch):
-    """64 / 40 / 33 channels: one workgroup per bin (k_csm_gemm64, partly filled second tile);
-    70 channels: the generic tile-pair kernel."""
+    """64 / 40 / 33 channels: one workgroup per bin (bf16-triple kernel, partly filled second tile, odd
+    count); 70 channels: two groups of channels (diagonal blocks + one off-diagonal block)."""
     rng = np.random.default_rng(4)
     n = 40000
     x = 0.1 * rng.standard_normal((n, n_ch)) + 0.2 * rng.standard_normal(n)[:, None]
@@ -1295,6 +1295,27 @@ def test_csm_64ch_vs_oracle(n_ch):
                                 SpectrumScaling.FFTBackward)
     fr, ref = orc.csm_welch_batched(x, 48000, 1024, "hann", 50, True, "FFTBackward")
     assert relmax(csm, ref, True) < TOL
+
+
+@pytest.mark.parametrize("n_ch", [96, 129, 193])
+def test_csm_channel_groups_vs_oracle(n_ch):
+    """More than 64 channels: groups of 64 (k_csm_group_b3 for the diagonal blocks, k_csm_offdiag_b3 for the
+    blocks below it): 2 groups with a half-filled second one, 3 groups with a single channel in the last,
+    4 groups with an odd one; coherent sources of either sign, amplitude and power scalings, a bin range."""
+    rng = np.random.default_rng(n_ch)
+    n, W = 6000, 128
+    src = rng.standard_normal((n, 6)) * 0.3 + 0.02
+    x = src @ rng.standard_normal((6, n_ch)) + 0.1 * rng.standard_normal((n, n_ch))
+    for sc in (SpectrumScaling.FFTBackward, SpectrumScaling.PowerSpectralDensity):
+        f, csm = backend._csm_welch(x, 48000, W, Window.Hann, 50, False, "mean", sc)
+        fr, ref = orc.csm_welch_batched(x, 48000, W, "hann", 50, False, sc.name)
+        assert csm.shape == ref.shape == (W // 2 + 1, n_ch, n_ch)
+        # amplitude scaling: the square root amplifies the fp32 error of the many near-zero elements of
+        # this rank-6 data (DESIGN 2, limit (ix): 1.1e-6 at 193 channels); the power scaling has no such step
+        lim = TOL if sc == SpectrumScaling.PowerSpectralDensity else 2 * TOL
+        assert relmax(csm, ref) < lim, (n_ch, sc, relmax(csm, ref))
+        part = backend._csm_welch_bins(x, 48000, W, Window.Hann, 50, False, sc, 3, 41)
+        assert relmax(part, ref[3:41]) < lim
 
 
 def test_deconvolve_batch_8192():
