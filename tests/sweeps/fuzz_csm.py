@@ -1,7 +1,7 @@
 """Dev tool: randomized Welch cross-spectral matrices (channel counts 2 ... 70, even and odd; 8 ... 300
 frames; windows 64 ... 2048; every scaling; bin ranges) against the oracle -- the bf16-triple
 kernel (up to 64 channels; odd counts read one value past the row into a tile row that is not stored)
-and the generic one (> 64); DSPTOOLBOX_AMD_CSM_F32=1 puts the fp32-matrix-instruction kernel in its place."""
+and the channel-group kernels (> 64); DSPTOOLBOX_AMD_CSM_F32=1 puts the fp32-matrix-instruction kernel in its place."""
 import os
 import sys
 import warnings
@@ -20,7 +20,7 @@ scalings = list(SpectrumScaling)
 worst, fails = {}, []
 for it in range(n_cases):
     W = int(rng.choice([64, 128, 256, 512, 1024, 2048]))
-    C = int(rng.choice([2, 3, 4, 6, 8, 16, 30, 32, 33, 34, 40, 62, 63, 64, 70]))
+    C = int(rng.choice([2, 3, 4, 6, 8, 16, 30, 32, 33, 34, 40, 62, 63, 64, 70, 97, 130]))
     F = int(rng.integers(8, 300))
     ov = float(rng.choice([0.0, 50.0, 75.0]))
     hop = max(1, int(W * (1 - ov / 100)))
@@ -41,7 +41,7 @@ for it in range(n_cases):
         fr, ref = orc.csm_welch_batched(x, 48000, W, "hann", ov, det, sc.name)
         lo = 1 if det else 0
         e = orc.rel_max(csm[lo:], ref[lo:])
-        kind = ("b3" if C % 2 == 0 else "b3 odd") if C <= 64 else "generic"
+        kind = ("b3" if C % 2 == 0 else "b3 odd") if C <= 64 else "groups"
         if rng.integers(0, 3) == 0 and W >= 128:
             a = int(rng.integers(0, W // 2))
             b = int(rng.integers(a + 1, W // 2 + 2))
