@@ -20,11 +20,14 @@ RES_PATH = os.path.join(LIB_DIR, "kernel_resources.json")
 # is compiled with ScratchSize > 0 (a spill inside a register-resident transform costs more than
 # the occupancy it buys).  Matched as substrings of the demangled-ish mangled names.
 NO_SCRATCH = [
-    "welch40964k_y3", "welch40964k_x3", "welch40963k_y", "welch40963k_x",
+    "welch40965k_h1f", "welch40964k_y3", "welch40964k_x3", "welch40963k_y", "welch40963k_x",
     "stft1k11k_stft_wave", "welch1k3k_y", "welch1k3k_x", "welch8k3k_y", "welch8k3k_x", "welch16k3k_y", "welch16k3k_x",
     "fir16k5k_firILb1E", "deconv8k8k_deconv", "k_csm_gemm64",
 ]
 
+
+# kernels whose workgroups wait for each other inside one launch (whole grid resident at once)
+RESIDENT_GRID = ["welch40965k_h1f"]
 
 HASH_PATH = os.path.join(LIB_DIR, "libdsptoolbox_amd.srchash")
 
@@ -113,10 +116,27 @@ def build_library(force: bool = False, verbose: bool = True) -> str:
                 if proc.returncode != 0:
                     sys.stderr.write(_without_remarks(proc.stderr))
                     raise subprocess.CalledProcessError(proc.returncode, cmd)
+                # the gate must not fail open: no parsed remarks, or a listed kernel that matches
+                # nothing (a rename, a changed remark format), is an error of the build itself
+                if not res:
+                    raise RuntimeError("no kernel-resource-usage remarks parsed from the compiler output; "
+                                       "the no-scratch gate cannot be checked")
+                unmatched = [t for t in NO_SCRATCH if not any(t in k for k in res)]
+                if unmatched:
+                    raise RuntimeError("NO_SCRATCH entries that match no compiled kernel: %r" % unmatched)
                 bad = {k: v["scratch"] for k, v in res.items()
                        if v.get("scratch", 0) > 0 and any(t in k for t in NO_SCRATCH)}
                 if bad and not os.environ.get("DSPTOOLBOX_AMD_ALLOW_SCRATCH"):
                     raise RuntimeError("hot kernels compiled with scratch (register spills), bytes/lane: %r" % bad)
+                # kernels that wait for other workgroups of their own grid: the occupancy query is only
+                # right up to 80 SGPRs (MI355X_MICROARCH.md, Residency) -- keep them there
+                wide = {k: v.get("sgpr", 0) for k, v in res.items()
+                        if any(t in k for t in RESIDENT_GRID) and v.get("sgpr", 0) > 80}
+                if wide:
+                    raise RuntimeError("resident-grid kernels with more than 80 SGPRs: %r" % wide)
+                rest = _without_remarks(proc.stderr)
+                if rest.strip() and verbose:
+                    sys.stderr.write(rest)  # warnings of a successful build are not swallowed
                 import json
                 with open(RES_PATH, "w") as fh:
                     json.dump(res, fh, indent=1, sort_keys=True)

@@ -19,6 +19,7 @@
 #include "kernels_generic.hpp"
 #include "kernels_welch4096.hpp"
 #include "kernels_welch4096w.hpp"
+#include "kernels_welch4096f.hpp"
 #include "kernels_fir16k.hpp"
 #include "kernels_deconv8k.hpp"
 #include "kernels_stft1024.hpp"
@@ -52,6 +53,9 @@ struct ds_ctx {
     size_t blue_bytes = 0;
     uint64_t blue_clock = 0;
     float2* w4_tables = nullptr;  // welch4096::host_tables()
+    unsigned* w4_sync = nullptr;  // counters of the one-launch Welch kernel (welch4096::k_h1f), zero between launches
+    bool w4_sync_used = false;    // a fused launch since the last check of its timeout word
+    int w4_fused_cap = -1;        // workgroups of k_h1f the device holds at once
     float2* fir16k_tables = nullptr;  // fir16k::host_tables()
     float2* deconv8k_tables = nullptr;  // deconv8k::host_tables()
     float2* stft1k_tables = nullptr;  // stft1k::host_tables<1024>()
@@ -210,6 +214,7 @@ extern "C" void ds_destroy(ds_ctx* c) {
     (void)hipStreamSynchronize(c->stream);
     for (auto& kv : c->tw) (void)hipFree(kv.second);
     if (c->w4_tables) (void)hipFree(c->w4_tables);
+    if (c->w4_sync) (void)hipFree(c->w4_sync);
     if (c->fir16k_tables) (void)hipFree(c->fir16k_tables);
     if (c->deconv8k_tables) (void)hipFree(c->deconv8k_tables);
     if (c->stft1k_tables) (void)hipFree(c->stft1k_tables);
@@ -258,11 +263,23 @@ extern "C" int ds_upload(ds_ctx* c, void* dst, const void* src, size_t bytes) {
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return DS_OK;
 }
+// The one-launch Welch kernel bounds its in-kernel waits; a wait that ran out leaves a code in
+// word 0 of its counter block.  Looked at whenever the host has just synchronised with the stream.
+static int check_fused_sync(ds_ctx* c) {
+    if (!c->w4_sync_used || !c->w4_sync) return DS_OK;
+    c->w4_sync_used = false;
+    unsigned code = 0;
+    HIPCHK(c, hipMemcpy(&code, c->w4_sync, sizeof(code), hipMemcpyDeviceToHost));
+    if (code == 0) return DS_OK;
+    HIPCHK(c, hipMemset(c->w4_sync, 0, sizeof(unsigned) * welch4096::F_SYNC_WORDS));
+    return fail(c, DS_ERR_HIP, "welch4096 one-launch kernel: an in-kernel hand-off timed out (code " +
+                                   std::to_string(code) + "); the result of that call is invalid");
+}
 extern "C" int ds_download(ds_ctx* c, void* dst, const void* src, size_t bytes) {
     if (!c || (bytes && (!dst || !src))) return fail(c, DS_ERR_ARG, "ds_download: null argument");
     HIPCHK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    return DS_OK;
+    return check_fused_sync(c);
 }
 extern "C" int ds_memset(ds_ctx* c, void* dst, int value, size_t bytes) {
     if (!c) return fail(c, DS_ERR_ARG, "ds_memset: null ctx");
@@ -272,7 +289,7 @@ extern "C" int ds_memset(ds_ctx* c, void* dst, int value, size_t bytes) {
 extern "C" int ds_sync(ds_ctx* c) {
     if (!c) return fail(c, DS_ERR_ARG, "ds_sync: null ctx");
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    return DS_OK;
+    return check_fused_sync(c);
 }
 extern "C" int ds_timer_start(ds_ctx* c) {
     if (!c) return fail(c, DS_ERR_ARG, "ds_timer_start: null ctx");
@@ -860,8 +877,33 @@ static int welch4096_run(ds_ctx* c, const float* x, int n_cx, int64_t ldx, const
     ay.sig = y;
     ay.ld = ldy;
     ay.n_ch = n_cy;
+    if (three) w4::place_remainder(ay, n_cy);
+    // one input channel, transfer function: the whole step in one launch when its grid is resident at once
+    if (three && n_cx == 1 && kind == 0 && w4::fused_enabled() && pl.n_chunks <= w4::F_MAX_UNITS && n_cy <= w4::F_MAX_UNITS) {
+        if (c->w4_fused_cap < 0) {
+            int per_cu = 0, cus = 0;
+            HIPCHK(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, w4::k_h1f, w4::NT, w4::LDS3_BYTES));
+            HIPCHK(c, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device));
+            c->w4_fused_cap = std::min(per_cu, 3) * cus;
+        }
+        if (pl.n_chunks * n_cy <= c->w4_fused_cap) {
+            if (!c->w4_sync) {
+                HIPCHK(c, hipMalloc((void**)&c->w4_sync, sizeof(unsigned) * w4::F_SYNC_WORDS));
+                HIPCHK(c, hipMemsetAsync(c->w4_sync, 0, sizeof(unsigned) * w4::F_SYNC_WORDS, c->stream));
+            }
+            w4::FusedArgs fa;
+            fa.a = ay;
+            fa.a.xsig = x;
+            fa.sync = c->w4_sync;
+            fa.mode = mode;
+            fa.fin = FinishPar{norm_scale / (double)n_frames, factor, halve_edges, amp_sqrt, w4::NB};
+            fa.tf = tf;
+            fa.coh = coh;
+            c->w4_sync_used = true;
+            return launch(c, "welch4096_fused", w4::k_h1f, dim3(pl.n_chunks * n_cy), w4::NT, w4::LDS3_BYTES, fa);
+        }
+    }
     if (three) {
-        w4::place_remainder(ay, n_cy);
         CHK(launch(c, "welch4096_x", w4::k_x3, dim3(pl.n_pairs * n_cx), w4::NT, w4::LDS3_BYTES, ax));
         if (n_cx > 1) CHK(launch(c, "welch4096_pxsum", w4::k_px_sum, dim3(pl.n_chunks, n_cx), 256, 0, ay));
         CHK(launch(c, "welch4096_main", w4::k_y3<false>, dim3(pl.n_chunks * n_cy), w4::NT, w4::LDS3_BYTES, ay));

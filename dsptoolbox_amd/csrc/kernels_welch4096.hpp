@@ -255,6 +255,7 @@ struct Args {
     // k_x3 / k_y3 only: number of input channels (0 or 1: one input for every output channel; else
     // one per output channel: xs[cx][pair][...], px[cx][pair][NB], psx[chunk][cx][NB])
     int n_cx;
+    const float* xsig;  // k_h1f only (kernels_welch4096f.hpp): the input channel (sig = the output channels)
 };
 
 // twt: fp64-computed tables, [15][256] W4096^(t k1) (k1 = 1..15) then [16][16] W256^(n3 k2)

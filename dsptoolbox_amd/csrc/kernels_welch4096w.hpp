@@ -227,10 +227,12 @@ __device__ __forceinline__ void set_prio(int level16, int dither) {
 // The barrier that protects the pass-1 image of the NEXT transform sits right behind this
 // transform's last LDS read, so the next transform's pass-1 stores can start while its own
 // butterflies are still running.
-template <typename LA, typename LB>
+//   mid():            called by every wave right behind the mid-transform barrier (before the first
+//                      ld_b): the fused kernel waits there, once, for its chunk's input spectra
+template <typename LA, typename LB, typename MID = NoHook>
 __device__ __forceinline__ void fft4096_wi(float2 (&v)[16], const Tw6& tw, float2* __restrict__ buf,
                                            const float2* __restrict__ tw2, int tid, LA ld_a, LB ld_b,
-                                           Stamp& ts, int level16) {
+                                           Stamp& ts, int level16, MID mid = MID()) {
     const int k1u = tid >> 4, n3 = tid & 15;
     float2* __restrict__ col = buf + tid;
     dft16_h(
@@ -261,6 +263,7 @@ __device__ __forceinline__ void fft4096_wi(float2 (&v)[16], const Tw6& tw, float
     });
     ts(2);
     W4_SYNC();
+    mid();
     ts(3);
     float2* __restrict__ row = buf + k1u * L1S;
     const uint32_t a_row = lds_addr(row + n3), a_tw2 = lds_addr(tw2 + n3);

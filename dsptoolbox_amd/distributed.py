@@ -58,16 +58,46 @@ def world() -> tuple[int, int]:
     return int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
 
 
+# Wire format of a host array: a fixed binary header -- magic, dtype code, ndim, dims -- then the
+# raw bytes.  Nothing in it is evaluated: the dtype comes from a closed table and the dimensions
+# are checked against the payload length, so a peer can at worst send a wrong array.
+_WIRE_MAGIC = b"DSA1"
+_WIRE_DTYPES = ("<f4", "<f8", "<c8", "<c16", "<i4", "<i8", "<u4", "<u8", "|u1", "|i1", "|b1", "<i2", "<u2")
+_WIRE_MAX_NDIM = 8
+
+
 def _pack(arr: np.ndarray) -> bytes:
-    a = np.ascontiguousarray(arr)
-    head = repr((a.shape, a.dtype.str)).encode()
-    return struct.pack("<I", len(head)) + head + a.tobytes()
+    a = np.asarray(arr)
+    if not a.flags.c_contiguous:  # (ascontiguousarray would turn a 0-d array into 1-d)
+        a = np.ascontiguousarray(a)
+    code = a.dtype.newbyteorder("<").str if a.dtype.byteorder == ">" else a.dtype.str
+    if a.dtype.byteorder == ">":
+        a = a.astype(a.dtype.newbyteorder("<"))
+    if code not in _WIRE_DTYPES:
+        raise TypeError(f"dtype {a.dtype} cannot travel through the host exchange")
+    if a.ndim > _WIRE_MAX_NDIM:
+        raise ValueError("too many dimensions for the host exchange")
+    head = _WIRE_MAGIC + struct.pack("<BB", _WIRE_DTYPES.index(code), a.ndim) + struct.pack(f"<{a.ndim}q", *a.shape)
+    return head + a.tobytes()
 
 
 def _unpack(b: bytes) -> np.ndarray:
-    (n,) = struct.unpack_from("<I", b, 0)
-    shape, dtype = eval(b[4:4 + n].decode(), {"__builtins__": {}})  # a tuple of ints and a dtype string
-    return np.frombuffer(b, dtype=np.dtype(dtype), offset=4 + n).reshape(shape).copy()
+    if len(b) < 6 or b[:4] != _WIRE_MAGIC:
+        raise ValueError("host exchange: not an array message")
+    code, ndim = struct.unpack_from("<BB", b, 4)
+    if code >= len(_WIRE_DTYPES) or ndim > _WIRE_MAX_NDIM or len(b) < 6 + 8 * ndim:
+        raise ValueError("host exchange: malformed array header")
+    shape = struct.unpack_from(f"<{ndim}q", b, 6)
+    dtype = np.dtype(_WIRE_DTYPES[code])
+    count = 1
+    for d in shape:
+        if d < 0:
+            raise ValueError("host exchange: negative dimension")
+        count *= d
+    off = 6 + 8 * ndim
+    if count * dtype.itemsize != len(b) - off:
+        raise ValueError("host exchange: array header does not match the payload length")
+    return np.frombuffer(b, dtype=dtype, count=count, offset=off).reshape(shape).copy()
 
 
 def broadcast_array(arr: np.ndarray | None, src: int = 0) -> np.ndarray:

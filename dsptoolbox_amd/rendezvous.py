@@ -13,6 +13,8 @@ group -- the package itself imports neither.
 
 from __future__ import annotations
 
+import hashlib
+import hmac
 import os
 import socket
 import struct
@@ -36,6 +38,24 @@ class Exchange:
 
     def close(self) -> None:
         pass
+
+
+def _is_loopback(addr: str) -> bool:
+    return addr in ("localhost", "::1") or addr.startswith("127.")
+
+
+def job_token() -> bytes:
+    """32 bytes every rank of ONE job derives alike and nobody else on the network can guess
+    without the job's environment: DSPTOOLBOX_AMD_RDZV_TOKEN if the launcher exports one, else
+    a digest of what torch.distributed.run hands to all its workers (run id, master address and
+    port, world size) plus the user id."""
+    explicit = os.environ.get("DSPTOOLBOX_AMD_RDZV_TOKEN")
+    if explicit:
+        seed = "explicit:" + explicit
+    else:
+        seed = "|".join(os.environ.get(k, "") for k in
+                        ("TORCHELASTIC_RUN_ID", "MASTER_ADDR", "MASTER_PORT", "WORLD_SIZE")) + f"|{os.getuid()}"
+    return hashlib.sha256(("dsptoolbox_amd rendezvous:" + seed).encode()).digest()
 
 
 def _send_msg(sock: socket.socket, data: bytes) -> None:
@@ -62,26 +82,47 @@ class TcpExchange(Exchange):
     are sequences of length-prefixed messages; every rank must call them in the same order."""
 
     def __init__(self, rank: int, world: int, addr: str = "127.0.0.1", port: int = 29523,
-                 timeout_s: float = 120.0):
+                 timeout_s: float = 120.0, token: bytes | None = None):
         assert 0 <= rank < world
         self.rank, self.world = rank, world
         self._peers = {}
         self._sock = None
         if world == 1:
             return
+        token = job_token() if token is None else token
         if rank == 0:
+            # Handshake: the server sends a fresh 16-byte challenge, the peer answers with its rank
+            # and HMAC-SHA256(token, challenge || rank).  A connection that fails it, names a rank
+            # outside 1 .. world-1 or one that is already connected is dropped and the wait goes on.
             srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
             srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
-            srv.bind((addr, port))
+            # a single-node job (the launcher's MASTER_ADDR is a loopback name) never listens on
+            # an outside interface
+            srv.bind(("127.0.0.1" if _is_loopback(addr) else addr, port))
             srv.listen(world)
-            srv.settimeout(timeout_s)
+            deadline = time.time() + timeout_s
             try:
                 while len(self._peers) < world - 1:
+                    left = deadline - time.time()
+                    if left <= 0:
+                        raise TimeoutError(f"rendezvous: {world - 1 - len(self._peers)} rank(s) never arrived")
+                    srv.settimeout(left)
                     conn, _ = srv.accept()
-                    conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
-                    conn.settimeout(timeout_s)
-                    (r,) = struct.unpack("<I", _recv_exact(conn, 4))
-                    self._peers[r] = conn
+                    try:
+                        conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                        conn.settimeout(min(10.0, timeout_s))
+                        challenge = os.urandom(16)
+                        conn.sendall(challenge)
+                        raw = _recv_exact(conn, 4 + 32)
+                        (r,) = struct.unpack_from("<I", raw, 0)
+                        want = hmac.new(token, challenge + raw[:4], hashlib.sha256).digest()
+                        if not hmac.compare_digest(want, raw[4:]) or not (0 < r < world) or r in self._peers:
+                            raise ConnectionError("rendezvous: handshake rejected")
+                        conn.sendall(b"\x01")
+                        conn.settimeout(timeout_s)
+                        self._peers[r] = conn
+                    except (OSError, ConnectionError, struct.error):
+                        conn.close()
             finally:
                 srv.close()
         else:
@@ -96,7 +137,11 @@ class TcpExchange(Exchange):
                     time.sleep(0.05)
             s.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
             s.settimeout(timeout_s)
-            s.sendall(struct.pack("<I", rank))
+            challenge = _recv_exact(s, 16)
+            me = struct.pack("<I", rank)
+            s.sendall(me + hmac.new(token, challenge + me, hashlib.sha256).digest())
+            if _recv_exact(s, 1) != b"\x01":
+                raise ConnectionError("rendezvous: rank 0 refused the handshake")
             self._sock = s
 
     # -- collectives -------------------------------------------------------------------

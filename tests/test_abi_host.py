@@ -79,6 +79,34 @@ def test_signal_container_semantics():
     assert s._spectrum_parameters["detrend"] is True and s._spectrogram_parameters["padding"] is True
 
 
+def test_channel_operations_of_the_containers():
+    """MultichannelData (reference classes/_multichannel_data.py:6-118): remove / swap / select / sum on
+    Signal and Spectrum; bad channel arguments are AssertionErrors as in the reference."""
+    rng = np.random.default_rng(5)
+    td = rng.standard_normal((50, 4))
+    s = dsp.Signal(None, td.copy(), 8000)
+    assert len(s) == 50 and s.number_of_channels == 4
+    assert np.array_equal(s.get_channels(2).time_data, td[:, [2]])
+    assert np.array_equal(s.get_channels([3, 0]).time_data, td[:, [3, 0]])
+    assert np.allclose(s.sum_channels().time_data[:, 0], td.sum(axis=1))
+    assert s.swap_channels(np.array([[3, 2, 1, 0]])) is s and np.array_equal(s.time_data, td[:, ::-1])
+    for bad in ([0, 1, 2], [0, 0, 1, 2], [0, 1, 2, 4], [-1, 0, 1, 2], [[0, 1], [2, 3]]):
+        with pytest.raises(AssertionError):
+            s.swap_channels(bad)
+    s.remove_channel()
+    assert np.array_equal(s.time_data, td[:, [3, 2, 1]])
+    s.remove_channel(0)
+    assert np.array_equal(s.time_data, td[:, [2, 1]])
+    with pytest.raises(AssertionError):
+        s.remove_channel(2)
+    s.remove_channel(1)
+    with pytest.raises(AssertionError):
+        s.remove_channel()
+    sp = dsp.Spectrum(np.linspace(0, 100, 9), rng.standard_normal((9, 3)) + 1j)
+    assert sp.number_of_channels == 3 and len(sp) == 9
+    assert sp.get_channels([1]).number_of_channels == 1
+
+
 def test_filter_and_bank_validation():
     f1 = dsp.Filter.fir_filter(20, 1000.0, dsp.FilterPassType.Lowpass, 48000)
     assert f1.is_fir and f1.order == 20 and len(f1) == 21

@@ -159,3 +159,81 @@ def test_sharded_transfer_function_world2(transport):
     assert sorted(r[0] for r in res) == [0, 1]
     assert all(r[1] for r in res), res
     assert {r[0]: r[2] for r in res} == {0: (0, 3), 1: (3, 5)}
+
+
+def test_host_array_wire_format_is_data_only():
+    """the header of a host array is a fixed struct (no eval); malformed headers raise."""
+    import struct
+    from dsptoolbox_amd import distributed as dd
+    rng = np.random.default_rng(0)
+    for a in (rng.standard_normal((3, 0, 2)), rng.standard_normal(7).astype(np.float32),
+              (rng.standard_normal((2, 3)) + 1j).astype(np.complex64), np.arange(6).reshape(2, 3),
+              np.array(3.5), np.zeros((4, 2), dtype=bool)):
+        b = dd._unpack(dd._pack(a))
+        assert b.dtype == a.dtype and b.shape == a.shape and np.array_equal(a, b)
+    good = dd._pack(np.arange(4.0))
+    # the round-2 format (repr of a tuple) and other text is refused, nothing is evaluated
+    evil = b"(__import__('os').system('true'), '<f8')"
+    with pytest.raises(ValueError):
+        dd._unpack(struct.pack("<I", len(evil)) + evil)
+    with pytest.raises(ValueError):
+        dd._unpack(good[:-1])  # payload shorter than the header says
+    with pytest.raises(ValueError):
+        dd._unpack(good[:4] + bytes([200, 1]) + good[6:])  # unknown dtype code
+    with pytest.raises(ValueError):
+        dd._unpack(good[:6] + struct.pack("<q", -4) + good[14:])
+    with pytest.raises(TypeError):
+        dd._pack(np.array([object()]))
+
+
+def _handshake_server(port, q):
+    sys.path.insert(0, ROOT)
+    from dsptoolbox_amd.rendezvous import TcpExchange
+    ex = TcpExchange(0, 2, "127.0.0.1", port, timeout_s=30.0, token=b"k" * 32)
+    q.put(ex.allgather_bytes(b"zero"))
+    ex.close()
+
+
+@pytest.mark.timeout(90)
+def test_tcp_rendezvous_rejects_strangers():
+    """a connection without the job's token, with a rank out of range or with rank 0 is
+    dropped; the real rank is still admitted afterwards."""
+    import hashlib
+    import hmac
+    import multiprocessing as mp
+    import struct
+    import time
+    from dsptoolbox_amd.rendezvous import TcpExchange
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    srv = ctx.Process(target=_handshake_server, args=(port, q))
+    srv.start()
+
+    def knock(rank, token):
+        for _ in range(200):
+            try:
+                s = socket.create_connection(("127.0.0.1", port), timeout=5.0)
+                break
+            except OSError:
+                time.sleep(0.05)
+        s.settimeout(10.0)
+        ch = s.recv(16)
+        me = struct.pack("<I", rank)
+        s.sendall(me + hmac.new(token, ch + me, hashlib.sha256).digest())
+        try:
+            ans = s.recv(1)
+        except OSError:
+            ans = b""
+        s.close()
+        return ans
+
+    assert knock(1, b"wrong" * 8) == b""      # no token
+    assert knock(0, b"k" * 32) == b""         # rank 0 is the server itself
+    assert knock(7, b"k" * 32) == b""         # outside the world
+    ex = TcpExchange(1, 2, "127.0.0.1", port, timeout_s=30.0, token=b"k" * 32)
+    assert ex.allgather_bytes(b"one") == [b"zero", b"one"]
+    ex.close()
+    assert q.get(timeout=30) == [b"zero", b"one"]
+    srv.join(timeout=30)
+    assert srv.exitcode == 0

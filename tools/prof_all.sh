@@ -15,6 +15,10 @@ for W in $WORKLOADS; do
   rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc2 -- $CMD > $OUT/pmc2.log 2>&1
   rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc3 -- $CMD > $OUT/pmc3.log 2>&1
   rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d $OUT/pmc4 -- $CMD > $OUT/pmc4.log 2>&1
+  # issue-side evidence: cycles the vector / LDS / memory instructions hold a wave's issue,
+  # instructions in flight at the LDS, scalar instruction count
+  rocprofv3 --pmc SQ_INST_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INST_LEVEL_LDS SQ_INSTS_SALU SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_WAIT_INST_LDS --output-format csv -d $OUT/pmc5 -- $CMD > $OUT/pmc5.log 2>&1
+  rocprofv3 --pmc SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INST_LEVEL_VMEM SQ_LDS_CMD_FIFO_FULL SQ_LDS_DATA_FIFO_FULL SQ_WAVES SQ_IFETCH SQ_INSTS_SMEM --output-format csv -d $OUT/pmc6 -- $CMD > $OUT/pmc6.log 2>&1
   python3 tools/prof_summary.py $OUT > $OUT/summary.txt 2>&1
   grep "^{\"metric" $OUT/trace.log > $OUT/bench_line.txt
 done
