@@ -488,8 +488,8 @@ EVENT_STRIDE = 4  # the dominant kernel is bracketed at every 4th launch of the 
 def timed_steps(ctx, dist, step, steps: int, events: bool, dominant):
     """W. warm-up done by the caller.  Times exactly `steps` steps between two
     barrier + synchronize brackets; only the dominant kernel is event-bracketed inside, at every
-    EVENT_STRIDE-th launch (an event pair costs ~3 us of stream time and sits on the step's
-    dependency chain: bracketing every launch adds ~4 % to the step it measures)."""
+    EVENT_STRIDE-th launch (timestamped dispatches cost stream time: stamping every launch adds a few % to
+    the step it measures)."""
     dist.barrier_sync(ctx)
     ctx.profile_only(dominant)  # None (no instrumented warm-up step): every kernel
     ctx.profile_stride(EVENT_STRIDE if dominant else 1)
@@ -597,13 +597,10 @@ def main():
         return
     if dom is None or dom not in prof:
         dom = next((k for k in dominant if k in prof), max(prof, key=lambda k: prof[k][0]))
-    # roofline.frac / achieved / kernel_avg_ms are the RAW HIP-event brackets of the dominant kernel,
-    # averaged over the bracketed launches.  An event pair brackets a little more than the kernel (the
-    # dispatch latency behind the start event, the completion signal in front of the stop event); an
-    # estimate of that fixed cost from brackets of empty kernels (2 b1 - b2) is reported beside it as
-    # `frac_net_of_bracket`, never as the headline, and capped at what rocprofv3 has shown (5 us).
+    # roofline.frac / achieved / kernel_avg_ms: the dominant kernel's own begin / end timestamps (the two
+    # events ride on its dispatch packet, hipExtLaunchKernel -- what rocprofv3's kernel trace reports),
+    # averaged over the sampled launches of the timed region.  Nothing is subtracted.
     dom_ms = prof[dom][0] / prof[dom][1]
-    ev_over_ms = min(ctx.profile_overhead(200), 0.005, 0.1 * dom_ms)
     launches_per_step = max(1, round(prof[dom][1] * EVENT_STRIDE / args.steps))
     # algorithmic work of ONE launch on THIS rank (strong scaling: its share of the job)
     alg_parts = alg if isinstance(alg, dict) else None  # per kernel (csm: two streaming kernels)
@@ -668,11 +665,8 @@ def main():
     roof["kernel"] = dom
     roof["kernel_event_sampling"] = f"every {EVENT_STRIDE}th launch of the timed region ({prof[dom][1]} brackets)"
     roof["kernel_avg_ms"] = dom_ms
-    roof["event_bracket_overhead_ms"] = ev_over_ms
-    roof["frac_net_of_bracket"] = roof["frac"] * dom_ms / (dom_ms - ev_over_ms)
-    roof["kernel_time_note"] = ("frac / achieved / kernel_avg_ms: raw HIP-event brackets on the library's stream; "
-                                "frac_net_of_bracket takes the bracket's own fixed cost (empty-kernel estimate) off; "
-                                "the rocprofv3 kernel-trace average of the same command is in profiles/")
+    roof["kernel_time_source"] = ("begin / end timestamps of the kernel's own dispatch (HIP events passed to hipExtLaunchKernel on the "
+                                  "library's stream); the rocprofv3 kernel-trace average of the same command is in profiles/")
     roof["algorithmic_per_launch"] = alg_launch
     out = {
         "metric": "Msamples/s + GB/s vs HBM roofline, 64ch Welch H1 nfft=4096 @1/2/4/8 GPU"

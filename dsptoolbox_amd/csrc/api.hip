@@ -1,6 +1,7 @@
 // C-ABI of dsptoolbox_amd (see include/dsptoolbox_amd.h): context, memory,
 // plan (twiddle) cache, launch logic.  gfx950 only.
 #include <dlfcn.h>
+#include <hip/hip_ext.h>
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -21,6 +22,7 @@
 #include "kernels_welch4096w.hpp"
 #include "kernels_welch4096f.hpp"
 #include "kernels_fir16k.hpp"
+#include "kernels_fir4k.hpp"
 #include "kernels_deconv8k.hpp"
 #include "kernels_stft1024.hpp"
 #include "kernels_welch1024.hpp"
@@ -425,16 +427,18 @@ static int launch(ds_ctx* c, const char* name, K kernel, dim3 grid, int threads,
     bool prof = c->prof && (c->prof_only.empty() || c->prof_only == name);
     if (prof && c->prof_stride > 1 && (c->prof_seen++ % c->prof_stride) != 0) prof = false;
     if (prof) {
+        // The two events ride on the dispatch itself (hipExtLaunchKernel): they carry the kernel's own
+        // begin / end timestamps -- what rocprofv3's kernel trace reports -- not the times of two marker
+        // packets around it (hipEventRecord brackets held 4-6 us of dispatch and completion latency on top).
         CHK(prof_event(c, &rec.a));
         CHK(prof_event(c, &rec.b));
-        HIPCHK(c, hipEventRecord(rec.a, c->stream));
+        hipExtLaunchKernelGGL(kernel, grid, dim3(threads), (std::uint32_t)lds, c->stream, rec.a, rec.b, 0u, args);
+        HIPCHK(c, hipGetLastError());
+        c->prof_recs.push_back(rec);
+        return DS_OK;
     }
     hipLaunchKernelGGL(kernel, grid, dim3(threads), lds, c->stream, args);
     HIPCHK(c, hipGetLastError());
-    if (prof) {
-        HIPCHK(c, hipEventRecord(rec.b, c->stream));
-        c->prof_recs.push_back(rec);
-    }
     return DS_OK;
 }
 
@@ -1979,8 +1983,49 @@ static int fir_long(ds_ctx* c, const float* x, int n_ch, int64_t ldx, int64_t n_
     return DS_OK;
 }
 
+// Up to 4097 taps: uniformly partitioned overlap-save on the 4096-point register transform, three (one
+// partition) or two (two partitions) independent workgroups per CU (kernels_fir4k.hpp).
+// DSPTOOLBOX_AMD_FIR_4K=0 keeps the block kernels below (A/B); =1 also sends the short filters here.
+static int fir4k_min_taps() {
+    if (const char* e = getenv("DSPTOOLBOX_AMD_FIR_4K")) {
+        if (e[0] == '0') return 1 << 30;
+        if (e[0] == '1') return 1;
+        if (atoi(e) > 1) return atoi(e);
+    }
+    return 1025;  // below: the generic kernels with 1024 ... 4096-point blocks (see DESIGN, tap-count sweep)
+}
+static int fir4k_run(ds_ctx* c, const float* x, int n_ch, int64_t ldx, int64_t n_samples, const float* taps,
+                     int n_filt, int n_taps, float* y, int64_t ld_y) {
+    namespace f4 = fir4k;
+    if (!c->w4_tables) {
+        std::vector<float2> h;
+        welch4096::host_tables(h);
+        HIPCHK(c, hipMalloc((void**)&c->w4_tables, sizeof(float2) * h.size()));
+        HIPCHK(c, hipMemcpyAsync(c->w4_tables, h.data(), sizeof(float2) * h.size(), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    const int P = f4::partitions(n_taps);
+    CHK(reserve(c, &c->ws, &c->ws_bytes, Carver::pad(sizeof(float4) * (size_t)n_filt * P * 8 * 256)));
+    Carver cv(c->ws);
+    float4* hp = cv.take<float4>((size_t)n_filt * P * 8 * 256);
+    f4::TapArgs ta{taps, n_filt, n_taps, P, c->w4_tables, hp};
+    CHK(launch(c, "fir_taps", f4::k_taps, dim3((unsigned)(n_filt * P)), f4::NT, f4::LDS_BYTES, ta));
+    const int pairs = (n_ch + 1) / 2;
+    const int n_blocks = (int)((n_samples + f4::HOP - 1) / f4::HOP);
+    // every workgroup resident at once (3 or 2 per CU): a run of blocks each, one extra forward
+    // transform per run with two partitions
+    int chunks = std::max(1, (P == 1 ? 768 : 512) / pairs);
+    if (const char* e = getenv("DSPTOOLBOX_AMD_FIR_CHUNKS")) chunks = std::max(1, atoi(e));
+    chunks = std::min(chunks, n_blocks);
+    f4::Args a{x, n_samples, ldx, ld_y, n_ch, n_filt, n_blocks, chunks, c->w4_tables, hp, y};
+    if (P == 1) return launch(c, "fir", f4::k_fir<1>, dim3((unsigned)(pairs * chunks)), f4::NT, f4::LDS_BYTES, a);
+    return launch(c, "fir", f4::k_fir<2>, dim3((unsigned)(pairs * chunks)), f4::NT, f4::LDS_BYTES, a);
+}
+
 static int fir_once(ds_ctx* c, const float* x, int n_ch, int64_t ldx, int64_t n_samples,
                     const float* taps, int n_filt, int n_taps, float* y, int64_t ld_y) {
+    if (n_taps >= fir4k_min_taps() && fir4k::partitions(n_taps) <= 2 && fir4k::fits(n_samples) && n_filt <= 16384)
+        return fir4k_run(c, x, n_ch, ldx, n_samples, taps, n_filt, n_taps, y, ld_y);
     const int N = fir_block_len(n_taps);
     if (n_taps - 1 > N / 2) return fir_long(c, x, n_ch, ldx, n_samples, taps, n_filt, n_taps, y, ld_y);
     const float2* tw;

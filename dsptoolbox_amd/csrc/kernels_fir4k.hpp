@@ -1,0 +1,232 @@
+// FIR filter bank, up to 4097 taps: uniformly partitioned overlap-save on the headline kernel's
+// 4096-point register transform (three independent 256-thread workgroups per CU).  gfx950.
+// (Filter.filter_signal / FilterBank.filter_signal: _lfilter_fir, classes/filter_helpers.py:454-503,
+// y = oaconvolve(x, b)[:N]; _filterbank_on_signal :385-451.)
+//
+//   hop B = 2048 new samples per block, transform length 4096, partitions of 2049 taps:
+//       h_0[j] = h[j]            j = 0 .. 2048
+//       h_p[j] = h[2048 p + j]   j = 1 .. 2048 ,  h_p[0] = 0        (p >= 1)
+//   so that partition p meets the input delayed by exactly p blocks.  With
+//       X_b = FFT4096( x[(b-1) B .. (b+1) B) )        (two channels ride one transform: xa + i xb)
+//       H_p = FFT4096( h_p, zero-padded ) / 4096
+//   the block's output is the second half of IFFT4096( X_b H_0 + X_{b-1} H_1 + ... ): the circular
+//   convolution of a 4096-sample segment with 2049 taps is exact from sample 2048 on.
+//
+//   A workgroup owns a run of blocks of one channel pair.  Per block: ONE forward transform, its
+//   spectrum stays in registers (X_b, and X_{b-1} handed down from the previous block) while ALL
+//   filters are applied: 16-byte loads of the tap spectra (stored in the transform's own register
+//   layout by k_taps, 2 MB for 32 x 2 partitions: L2 resident), multiply-add, inverse transform
+//   (the mirror image of welch4096::fft4096_w: one LDS image, the 16 x 16 transpose wave-local in the
+//   row, two workgroup barriers), 2 x 8 coalesced 4-byte stores per thread.  Every output sample is
+//   produced and stored once; signal edges are the buffer range check (loads return 0 before the
+//   first and past the last sample, stores past the end are dropped): no edge code path.
+//
+//   Against kernels_fir16k.hpp (16384-point blocks, one 1024-thread workgroup per CU): 24 instead of
+//   18.7 transform points per output sample, but the 4096-point transform runs at 2.4 x the rate in
+//   three independent workgroups per CU (226 against 94 transforms per microsecond, measured on the
+//   Welch / FIR benchmarks of round 2).
+#pragma once
+#include "kernels_fir16k.hpp"
+#include "kernels_welch4096w.hpp"
+
+namespace fir4k {
+
+namespace w4 = welch4096;
+using fir16k::cmulc;
+using fir16k::idft16;
+using w4::cmul;
+constexpr int N = 4096, NT = 256, HOP = 2048, PART = 2049;
+constexpr int LDS_BYTES = (16 * w4::L1S + 256) * 8;  // exchange image + W256 table: 36 864 B
+// Two partitions: X_b, X_{b-1}, the working set and two tap spectra in flight are 192 registers; the 168
+// of three workgroups per CU were tried (half of X_{b-1} parked in LDS, staged tap loads: hipcc kept
+// 10-46 spilled values inside the filter loop) -- that kernel is built for TWO workgroups per CU.
+
+inline int partitions(int n_taps) { return n_taps <= 1 ? 1 : (n_taps - 2) / HOP + 1; }  // ceil((T - 1) / 2048)
+
+__device__ __forceinline__ void apply_tw6_conj(float2 (&v)[16], const w4::Tw6& tw) {
+#pragma unroll
+    for (int k1 = 1; k1 < 16; ++k1) {
+        const int lo = k1 & 3, hi = k1 >> 2;
+        float2 z = v[w4::pos16(k1)];
+        if (lo) z = cmulc(z, tw.a[lo - 1]);
+        if (hi) z = cmulc(z, tw.b[hi - 1]);
+        v[w4::pos16(k1)] = z;
+    }
+}
+
+// Mirror image of welch4096::fft4096_w: v[pos16(k3)] = Y[bt + 256 k3] (bt = bin_thread(tid)) on entry,
+// v[n1] = sum_k Y[k] W4096^(-k (tid + 256 n1)) on return (unscaled).  `buf`: the workgroup's one
+// exchange image.  Two workgroup barriers: in front of the first write of the image (the column reads
+// of the previous transform) and behind the last.
+//   after_t():  called behind the wave-local transpose (the caller's loads go there)
+template <typename HT = w4::NoHook, typename HB = w4::NoHook>
+__device__ __forceinline__ void ifft4096_w(float2 (&v)[16], const w4::Tw6& tw, float2* __restrict__ buf,
+                                           const float2* __restrict__ tw2, int tid, HT after_t = HT(), HB after_b = HB()) {
+    const int k1u = tid >> 4, n3 = tid & 15;
+    idft16(v);  // over k3: v[j], the lane plays k2 = n3
+    float2* __restrict__ row = buf + k1u * w4::L1S;
+    __syncthreads();  // every wave has read its columns (last pass of the previous transform)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) row[j * w4::L3S + n3] = v[j];
+    w4::wave_sync();
+#pragma unroll
+    for (int k2 = 0; k2 < 16; ++k2) v[w4::pos16(k2)] = row[n3 * w4::L3S + k2];  // lane now plays n3
+    after_t();
+#pragma unroll
+    for (int k2 = 1; k2 < 16; ++k2) v[w4::pos16(k2)] = cmulc(v[w4::pos16(k2)], tw2[k2 * 16 + n3]);
+    idft16(v);  // over k2: v[n2]
+    w4::wave_sync();  // the transpose reads of this row (the same 16 lanes) are done
+#pragma unroll
+    for (int n2 = 0; n2 < 16; ++n2) row[16 * n2 + n3] = v[n2];
+    after_b();
+    __syncthreads();
+#pragma unroll
+    for (int k1 = 0; k1 < 16; ++k1) v[w4::pos16(k1)] = buf[k1 * w4::L1S + tid];
+    apply_tw6_conj(v, tw);
+    idft16(v);  // over k1: v[n1]
+}
+
+// ---- tap spectra in register layout ---------------------------------------------------------------
+// hp[((f P + p) 8 + g) 256 + tid] = (H_p[slot 2g], H_p[slot 2g + 1]) of thread tid, slot s = pos16(k3)
+// <-> bin bin_thread(tid) + 256 k3;  1 / 4096 folded in.  grid = n_filt * P.
+struct TapArgs {
+    const float* taps;  // [n_filt][n_taps]
+    int n_filt, n_taps, n_part;
+    const float2* twt;  // welch4096::host_tables()
+    float4* hp;
+};
+__global__ __launch_bounds__(NT) void k_taps(TapArgs p) {
+    extern __shared__ __align__(16) float2 lds[];
+    float2* buf = lds;
+    float2* tw2 = lds + 16 * w4::L1S;
+    const int tid = threadIdx.x;
+    const int f = (int)blockIdx.x / p.n_part, part = (int)blockIdx.x - f * p.n_part;
+    w4::Tw6 tw;
+    w4::load_tw6(tw, p.twt, tid);
+    tw2[tid] = p.twt[15 * 256 + tid];
+    const float* h = p.taps + (int64_t)f * p.n_taps;
+    float2 v[16];
+#pragma unroll
+    for (int n1 = 0; n1 < 16; ++n1) {
+        const int j = tid + 256 * n1, src = HOP * part + j;
+        const bool in = j <= HOP && (part == 0 || j >= 1) && src < p.n_taps;
+        v[n1] = make_float2(in ? h[src] : 0.f, 0.f);
+    }
+    w4::fft4096_w(v, tw, buf, tw2, tid);
+    const float s = 1.0f / (float)N;
+    float4* o = p.hp + (int64_t)blockIdx.x * (8 * 256) + tid;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) o[256 * g] = make_float4(v[2 * g].x * s, v[2 * g].y * s, v[2 * g + 1].x * s, v[2 * g + 1].y * s);
+}
+
+struct Args {
+    const float* x;
+    int64_t n_samples, ldx, ld_y;
+    int n_ch, n_filt;
+    int n_blocks;  // ceil(n_samples / 2048) per channel
+    int n_chunks;  // workgroups per channel pair
+    const float2* twt;
+    const float4* hp;  // [n_filt][P][8][256]
+    float* y;          // [(f n_ch + c) ld_y + n]
+};
+
+// grid = ceil(n_ch / 2) * n_chunks
+template <int P>
+__global__ __launch_bounds__(NT, P == 1 ? 3 : 2) void k_fir(Args p) {
+    static_assert(P == 1 || P == 2, "one or two partitions of 2049 taps");
+    extern __shared__ __align__(16) float2 lds[];
+    float2* buf = lds;
+    float2* tw2 = lds + 16 * w4::L1S;
+    const int tid = threadIdx.x;
+    const int cp = (int)blockIdx.x / p.n_chunks, q = (int)blockIdx.x - cp * p.n_chunks;
+    const int b0 = (int)((int64_t)q * p.n_blocks / p.n_chunks), b1 = (int)((int64_t)(q + 1) * p.n_blocks / p.n_chunks);
+    const int ca = 2 * cp, cb = ca + 1;
+    const bool vb = cb < p.n_ch;
+    const uint32_t sig_bytes = (uint32_t)(p.n_samples * 4);
+    // a missing second channel is a buffer of no records: loads give 0, stores are dropped
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x + (int64_t)ca * p.ldx), 0, (int)sig_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x + (int64_t)(vb ? cb : ca) * p.ldx), 0, vb ? (int)sig_bytes : 0, 0x00020000);
+    w4::Tw6 tw;
+    w4::load_tw6(tw, p.twt, tid);
+    tw2[tid] = p.twt[15 * 256 + tid];
+
+    // spectrum of the segment that ends with block b (samples [(b - 1) 2048, (b + 1) 2048)); a negative
+    // byte offset wraps to a huge unsigned one: out of range, 0 -- the zeros in front of the signal
+    auto forward = [&](float2 (&v)[16], int b) {
+        const int off0 = 4 * ((b - 1) * HOP + tid);
+#pragma unroll
+        for (int n1 = 0; n1 < 16; ++n1)
+            v[n1] = make_float2(w4::ld_sample(ra, off0 + 1024 * n1), w4::ld_sample(rb, off0 + 1024 * n1));
+        w4::fft4096_w(v, tw, buf, tw2, tid);
+    };
+    float2 xp[16];
+    if (P == 2) forward(xp, b0 - 1);
+    // the tap spectra through ONE raw-buffer descriptor with 32-bit byte offsets (64-bit addresses per
+    // load are what hipcc spills first in these kernels)
+    const __amdgpu_buffer_rsrc_t hrs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float4*>(p.hp), 0, (int)((uint32_t)p.n_filt * P * (8 * 256 * 16)), 0x00020000);
+    auto ld_h = [&](int byte_off) {
+        return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(hrs, byte_off, 0, 0));
+    };
+    const int hq = 16 * tid;
+    for (int b = b0; b < b1; ++b) {
+        float2 xc[16];
+        forward(xc, b);
+        const int out_off = 4 * (b * HOP + tid);
+        float4 h0[8], h1[8];
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            h0[g] = ld_h(hq + 4096 * g);
+            if (P == 2) h1[g] = ld_h(hq + 4096 * (8 + g));
+        }
+        for (int f = 0; f < p.n_filt; ++f) {
+            float2 v[16];
+#pragma unroll
+            for (int g = 0; g < 8; ++g) {
+                v[2 * g] = cmul(xc[2 * g], make_float2(h0[g].x, h0[g].y));
+                v[2 * g + 1] = cmul(xc[2 * g + 1], make_float2(h0[g].z, h0[g].w));
+                if (P == 2) {
+                    const float2 a = xp[2 * g], c = xp[2 * g + 1];
+                    v[2 * g].x = fmaf(a.x, h1[g].x, fmaf(-a.y, h1[g].y, v[2 * g].x));
+                    v[2 * g].y = fmaf(a.x, h1[g].y, fmaf(a.y, h1[g].x, v[2 * g].y));
+                    v[2 * g + 1].x = fmaf(c.x, h1[g].z, fmaf(-c.y, h1[g].w, v[2 * g + 1].x));
+                    v[2 * g + 1].y = fmaf(c.x, h1[g].w, fmaf(c.y, h1[g].z, v[2 * g + 1].y));
+                }
+            }
+            // the next filter's tap spectra are requested behind the second exchange of this inverse transform
+            // (not behind the last filter: the spectra would stay live across the next block's forward
+            // transform, which has no registers for them)
+            const int hn = hq + (f + 1) * (P * 8 * 4096);
+            const bool more = f + 1 < p.n_filt;
+            // (both behind the SECOND exchange: in front of it the W256 twiddles of the middle pass are
+            // live and the two spectra would not fit beside them)
+            ifft4096_w(v, tw, buf, tw2, tid, w4::NoHook(), [&]() {
+                if (more) {
+#pragma unroll
+                    for (int g = 0; g < 8; ++g) {
+                        h0[g] = ld_h(hn + 4096 * g);
+                        if (P == 2) h1[g] = ld_h(hn + 4096 * (8 + g));
+                    }
+                }
+            });
+            float* __restrict__ ya = p.y + ((int64_t)f * p.n_ch + ca) * p.ld_y;
+            const __amdgpu_buffer_rsrc_t oa = __builtin_amdgcn_make_buffer_rsrc(ya, 0, (int)sig_bytes, 0x00020000);
+            const __amdgpu_buffer_rsrc_t ob = __builtin_amdgcn_make_buffer_rsrc(ya + p.ld_y, 0, vb ? (int)sig_bytes : 0, 0x00020000);
+#pragma unroll
+            for (int m = 0; m < 8; ++m) {
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[8 + m].x), oa, out_off + 1024 * m, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[8 + m].y), ob, out_off + 1024 * m, 0, 0);
+            }
+        }
+        if (P == 2) {
+#pragma unroll
+            for (int s = 0; s < 16; ++s) xp[s] = xc[s];
+        }
+    }
+}
+
+// 32-bit byte offsets, OOB stores dropped by the range check
+inline bool fits(int64_t n_samples) { return n_samples > 0 && n_samples < ((int64_t)1 << 30) - 8192; }
+
+}  // namespace fir4k

@@ -18,12 +18,14 @@
 //               same time and had one transform to do) are normally done.
 //   3. PARTIALS every workgroup sums its slice of the chunk's px rows (fp64) -> psx[q], folds its
 //               T / P accumulators -> pxy / pyy[q][c]; all write-through; drain, barrier, one lane
-//               adds 1 to psxdone and draws a ticket from done[c].
-//   4. FINISH   the workgroup that draws the last ticket of channel c (its n_chunks partials are
-//               published) waits for psxdone == grid (the input auto spectrum needs every slice),
-//               acquires, sums the chunks in fp64 and writes H and the coherence of channel c
-//               (dsk::tf_from_sums, the finish kernel's own code).  The last finisher of all
-//               resets the counters for the next launch.
+//               adds 1 to `published`.
+//   4. FINISH   every workgroup waits for published == grid (one lane polls; the input auto spectrum
+//               of a bin is the work of another channel's workgroups, so the wait is grid-wide),
+//               acquires, and finishes slice q of channel c's bins: chunk sums in fp64, then H and the
+//               coherence (dsk::tf_from_sums, the finish kernel's own code) -- all 768 workgroups
+//               share the finish, one round of loads each.  (A first version let the last arriver of
+//               a channel finish it alone: 46 us of dependent slab reads in one workgroup.)  The last
+//               workgroup through resets the counters for the next launch.
 //
 // Inter-workgroup visibility follows cdna_hip_programming.md Guideline 16: payload stored
 // write-through (sc1) and drained by EVERY storing wave before the workgroup's barrier, one
@@ -42,8 +44,20 @@
 namespace welch4096 {
 
 constexpr int F_MAX_UNITS = 768;                     // chunks <= 768, channels <= 768
-constexpr int F_SYNC_WORDS = 16 + 2 * F_MAX_UNITS;   // [0] timeout code, [1] psxdone, [2] alldone, [16 + q] xready, [16 + 768 + c] done
+constexpr int F_SYNC_WORDS = 16 + F_MAX_UNITS;       // [0] timeout code, [1] published, [2] through, [16 + q] xready
 constexpr unsigned long long F_SPIN_TICKS = 30000000ull;  // 0.3 s of the 100 MHz s_memrealtime clock
+
+#ifndef W4F_STAMPS
+#define W4F_STAMPS 0  // dev only: per-workgroup s_memrealtime stamps -> FusedArgs::stamps[block][8]
+#endif
+#if W4F_STAMPS
+#define W4F_STAMP(i)                                                                                   \
+    do {                                                                                               \
+        if (threadIdx.x == 0) fa.stamps[(size_t)blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memrealtime(); \
+    } while (0)
+#else
+#define W4F_STAMP(i)
+#endif
 
 struct FusedArgs {
     Args a;
@@ -52,6 +66,9 @@ struct FusedArgs {
     dsk::FinishPar fin;
     float2* tf;      // [NB][n_ch]
     float* coh;      // [NB][n_ch]
+#if W4F_STAMPS
+    unsigned long long* stamps;
+#endif
 };
 
 __device__ __forceinline__ unsigned ld_agent(const unsigned* w) {
@@ -59,13 +76,25 @@ __device__ __forceinline__ unsigned ld_agent(const unsigned* w) {
 }
 __device__ __forceinline__ void drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
-// one lane: wait until *w >= target (counters only grow inside a launch); false on a timeout
+// one lane: wait until *w >= target (counters only grow inside a launch); false on a timeout.
+// Hundreds of workgroups poll the same few words: the pause between two polls grows with the
+// distance to the target (a first version polled every 0.1 us from 500-768 lanes at once and the
+// memory channel of those words backed up -- the producers it was waiting for took 20-30 us
+// instead of 6, and the last workgroups of the launch slowed down by as much).
 __device__ __forceinline__ bool spin_until(const unsigned* w, unsigned target, unsigned* err, unsigned code) {
-    if (ld_agent(w) >= target) return true;
+    unsigned seen = ld_agent(w);
+    if (seen >= target) return true;
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
     for (;;) {
-        __builtin_amdgcn_s_sleep(4);
-        if (ld_agent(w) >= target) return true;
+        const unsigned left = target - seen;
+        if (left > 16)
+            __builtin_amdgcn_s_sleep(48);  // ~1.5 us
+        else if (left > 2)
+            __builtin_amdgcn_s_sleep(16);  // ~0.5 us
+        else
+            __builtin_amdgcn_s_sleep(6);
+        seen = ld_agent(w);
+        if (seen >= target) return true;
         if (__builtin_amdgcn_s_memrealtime() - t0 > F_SPIN_TICKS) {
             __hip_atomic_store(err, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             return false;
@@ -106,6 +135,10 @@ __global__ __launch_bounds__(NT, 3) void k_h1f(FusedArgs fa) {
         q = u / p.n_ch;
         c = u - q * p.n_ch;
     }
+    W4F_STAMP(0);
+    // the pair loop runs at priority 3 ... 0 as a chunk gets done; the input-spectrum transforms in
+    // front of it must not start below their neighbours' loops (at priority 0 they took 20-30 us)
+    __builtin_amdgcn_s_setprio(3);
     Tw6 tw;
     load_tw6(tw, p.twt, tid);
     tw2[tid] = p.twt[15 * 256 + tid];
@@ -137,7 +170,9 @@ __global__ __launch_bounds__(NT, 3) void k_h1f(FusedArgs fa) {
                 }
                 if (needs_drop(p, pr)) drop_second(v);
             }
+            W4F_STAMP(8);
             fft4096_w(v, tw, buf, tw2, tid);
+            W4F_STAMP(9);
             if (p.detrend && tid == 0) v[pos16(0)] = make_float2(0.f, 0.f);
             const __amdgpu_buffer_rsrc_t xo = rsrc_of(p.xs + (int64_t)pr * N, N * 8);
 #pragma unroll
@@ -159,13 +194,16 @@ __global__ __launch_bounds__(NT, 3) void k_h1f(FusedArgs fa) {
                 st_wt_b32(0.5f * (pw[fold_pos(k)] + pw[fold_pos((N - k) & (N - 1))]), po, 4 * k);
         }
         if (made) {  // (workgroup-uniform)
+            W4F_STAMP(10);
             drain_stores();
             __syncthreads();
+            W4F_STAMP(11);
             if (tid == 0)
                 __hip_atomic_fetch_add(&sy[16 + q], (unsigned)made, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
 
+    W4F_STAMP(1);
     // ---- 2. MAIN: the pair loop of k_y3 -----------------------------------------------------------
     float2 T[16];
     float P[16];
@@ -224,12 +262,14 @@ __global__ __launch_bounds__(NT, 3) void k_h1f(FusedArgs fa) {
             [&]() {
                 // the chunk's input spectra: polled once, in front of their first use
                 if (pr == p0) {
+                    W4F_STAMP(2);
                     if (tid == 0) {
                         spin_until(&sy[16 + q], (unsigned)(p1 - p0), &sy[0], 1u);
                         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     }
                     __syncthreads();
+                    W4F_STAMP(3);
                 }
             });
 #pragma unroll
@@ -245,6 +285,7 @@ __global__ __launch_bounds__(NT, 3) void k_h1f(FusedArgs fa) {
         for (int n1 = 0; n1 < 16; ++n1) winr[n1] = winl[tid + 256 * n1];
         __builtin_amdgcn_sched_barrier(0);
     }
+    W4F_STAMP(4);
     __builtin_amdgcn_s_setprio(3);  // what follows is the tail of the launch
     return tail(fa, lds, T, P, q, c, p0, p1, bpc,
                 (wave_s << 6) | (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)));
@@ -304,52 +345,91 @@ __device__ __forceinline__ void tail(const FusedArgs& fa, float2* lds, float2 (&
     }
     drain_stores();
     __syncthreads();
-    unsigned* const flag = reinterpret_cast<unsigned*>(lds);  // (the fold image is dead behind the barrier)
+    W4F_STAMP(5);
+    // ---- 4. FINISH: slice q of channel c's bins, once every workgroup of the grid has published -------
+    // (the input auto spectrum of a bin comes from the workgroups of ANOTHER channel index, so the
+    // wait is for the whole grid: one counter; nobody can end before the slowest workgroup anyway, and
+    // behind the wait all 768 workgroups share the finish -- one round of loads each)
+    const unsigned grid = (unsigned)(p.n_chunks * p.n_ch);
     if (tid == 0) {
         __hip_atomic_fetch_add(&sy[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        flag[0] = __hip_atomic_fetch_add(&sy[16 + F_MAX_UNITS + c], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    __syncthreads();
-    if (flag[0] != (unsigned)(p.n_chunks - 1)) return;  // (workgroup-uniform)
-
-    // ---- 4. FINISH channel c: every chunk of it is published -----------------------------------
-    if (tid == 0) {
-        spin_until(&sy[1], (unsigned)(p.n_chunks * p.n_ch), &sy[0], 2u);
+        spin_until(&sy[1], grid, &sy[0], 2u);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __syncthreads();
+    W4F_STAMP(6);
     {
+        const int bps = (NB + p.n_chunks - 1) / p.n_chunks;       // bins per slice
+        const int k0 = q * bps, k1 = min(k0 + bps, NB);
+        int lw = 0;                                                 // 2^lw bins side by side, 256 >> lw chunk groups
+        while ((1 << lw) < bps && lw < 8) ++lw;
+        const int width = 1 << lw, groups = NT >> lw;
+        const int kl = tid & (width - 1), g = tid >> lw;
         const int64_t sq = (int64_t)p.n_ch * NB;
         const float2* __restrict__ pxy = p.pxy + (int64_t)c * NB;
         const float* __restrict__ pyy = p.pyy + (int64_t)c * NB;
-        for (int k = tid; k < NB; k += NT) {
-            double sxx = 0.0, syy = 0.0;
-            dsk::cd sxy{0.0, 0.0};
-            for (int qq = 0; qq < p.n_chunks; ++qq) {
-                const float2 t = pxy[qq * sq + k];
-                sxy.x += (double)t.x;
-                sxy.y += (double)t.y;
-                syy += (double)pyy[qq * sq + k];
-                sxx += (double)p.psx[(int64_t)qq * NB + k];
+        const float* __restrict__ psx = p.psx;
+        double* red = reinterpret_cast<double*>(lds);  // [4][256]
+        for (int kb = k0; kb < k1; kb += width) {
+            const int k = kb + kl;
+            const bool live = k < k1;
+            double sxx = 0.0, syy = 0.0, sxr = 0.0, sxi = 0.0;
+            if (live) {
+                // up to 16 chunks (48 loads) in flight per thread: one round trip for the usual grids
+                for (int base = g; base < p.n_chunks; base += 16 * groups) {
+                    float2 t[16];
+                    float yy[16], xx[16];
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) {
+                        const int qq = min(base + j * groups, p.n_chunks - 1);
+                        t[j] = pxy[qq * sq + k];
+                        yy[j] = pyy[qq * sq + k];
+                        xx[j] = psx[(int64_t)qq * NB + k];
+                    }
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) {
+                        if (base + j * groups < p.n_chunks) {
+                            sxr += (double)t[j].x;
+                            sxi += (double)t[j].y;
+                            syy += (double)yy[j];
+                            sxx += (double)xx[j];
+                        }
+                    }
+                }
             }
-            sxy.y += 0.0;  // a sum of -0 partials becomes +0 like the reference's mean
-            dsk::tf_from_sums(sxx, sxy, syy, k, fa.mode, fa.fin, fa.tf[(int64_t)k * p.n_ch + c],
-                              fa.coh[(int64_t)k * p.n_ch + c]);
+            if (groups > 1) {
+                red[tid] = sxx;
+                red[256 + tid] = sxr;
+                red[512 + tid] = sxi;
+                red[768 + tid] = syy;
+                __syncthreads();
+                if (g == 0) {
+                    for (int j = 1; j < groups; ++j) {
+                        sxx += red[j * width + kl];
+                        sxr += red[256 + j * width + kl];
+                        sxi += red[512 + j * width + kl];
+                        syy += red[768 + j * width + kl];
+                    }
+                }
+                __syncthreads();
+            }
+            if (live && g == 0) {
+                dsk::cd sxy{sxr, sxi + 0.0};  // + 0.0: a sum of -0 partials becomes +0 like the reference's mean
+                dsk::tf_from_sums(sxx, sxy, syy, k, fa.mode, fa.fin, fa.tf[(int64_t)k * p.n_ch + c],
+                                  fa.coh[(int64_t)k * p.n_ch + c]);
+            }
         }
     }
+    W4F_STAMP(7);
+    // the last workgroup through: everybody has seen the counters -> back to zero for the next launch
+    unsigned* const flag = reinterpret_cast<unsigned*>(lds) + 4096;
     __syncthreads();
-    if (tid == 0) {
-        const unsigned t = __hip_atomic_fetch_add(&sy[2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        flag[1] = t;
-    }
+    if (tid == 0) flag[0] = __hip_atomic_fetch_add(&sy[2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
-    if (flag[1] != (unsigned)(p.n_ch - 1)) return;
-    // the last finisher of all: nobody polls or adds any more -> counters back to zero for the next launch
+    if (flag[0] != grid - 1) return;
     for (int i = tid; i < p.n_chunks; i += NT)
         __hip_atomic_store(&sy[16 + i], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    for (int i = tid; i < p.n_ch; i += NT)
-        __hip_atomic_store(&sy[16 + F_MAX_UNITS + i], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (tid == 0) {
         __hip_atomic_store(&sy[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(&sy[2], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -357,9 +437,18 @@ __device__ __forceinline__ void tail(const FusedArgs& fa, float2* lds, float2 (&
 }
 
 // the fused launch needs every workgroup resident at once
+// OPT-IN (DSPTOOLBOX_AMD_W4_ONE_LAUNCH=1, read per call).  Measured on MI355X, 64 x 2^20 samples
+// (tools/exp/exp_fused.hip, per-workgroup s_memrealtime stamps, gpurun_out/exp_fused*.log of round 3):
+// the one launch is correct (bit-identical to the three launches, also beside a competing kernel and
+// over repeated launches) but SLOWER, 165-190 us against 107-110 us: what a kernel boundary does for
+// free -- making one workgroup's stores visible to workgroups on other XCDs -- costs as much inside a
+// launch as the boundary itself.  Write-through stores drain in 0.5 us at the median but 15-25 us at
+// the 90th percentile while every CU streams reads (input spectra "ready" at 25 us instead of 6; chunk
+// partials "published" 5-20 us behind the end of the pair loop), and the grid-wide wait in front of the
+// finish is a barrier at the slowest workgroup either way.  The three-launch path stays the default.
 inline bool fused_enabled() {
-    const char* e = getenv("DSPTOOLBOX_AMD_W4_THREE_LAUNCHES");  // A/B: k_x3 + k_y3 + k_welch_finish (read per call)
-    return !(e && e[0] == '1');
+    const char* e = getenv("DSPTOOLBOX_AMD_W4_ONE_LAUNCH");
+    return e && e[0] == '1';
 }
 
 }  // namespace welch4096

@@ -421,6 +421,47 @@ def gen_welch_long(dsp):
     save("welch_long", dict(cases=cases, fs=fs, note="outputs at bins_<i> only; tf / coh stored as complex64 / float32 (compare at 1e-6)"), arrs)
 
 
+def gen_welch4096(dsp):
+    """compute_transfer_function with 4096-sample windows at 50 % overlap on noise inputs, 66 frames:
+    the shape of the headline kernels (one input channel for all outputs -> welch4096::k_h1f / k_y3;
+    one per output -> k_x3 + k_px_sum + k_y3) against the reference itself.
+    3 output channels + the input(s); outputs at every 5th bin and the edges, float64."""
+    from dsptoolbox.standard.enums import SpectrumScaling as S, Window
+    from dsptoolbox.transfer_functions.enums import TransferFunctionType
+    fs = 48000
+    rng = np.random.default_rng(4096)
+    n = 2048 * 66 - 333
+    # inputs live on a 2^-13 grid (stored as int16, like the reference's own PCM examples): the
+    # reference runs on exactly the values the fixture holds
+    def grid(a):
+        return np.clip(np.round(a * 8192.0), -32768, 32767).astype(np.int16)
+    xq = grid(rng.standard_normal((n, 3)) * 0.3 + 0.02)
+    x = xq.astype(np.float64) / 8192.0
+    h = rng.standard_normal((3, 24)) * np.exp(-np.arange(24) / 6.0)
+    h *= 0.5 / np.max(np.abs(h), axis=1, keepdims=True)
+    yq = grid(np.stack([np.convolve(x[:, c], h[c])[:n] for c in range(3)], axis=1) + 0.05 * rng.standard_normal((n, 3)))
+    y1q = grid(np.stack([np.convolve(x[:, 0], h[c])[:n] for c in range(3)], axis=1) + 0.05 * rng.standard_normal((n, 3)))
+    y, y1 = yq.astype(np.float64) / 8192.0, y1q.astype(np.float64) / 8192.0
+    W, nb = 4096, 2049
+    bins = np.unique(np.r_[0:8, 0:nb:5, nb - 8:nb])
+    cases, arrs = [], {"x_q13": xq, "y_multi_q13": yq, "y_single_q13": y1q, "bins": bins}
+    for i, (det, sc) in enumerate(((True, S.FFTBackward), (False, S.PowerSpectralDensity), (True, S.AmplitudeSpectrum))):
+        case = dict(W=W, overlap=50, detrend=det, scaling=sc.name, tf=[])
+        for mode in TransferFunctionType:
+            for single in (True, False):
+                inp = dsp.Signal(None, x[:, :1].copy() if single else x.copy(), fs)
+                out = dsp.Signal(None, (y1 if single else y).copy(), fs)
+                inp.set_spectrum_parameters(window_length_samples=W, window_type=Window.Hann, overlap_percent=50,
+                                            detrend=det, average="mean", scaling=sc)
+                sp = dsp.transfer_functions.compute_transfer_function(out, inp, W, mode)
+                key = f"{i}_{mode.name}_{'single' if single else 'multi'}"
+                arrs["tf_" + key] = np.asarray(sp.spectral_data)[bins]
+                arrs["coh_" + key] = np.asarray(sp.coherence)[bins]
+                case["tf"].append(key)
+        cases.append(case)
+    save("welch4096", dict(cases=cases, fs=fs, frames=66, note="inputs = int16 / 8192; outputs at `bins` only, float64 / complex128"), arrs)
+
+
 def gen_csm_coherent(dsp):
     """Cross-spectral matrices of coherent channels (one source through responses of either sign): at DC
     and Nyquist the cross spectra are real and some are negative, where the amplitude scalings take the
@@ -468,6 +509,8 @@ def main():
         import warnings
         warnings.simplefilter("ignore")
         return gen_csm_coherent(dsp)
+    if "--only-welch4096" in sys.argv:
+        return gen_welch4096(dsp)
     if "--only-welch-long" in sys.argv:
         import warnings
         warnings.simplefilter("ignore")
@@ -777,6 +820,7 @@ def main():
               ir_head=ir.time_data[:48000], ir_tail=ir.time_data[-4096:],
               ir_peak=np.array([np.max(np.abs(ir.time_data))])))
     gen_welch_long(dsp)
+    gen_welch4096(dsp)
     gen_csm_coherent(dsp)
     gen_stft_manych(dsp)
     gen_fir_state(dsp)

@@ -65,7 +65,12 @@ def test_welch_golden():
     print("welch worst rel-max", worst)
 
 
-def test_transfer_function_golden():
+@pytest.mark.parametrize("precision", ["auto", "f32"])
+def test_transfer_function_golden(precision, monkeypatch):
+    """The reference's H1 / H2 / H3 fixtures through the reference-shaped API: "auto" is what a user
+    gets (these small problems take the float64 route), "f32" holds the fp32 register kernels
+    (welch1k, 1024-sample windows) to the same reference-produced vectors."""
+    monkeypatch.setattr(backend, "TF_PRECISION", precision)
     meta, z = load_golden("transfer_function")
     worst = 0.0
     for i, c in enumerate(meta["cases"]):
@@ -346,6 +351,46 @@ def test_welch_long_windows_golden():
                 tf = tf[bins]
             # 2 TOL: the fixture holds tf / coh rounded to complex64 / float32 (6e-8 of their own)
             assert relmax(tf, rt, dc) < 2 * TOL and relmax(coh[bins], rc, dc) < 2 * TOL, (c["W"], key)
+
+
+@pytest.mark.parametrize("three_launches", [True, False])
+def test_welch4096_headline_shape_golden(three_launches, monkeypatch):
+    """tests/golden/welch4096.npz (made by oracle/gen_golden.py from dsptoolbox 0.8): 4096-sample
+    windows, 50 % overlap, 66 frames of noise.  One input for all outputs runs the one-launch kernel
+    k_x3 + k_y3 + k_welch_finish (the default) or, with DSPTOOLBOX_AMD_W4_ONE_LAUNCH=1, the one-launch
+    kernel welch4096::k_h1f (correct but slower, kept opt-in: kernels_welch4096f.hpp); one input per
+    output runs k_x3 + k_px_sum + k_y3.  fp32 kernels against the reference at 1e-6."""
+    from dsptoolbox_amd._lib import get_context
+    monkeypatch.setenv("DSPTOOLBOX_AMD_W4_ONE_LAUNCH", "0" if three_launches else "1")
+    meta, z = load_golden("welch4096")
+    x, ym, ys = (z[k].astype(np.float64) / 8192.0 for k in ("x_q13", "y_multi_q13", "y_single_q13"))
+    bins = z["bins"]
+    ctx = get_context()
+    worst = 0.0
+    for c in meta["cases"]:
+        dc, sc = c["detrend"], SpectrumScaling[c["scaling"]]
+        for key in c["tf"]:
+            _, mode, which = key.split("_")
+            xin, yout = (x[:, :1], ys) if which == "single" else (x, ym)
+            ctx.profile_enable(True)
+            ctx.profile_report()
+            tf, coh = backend.welch_transfer_function(yout, xin, meta["fs"], c["W"], mode, overlap_percent=c["overlap"],
+                                                      detrend=dc, scaling=sc, precision="f32")
+            launched = ctx.profile_report()
+            ctx.profile_enable(False)
+            if which == "single" and not three_launches:
+                assert sorted(launched) == ["welch4096_fused"], sorted(launched)
+            else:
+                assert "welch4096_main" in launched and "welch_finish" in launched, sorted(launched)
+            rt, rc = z["tf_" + key], z["coh_" + key]
+            tfb = tf[bins]
+            if mode == "H2":  # Gyy / Gyx where the coherence vanishes is noise in float64 too
+                weak = rc < 0.1
+                tfb, rt = np.where(weak, 0.0, tfb), np.where(weak, 0.0, rt)
+            e1, e2 = relmax(tfb, rt, dc), relmax(coh[bins], rc, dc)
+            worst = max(worst, e1, e2)
+            assert e1 < TOL and e2 < TOL, (key, c, e1, e2)
+    print("welch4096 golden worst rel-max", worst)
 
 
 def test_welch4096_cross_spectra_on_register_kernels():
@@ -722,9 +767,10 @@ def test_bench_default_line_contract():
     assert roof["bound"] == "hbm" and roof["unit"] == "GB/s" and roof["peak"] == 8000.0
     assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-12 and 0.05 < roof["frac"] < 1.0
     assert roof["kernel"] == "welch4096_main"
-    assert 0.0 <= roof["event_bracket_overhead_ms"] < 0.5 * roof["kernel_avg_ms_raw_events"]
-    assert abs(roof["kernel_avg_ms"] + roof["event_bracket_overhead_ms"] - roof["kernel_avg_ms_raw_events"]) < 1e-9
-    assert roof["frac_raw_events"] <= roof["frac"] and roof["measured_copy_gbs"] > 1000.0
+    # frac is the measured kernel time as it is: nothing subtracted, no derived "net" figure
+    assert abs(roof["frac"] - roof["algorithmic_per_launch"] / (roof["kernel_avg_ms"] * 1e-3) / 1e9 / roof["peak"]) < 1e-9
+    assert "dispatch" in roof["kernel_time_source"] and roof["measured_copy_gbs"] > 1000.0
+    assert roof["kernel_avg_ms"] < out["ms_per_step"]
     cpu = out["cpu_baseline"]
     assert cpu["kind"] == "port" and cpu["cores"] == 1 and cpu["value"] > 0 and "sample" in cpu
     assert cpu["parity_rel_max_vs_gpu"] < TOL

@@ -355,6 +355,22 @@ def test_welch_long_windows_paired_inputs_and_cross_spectra():
             close(coh[bins], z["coh_" + key], tol=1e-6, skip_dc=dc)
 
 
+def test_welch4096_headline_shape_golden():
+    """tests/golden/welch4096.npz: the reference's H1 / H2 / H3 and coherence for 4096-sample windows at
+    50 % overlap over 66 frames of noise -- one input for all outputs and one per output."""
+    meta, z = load_golden("welch4096")
+    x, ym, ys = (z[k].astype(np.float64) / 8192.0 for k in ("x_q13", "y_multi_q13", "y_single_q13"))
+    bins = z["bins"]
+    for c in meta["cases"]:
+        for key in c["tf"]:
+            _, mode, which = key.split("_")
+            xin, yout = (x[:, :1], ys) if which == "single" else (x, ym)
+            tf, coh = orc.compute_transfer_function(yout, xin, meta["fs"], c["W"], mode, overlap_percent=c["overlap"],
+                                                    detrend=c["detrend"], scaling=c["scaling"])
+            close(tf[bins], z["tf_" + key], skip_dc=c["detrend"])
+            close(coh[bins], z["coh_" + key], skip_dc=c["detrend"])
+
+
 @pytest.mark.parametrize("mode", ["H1", "H2", "H3"])
 def test_property_linearity_of_h1(mode):
     """Scaling the output by g scales H by g and leaves coherence unchanged."""

@@ -92,6 +92,9 @@ int main(int argc, char** argv) {
     fa.fin = fin;
     fa.tf = tf1;
     fa.coh = coh1;
+#if W4F_STAMPS
+    fa.stamps = dalloc<unsigned long long>((size_t)pl.n_chunks * n_ch * 16);
+#endif
     hipStream_t st, st2;
     CK(hipStreamCreate(&st));
     CK(hipStreamCreate(&st2));
@@ -135,10 +138,24 @@ int main(int argc, char** argv) {
     compare("after 5 more launches");
     // uneven load: a streaming kernel on a second stream occupies part of the chip while the fused one runs
     float* junk = dalloc<float>((size_t)64 << 20);
+    hipEvent_t n0, n1, f0e, f1e;
+    CK(hipEventCreate(&n0));
+    CK(hipEventCreate(&n1));
+    CK(hipEventCreate(&f0e));
+    CK(hipEventCreate(&f1e));
     for (int rep = 0; rep < 4; ++rep) {
+        CK(hipEventRecord(n0, st2));
         hipLaunchKernelGGL(k_noise, dim3(64 * (rep + 1)), dim3(256), 0, st2, junk, (size_t)64 << 20, 3);
+        CK(hipEventRecord(n1, st2));
+        CK(hipEventRecord(f0e, st));
         runf();
+        CK(hipEventRecord(f1e, st));
         CK(hipStreamSynchronize(st2));
+        CK(hipStreamSynchronize(st));
+        float tn, tf_ms;
+        CK(hipEventElapsedTime(&tn, n0, n1));
+        CK(hipEventElapsedTime(&tf_ms, f0e, f1e));
+        printf("  competing kernel %.2f ms, one-launch kernel beside it %.2f ms\n", tn, tf_ms);
         compare("beside a competing kernel");
     }
     // other data in between (the spectra buffers are rewritten every launch: stale copies would show)
@@ -170,5 +187,27 @@ int main(int argc, char** argv) {
         printf("round %d: three launches %.1f us | one launch %.1f us\n", r, 1e3 * ms[0] / iters, 1e3 * ms[1] / iters);
     }
     compare("after timing");
+#if W4F_STAMPS
+    {
+        const int nb = pl.n_chunks * n_ch;
+        CK(hipMemset(fa.stamps, 0, (size_t)nb * 128));
+        for (int i = 0; i < 3; ++i) runf();
+        CK(hipStreamSynchronize(st));
+        std::vector<unsigned long long> h((size_t)nb * 16);
+        CK(hipMemcpy(h.data(), fa.stamps, h.size() * 8, hipMemcpyDeviceToHost));
+        unsigned long long t0 = ~0ull;
+        for (int b = 0; b < nb; ++b) t0 = std::min(t0, h[16 * b]);
+        const char* names[16] = {"start", "produce done", "first xs poll", "poll satisfied", "loop done", "partials published", "grid wait over", "finish done",
+                                 "P: samples windowed", "P: transform done", "P: stores issued", "P: drained", "", "", "", ""};
+        for (int i = 0; i < 12; ++i) {
+            std::vector<double> v;
+            for (int b = 0; b < nb; ++b)
+                if (h[16 * b + i]) v.push_back((double)(h[16 * b + i] - t0) / 100.0);
+            if (v.empty()) continue;
+            std::sort(v.begin(), v.end());
+            printf("  %-20s n %4zu  min %7.1f  p10 %7.1f  p50 %7.1f  p90 %7.1f  max %7.1f us\n", names[i], v.size(), v[0], v[v.size() / 10], v[v.size() / 2], v[9 * v.size() / 10], v.back());
+        }
+    }
+#endif
     return 0;
 }
