@@ -1893,6 +1893,12 @@ extern "C" int ds_deconv_dev(ds_ctx* c, const float* y, int n_items, int n_ch, i
         }
         deconv8k::Args a8{y, n_samples, ld, n_out, ld_out, n_ch, c->w4_tables, c->deconv8k_tables,
                           (const float2*)r, ir};
+        // one 256-thread group per channel pair, its two sub-spectra one after the other: three independent
+        // workgroups per CU (k_deconv3); DSPTOOLBOX_AMD_DECONV_2PERCU=1 keeps the 512-thread kernel (A/B)
+        static const bool two = getenv("DSPTOOLBOX_AMD_DECONV_2PERCU") != nullptr;
+        if (!two && (int64_t)((n_ch + 1) / 2) * n_items < ((int64_t)1 << 31))
+            return launch(c, "deconv", deconv8k::k_deconv3, dim3((unsigned)(((n_ch + 1) / 2) * n_items)), 256,
+                          deconv8k::LDS_BYTES_3, a8);
         CHK(launch(c, "deconv", deconv8k::k_deconv, dim3((n_ch + 1) / 2, n_items), deconv8k::NTB,
                    deconv8k::LDS_BYTES, a8));
         return DS_OK;

@@ -36,7 +36,7 @@ using fir16k::cmulc;
 using fir16k::idft16;
 using w4::cmul;
 constexpr int N = 4096, NT = 256, HOP = 2048, PART = 2049;
-constexpr int LDS_BYTES = (16 * w4::L1S + 256) * 8;  // exchange image + W256 table: 36 864 B
+constexpr int LDS_BYTES = (16 * w4::L1S + 256) * 8 + 2304;  // exchange image + W256 table + its padded copy
 // Two partitions: X_b, X_{b-1}, the working set and two tap spectra in flight are 192 registers; the 168
 // of three workgroups per CU were tried (half of X_{b-1} parked in LDS, staged tap loads: hipcc kept
 // 10-46 spilled values inside the filter loop) -- that kernel is built for TWO workgroups per CU.
@@ -84,6 +84,148 @@ __device__ __forceinline__ void ifft4096_w(float2 (&v)[16], const w4::Tw6& tw, f
     for (int k1 = 0; k1 < 16; ++k1) v[w4::pos16(k1)] = buf[k1 * w4::L1S + tid];
     apply_tw6_conj(v, tw);
     idft16(v);  // over k1: v[n1]
+}
+
+// idft16 with call-outs (mirror of welch4096::dft16_h): pre_a(g) / after_a(g) around the four first-stage
+// butterflies (inputs X[k] in v[4 g + i] = pos16(g + 4 i)), after_b(g) behind the four second-stage
+// butterflies: x[g], x[g + 4], x[g + 8], x[g + 12] are final in v[g + 4 i].
+template <typename PA, typename HA, typename HB>
+__device__ __forceinline__ void idft16_h(float2 (&v)[16], PA pre_a, HA after_a, HB after_b) {
+    constexpr float C8 = 0.92387953251128673848f, S8 = 0.38268343236508978178f;
+    constexpr float R2 = 0.70710678118654752440f;
+    using fir16k::r4i;
+    auto mulw = [](float2 z, float c, float s) {  // z * (c + i s)
+        return make_float2(fmaf(z.x, c, -z.y * s), fmaf(z.y, c, z.x * s));
+    };
+    pre_a(std::integral_constant<int, 0>{});
+    r4i(v[0], v[1], v[2], v[3]);
+    after_a(0);
+    pre_a(std::integral_constant<int, 1>{});
+    r4i(v[4], v[5], v[6], v[7]);
+    v[5] = mulw(v[5], C8, S8);                                                  // W16^-1
+    v[6] = make_float2((v[6].x - v[6].y) * R2, (v[6].x + v[6].y) * R2);         // W16^-2
+    v[7] = mulw(v[7], S8, C8);                                                  // W16^-3
+    after_a(1);
+    pre_a(std::integral_constant<int, 2>{});
+    r4i(v[8], v[9], v[10], v[11]);
+    v[9] = make_float2((v[9].x - v[9].y) * R2, (v[9].x + v[9].y) * R2);         // W16^-2
+    v[10] = make_float2(-v[10].y, v[10].x);                                     // W16^-4 = +i
+    v[11] = make_float2(-(v[11].x + v[11].y) * R2, (v[11].x - v[11].y) * R2);   // W16^-6
+    after_a(2);
+    pre_a(std::integral_constant<int, 3>{});
+    r4i(v[12], v[13], v[14], v[15]);
+    v[13] = mulw(v[13], S8, C8);                                                // W16^-3
+    v[14] = make_float2(-(v[14].x + v[14].y) * R2, (v[14].x - v[14].y) * R2);   // W16^-6
+    v[15] = mulw(v[15], -C8, -S8);                                              // W16^-9
+    after_a(3);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        r4i(v[g], v[g + 4], v[g + 8], v[g + 12]);
+        after_b(g);
+    }
+}
+
+// ifft4096_w with the exchange traffic spread between the butterflies (mirror of
+// welch4096::fft4096_wi): the transposed stores of the first pass leave four at a time behind the
+// butterfly that made them, the row stores of the second pass likewise; the barrier in front of the
+// first image write sits behind the first pass's stage A (whose arithmetic needs no LDS), the reads of
+// the second and third pass are requested in the order their butterflies consume them and waited for
+// with counted lgkmcnt (8-byte reads that stay single: welch4096::lds_rd64).  The W256 twiddles of the
+// middle exchange ride on the first pass's OUTPUTS (lane k2, values j: row k2 of the symmetric table,
+// eight 16-byte reads from `tw2p`, a copy with rows of 18 values: conflict-free) instead of on the
+// second pass's inputs (fifteen 8-byte reads on the critical path of its first butterfly).
+//   ld_a(g), g = 0..3: call-outs of the first pass's stage A;  ld_b(g): of the second pass's stage B
+constexpr int TW2P_ROW = 18;                    // float2 per padded table row
+constexpr int TW2P_BYTES = 16 * TW2P_ROW * 8;   // 2304
+__device__ __forceinline__ void fill_tw2p(float2* tw2p, const float2* __restrict__ twt, int tid) {
+    tw2p[(tid >> 4) * TW2P_ROW + (tid & 15)] = twt[15 * 256 + tid];  // W256^((tid >> 4) (tid & 15))
+}
+template <typename LA, typename LB>
+__device__ __forceinline__ void ifft4096_wi(float2 (&v)[16], const w4::Tw6& tw, float2* __restrict__ buf,
+                                            const float2* __restrict__ tw2p, int tid, LA ld_a, LB ld_b) {
+    using w4::lds_rd64;
+    using w4::lgkm_wait;
+    using w4::static_for;
+    const int k1u = tid >> 4, n3 = tid & 15;
+    float2* __restrict__ row = buf + k1u * w4::L1S;
+    // ---- over k3 (inputs in registers); the lane plays k2 = n3: x[j] W256^(-j k2) -> row[j L3S + k2]
+    float2 w2[16];
+    {
+        const float4* __restrict__ tr = reinterpret_cast<const float4*>(tw2p + n3 * TW2P_ROW);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float4 q = tr[i];
+            w2[2 * i] = make_float2(q.x, q.y);
+            w2[2 * i + 1] = make_float2(q.z, q.w);
+        }
+    }
+    idft16_h(
+        v, w4::NoHookI(),
+        [&](int g) {
+            W4_PIN();
+            ld_a(g);
+            W4_PIN();
+            if (g == 3) __syncthreads();  // every wave has read its columns (last pass of the previous transform)
+        },
+        [&](int g) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int j = g + 4 * i;
+                float2 z = v[j];
+                if (j) z = cmulc(z, w2[j]);
+                W4_PIN();
+                row[j * w4::L3S + n3] = z;
+                W4_PIN();
+            }
+        });
+    w4::wave_sync();
+    // ---- over k2: slot 4 a + b <-> k2 = a + 4 b, butterfly a consumes slots 4 a .. 4 a + 3
+    const uint32_t a_rt = w4::lds_addr(row + n3 * w4::L3S);
+    W4_PIN();
+    static_for<16>([&](auto ic) {
+        constexpr int i = decltype(ic)::value, a = i >> 2, b = i & 3;
+        lds_rd64<(a + 4 * b) * 8>(v[4 * a + b], a_rt);
+    });
+    idft16_h(
+        v,
+        [&](auto gc) {
+            constexpr int g = decltype(gc)::value;
+            lgkm_wait<12 - 4 * g>();
+        },
+        w4::NoHookI(),
+        [&](int g) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                W4_PIN();
+                row[16 * (g + 4 * i) + n3] = v[g + 4 * i];
+                W4_PIN();
+            }
+            W4_PIN();
+            ld_b(g);
+            W4_PIN();
+        });
+    __syncthreads();
+    // ---- over k1: v[pos16(k1)] = buf[k1 L1S + tid] W4096^(-tid k1)
+    const uint32_t a_col = w4::lds_addr(buf + tid);
+    W4_PIN();
+    static_for<16>([&](auto ic) {
+        constexpr int i = decltype(ic)::value, a = i >> 2, b = i & 3;
+        lds_rd64<(a + 4 * b) * w4::L1S * 8>(v[4 * a + b], a_col);
+    });
+    idft16_h(
+        v,
+        [&](auto gc) {
+            constexpr int g = decltype(gc)::value;
+            lgkm_wait<12 - 4 * g>();
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                float2 z = v[4 * g + b];
+                if (g) z = cmulc(z, tw.a[g - 1]);  // k1 = g + 4 b: lo = g, hi = b
+                if (b) z = cmulc(z, tw.b[b - 1]);
+                v[4 * g + b] = z;
+            }
+        },
+        w4::NoHookI(), w4::NoHookI());
 }
 
 // ---- tap spectra in register layout ---------------------------------------------------------------
@@ -150,6 +292,8 @@ __global__ __launch_bounds__(NT, P == 1 ? 3 : 2) void k_fir(Args p) {
     w4::Tw6 tw;
     w4::load_tw6(tw, p.twt, tid);
     tw2[tid] = p.twt[15 * 256 + tid];
+    float2* tw2p = lds + 16 * w4::L1S + 256;
+    fill_tw2p(tw2p, p.twt, tid);
 
     // spectrum of the segment that ends with block b (samples [(b - 1) 2048, (b + 1) 2048)); a negative
     // byte offset wraps to a huge unsigned one: out of range, 0 -- the zeros in front of the signal
@@ -194,22 +338,23 @@ __global__ __launch_bounds__(NT, P == 1 ? 3 : 2) void k_fir(Args p) {
                     v[2 * g + 1].y = fmaf(c.x, h1[g].w, fmaf(c.y, h1[g].z, v[2 * g + 1].y));
                 }
             }
-            // the next filter's tap spectra are requested behind the second exchange of this inverse transform
-            // (not behind the last filter: the spectra would stay live across the next block's forward
-            // transform, which has no registers for them)
-            const int hn = hq + (f + 1) * (P * 8 * 4096);
-            const bool more = f + 1 < p.n_filt;
-            // (both behind the SECOND exchange: in front of it the W256 twiddles of the middle pass are
-            // live and the two spectra would not fit beside them)
-            ifft4096_w(v, tw, buf, tw2, tid, w4::NoHook(), [&]() {
-                if (more) {
-#pragma unroll
-                    for (int g = 0; g < 8; ++g) {
-                        h0[g] = ld_h(hn + 4096 * g);
-                        if (P == 2) h1[g] = ld_h(hn + 4096 * (8 + g));
+            // The next filter's tap spectra ride in the transform's call-outs (two 16-byte loads each; the
+            // second partition's in the first pass, the first partition's in the second).  Behind the last
+            // filter the same spectra are fetched again: a branch around loads in the middle of the
+            // transform costs more than eight L2 hits.
+            const int hn = hq + min(f + 1, p.n_filt - 1) * (P * 8 * 4096);
+            ifft4096_wi(
+                v, tw, buf, tw2p, tid,
+                [&](int g) {
+                    if (P == 2) {
+                        h1[2 * g] = ld_h(hn + 4096 * (8 + 2 * g));
+                        h1[2 * g + 1] = ld_h(hn + 4096 * (9 + 2 * g));
                     }
-                }
-            });
+                },
+                [&](int g) {
+                    h0[2 * g] = ld_h(hn + 4096 * (2 * g));
+                    h0[2 * g + 1] = ld_h(hn + 4096 * (2 * g + 1));
+                });
             float* __restrict__ ya = p.y + ((int64_t)f * p.n_ch + ca) * p.ld_y;
             const __amdgpu_buffer_rsrc_t oa = __builtin_amdgcn_make_buffer_rsrc(ya, 0, (int)sig_bytes, 0x00020000);
             const __amdgpu_buffer_rsrc_t ob = __builtin_amdgcn_make_buffer_rsrc(ya + p.ld_y, 0, vb ? (int)sig_bytes : 0, 0x00020000);
