@@ -384,8 +384,8 @@ def _istft(stft, nfft: int, W: int, step: int, window, scale: float, frame_offse
     """Frame-wise irfft (length nfft, cropped to W) * scale * window, overlap-added at
     (frame + frame_offset) * step and divided by the squared-window envelope clipped at 1e-4
     (standard/_framed_signal_representation.py:70-137).  stft (B, F, C) -> (total_length, C)."""
-    if nfft & (nfft - 1) or nfft < 8:
-        raise NotImplementedError("fft_length_samples must be a power of two >= 8 on the GPU path")
+    if nfft < 2:
+        raise ValueError("fft_length_samples must be at least 2")
     if np.isrealobj(stft):
         stft = stft.astype(np.complex128)
     sp = np.ascontiguousarray(stft, dtype=np.complex64)
@@ -580,9 +580,13 @@ def _lfilter_fir(b, a, x, zi=None, axis: int = 0):
     if b.ndim != 1:
         b = np.squeeze(b)
         assert b.ndim == 1, "FIR Filters for audio must be 1D-arrays"
-    if np.iscomplexobj(b) or np.iscomplexobj(x):
-        raise NotImplementedError("complex FIR filtering is not built on the GPU path yet")
     x = np.asarray(x)
+    if np.iscomplexobj(x):
+        raise NotImplementedError("complex input signals are outside the GPU hot path (Signal.time_data is real)")
+    if np.iscomplexobj(b):
+        # complex taps on a real signal (filter_helpers.py:364-371 stores the imaginary part of the output in
+        # Signal.time_data_imaginary): two real convolutions, x * Re b + i x * Im b, one device call
+        return _lfilter_fir_complex(b, x, zi)
     if zi is not None:
         zi = np.asarray(zi)
         assert zi.ndim == x.ndim, \
@@ -602,11 +606,34 @@ def _lfilter_fir(b, a, x, zi=None, axis: int = 0):
     return y[: x.shape[0], :], zf
 
 
+def _lfilter_fir_complex(b, x, zi=None):
+    """_lfilter_fir for complex taps b on a real x: the real and the imaginary part of b are two band
+    filters of one parallel bank; state (complex) as in the real case."""
+    if zi is not None:
+        zi = np.asarray(zi)
+    if x.ndim < 2:
+        x = x[..., None]
+        if zi is not None:
+            zi = zi[..., None]
+    assert x.ndim == 2, "Filtering only works on 2D-arrays"
+    br, bi = np.ascontiguousarray(b.real), np.ascontiguousarray(b.imag)
+    if zi is None:
+        out = fir_filter_bank(x, [br, bi], DS_FB_PARALLEL)
+        return out[0] + 1j * out[1]
+    xfull = np.concatenate([x, np.zeros((len(b) - 1, x.shape[1]))], axis=0)
+    out = fir_filter_bank(xfull, [br, bi], DS_FB_PARALLEL)
+    y = out[0] + 1j * out[1]
+    y[: zi.shape[0], :] += zi
+    zf = y[-zi.shape[0]:, :]
+    return y[: x.shape[0], :], zf
+
+
 def _lfilter_zi_fir(b):
     """scipy.signal.lfilter_zi(b, [1.0]) in closed form (the reference's Filter.initialize_zi,
     classes/filter.py:331-353): steady-state step-response state of a transposed direct-form
     FIR filter, zi[i] = sum_{j > i} b[j].  Host-side parameter preparation."""
-    b = np.asarray(b, dtype=np.float64)
+    b = np.asarray(b)
+    b = b.astype(np.complex128 if np.iscomplexobj(b) else np.float64)
     return np.cumsum(b[::-1])[::-1][1:].copy()
 
 

@@ -156,6 +156,12 @@ class Filter:
             y = backend._filtfilt_fir(self.ba[0], signal.time_data[:, channels])
         else:
             y = backend._lfilter_fir(self.ba[0], self.ba[1], signal.time_data[:, channels])
+        if np.iscomplexobj(y):  # filter_helpers.py:364-371
+            if self.warning_if_complex:
+                warn("Filter output is complex. Imaginary part is saved in Signal as time_data_imaginary")
+            new_time_data = new_time_data.astype(np.complex128)
+            if zi is not None:
+                zi = zi.astype(np.complex128) if not np.iscomplexobj(zi) else zi
         new_time_data[:, channels] = y
         if activate_zi:
             # the reference hands back the (T-1, C) state array itself, not a per-channel list

@@ -636,6 +636,67 @@ extern "C" int ds_stft_r2c_dev(ds_ctx* c, const float* x, int64_t n_samples, int
 }
 
 // ---- inverse STFT ----------------------------------------------------------
+// ---- inverse STFT with an FFT length that is not a power of two (transforms/transforms.py:548-577 calls
+// np.fft.irfft(stft, n=fft_length_samples) with any n) ------------------------------------------------------
+// Every (channel, frame) spectrum is one "channel" of the spectral-division machinery, which already
+// inverts any length (Bluestein on the four-step transform): irfft_n(1 * R) with a unit impulse as the
+// numerator.  k_istft_spec lays the spectra out per (channel, frame) -- cropped or zero-padded to
+// n / 2 + 1 bins as numpy does --, the division writes the frames [c][f][W], k_istft_scale applies the
+// synthesis window and the scale; the overlap-add kernel is the same as for powers of two.
+extern "C" int ds_deconv_dev(ds_ctx* c, const float* y, int n_items, int n_ch, int64_t ld, int64_t n_samples, int n_fft,
+                             const ds_c32* r, int r_per_channel, int64_t n_out, int64_t ld_out, float* ir);
+static int64_t blue_len(int64_t L);
+static int check_blue_len(ds_ctx* c, int64_t L, const char* what);
+__global__ void k_istft_spec(const float2* stft, int n_bins, int n_frames, int n_ch, int f0, int nf, int nb, float2* r,
+                             float* ones) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, total = (int64_t)n_ch * nf * nb;
+    if (i < (int64_t)n_ch * nf) ones[i] = 1.f;
+    if (i >= total) return;
+    const int k = (int)(i % nb);
+    const int64_t cf = i / nb;
+    const int f = (int)(cf % nf), ch = (int)(cf / nf);
+    r[i] = k < n_bins ? stft[((int64_t)k * n_frames + f0 + f) * n_ch + ch] : make_float2(0.f, 0.f);
+}
+__global__ void k_istft_scale(float* frames, int64_t total, int W, const float* window, float scale) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < total) frames[i] *= scale * window[i % W];
+}
+static int istft_any_frames(ds_ctx* c, const float2* stft, int n_bins, int n_frames, int n_ch, int nfft, int W,
+                            const float* window, float scale, float* frames /* [c][f][W] */) {
+    CHK(check_blue_len(c, nfft, "ds_istft nfft"));
+    const int nb = nfft / 2 + 1;
+    // groups of frames: the division's scratch is ~4 x 8 bytes x (frames x channels / 2) x transform length
+    const int64_t m_len = blue_len(nfft);
+    int group = (int)std::max<int64_t>(1, ((int64_t)64 << 20) / std::max<int64_t>(1, m_len * n_ch));
+    group = std::min(group, n_frames);
+    CHK(reserve(c, &c->aux, &c->aux_bytes,
+                Carver::pad(sizeof(float2) * (size_t)n_ch * group * nb) + Carver::pad(sizeof(float) * (size_t)n_ch * group) +
+                    Carver::pad(sizeof(float) * (size_t)n_ch * group * W) + 4096));
+    Carver cv(c->aux);
+    float2* r = cv.take<float2>((size_t)n_ch * group * nb);
+    float* ones = cv.take<float>((size_t)n_ch * group);
+    float* part = cv.take<float>((size_t)n_ch * group * W);
+    for (int f0 = 0; f0 < n_frames; f0 += group) {
+        const int nf = std::min(group, n_frames - f0);
+        const int64_t total = (int64_t)n_ch * nf * nb;
+        hipLaunchKernelGGL(k_istft_spec, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, stft, n_bins, n_frames,
+                           n_ch, f0, nf, nb, r, ones);
+        HIPCHK(c, hipGetLastError());
+        CHK(ds_deconv_dev(c, ones, 1, n_ch * nf, 1, 1, nfft, (const ds_c32*)r, 1, W, W, part));
+        // part: [(ch nf + f) W + m] -> frames [(ch n_frames + f0 + f) W + m], windowed and scaled
+        const int64_t tw = (int64_t)n_ch * nf * W;
+        // (`scale` is defined against an UNnormalised inverse transform, as k_istft computes it; the division
+        // machinery returns numpy's normalised irfft)
+        hipLaunchKernelGGL(k_istft_scale, dim3((unsigned)((tw + 255) / 256)), dim3(256), 0, c->stream, part, tw, W, window,
+                           scale * (float)nfft);
+        HIPCHK(c, hipGetLastError());
+        for (int ch = 0; ch < n_ch; ++ch)
+            HIPCHK(c, hipMemcpyAsync(frames + ((int64_t)ch * n_frames + f0) * W, part + (int64_t)ch * nf * W,
+                                     sizeof(float) * (size_t)nf * W, hipMemcpyDeviceToDevice, c->stream));
+    }
+    return DS_OK;
+}
+
 extern "C" int ds_istft_dev(ds_ctx* c, const ds_c32* stft, int n_bins, int n_frames, int n_ch, int nfft,
                             int W, int step, int frame_offset, int n_frames_total, const float* window,
                             float scale, int64_t total_length, float* out, int64_t ld_out) {
@@ -644,6 +705,20 @@ extern "C" int ds_istft_dev(ds_ctx* c, const ds_c32* stft, int n_bins, int n_fra
         n_frames_total < n_frames + frame_offset || total_length <= 0 || ld_out < total_length)
         return fail(c, DS_ERR_ARG, "ds_istft: bad shape");
     if (W > nfft) return fail(c, DS_ERR_ARG, "ds_istft: window longer than the FFT length");
+    if (!is_pow2(nfft) || nfft < kMinFft || nfft > kMaxFft) {
+        // (ws, io and aux are all taken -- the division's scratch, the host entry point's staging, the
+        // per-group spectra -- so the frames get a buffer of their own; this route is correct, not tuned)
+        float* frames = nullptr;
+        HIPCHK(c, hipMalloc((void**)&frames, sizeof(float) * (size_t)n_ch * n_frames * W));
+        int rc = istft_any_frames(c, (const float2*)stft, n_bins, n_frames, n_ch, nfft, W, window, scale, frames);
+        if (rc == DS_OK) {
+            IstftOlaArgs o{frames, n_frames, n_ch, W, step, frame_offset, n_frames_total, window, total_length, ld_out, out};
+            rc = launch(c, "istft_ola", k_istft_ola, dim3((unsigned)((total_length + 255) / 256), n_ch), 256, 0, o);
+        }
+        (void)hipStreamSynchronize(c->stream);
+        (void)hipFree(frames);
+        return rc;
+    }
     CHK(check_fft_len(c, nfft, "ds_istft nfft"));
     const float2* tw;
     CHK(get_twiddles(c, nfft, &tw));

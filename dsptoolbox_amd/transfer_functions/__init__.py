@@ -69,6 +69,56 @@ def _inverse_hann_band(ids, length: int):
     return 1 - w
 
 
+def _spectral_deconvolve_scaled(output, input, apply_regularization, start_stop_hz, threshold_db, padding,
+                                keep_original_length, multichannel):
+    """spectral_deconvolve for signals whose spectrum parameters ask for a scaling other than the plain
+    transform (FFTForward / FFTOrthogonal norms, amplitude or power spectra in physical units): the
+    reference divides whatever `get_spectrum` returns (transfer_functions.py:142-177, classes/signal.py:
+    899-938 -- power scalings make both spectra real, |X|^2 k).  Transforms on the device
+    (Signal.get_spectrum), the B x C division in float64 on the host, the inverse transform of any length
+    on the device."""
+    fs_hz = output.sampling_rate_hz
+    original_length = output.time_data.shape[0]
+    n_time = original_length * 2 if padding else original_length
+
+    def spectrum_of(sig):
+        td = sig.time_data
+        if padding:
+            td = np.concatenate((td, np.zeros_like(td)), axis=0)
+        tmp = Signal(None, td, fs_hz)
+        tmp._spectrum_parameters = dict(sig._spectrum_parameters)
+        tmp.spectrum_method = SpectrumMethod.FFT
+        return tmp.get_spectrum()
+
+    _, denum_fft = spectrum_of(input)
+    freqs_hz, num_fft = spectrum_of(output)
+    if apply_regularization:
+        if start_stop_hz is None:
+            start_stop_hz = find_frequencies_above_threshold(denum_fft[:, 0], freqs_hz, threshold_db)
+        if len(start_stop_hz) == 2:
+            start_stop_hz = np.array([start_stop_hz[0] / np.sqrt(2), start_stop_hz[0], start_stop_hz[1],
+                                      np.min([start_stop_hz[1] * np.sqrt(2), fs_hz / 2])])
+        elif len(start_stop_hz) != 4:
+            raise ValueError("start_stop_hz vector should have 2 or 4 values")
+        ids = find_nearest_points_index_in_vector(start_stop_hz, freqs_hz)
+        eps = _inverse_hann_band(ids, len(freqs_hz)) * 10 ** (30 / 20)
+        den = denum_fft[:, :1] if multichannel else denum_fft
+        prod = num_fft * (np.conj(den) / (np.abs(den) ** 2 + eps[:, None]))
+    else:
+        prod = num_fft / (denum_fft[:, :1] if multichannel else denum_fft)
+    # np.fft.irfft(prod, n=n_time): the spectrum is cropped or zero-padded to n_time // 2 + 1 bins
+    nb = n_time // 2 + 1
+    spec = np.zeros((nb, prod.shape[1]), dtype=np.complex128)
+    spec[: min(nb, prod.shape[0])] = prod[:nb]
+    delta = np.zeros((n_time, prod.shape[1]))
+    delta[0, :] = 1.0
+    new_time_data = backend.spectral_division(delta, n_time, spec, n_time)
+    new_sig = ImpulseResponse(None, new_time_data, fs_hz, constrain_amplitude=False)
+    if padding and keep_original_length:
+        new_sig.time_data = new_sig.time_data[:original_length].copy()
+    return new_sig
+
+
 def spectral_deconvolve(output: Signal, input: Signal, apply_regularization: bool = True,
                         start_stop_hz=None, threshold_db: float = -30.0, padding: bool = False,
                         keep_original_length: bool = False) -> ImpulseResponse:
@@ -84,12 +134,16 @@ def spectral_deconvolve(output: Signal, input: Signal, apply_regularization: boo
         assert start_stop_hz is None, \
             "No start_stop_hz vector can be passed when using standard mode"
     for s in (output, input):
-        par = s._spectrum_parameters
-        if (par["scaling"].fft_norm() != "backward" or par["scaling"].has_physical_units()
-                or par["smoothing"] != 0):
-            raise NotImplementedError(
-                "spectral_deconvolve on the GPU path expects unscaled spectra "
-                "(FFTBackward, no smoothing)")
+        if s._spectrum_parameters["smoothing"] != 0:
+            raise NotImplementedError("fractional-octave spectrum smoothing is outside the GPU hot path")
+    # Only the spectrum METHOD is forced (transfer_functions.py:142-143): each signal's own scaling still
+    # applies inside get_spectrum (classes/signal.py:899-938).  The defaults (FFTBackward) give the plain
+    # transform and take the fused device path below; any other scaling goes through the general one.
+    plain = all(s._spectrum_parameters["scaling"].fft_norm() == "backward"
+                and not s._spectrum_parameters["scaling"].has_physical_units() for s in (output, input))
+    if not plain:
+        return _spectral_deconvolve_scaled(output, input, apply_regularization, start_stop_hz, threshold_db,
+                                           padding, keep_original_length, multichannel)
     fs_hz = output.sampling_rate_hz
     original_length = output.time_data.shape[0]
     n_time = original_length * 2 if padding else original_length

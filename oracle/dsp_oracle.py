@@ -491,9 +491,11 @@ def regularization_eps(denum_fft_ch0, freqs_hz, fs_hz, start_stop_hz, threshold_
 
 def spectral_deconvolve(y, x, fs_hz: int, apply_regularization: bool = True,
                         start_stop_hz=None, threshold_db: float = -30.0,
-                        padding: bool = False, keep_original_length: bool = False):
-    """transfer_functions.py:61-184 with default spectrum parameters
-    (FFTBackward, pad_to_fast_length=True).  y (N,C); x (N,1|C) -> (N|2N, C)."""
+                        padding: bool = False, keep_original_length: bool = False,
+                        scaling_y: str = "FFTBackward", scaling_x: str = "FFTBackward"):
+    """transfer_functions.py:61-184 (pad_to_fast_length=True).  y (N,C); x (N,1|C) -> (N|2N, C).
+    scaling_y / scaling_x: the spectrum scaling each Signal carries -- only the METHOD is forced to FFT
+    (:142-143), get_spectrum still applies the scaling (classes/signal.py:899-938)."""
     y = np.asarray(y, dtype=np.float64)
     x = np.asarray(x, dtype=np.float64)
     assert y.shape[0] == x.shape[0]
@@ -506,10 +508,8 @@ def spectral_deconvolve(y, x, fs_hz: int, apply_regularization: bool = True,
     if padding:
         y = np.concatenate([y, np.zeros_like(y)], axis=0)
         x = np.concatenate([x, np.zeros_like(x)], axis=0)
-    L = next_fast_len(y.shape[0], True)
-    den = sp_rfft(x, axis=0, n=L)
-    num = sp_rfft(y, axis=0, n=L)
-    freqs = np.fft.rfftfreq(L, 1 / fs_hz)
+    freqs, den = spectrum_fft(x, fs_hz, scaling_x)
+    _, num = spectrum_fft(y, fs_hz, scaling_y)
     nt = y.shape[0]
     out = np.zeros_like(y)
     eps = None
@@ -534,7 +534,8 @@ def spectral_deconvolve(y, x, fs_hz: int, apply_regularization: bool = True,
 def lfilter_fir(b, x, zi=None):
     """filter_helpers.py:454-503: oaconvolve(...)[:N]; with zi (T-1, C) the state is added to
     the head of the full convolution and the new state is its tail (:493-500)."""
-    b = np.asarray(b, dtype=np.float64)
+    b = np.asarray(b)
+    b = b.astype(np.complex128 if np.iscomplexobj(b) else np.float64)  # complex taps: complex output (:364-371)
     if b.ndim != 1:  # :475-477 (a one-tap filter is already 1-D and stays so)
         b = np.squeeze(b)
         assert b.ndim == 1, "FIR Filters for audio must be 1D-arrays"
@@ -555,7 +556,8 @@ def lfilter_zi_fir(b):
     """scipy.signal.lfilter_zi(b, [1.0]) (Filter.initialize_zi, filter.py:331-353) in closed
     form: the step-response steady state of a transposed direct-form FIR filter is the tail
     sum of the taps, zi[i] = sum_{j > i} b[j]."""
-    b = np.asarray(b, dtype=np.float64)
+    b = np.asarray(b)
+    b = b.astype(np.complex128 if np.iscomplexobj(b) else np.float64)
     return np.cumsum(b[::-1])[::-1][1:].copy()
 
 

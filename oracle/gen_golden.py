@@ -168,15 +168,15 @@ def gen_fir_state(dsp):
     save("fir_state", dict(cases=cases, fs=fs), arrs)
 
 
-def gen_istft(dsp):
+def gen_istft(dsp, name="istft", variants=None, seed=21):
     """transforms.istft (transforms/transforms.py:444-586) on spectrograms of the reference's own
     Signal.get_spectrogram, with the original signal and with an explicit parameter dict."""
     from dsptoolbox.standard.enums import SpectrumScaling, Window
     fs = 48000
-    rng = np.random.default_rng(21)
+    rng = np.random.default_rng(seed)
     x = rng.standard_normal((6000, 2)) * 0.2
     cases, arrs = [], {"x": x}
-    variants = [
+    variants = variants or [
         dict(W=256, ov=50.0, nfft=None, pad=True, sc="FFTBackward", win="Hann"),
         dict(W=256, ov=75.0, nfft=512, pad=True, sc="FFTBackward", win="Hann"),
         dict(W=512, ov=50.0, nfft=None, pad=False, sc="FFTBackward", win="Hann"),
@@ -200,7 +200,18 @@ def gen_istft(dsp):
         v = dict(v)
         v["has_par"] = f"rec_par_{i}" in arrs
         cases.append(v)
-    save("istft", dict(cases=cases, fs=fs), arrs)
+    save(name, dict(cases=cases, fs=fs), arrs)
+
+
+def gen_istft_anylen(dsp):
+    """The same with fft_length_samples that are not powers of two: transforms.py:548-577 inverts with
+    np.fft.irfft(stft, n=fft_length_samples) of any length (zero-padded frames: nfft >= window)."""
+    gen_istft(dsp, "istft_anylen", [
+        dict(W=256, ov=50.0, nfft=384, pad=True, sc="FFTBackward", win="Hann"),       # 3 * 2^7
+        dict(W=256, ov=75.0, nfft=1000, pad=True, sc="FFTBackward", win="Hann"),      # 2^3 5^3
+        dict(W=512, ov=50.0, nfft=600, pad=False, sc="AmplitudeSpectrum", win="Hann"),
+        dict(W=128, ov=50.0, nfft=255, pad=True, sc="FFTOrthogonal", win="Hamming"),  # odd: no Nyquist bin
+    ], seed=22)
 
 
 def gen_rir(dsp):
@@ -462,6 +473,73 @@ def gen_welch4096(dsp):
     save("welch4096", dict(cases=cases, fs=fs, frames=66, note="inputs = int16 / 8192; outputs at `bins` only, float64 / complex128"), arrs)
 
 
+def gen_deconv_scaled(dsp):
+    """spectral_deconvolve on signals whose spectrum parameters carry a scaling other than the plain
+    transform: only the method is forced to FFT (transfer_functions.py:142-143), the scaling still applies
+    in get_spectrum (classes/signal.py:899-938).  Norms, amplitude and power scalings, with and without
+    regularisation / padding, one denominator for all channels and one per channel."""
+    from dsptoolbox.standard.enums import SpectrumScaling as S
+    fs = 48000
+    rng = np.random.default_rng(77)
+    n = 6000
+    t = np.arange(n) / fs
+    x = (0.5 * np.sin(2 * np.pi * (30 * t + (9000 - 30) / (2 * t[-1]) * t * t)))[:, None]
+    h = rng.standard_normal((64, 2)) * np.exp(-np.arange(64) / 12.0)[:, None]
+    y = np.stack([np.convolve(x[:, 0], h[:, j])[:n] for j in range(2)], axis=1) + 1e-3 * rng.standard_normal((n, 2))
+    xn = rng.standard_normal((n, 1)) * 0.3   # white denominator for the unregularised cases
+    yn = np.stack([np.convolve(xn[:, 0], h[:, j])[:n] for j in range(2)], axis=1)
+    cases, arrs = [], {"x": x, "y": y, "xn": xn, "yn": yn}
+    combos = [
+        (S.FFTForward, S.FFTForward, True, False, False, False),
+        (S.FFTOrthogonal, S.FFTBackward, True, True, True, False),
+        (S.AmplitudeSpectrum, S.AmplitudeSpectrum, True, False, False, True),
+        (S.AmplitudeSpectralDensity, S.FFTForward, False, False, False, False),
+        (S.PowerSpectralDensity, S.PowerSpectralDensity, True, False, False, False),
+        (S.PowerSpectrum, S.AmplitudeSpectrum, True, True, False, True),
+    ]
+    for i, (sy, sx, reg, pad, keep, per_ch) in enumerate(combos):
+        xi, yi = (x, y) if reg else (xn, yn)
+        xin = np.repeat(xi, 2, axis=1) * np.array([1.0, 0.8]) if per_ch else xi
+        out = dsp.Signal(None, yi.copy(), fs)
+        inp = dsp.Signal(None, xin.copy(), fs)
+        out.set_spectrum_parameters(method=dsp.SpectrumMethod.FFT, scaling=sy)
+        inp.set_spectrum_parameters(method=dsp.SpectrumMethod.FFT, scaling=sx)
+        ir = dsp.transfer_functions.spectral_deconvolve(out, inp, apply_regularization=reg, padding=pad,
+                                                        keep_original_length=keep)
+        arrs[f"ir_{i}"] = ir.time_data
+        cases.append(dict(scaling_y=sy.name, scaling_x=sx.name, regularized=reg, padding=pad, keep=keep,
+                          per_channel=per_ch))
+    save("deconv_scaled", dict(cases=cases, fs=fs), arrs)
+
+
+def gen_fir_complex(dsp):
+    """Filter.filter_signal with COMPLEX taps (a one-sided band pass: real prototype times exp(j w n)): the
+    reference keeps the imaginary part of the output in Signal.time_data_imaginary
+    (classes/filter_helpers.py:364-371).  Plain call, a channel subset, and with filter state."""
+    import warnings
+    fs = 48000
+    rng = np.random.default_rng(364)
+    n = 9000
+    x = rng.standard_normal((n, 3)) * 0.3
+    cases, arrs = [], {"x": x}
+    from scipy.signal import firwin
+    for i, (T, channels, zi) in enumerate(((301, None, False), (2500, [0, 2], False), (129, None, True))):
+        proto = firwin(T, 3000.0, fs=fs)
+        b = proto * np.exp(1j * 2 * np.pi * 6000.0 / fs * np.arange(T))
+        f = dsp.Filter.from_ba(b, [1.0], fs)
+        s = dsp.Signal(None, x.copy(), fs)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            if zi:
+                f.initialize_zi(3)
+            out = f.filter_signal(s, channels=channels, activate_zi=zi)
+        arrs[f"b_{i}"] = b
+        arrs[f"re_{i}"] = out.time_data
+        arrs[f"im_{i}"] = out.time_data_imaginary
+        cases.append(dict(taps=T, channels=channels, zi=zi))
+    save("fir_complex", dict(cases=cases, fs=fs), arrs)
+
+
 def gen_csm_coherent(dsp):
     """Cross-spectral matrices of coherent channels (one source through responses of either sign): at DC
     and Nyquist the cross spectra are real and some are negative, where the amplitude scalings take the
@@ -509,6 +587,16 @@ def main():
         import warnings
         warnings.simplefilter("ignore")
         return gen_csm_coherent(dsp)
+    if "--only-deconv-scaled" in sys.argv:
+        import warnings
+        warnings.simplefilter("ignore")
+        return gen_deconv_scaled(dsp)
+    if "--only-fir-complex" in sys.argv:
+        return gen_fir_complex(dsp)
+    if "--only-istft-anylen" in sys.argv:
+        import warnings
+        warnings.simplefilter("ignore")
+        return gen_istft_anylen(dsp)
     if "--only-welch4096" in sys.argv:
         return gen_welch4096(dsp)
     if "--only-welch-long" in sys.argv:
@@ -821,10 +909,13 @@ def main():
               ir_peak=np.array([np.max(np.abs(ir.time_data))])))
     gen_welch_long(dsp)
     gen_welch4096(dsp)
+    gen_deconv_scaled(dsp)
+    gen_fir_complex(dsp)
     gen_csm_coherent(dsp)
     gen_stft_manych(dsp)
     gen_fir_state(dsp)
     gen_istft(dsp)
+    gen_istft_anylen(dsp)
     gen_stft_anylen(dsp)
     gen_rir(dsp)
     gen_das(dsp)

@@ -353,6 +353,44 @@ def test_welch_long_windows_golden():
             assert relmax(tf, rt, dc) < 2 * TOL and relmax(coh[bins], rc, dc) < 2 * TOL, (c["W"], key)
 
 
+def test_fir_complex_taps_golden():
+    """Filter.filter_signal with complex taps (missing 5): two real device convolutions, the
+    imaginary part of the output lands in Signal.time_data_imaginary (filter_helpers.py:364-371)."""
+    import warnings
+    meta, z = load_golden("fir_complex")
+    for i, c in enumerate(meta["cases"]):
+        f = dsp.Filter.from_ba(z[f"b_{i}"], [1.0], meta["fs"])
+        s = dsp.Signal(None, z["x"].copy(), meta["fs"])
+        with warnings.catch_warnings(record=True) as rec:
+            warnings.simplefilter("always")
+            if c["zi"]:
+                f.initialize_zi(3)
+            out = f.filter_signal(s, channels=c["channels"], activate_zi=c["zi"])
+        assert any("complex" in str(w.message) for w in rec)
+        assert out.time_data_imaginary is not None
+        assert relmax(out.time_data, z[f"re_{i}"]) < TOL and relmax(out.time_data_imaginary, z[f"im_{i}"]) < TOL, c
+        assert np.array_equal(s.time_data, z["x"])  # the input is untouched
+
+
+def test_deconvolve_scaled_spectra_golden():
+    """spectral_deconvolve on signals that carry a spectrum scaling (missing 4): the reference
+    divides the SCALED spectra -- norms, amplitude and power scalings -- tests/golden/deconv_scaled.npz."""
+    meta, z = load_golden("deconv_scaled")
+    for i, c in enumerate(meta["cases"]):
+        x, y = (z["x"], z["y"]) if c["regularized"] else (z["xn"], z["yn"])
+        xin = np.repeat(x, 2, axis=1) * np.array([1.0, 0.8]) if c["per_channel"] else x
+        out, inp = dsp.Signal(None, y.copy(), meta["fs"]), dsp.Signal(None, xin.copy(), meta["fs"])
+        out.set_spectrum_parameters(method=dsp.SpectrumMethod.FFT, scaling=SpectrumScaling[c["scaling_y"]])
+        inp.set_spectrum_parameters(method=dsp.SpectrumMethod.FFT, scaling=SpectrumScaling[c["scaling_x"]])
+        ir = dsp.transfer_functions.spectral_deconvolve(out, inp, apply_regularization=c["regularized"],
+                                                        padding=c["padding"], keep_original_length=c["keep"])
+        ref = z[f"ir_{i}"]
+        assert isinstance(ir, dsp.ImpulseResponse) and ir.time_data.shape == ref.shape
+        # unregularised: |X| of white noise dips to ~1e-2 of its mean (see fuzz_misc.py)
+        tol = TOL if c["regularized"] else 1e-4
+        assert relmax(ir.time_data, ref) < tol, (c, relmax(ir.time_data, ref))
+
+
 @pytest.mark.parametrize("three_launches", [True, False])
 def test_welch4096_headline_shape_golden(three_launches, monkeypatch):
     """tests/golden/welch4096.npz (made by oracle/gen_golden.py from dsptoolbox 0.8): 4096-sample
@@ -600,11 +638,13 @@ def test_fir_long_filters_vs_oracle():
         assert relmax(y, r) < TOL, (name, relmax(y, r))
 
 
-def test_istft_golden_and_round_trip():
+@pytest.mark.parametrize("fixture", ["istft", "istft_anylen"])
+def test_istft_golden_and_round_trip(fixture):
     """transforms.istft against the reference's outputs, and the reference's own fidelity test
-    (tests/test_transforms.py:102-134): get_spectrogram -> istft reproduces the signal."""
+    (tests/test_transforms.py:102-134): get_spectrogram -> istft reproduces the signal.  istft_anylen:
+    fft_length_samples that are not powers of two (missing 6)."""
     from dsptoolbox_amd.standard.enums import SpectrumScaling as S
-    meta, z = load_golden("istft")
+    meta, z = load_golden(fixture)
     fs = meta["fs"]
     x = z["x"]
     for i, c in enumerate(meta["cases"]):
@@ -622,7 +662,7 @@ def test_istft_golden_and_round_trip():
     # device STFT -> device inverse STFT, larger signal
     rng = np.random.default_rng(31)
     y = rng.standard_normal((100000, 3)) * 0.3
-    for W, nfft in ((1024, None), (512, 1024), (4096, None)):
+    for W, nfft in (((1024, None), (512, 1024), (4096, None)) if fixture == "istft" else ((512, 768), (256, 1001))):
         s = dsp.Signal(None, y.copy(), fs)
         s.set_spectrogram_parameters(window_length_samples=W, fft_length_samples=nfft)
         t, f, sp = s.get_spectrogram()

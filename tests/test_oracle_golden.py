@@ -187,9 +187,11 @@ def test_stft_many_channels():
         close(s[z[f"bins_{i}"]], z[f"stft_{i}"], tol=1e-6)  # stored as complex64
 
 
-def test_istft():
-    """transforms.istft incl. its quirks (step from the un-rounded overlap, empty edge frames)."""
-    meta, z = load_golden("istft")
+@pytest.mark.parametrize("fixture", ["istft", "istft_anylen"])
+def test_istft(fixture):
+    """transforms.istft incl. its quirks (step from the un-rounded overlap, empty edge frames); istft_anylen:
+    fft_length_samples that are not powers of two."""
+    meta, z = load_golden(fixture)
     x = z["x"]
     for i, c in enumerate(meta["cases"]):
         sp = z[f"stft_{i}"]
@@ -353,6 +355,34 @@ def test_welch_long_windows_paired_inputs_and_cross_spectra():
                                                     detrend=c["detrend"], scaling=c["scaling"])
             close(tf[bins], z["tf_" + key], tol=1e-6, skip_dc=dc)
             close(coh[bins], z["coh_" + key], tol=1e-6, skip_dc=dc)
+
+
+def test_fir_complex_taps_golden():
+    """tests/golden/fir_complex.npz: complex taps on a real signal (filter_helpers.py:364-371, 454-503)."""
+    meta, z = load_golden("fir_complex")
+    x = z["x"]
+    for i, c in enumerate(meta["cases"]):
+        b = z[f"b_{i}"]
+        ch = list(range(x.shape[1])) if c["channels"] is None else c["channels"]
+        ref = z[f"re_{i}"][:, ch] + 1j * z[f"im_{i}"][:, ch]
+        if c["zi"]:
+            zi = np.repeat(orc.lfilter_zi_fir(b)[:, None], len(ch), axis=1)
+            y, _ = orc.lfilter_fir(b, x[:, ch], zi=zi)
+        else:
+            y = orc.lfilter_fir(b, x[:, ch])
+        close(y, ref, tol=1e-12)
+
+
+def test_deconvolve_scaled_spectra_golden():
+    """tests/golden/deconv_scaled.npz: spectral_deconvolve where the signals carry a spectrum scaling
+    (only the method is forced to FFT: transfer_functions.py:142-143)."""
+    meta, z = load_golden("deconv_scaled")
+    for i, c in enumerate(meta["cases"]):
+        x, y = (z["x"], z["y"]) if c["regularized"] else (z["xn"], z["yn"])
+        xin = np.repeat(x, 2, axis=1) * np.array([1.0, 0.8]) if c["per_channel"] else x
+        ir = orc.spectral_deconvolve(y, xin, meta["fs"], apply_regularization=c["regularized"], padding=c["padding"],
+                                     keep_original_length=c["keep"], scaling_y=c["scaling_y"], scaling_x=c["scaling_x"])
+        close(ir, z[f"ir_{i}"], tol=1e-9)
 
 
 def test_welch4096_headline_shape_golden():
