@@ -72,6 +72,7 @@ SIGNATURES = {
                                 C.c_int, f32_p]),
     "ds_das_map_dev": (C.c_int, [ctx_p, c32_p, c32_p, C.c_int, C.c_int, C.c_int, f32_p]),
     "ds_das_map": (C.c_int, [ctx_p, c32_p, c32_p, C.c_int, C.c_int, C.c_int, f32_p]),
+    "ds_csm_das_prepare_dev": (C.c_int, [ctx_p, c32_p, C.c_int, C.c_int, C.c_double, C.c_int, c32_p]),
     "ds_istft_dev": (C.c_int, [ctx_p, c32_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                C.c_int, f32_p, C.c_float, i64, f32_p, i64]),
     "ds_istft": (C.c_int, [ctx_p, c32_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,

@@ -432,6 +432,75 @@ def _csm_welch(time_data, sampling_rate_hz: int, window_length_samples: int, win
     return np.fft.rfftfreq(W, 1 / sampling_rate_hz), out.astype(np.complex128)
 
 
+class DeviceCSM:
+    """A Welch cross-spectral matrix that stays in HBM: (bins, C, C) complex64 in `buf`, the frequency
+    vector on the host.  What `Signal.get_csm(on_device=True)` returns and the device delay-and-sum map
+    consumes (the reference's beamformers take `self.signal.get_csm()` and keep going,
+    beamforming/beamforming.py:838-876)."""
+
+    def __init__(self, ctx, buf, freqs_hz, n_ch: int):
+        self.ctx, self.buf, self.freqs_hz, self.n_ch = ctx, buf, freqs_hz, int(n_ch)
+        self.n_bins = len(freqs_hz)
+
+    def to_host(self) -> np.ndarray:
+        return self.buf.to_array((self.n_bins, self.n_ch, self.n_ch), np.complex64).astype(np.complex128)
+
+    def free(self):
+        self.buf.free()
+
+
+def _csm_welch_device(time_data, sampling_rate_hz: int, window_length_samples: int, window_type,
+                      overlap_percent, detrend: bool, average: str, scaling: SpectrumScaling) -> DeviceCSM:
+    """_csm_welch whose result stays on the device (ds_csm_dev) -> DeviceCSM."""
+    _welch_checks(window_length_samples, overlap_percent, average)
+    W = int(window_length_samples)
+    window = _window_array(window_type, W)
+    xp = _planar_f32(np.asarray(time_data))
+    n_ch, n = xp.shape
+    hop, n_frames = _welch_framing(n, W, overlap_percent, window)
+    amp, norm_scale, factor, phys = _finish_params(scaling, W, sampling_rate_hz, window)
+    B = W // 2 + 1
+    ctx = get_context()
+    d_x = DeviceBuffer.from_array(ctx, xp)
+    d_w = DeviceBuffer.from_array(ctx, window.astype(np.float32))
+    d_c = DeviceBuffer(ctx, B * n_ch * n_ch * 8)
+    try:
+        ctx.check(ctx.lib.ds_csm_dev(ctx.handle, C.c_void_p(d_x.ptr), n_ch, n, n, W, hop, n_frames,
+                                     C.c_void_p(d_w.ptr), int(bool(detrend)), DS_AVG[average], amp, norm_scale, factor,
+                                     phys, C.c_void_p(d_c.ptr)), "ds_csm_dev")
+        ctx.sync()
+    finally:
+        d_x.free()
+        d_w.free()
+    return DeviceCSM(ctx, d_c, np.fft.rfftfreq(W, 1 / sampling_rate_hz), n_ch)
+
+
+def _das_map_device(csm: DeviceCSM, id1: int, id2: int, h, remove_csm_diagonal: bool):
+    """Delay-and-sum map of the bins [id1, id2) of a device-resident CSM: the diagonal treatment
+    (beamforming.py:840-845) and Re(h^H csm h) (:853-858) on the device; only the steering vectors go up and
+    the (grid points, bins) map comes down.  h (bins, C, G) complex -> (G, bins) float64."""
+    hs = np.ascontiguousarray(h, dtype=np.complex64)
+    nb = id2 - id1
+    assert hs.ndim == 3 and hs.shape[0] == nb and hs.shape[1] == csm.n_ch, "steering vector must be (bins, C, grid points)"
+    n_grid = hs.shape[2]
+    ctx = csm.ctx
+    d_h = DeviceBuffer.from_array(ctx, hs)
+    d_s = DeviceBuffer(ctx, nb * csm.n_ch * csm.n_ch * 8)
+    d_m = DeviceBuffer(ctx, n_grid * nb * 4)
+    try:
+        src = csm.buf.ptr + id1 * csm.n_ch * csm.n_ch * 8
+        scale = csm.n_ch / (csm.n_ch - 1) if remove_csm_diagonal else 1.0
+        ctx.check(ctx.lib.ds_csm_das_prepare_dev(ctx.handle, C.c_void_p(src), nb, csm.n_ch, float(scale),
+                                                 int(bool(remove_csm_diagonal)), C.c_void_p(d_s.ptr)), "ds_csm_das_prepare_dev")
+        ctx.check(ctx.lib.ds_das_map_dev(ctx.handle, C.c_void_p(d_s.ptr), C.c_void_p(d_h.ptr), nb, csm.n_ch, n_grid,
+                                         C.c_void_p(d_m.ptr)), "ds_das_map_dev")
+        out = d_m.to_array((n_grid, nb), np.float32)
+    finally:
+        for d in (d_h, d_s, d_m):
+            d.free()
+    return out.astype(np.float64)
+
+
 def _csm_welch_bins(time_data, sampling_rate_hz: int, window_length_samples: int, window_type,
                     overlap_percent, detrend: bool, scaling: SpectrumScaling, bin_start: int,
                     bin_stop: int):

@@ -280,10 +280,19 @@ class Signal(MultichannelData):
             self.__spectrum_state_update = False
         return freqs, spectrum
 
-    def get_csm(self, force_computation=False):
-        """-> (freqs_hz, csm (bins, channels, channels))."""
+    def get_csm(self, force_computation=False, on_device: bool = False):
+        """-> (freqs_hz, csm (bins, channels, channels)).  on_device=True (an extension; Welch method only):
+        the matrix stays in HBM, csm is a backend.DeviceCSM handle for the device beamformer map."""
         assert self.number_of_channels > 1, (
             "Cross spectral matrix can only be computed when at least two channels are available")
+        if on_device:
+            assert self.spectrum_method == SpectrumMethod.WelchPeriodogram, \
+                "a device-resident CSM is built for the Welch method"
+            par = self._spectrum_parameters
+            dc = backend._csm_welch_device(self.time_data, self.sampling_rate_hz, par["window_length_samples"],
+                                           par["window_type"], par["overlap_percent"], par["detrend"],
+                                           par["average"], par["scaling"])
+            return dc.freqs_hz.copy(), dc
         if not (not hasattr(self, "csm") or force_computation or self.__csm_state_update):
             return self.csm[0].copy(), self.csm[1].copy()
         par = self._spectrum_parameters

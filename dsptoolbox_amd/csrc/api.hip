@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "../../include/dsptoolbox_amd.h"
+#include "host_marshal.hpp"
 #include "kernels_bigfft.hpp"
 #include "kernels_bluestein.hpp"
 #include "kernels_finish.hpp"
@@ -111,73 +112,26 @@ static const int64_t kMaxBigFft = (int64_t)1 << 24;  // four-step path (kernels_
 
 extern "C" int ds_version(void) { return 100; }
 
-// ---- host marshalling helpers (no device work) --------------------------------
-static int host_threads(int threads, int64_t work_items) {
-    if (threads <= 0) {
-        unsigned hc = std::thread::hardware_concurrency();
-        threads = (int)std::min<unsigned>(16u, hc ? hc : 1u);
-        if (const char* e = getenv("DSPTOOLBOX_AMD_HOST_THREADS")) threads = std::max(1, atoi(e));
-    }
-    // below ~1 M elements a thread start costs more than it saves
-    const int64_t by_work = std::max<int64_t>(1, work_items / (1 << 20));
-    return (int)std::min<int64_t>(threads, by_work);
-}
-template <typename F>
-static void host_parallel(int threads, int64_t n, F body) {  // body(begin, end) over [0, n)
-    if (threads <= 1) {
-        body((int64_t)0, n);
-        return;
-    }
-    std::vector<std::thread> pool;
-    const int64_t per = ((n + threads - 1) / threads + 255) & ~(int64_t)255;
-    for (int t = 0; t < threads; ++t) {
-        const int64_t b = (int64_t)t * per, e = std::min(n, b + per);
-        if (b >= e) break;
-        pool.emplace_back([=]() { body(b, e); });
-    }
-    for (auto& th : pool) th.join();
-}
+// ---- host marshalling helpers (no device work): csrc/host_marshal.hpp --------
+using dshost::host_parallel;
+using dshost::host_threads;
 extern "C" int ds_host_planar_f32(const double* src, int64_t n_samples, int n_ch, float* dst, int64_t ld,
                                   int threads) {
     if (!src || !dst || n_samples < 0 || n_ch <= 0 || ld < n_samples)
         return fail(nullptr, DS_ERR_ARG, "ds_host_planar_f32: bad argument");
-    host_parallel(host_threads(threads, n_samples * n_ch), n_samples, [=](int64_t b, int64_t e) {
-        constexpr int64_t TILE = 256;  // samples per tile: TILE x n_ch doubles stay in the cache
-        for (int64_t s0 = b; s0 < e; s0 += TILE) {
-            const int64_t s1 = std::min(e, s0 + TILE);
-            for (int c = 0; c < n_ch; ++c) {
-                float* __restrict__ d = dst + (int64_t)c * ld;
-                const double* __restrict__ s = src + c;
-                for (int64_t n = s0; n < s1; ++n) d[n] = (float)s[n * n_ch];
-            }
-        }
-    });
+    dshost::planar_f32(src, n_samples, n_ch, dst, ld, host_threads(threads, n_samples * n_ch));
     return DS_OK;
 }
 extern "C" int ds_host_widen_f64(const float* src, int64_t n, double* dst, int threads) {
     if (!src || !dst || n < 0) return fail(nullptr, DS_ERR_ARG, "ds_host_widen_f64: bad argument");
-    host_parallel(host_threads(threads, n), n, [=](int64_t b, int64_t e) {
-        const float* __restrict__ s = src;
-        double* __restrict__ d = dst;
-        for (int64_t i = b; i < e; ++i) d[i] = (double)s[i];
-    });
+    dshost::widen_f64(src, n, dst, host_threads(threads, n));
     return DS_OK;
 }
 extern "C" int ds_host_interleave_f64(const float* src, int64_t n_samples, int n_ch, int64_t ld, double* dst,
                                       int threads) {
     if (!src || !dst || n_samples < 0 || n_ch <= 0 || ld < n_samples)
         return fail(nullptr, DS_ERR_ARG, "ds_host_interleave_f64: bad argument");
-    host_parallel(host_threads(threads, n_samples * n_ch), n_samples, [=](int64_t b, int64_t e) {
-        constexpr int64_t TILE = 256;
-        for (int64_t s0 = b; s0 < e; s0 += TILE) {
-            const int64_t s1 = std::min(e, s0 + TILE);
-            for (int c = 0; c < n_ch; ++c) {
-                const float* __restrict__ s = src + (int64_t)c * ld;
-                double* __restrict__ d = dst + c;
-                for (int64_t n = s0; n < s1; ++n) d[n * n_ch] = (double)s[n];
-            }
-        }
-    });
+    dshost::interleave_f64(src, n_samples, n_ch, ld, dst, host_threads(threads, n_samples * n_ch));
     return DS_OK;
 }
 extern "C" int ds_max_fft_len(void) { return kMaxFft; }
@@ -1593,6 +1547,24 @@ extern "C" int ds_das_map_dev(ds_ctx* c, const ds_c32* csm, const ds_c32* h, int
     return DS_OK;
 }
 
+__global__ void k_csm_das_prepare(const float2* in, int64_t total, int n_ch, float scale, int zero_diag, float2* out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int64_t e = i % ((int64_t)n_ch * n_ch);
+    const bool diag = zero_diag && (e / n_ch == e % n_ch);
+    const float2 v = in[i];
+    out[i] = diag ? make_float2(0.f, 0.f) : make_float2(v.x * scale, v.y * scale);
+}
+extern "C" int ds_csm_das_prepare_dev(ds_ctx* c, const ds_c32* csm, int n_bins, int n_ch, double scale,
+                                      int zero_diagonal, ds_c32* out) {
+    if (!c || !csm || !out) return fail(c, DS_ERR_ARG, "ds_csm_das_prepare: null argument");
+    if (n_bins <= 0 || n_ch <= 0) return fail(c, DS_ERR_ARG, "ds_csm_das_prepare: bad shape");
+    const int64_t total = (int64_t)n_bins * n_ch * n_ch;
+    hipLaunchKernelGGL(k_csm_das_prepare, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, (const float2*)csm,
+                       total, n_ch, (float)scale, zero_diagonal, (float2*)out);
+    HIPCHK(c, hipGetLastError());
+    return DS_OK;
+}
 extern "C" int ds_das_map(ds_ctx* c, const ds_c32* csm, const ds_c32* h, int n_bins, int n_ch, int n_grid,
                           float* map) {
     if (!c || !csm || !h || !map) return fail(c, DS_ERR_ARG, "ds_das_map: null argument");
@@ -2342,118 +2314,73 @@ extern "C" int ds_istft(ds_ctx* c, const ds_c32* stft, int n_bins, int n_frames,
 // chunk k (a pageable hipMemcpy of the pre-cast array moves ~13 GB/s; this path is bound by the
 // threads' cast, ~35 GB/s of float64 input).
 static const size_t kPinBytes = (size_t)32 << 20;
+// The transport of the pipelines in host_marshal.hpp: asynchronous copies on the context's stream, one
+// event per pinned staging chunk.
+struct HipTransport {
+    ds_ctx* c;
+    hipError_t err = hipSuccess;
+    bool ok(hipError_t e) {
+        if (e != hipSuccess) err = e;
+        return e == hipSuccess;
+    }
+    bool mark(int b) {
+        if (!ok(hipEventRecord(c->pin_ev[b], c->stream))) return false;
+        c->pin_busy[b] = true;
+        return true;
+    }
+    bool wait(int b) {
+        if (c->pin_busy[b] && !ok(hipEventSynchronize(c->pin_ev[b]))) return false;
+        c->pin_busy[b] = false;
+        return true;
+    }
+    bool h2d_2d(float* dst, size_t dpitch, const float* src, size_t spitch, size_t width, size_t rows, int b) {
+        return ok(hipMemcpy2DAsync(dst, dpitch, src, spitch, width, rows, hipMemcpyHostToDevice, c->stream)) && mark(b);
+    }
+    bool d2h_2d(float* dst, size_t dpitch, const float* src, size_t spitch, size_t width, size_t rows, int b) {
+        return ok(hipMemcpy2DAsync(dst, dpitch, src, spitch, width, rows, hipMemcpyDeviceToHost, c->stream)) && mark(b);
+    }
+    bool d2h(float* dst, const float* src, size_t bytes, int b) {
+        return ok(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream)) && mark(b);
+    }
+};
+static int pin_ready(ds_ctx* c, bool drain) {
+    for (int i = 0; i < 2; ++i) {
+        if (!c->pin[i]) {
+            HIPCHK(c, hipHostMalloc(&c->pin[i], kPinBytes, hipHostMallocDefault));
+            HIPCHK(c, hipEventCreateWithFlags(&c->pin_ev[i], hipEventDisableTiming));
+        }
+        if (drain && c->pin_busy[i]) {
+            HIPCHK(c, hipEventSynchronize(c->pin_ev[i]));
+            c->pin_busy[i] = false;
+        }
+    }
+    return DS_OK;
+}
+static int pipe_result(ds_ctx* c, bool ok, const HipTransport& tr, const char* what) {
+    if (ok) return DS_OK;
+    if (tr.err != hipSuccess) return fail(c, DS_ERR_HIP, std::string(what) + ": " + hipGetErrorString(tr.err));
+    return fail(c, DS_ERR_UNSUP, std::string(what) + ": too many channels for the staging chunk");
+}
 static int upload_planar_f64(ds_ctx* c, const double* src, int64_t n_samples, int n_ch, float* dst_dev,
                              int64_t ld) {
-    for (int i = 0; i < 2; ++i) {
-        if (!c->pin[i]) {
-            HIPCHK(c, hipHostMalloc(&c->pin[i], kPinBytes, hipHostMallocDefault));
-            HIPCHK(c, hipEventCreateWithFlags(&c->pin_ev[i], hipEventDisableTiming));
-        }
-    }
-    int64_t cs = (int64_t)(kPinBytes / ((size_t)n_ch * sizeof(float))) & ~(int64_t)255;
-    if (cs < 256) return fail(c, DS_ERR_UNSUP, "upload_planar_f64: too many channels for the staging chunk");
-    int k = 0;
-    for (int64_t s0 = 0; s0 < n_samples; s0 += cs, ++k) {
-        const int b = k & 1;
-        const int64_t cn = std::min(cs, n_samples - s0);
-        if (c->pin_busy[b]) HIPCHK(c, hipEventSynchronize(c->pin_ev[b]));  // its previous DMA has finished
-        float* pin = (float*)c->pin[b];
-        const double* sp = src + s0 * n_ch;
-        host_parallel(host_threads(0, cn * n_ch), cn, [=](int64_t lo, int64_t hi) {
-            constexpr int64_t TILE = 256;
-            for (int64_t t0 = lo; t0 < hi; t0 += TILE) {
-                const int64_t t1 = std::min(hi, t0 + TILE);
-                for (int ch = 0; ch < n_ch; ++ch) {
-                    float* __restrict__ d = pin + (int64_t)ch * cn;
-                    const double* __restrict__ q = sp + ch;
-                    for (int64_t n = t0; n < t1; ++n) d[n] = (float)q[n * n_ch];
-                }
-            }
-        });
-        HIPCHK(c, hipMemcpy2DAsync(dst_dev + s0, (size_t)ld * sizeof(float), pin, (size_t)cn * sizeof(float),
-                                   (size_t)cn * sizeof(float), (size_t)n_ch, hipMemcpyHostToDevice, c->stream));
-        HIPCHK(c, hipEventRecord(c->pin_ev[b], c->stream));
-        c->pin_busy[b] = true;
-    }
-    return DS_OK;
+    CHK(pin_ready(c, false));
+    HipTransport tr{c};
+    float* pin[2] = {(float*)c->pin[0], (float*)c->pin[1]};
+    return pipe_result(c, dshost::upload_planar(tr, pin, kPinBytes, src, n_samples, n_ch, dst_dev, ld), tr, "upload_planar_f64");
 }
-
-// The way back: device float32 -> host float64, chunk by chunk through the two pinned buffers, the
-// asynchronous copy of chunk k+1 running while host threads widen chunk k.
-// (a) contiguous: dst[i] = (double)src[i] (complex64 -> complex128 is the same on 2 n floats)
 static int download_widen(ds_ctx* c, const float* src_dev, int64_t n, double* dst) {
-    for (int i = 0; i < 2; ++i) {
-        if (!c->pin[i]) {
-            HIPCHK(c, hipHostMalloc(&c->pin[i], kPinBytes, hipHostMallocDefault));
-            HIPCHK(c, hipEventCreateWithFlags(&c->pin_ev[i], hipEventDisableTiming));
-        }
-        if (c->pin_busy[i]) HIPCHK(c, hipEventSynchronize(c->pin_ev[i]));
-        c->pin_busy[i] = false;
-    }
-    const int64_t cs = (int64_t)(kPinBytes / sizeof(float));
-    const int64_t n_chunks = (n + cs - 1) / cs;
-    auto issue = [&](int64_t k) -> hipError_t {
-        const int64_t s0 = k * cs, cn = std::min(cs, n - s0);
-        hipError_t e = hipMemcpyAsync(c->pin[k & 1], src_dev + s0, (size_t)cn * sizeof(float), hipMemcpyDeviceToHost,
-                                      c->stream);
-        if (e != hipSuccess) return e;
-        return hipEventRecord(c->pin_ev[k & 1], c->stream);
-    };
-    if (n_chunks > 0) HIPCHK(c, issue(0));
-    for (int64_t k = 0; k < n_chunks; ++k) {
-        if (k + 1 < n_chunks) HIPCHK(c, issue(k + 1));
-        HIPCHK(c, hipEventSynchronize(c->pin_ev[k & 1]));
-        const int64_t s0 = k * cs, cn = std::min(cs, n - s0);
-        const float* pin = (const float*)c->pin[k & 1];
-        double* d = dst + s0;
-        host_parallel(host_threads(0, cn), cn, [=](int64_t lo, int64_t hi) {
-            for (int64_t i = lo; i < hi; ++i) d[i] = (double)pin[i];
-        });
-    }
-    return DS_OK;
+    CHK(pin_ready(c, true));
+    HipTransport tr{c};
+    float* pin[2] = {(float*)c->pin[0], (float*)c->pin[1]};
+    return pipe_result(c, dshost::download_widen(tr, pin, kPinBytes, src_dev, n, dst), tr, "download_widen");
 }
-// (b) planar device rows src[ch*ld + n] -> (samples, channels) float64 dst[n*n_ch + ch]
 static int download_interleave(ds_ctx* c, const float* src_dev, int64_t n_samples, int n_ch, int64_t ld,
                                double* dst) {
-    for (int i = 0; i < 2; ++i) {
-        if (!c->pin[i]) {
-            HIPCHK(c, hipHostMalloc(&c->pin[i], kPinBytes, hipHostMallocDefault));
-            HIPCHK(c, hipEventCreateWithFlags(&c->pin_ev[i], hipEventDisableTiming));
-        }
-        if (c->pin_busy[i]) HIPCHK(c, hipEventSynchronize(c->pin_ev[i]));
-        c->pin_busy[i] = false;
-    }
-    const int64_t cs = (int64_t)(kPinBytes / ((size_t)n_ch * sizeof(float))) & ~(int64_t)255;
-    if (cs < 256) return fail(c, DS_ERR_UNSUP, "download_interleave: too many channels for the staging chunk");
-    const int64_t n_chunks = (n_samples + cs - 1) / cs;
-    auto issue = [&](int64_t k) -> hipError_t {
-        const int64_t s0 = k * cs, cn = std::min(cs, n_samples - s0);
-        hipError_t e = hipMemcpy2DAsync(c->pin[k & 1], (size_t)cn * sizeof(float), src_dev + s0,
-                                        (size_t)ld * sizeof(float), (size_t)cn * sizeof(float), (size_t)n_ch,
-                                        hipMemcpyDeviceToHost, c->stream);
-        if (e != hipSuccess) return e;
-        return hipEventRecord(c->pin_ev[k & 1], c->stream);
-    };
-    if (n_chunks > 0) HIPCHK(c, issue(0));
-    for (int64_t k = 0; k < n_chunks; ++k) {
-        if (k + 1 < n_chunks) HIPCHK(c, issue(k + 1));
-        HIPCHK(c, hipEventSynchronize(c->pin_ev[k & 1]));
-        const int64_t s0 = k * cs, cn = std::min(cs, n_samples - s0);
-        const float* pin = (const float*)c->pin[k & 1];
-        double* d0 = dst + s0 * n_ch;
-        host_parallel(host_threads(0, cn * n_ch), cn, [=](int64_t lo, int64_t hi) {
-            constexpr int64_t TILE = 256;
-            for (int64_t t0 = lo; t0 < hi; t0 += TILE) {
-                const int64_t t1 = std::min(hi, t0 + TILE);
-                for (int ch = 0; ch < n_ch; ++ch) {
-                    const float* __restrict__ q = pin + (int64_t)ch * cn;
-                    double* __restrict__ d = d0 + ch;
-                    for (int64_t i = t0; i < t1; ++i) d[i * n_ch] = (double)q[i];
-                }
-            }
-        });
-    }
-    return DS_OK;
+    CHK(pin_ready(c, true));
+    HipTransport tr{c};
+    float* pin[2] = {(float*)c->pin[0], (float*)c->pin[1]};
+    return pipe_result(c, dshost::download_interleave(tr, pin, kPinBytes, src_dev, n_samples, n_ch, ld, dst), tr,
+                       "download_interleave");
 }
 
 // ds_stft_r2c with the reference's layouts on both sides: x (n_samples, n_ch) float64 C-order in,

@@ -197,6 +197,12 @@ int ds_das_map_dev(ds_ctx* ctx, const ds_c32* csm_dev, const ds_c32* h_dev, int 
                    int n_grid, float* map_dev);
 int ds_das_map(ds_ctx* ctx, const ds_c32* csm, const ds_c32* h, int n_bins, int n_ch, int n_grid,
                float* map);
+/* The diagonal treatment in front of the map, on the device (beamforming.py:840-845:
+ * `csm *= C / (C - 1)` then `np.fill_diagonal(csm[i], 0)` for every bin): out = scale * csm, the
+ * diagonal zeroed when zero_diagonal != 0.  csm_dev / out_dev [n_bins][n_ch][n_ch]; out_dev may be
+ * csm_dev.  Lets a CSM that ds_csm_dev left in HBM feed ds_das_map_dev without a host round trip.  */
+int ds_csm_das_prepare_dev(ds_ctx* ctx, const ds_c32* csm_dev, int n_bins, int n_ch, double scale,
+                           int zero_diagonal, ds_c32* out_dev);
 
 /* ---- inverse STFT: replaces transforms.istft, transforms/transforms.py:444-586
  * (np.fft.irfft of every frame + _reconstruct_framed_signal,

@@ -270,6 +270,41 @@ def gen_das(dsp):
     save("das", dict(cases=cases, fs=fs, n_mics=n_mics), arrs)
 
 
+def gen_das_signal(dsp):
+    """BeamformerDASFrequency end to end FROM THE MICROPHONE SIGNALS (beamforming.py:799-880): the signals
+    (float32 values), the steering vectors the reference built for the selected bins, the final maps --
+    for the device chain Signal.get_csm(on_device=True) -> diagonal treatment -> map."""
+    from dsptoolbox.helpers.other import (_get_fractional_octave_bandwidth,
+                                          find_nearest_points_index_in_vector)
+    fs = 10_000
+    rng = np.random.default_rng(31)
+    n_mics = 12
+    pts = dict(x=rng.uniform(-0.3, 0.3, n_mics), y=rng.uniform(-0.3, 0.3, n_mics), z=np.zeros(n_mics))
+    ma = dsp.beamforming.MicArray(pts)
+    src = dsp.Signal(None, rng.standard_normal(20_000) * 0.3, fs)
+    s0 = dsp.beamforming.MonopoleSource(src, [0.05, 0.3, 0.5]).get_signals_on_array(ma)
+    td = s0.time_data.astype(np.float32)
+    s = dsp.Signal(None, td.astype(np.float64), fs)
+    s.set_spectrum_parameters(window_length_samples=512)
+    g = dsp.beamforming.Regular2DGrid(np.arange(-0.3, 0.3, 0.05), np.arange(-0.5, 0.5, 0.05), ["x", "y"], value3=0.5)
+    cases, arrs = [], {"time_data": td}
+    f_all, _ = s.get_csm()
+    for i, (form, fc, frac, rm) in enumerate((("TrueLocation", 2000.0, 3, True), ("Classic", 1500.0, 0, False))):
+        st = dsp.beamforming.SteeringVector(formulation=dsp.beamforming.SteeringVectorType[form])
+        bf = dsp.beamforming.BeamformerDASFrequency(s, ma, g, st)
+        m = bf.get_beamformer_map(fc, frac, remove_csm_diagonal=rm)
+        ids = find_nearest_points_index_in_vector(_get_fractional_octave_bandwidth(fc, frac), f_all)
+        id1, id2 = int(ids[0]), int(ids[1])
+        if id1 == id2:
+            id2 += 1
+        f = f_all[id1:id2]
+        arrs[f"h_{i}"] = st.get_vector(f * np.pi * 2 / bf.c, grid=g, mic=ma).astype(np.complex64)
+        arrs[f"map_{i}"] = m
+        cases.append(dict(formulation=form, center_hz=fc, octave_fraction=frac, remove_csm_diagonal=rm,
+                          bins=[id1, id2], grid_shape=list(m.shape), n_points=int(g.number_of_points)))
+    save("das_signal", dict(cases=cases, fs=fs, n_mics=n_mics, window=512), arrs)
+
+
 def gen_mel(dsp):
     """transforms.log_mel_spectrogram / mfcc / mel_filterbank (transforms/transforms.py:113-441),
     generate_plot=False."""
@@ -597,6 +632,10 @@ def main():
         import warnings
         warnings.simplefilter("ignore")
         return gen_istft_anylen(dsp)
+    if "--only-das-signal" in sys.argv:
+        import warnings
+        warnings.simplefilter("ignore")
+        return gen_das_signal(dsp)
     if "--only-welch4096" in sys.argv:
         return gen_welch4096(dsp)
     if "--only-welch-long" in sys.argv:
@@ -911,6 +950,7 @@ def main():
     gen_welch4096(dsp)
     gen_deconv_scaled(dsp)
     gen_fir_complex(dsp)
+    gen_das_signal(dsp)
     gen_csm_coherent(dsp)
     gen_stft_manych(dsp)
     gen_fir_state(dsp)

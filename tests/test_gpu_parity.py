@@ -353,6 +353,41 @@ def test_welch_long_windows_golden():
             assert relmax(tf, rt, dc) < 2 * TOL and relmax(coh[bins], rc, dc) < 2 * TOL, (c["W"], key)
 
 
+def test_das_beamformer_device_chain_golden():
+    """BeamformerDASFrequency.get_beamformer_map end to end from the microphone signals (missing 3):
+    Signal.get_csm(on_device=True) keeps the cross-spectral matrix in HBM, ds_csm_das_prepare_dev treats the
+    diagonal there, ds_das_map_dev forms the map; tests/golden/das_signal.npz is the reference's own map."""
+    from dsptoolbox_amd.beamforming import BeamformerDASFrequency
+    meta, z = load_golden("das_signal")
+    s = dsp.Signal(None, z["time_data"].astype(np.float64), meta["fs"])
+    s.set_spectrum_parameters(window_length_samples=meta["window"])
+
+    class Grid:  # the reference's geometry classes stay the reference's: stand-ins with its interface
+        def __init__(self, n, shape):
+            self.number_of_points, self.shape = n, shape
+
+        def reconstruct_map_shape(self, m):
+            return np.asarray(m).reshape(self.shape)  # Regular2DGrid: row-major over (x, y)
+
+    for i, c in enumerate(meta["cases"]):
+        class Steering:
+            def get_vector(self, wave_numbers, grid, mic, _h=z[f"h_{i}"], _n=c["bins"][1] - c["bins"][0]):
+                assert len(wave_numbers) == _n  # the same bins as the reference selected
+                return _h
+
+        bf = BeamformerDASFrequency(s, None, Grid(c["n_points"], c["grid_shape"]), Steering())
+        m = bf.get_beamformer_map(c["center_hz"], c["octave_fraction"], remove_csm_diagonal=c["remove_csm_diagonal"])
+        ref = z[f"map_{i}"]
+        # (the reference reshapes with its own grid class; compare as flat maps in either order)
+        e = min(relmax(m.ravel(), ref.ravel()), relmax(m.ravel(), ref.T.ravel()))
+        assert m.size == ref.size and e < 2 * TOL, (c, e)
+    # the handle by itself: device matrix == host matrix
+    f, dc = s.get_csm(on_device=True)
+    f2, csm = s.get_csm()
+    assert np.array_equal(f, f2) and relmax(dc.to_host(), csm) < TOL
+    dc.free()
+
+
 def test_fir_complex_taps_golden():
     """Filter.filter_signal with complex taps (missing 5): two real device convolutions, the
     imaginary part of the output lands in Signal.time_data_imaginary (filter_helpers.py:364-371)."""
