@@ -42,6 +42,13 @@ MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense, MI355X_MICROARCH.md
 
 FS = 48000
 
+# bench kernel name (ds_profile_*) -> how rocprofv3's kernel trace names the same kernel
+KERNEL_HINTS = {"welch4096_fused": ("welch4096::k_h1f",), "welch4096_main": ("welch4096::k_y3<", "welch4096::k_y<"),
+                "welch1024_main": ("welch1k::k_y<",), "welch_yacc": ("k_yacc",),
+                "fir": ("fir4k::k_fir<", "fir16k::k_fir<true>", "fir16k::k_fir", "k_fir<"),
+                "csm_gemm": ("k_csm_fused", "k_csm_gemm"), "stft": ("k_stft_wave", "k_stft"),
+                "deconv": ("k_deconv3", "k_deconv")}
+
 
 def parse_args():
     ap = argparse.ArgumentParser()
@@ -622,9 +629,7 @@ def main():
         achieved = alg_launch / (dom_ms * 1e-3) / 1e12
         roof = dict(bound="mfma", achieved=achieved, peak=MFMA_F32_PEAK_TFLOPS, unit="TFLOP/s",
                     frac=achieved / MFMA_F32_PEAK_TFLOPS, traffic=None)
-    hints = {"welch4096_fused": ("welch4096::k_h1f",), "welch4096_main": ("welch4096::k_y3<", "welch4096::k_y<"), "welch1024_main": ("welch1k::k_y<",),
-             "welch_yacc": ("k_yacc",), "fir": ("fir16k::k_fir<true>", "fir16k::k_fir", "k_fir<"),
-             "csm_gemm": ("k_csm_fused", "k_csm_gemm"), "deconv": ("k_deconv",)}.get(dom, (dom,))
+    hints = KERNEL_HINTS.get(dom, (dom,))
     pmc, src = pmc_summary(args.workload, hints)
     if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
         # KiB, separate --pmc passes; on gfx950 FETCH_SIZE counts half of a coalesced streaming

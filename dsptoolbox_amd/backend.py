@@ -167,11 +167,15 @@ def _welch(x, y, fs_hz: int, window_type, window_length_samples: int, overlap_pe
 # (transfer_functions.compute_transfer_function): "auto" takes the float64 route
 # (ds_welch_tf_x64: float64 transforms, sums and finish, the reference's own precision) when the
 # problem is small -- frame spectra of all channels <= 64 MB, window <= 8192 (median averaging: at
-# most 4096 frames) --
+# most 4096 frames) -- or when it is SHORT: fewer than 128 frames (and <= 1 GB of frame spectra), where
+# an fp32 estimate has too few frames to average its transform rounding down (the two sweep cases of
+# round 2 that reached 1.1e-6 / 1.8e-6 in the coherence had 98 and 110 frames of 8192 samples: they are
+# tests now) --
 # and the fp32 kernels otherwise; "f32" / "f64" force one.  Environment:
 # DSPTOOLBOX_AMD_TF_PRECISION.  backend.welch_transfer_function itself defaults to "f32".
 TF_PRECISION = os.environ.get("DSPTOOLBOX_AMD_TF_PRECISION", "auto")
 _X64_AUTO_BYTES = 64 << 20
+_X64_SHORT_BYTES = 1 << 30
 
 
 def _tf_x64_applies(precision, n_cx: int, n_cy: int, n_frames: int, W: int, average: str) -> bool:
@@ -181,7 +185,8 @@ def _tf_x64_applies(precision, n_cx: int, n_cy: int, n_frames: int, W: int, aver
             raise NotImplementedError("the float64 route covers windows up to 8192 (median: up to 4096 frames)")
         return True
     if precision == "auto":
-        return ok and (n_cx + n_cy) * n_frames * (W // 2 + 1) * 16 <= _X64_AUTO_BYTES
+        nbytes = (n_cx + n_cy) * n_frames * (W // 2 + 1) * 16
+        return ok and (nbytes <= _X64_AUTO_BYTES or (n_frames < 128 and nbytes <= _X64_SHORT_BYTES))
     assert precision in (None, "f32"), "precision: 'f32', 'f64' or 'auto'"
     return False
 

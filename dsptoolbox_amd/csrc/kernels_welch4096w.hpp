@@ -27,7 +27,7 @@ namespace welch4096 {
 // dev only (-DW4_TIMING=1): per-phase s_memtime stamps of workgroup 0 / lane 0 -> w3_timing[]
 #if W4_TIMING
 __device__ unsigned long long w3_timing[16];
-__device__ unsigned long long w3_life[4096][6];  // per workgroup: memtime start/end, memrealtime start/end
+__device__ unsigned long long w3_life[4096][8];  // per workgroup: memtime start/end, memrealtime start/end, loop start/end, HW_ID, XCC_ID
 struct Stamp {
     unsigned long long ph[12] = {}, prev = 0;
     __device__ __forceinline__ void operator()(int i) {
@@ -624,6 +624,8 @@ __global__ __launch_bounds__(NT, W4_OCC) void k_y3(Args p) {
         w3_life[blockIdx.x][3] = __builtin_amdgcn_s_memrealtime();
         w3_life[blockIdx.x][4] = life_r1;
         w3_life[blockIdx.x][5] = life_r2;
+        w3_life[blockIdx.x][6] = __builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11));   // HW_REG_HW_ID
+        w3_life[blockIdx.x][7] = __builtin_amdgcn_s_getreg((20) | (0 << 6) | (31 << 11));  // HW_REG_XCC_ID
     }
 #endif
 }

@@ -10,21 +10,13 @@ from dsptoolbox_amd import backend  # noqa: E402
 from dsptoolbox_amd.standard.enums import SpectrumScaling, Window  # noqa: E402
 from oracle import dsp_oracle as orc  # noqa: E402
 
-n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
-rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 scalings = list(SpectrumScaling)
-worst = {}
-fails = []
 
 
-def relmax(a, b, skip_dc=False):
-    a, b = np.asarray(a), np.asarray(b)
-    if skip_dc:
-        a, b = a[1:], b[1:]
-    return float(np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-300))
-
-
-for it in range(n_cases):
+def draw_case(rng, data: bool = True):
+    """One random case, consuming `rng` exactly as this sweep always has (so that a case of an earlier
+    run can be drawn again from its seed and position: tests/test_gpu_parity.py promotes two of them).
+    data=False: the same draws, without the convolutions (for searching a seed)."""
     kind = rng.choice(["tf", "tf_paired", "csd", "psd", "stft", "csm"])
     W = int(rng.choice([256, 512, 1024, 2048, 4096, 8192, 16384] if kind in ("tf", "tf_paired", "csd", "psd")
                        else [256, 512, 1024, 2048]))
@@ -41,67 +33,94 @@ for it in range(n_cases):
     sc = scalings[int(rng.integers(0, len(scalings)))]
     x = rng.standard_normal((n, 1)) * 0.3 + 0.05
     h = rng.standard_normal((32, n_ch)) * np.exp(-np.arange(32) / 6.0)[:, None]
-    y = np.stack([np.convolve(x[:, 0], h[:, c])[:n] for c in range(n_ch)], axis=1) + 0.05 * rng.standard_normal((n, n_ch))
-    try:
-        if kind == "tf":
-            mode = str(rng.choice(["H1", "H2", "H3"]))
-            tf, coh = backend.welch_transfer_function(y, x, 48000, W, mode, overlap_percent=ov, detrend=det, scaling=sc)
-            rt, rc = orc.compute_transfer_function_batched(y, x, 48000, W, mode, overlap_percent=ov, detrend=det,
-                                                           scaling=sc.name)
-            if mode == "H2":  # Gyy / Gyx: dividing by a nearly cancelled cross spectrum where the coherence
-                good = rc > 0.1  # vanishes (nulls of the random test responses) is noise in float64 too
-                tf = np.where(good, tf, rt)
-            e_tf, e_coh = relmax(tf, rt, det), relmax(coh, rc, det)
-            e = max(e_tf, e_coh)
-            if e > 1e-6:
-                d = np.abs(np.asarray(tf) - rt)[1 if det else 0:]
-                b, c_ = np.unravel_index(np.argmax(d), d.shape)
-                print(f"  tf case W={W} n={n} ch={n_ch} ov={ov} det={det} {sc.name} mode={mode}: e_tf={e_tf:.2e} e_coh={e_coh:.2e} "
-                      f"worst bin {b + (1 if det else 0)} ch {c_} |ref|={abs(rt[b + (1 if det else 0), c_]):.3e} max|ref|={np.max(np.abs(rt)):.3e} "
-                      f"coh_ref there={rc[b + (1 if det else 0), c_]:.6f}")
-        elif kind in ("tf_paired", "csd"):
-            # one input channel per output channel: y_c = h_c * x_c + noise
-            xs = rng.standard_normal((n, n_ch)) * 0.3 + 0.05
-            ys = np.stack([np.convolve(xs[:, c], h[:, c])[:n] for c in range(n_ch)], axis=1) + 0.05 * rng.standard_normal((n, n_ch))
-            if kind == "csd":
-                k = backend._welch(xs, ys, 48000, Window.Hann, W, ov, det, "mean", sc)
-                r = orc.welch(xs, ys, 48000, "hann", W, ov, det, "mean", sc.name)
-                e = relmax(k, r, det)
-            else:
-                mode = str(rng.choice(["H1", "H2", "H3"]))
-                tf, coh = backend.welch_transfer_function(ys, xs, 48000, W, mode, overlap_percent=ov, detrend=det, scaling=sc)
-                rt, rc = orc.compute_transfer_function(ys, xs, 48000, W, mode, overlap_percent=ov, detrend=det, scaling=sc.name)
-                if mode == "H2":
-                    tf = np.where(rc > 0.1, tf, rt)
+    noise = rng.standard_normal((n, n_ch))
+    y = (np.stack([np.convolve(x[:, 0], h[:, c])[:n] for c in range(n_ch)], axis=1) + 0.05 * noise) if data else None
+    case = dict(kind=str(kind), W=W, ov=ov, n=n, n_ch=n_ch, det=det, sc=sc, x=x, y=y, h=h)
+    if kind == "tf":
+        case["mode"] = str(rng.choice(["H1", "H2", "H3"]))
+    elif kind in ("tf_paired", "csd"):
+        xs = rng.standard_normal((n, n_ch)) * 0.3 + 0.05
+        noise2 = rng.standard_normal((n, n_ch))
+        case["xs"] = xs
+        case["ys"] = (np.stack([np.convolve(xs[:, c], h[:, c])[:n] for c in range(n_ch)], axis=1) + 0.05 * noise2) if data else None
+        if kind == "tf_paired":
+            case["mode"] = str(rng.choice(["H1", "H2", "H3"]))
+    elif kind == "stft":
+        case["pad"] = bool(rng.integers(0, 2))
+    return case
+
+
+def main():
+    n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+    worst = {}
+    fails = []
+    for it in range(n_cases):
+        cs = draw_case(rng)
+        kind, W, ov, n, n_ch, det, sc, x, y = (cs[k] for k in ("kind", "W", "ov", "n", "n_ch", "det", "sc", "x", "y"))
+        try:
+            if kind == "tf":
+                mode = cs["mode"]
+                tf, coh = backend.welch_transfer_function(y, x, 48000, W, mode, overlap_percent=ov, detrend=det, scaling=sc)
+                rt, rc = orc.compute_transfer_function_batched(y, x, 48000, W, mode, overlap_percent=ov, detrend=det,
+                                                               scaling=sc.name)
+                if mode == "H2":  # Gyy / Gyx: dividing by a nearly cancelled cross spectrum where the coherence
+                    good = rc > 0.1  # vanishes (nulls of the random test responses) is noise in float64 too
+                    tf = np.where(good, tf, rt)
                 e_tf, e_coh = relmax(tf, rt, det), relmax(coh, rc, det)
                 e = max(e_tf, e_coh)
                 if e > 1e-6:
-                    lo = 1 if det else 0
-                    d = (np.abs(np.asarray(tf) - rt) if e_tf >= e_coh else np.abs(np.asarray(coh) - rc))[lo:]
+                    d = np.abs(np.asarray(tf) - rt)[1 if det else 0:]
                     b, c_ = np.unravel_index(np.argmax(d), d.shape)
-                    print(f"  tf_paired case W={W} n={n} ch={n_ch} ov={ov} det={det} {sc.name} mode={mode}: e_tf={e_tf:.2e} "
-                          f"e_coh={e_coh:.2e} worst bin {b + lo} ch {c_} coh_ref there={rc[b + lo, c_]:.6f}")
-        elif kind == "psd":
-            a = backend._welch(y, None, 48000, Window.Hann, W, ov, det, "mean", sc)
-            r = orc.welch(y, None, 48000, "hann", W, ov, det, "mean", sc.name)
-            e = relmax(a, r, det)
-        elif kind == "stft":
-            pad = bool(rng.integers(0, 2))
-            t, f, st = backend._stft(y, 48000, W, Window.Hann, ov, None, det, pad, sc)
-            rt_, rf_, rs = orc.stft(y, 48000, W, "hann", ov, None, det, pad, sc.name)
-            assert st.shape == rs.shape
-            e = relmax(st, rs)
-        else:
-            f, c = backend._csm_welch(y, 48000, W, Window.Hann, ov, det, "mean", sc)
-            rf, rcm = orc.csm_welch(y, 48000, W, "hann", ov, det, "mean", sc.name)
-            e = relmax(c, rcm)
-    except Exception as ex:  # noqa: BLE001
-        fails.append((kind, W, n, n_ch, ov, det, sc.name, repr(ex)[:200]))
-        continue
-    worst[kind] = max(worst.get(kind, 0.0), e)
-    if not np.isfinite(e) or e > 1e-6:
-        fails.append((kind, W, n, n_ch, ov, det, sc.name, e))
-print("worst", worst)
-print("failures", len(fails))
-for f in fails[:20]:
-    print("  ", f)
+                    print(f"  tf case #{it} W={W} n={n} ch={n_ch} ov={ov} det={det} {sc.name} mode={mode}: e_tf={e_tf:.2e} e_coh={e_coh:.2e} "
+                          f"worst bin {b + (1 if det else 0)} ch {c_} |ref|={abs(rt[b + (1 if det else 0), c_]):.3e} max|ref|={np.max(np.abs(rt)):.3e} "
+                          f"coh_ref there={rc[b + (1 if det else 0), c_]:.6f}")
+            elif kind in ("tf_paired", "csd"):
+                # one input channel per output channel: y_c = h_c * x_c + noise
+                xs, ys = cs["xs"], cs["ys"]
+                if kind == "csd":
+                    k = backend._welch(xs, ys, 48000, Window.Hann, W, ov, det, "mean", sc)
+                    r = orc.welch(xs, ys, 48000, "hann", W, ov, det, "mean", sc.name)
+                    e = relmax(k, r, det)
+                else:
+                    mode = cs["mode"]
+                    tf, coh = backend.welch_transfer_function(ys, xs, 48000, W, mode, overlap_percent=ov, detrend=det, scaling=sc)
+                    rt, rc = orc.compute_transfer_function(ys, xs, 48000, W, mode, overlap_percent=ov, detrend=det, scaling=sc.name)
+                    if mode == "H2":
+                        tf = np.where(rc > 0.1, tf, rt)
+                    e_tf, e_coh = relmax(tf, rt, det), relmax(coh, rc, det)
+                    e = max(e_tf, e_coh)
+                    if e > 1e-6:
+                        lo = 1 if det else 0
+                        d = (np.abs(np.asarray(tf) - rt) if e_tf >= e_coh else np.abs(np.asarray(coh) - rc))[lo:]
+                        b, c_ = np.unravel_index(np.argmax(d), d.shape)
+                        print(f"  tf_paired case #{it} W={W} n={n} ch={n_ch} ov={ov} det={det} {sc.name} mode={mode}: e_tf={e_tf:.2e} "
+                              f"e_coh={e_coh:.2e} worst bin {b + lo} ch {c_} coh_ref there={rc[b + lo, c_]:.6f}")
+            elif kind == "psd":
+                a = backend._welch(y, None, 48000, Window.Hann, W, ov, det, "mean", sc)
+                r = orc.welch(y, None, 48000, "hann", W, ov, det, "mean", sc.name)
+                e = relmax(a, r, det)
+            elif kind == "stft":
+                pad = cs["pad"]
+                t, f, st = backend._stft(y, 48000, W, Window.Hann, ov, None, det, pad, sc)
+                rt_, rf_, rs = orc.stft(y, 48000, W, "hann", ov, None, det, pad, sc.name)
+                assert st.shape == rs.shape
+                e = relmax(st, rs)
+            else:
+                f, c = backend._csm_welch(y, 48000, W, Window.Hann, ov, det, "mean", sc)
+                rf, rcm = orc.csm_welch(y, 48000, W, "hann", ov, det, "mean", sc.name)
+                e = relmax(c, rcm)
+        except Exception as ex:  # noqa: BLE001
+            fails.append((kind, W, n, n_ch, ov, det, sc.name, repr(ex)[:200]))
+            continue
+        worst[kind] = max(worst.get(kind, 0.0), e)
+        if not np.isfinite(e) or e > 1e-6:
+            fails.append((kind, W, n, n_ch, ov, det, sc.name, e))
+    print("worst", worst)
+    print("failures", len(fails))
+    for f in fails[:20]:
+        print("  ", f)
+
+
+if __name__ == "__main__":
+    main()

@@ -237,3 +237,26 @@ def test_tcp_rendezvous_rejects_strangers():
     assert q.get(timeout=30) == [b"zero", b"one"]
     srv.join(timeout=30)
     assert srv.exitcode == 0
+
+
+@pytest.mark.timeout(300)
+def test_bench_gpus_without_launcher_never_reports_one_gpu():
+    """`python bench.py --gpus N` with no launcher environment starts N ranks itself
+    (torch.distributed.run children of a process that has not touched the GPU); a launcher environment of
+    another size is refused.  Here (no GPU) the children fail -- what matters: no JSON line with n_gpus 1 is
+    ever printed for --gpus 2, and the exit status is non-zero."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    bench = os.path.join(ROOT, "bench.py")
+    r = subprocess.run([sys.executable, bench, "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=280, env=env, cwd=ROOT)
+    assert "starting 2 ranks" in r.stderr, r.stderr[-2000:]
+    assert '"n_gpus": 1' not in r.stdout
+    import torch
+    if not torch.cuda.is_available():
+        assert r.returncode != 0
+    # a launcher that made ONE rank while --gpus says 2: refused before anything is measured
+    env1 = dict(env, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    r1 = subprocess.run([sys.executable, bench, "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"],
+                        capture_output=True, text=True, timeout=200, env=env1, cwd=ROOT)
+    assert r1.returncode == 2 and "refusing" in r1.stderr and '"n_gpus"' not in r1.stdout, (r1.returncode, r1.stderr[-1000:])

@@ -353,6 +353,37 @@ def test_welch_long_windows_golden():
             assert relmax(tf, rt, dc) < 2 * TOL and relmax(coh[bins], rc, dc) < 2 * TOL, (c["W"], key)
 
 
+@pytest.mark.parametrize("case", [
+    dict(W=8192, n=199273, n_ch=16, ov=75.0, det=True, sc="AmplitudeSpectralDensity", mode="H3", seed=8192),
+    dict(W=8192, n=674937, n_ch=33, ov=25.0, det=False, sc="AmplitudeSpectrum", mode="H3", seed=8193),
+])
+def test_short_long_window_estimates_from_the_round2_sweep(case):
+    """The two shapes of gpurun_out/sweeps_r02.log whose coherence reached 1.8e-6 / 1.1e-6 on the fp32 kernels
+    (VERDICT r2, next 3c): 8192-sample windows, 98 / 110 frames, overlaps other than 50 %, amplitude scalings.
+    An estimate this short has too few frames to average the fp32 transform rounding down -- across such cases
+    the fp32 kernels' worst coherence error is 3-5e-7 (tools/dev/coh_margin.py: a third of what a float32 numpy
+    restatement reaches) with a tail to ~2e-6.  The API's "auto" arithmetic now sends estimates of fewer than
+    128 frames through the float64 route: asserted at 1e-6 here, with the fp32 kernels held to 3e-6."""
+    import sys as _sys
+    _sys.path.insert(0, os.path.join(ROOT, "tests", "sweeps"))
+    rng = np.random.default_rng(case["seed"])
+    n, n_ch = case["n"], case["n_ch"]
+    x = rng.standard_normal((n, 1)) * 0.3 + 0.05
+    h = rng.standard_normal((32, n_ch)) * np.exp(-np.arange(32) / 6.0)[:, None]
+    y = np.stack([np.convolve(x[:, 0], h[:, c])[:n] for c in range(n_ch)], axis=1) + 0.05 * rng.standard_normal((n, n_ch))
+    sc = SpectrumScaling[case["sc"]]
+    rt, rc = orc.compute_transfer_function_batched(y, x, 48000, case["W"], case["mode"], overlap_percent=case["ov"],
+                                                   detrend=case["det"], scaling=sc.name)
+    for precision, tol in (("auto", TOL), ("f32", 3e-6)):
+        tf, coh = backend.welch_transfer_function(y, x, 48000, case["W"], case["mode"], overlap_percent=case["ov"],
+                                                  detrend=case["det"], scaling=sc, precision=precision)
+        e_tf, e_coh = relmax(tf, rt, case["det"]), relmax(coh, rc, case["det"])
+        print(f"W={case['W']} n={n} {precision}: tf {e_tf:.2e} coherence {e_coh:.2e}")
+        assert e_tf < tol and e_coh < tol, (precision, e_tf, e_coh)
+    hop = case["W"] - int(case["ov"] / 100 * case["W"])
+    assert backend._tf_x64_applies("auto", 1, n_ch, -(-n // hop), case["W"], "mean")
+
+
 def test_das_beamformer_device_chain_golden():
     """BeamformerDASFrequency.get_beamformer_map end to end from the microphone signals (missing 3):
     Signal.get_csm(on_device=True) keeps the cross-spectral matrix in HBM, ds_csm_das_prepare_dev treats the

@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <random>
+#include <map>
 #include <vector>
 
 #include "../../dsptoolbox_amd/csrc/kernels_welch4096w.hpp"
@@ -164,20 +165,20 @@ int main(int argc, char** argv) {
     for (int i = 0; i < 11; ++i) printf("  %-52s %8.0f %5.1f %%\n", names[i], (double)tm[i] / tm[15], 100.0 * tm[i] / tot);
     {
         const int nb = new_chunks * n_ch;
-        std::vector<unsigned long long> life((size_t)4096 * 6);
+        std::vector<unsigned long long> life((size_t)4096 * 8);
         CK(hipMemcpyFromSymbol(life.data(), HIP_SYMBOL(w4::w3_life), life.size() * 8));
         unsigned long long r_min = ~0ull, r_max = 0;
         for (int b = 0; b < nb; ++b) {
-            r_min = std::min(r_min, life[6 * b + 2]);
-            r_max = std::max(r_max, life[6 * b + 3]);
+            r_min = std::min(r_min, life[8 * b + 2]);
+            r_max = std::max(r_max, life[8 * b + 3]);
         }
         double cyc = 0, rt = 0;
         int late = 0;
         std::vector<double> starts;
         for (int b = 0; b < nb; ++b) {
-            cyc += (double)(life[6 * b + 1] - life[6 * b]);
-            rt += (double)(life[6 * b + 3] - life[6 * b + 2]);
-            const double st_us = (double)(life[6 * b + 2] - r_min) / 100.0;
+            cyc += (double)(life[8 * b + 1] - life[8 * b]);
+            rt += (double)(life[8 * b + 3] - life[8 * b + 2]);
+            const double st_us = (double)(life[8 * b + 2] - r_min) / 100.0;
             if (st_us > 5.0) ++late;
             starts.push_back(st_us);
         }
@@ -185,10 +186,10 @@ int main(int argc, char** argv) {
         std::vector<double> lt, pro, loop, epi;
         double xcd_lt[8] = {};
         for (int b = 0; b < nb; ++b) {
-            lt.push_back((double)(life[6 * b + 3] - life[6 * b + 2]) / 100.0);
-            pro.push_back((double)(life[6 * b + 4] - life[6 * b + 2]) / 100.0);
-            loop.push_back((double)(life[6 * b + 5] - life[6 * b + 4]) / 100.0);
-            epi.push_back((double)(life[6 * b + 3] - life[6 * b + 5]) / 100.0);
+            lt.push_back((double)(life[8 * b + 3] - life[8 * b + 2]) / 100.0);
+            pro.push_back((double)(life[8 * b + 4] - life[8 * b + 2]) / 100.0);
+            loop.push_back((double)(life[8 * b + 5] - life[8 * b + 4]) / 100.0);
+            epi.push_back((double)(life[8 * b + 3] - life[8 * b + 5]) / 100.0);
             xcd_lt[b & 7] += lt.back() / (nb / 8);
         }
         auto pct = [](std::vector<double> v, const char* nm) {
@@ -200,6 +201,26 @@ int main(int argc, char** argv) {
         pct(pro, "prologue");
         pct(loop, "loop");
         pct(epi, "epilogue");
+        {   // per CU: do the three workgroups of a CU end together, and do CUs differ?
+            std::map<unsigned, std::vector<double>> by_cu;
+            for (int b = 0; b < nb; ++b) {
+                const unsigned hw = (unsigned)life[8 * b + 6], xcc = (unsigned)life[8 * b + 7] & 0xf;
+                const unsigned cu = (hw >> 8) & 0xf, sh = (hw >> 12) & 1, se = (hw >> 13) & 0x7;
+                by_cu[(xcc << 8) | (se << 5) | (sh << 4) | cu].push_back((double)(life[8 * b + 3] - r_min) / 100.0);
+            }
+            std::vector<double> cu_end, cu_spread;
+            size_t n3 = 0;
+            for (auto& kv : by_cu) {
+                auto& v = kv.second;
+                std::sort(v.begin(), v.end());
+                cu_end.push_back(v.back());
+                cu_spread.push_back(v.back() - v.front());
+                n3 += v.size() == 3;
+            }
+            printf("  CUs seen %zu (with exactly three workgroups: %zu)\n", by_cu.size(), n3);
+            pct(cu_end, "CU end");
+            pct(cu_spread, "in-CU gap");
+        }
         printf("  mean lifetime by blockIdx & 7:");
         for (int x = 0; x < 8; ++x) printf(" %.1f", xcd_lt[x]);
         printf("\n");

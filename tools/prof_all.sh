@@ -21,5 +21,7 @@ for W in $WORKLOADS; do
   rocprofv3 --pmc SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INST_LEVEL_VMEM SQ_LDS_CMD_FIFO_FULL SQ_LDS_DATA_FIFO_FULL SQ_WAVES SQ_IFETCH SQ_INSTS_SMEM --output-format csv -d $OUT/pmc6 -- $CMD > $OUT/pmc6.log 2>&1
   python3 tools/prof_summary.py $OUT > $OUT/summary.txt 2>&1
   grep "^{\"metric" $OUT/trace.log > $OUT/bench_line.txt
+  echo "== bench line of the traced run (rocprofv3 --kernel-trace --stats -- python3 bench.py --workload $W)" >> $OUT/summary.txt
+  cat $OUT/bench_line.txt >> $OUT/summary.txt
 done
 echo done
