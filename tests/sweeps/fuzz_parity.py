@@ -13,6 +13,13 @@ from oracle import dsp_oracle as orc  # noqa: E402
 scalings = list(SpectrumScaling)
 
 
+def relmax(a, b, skip_dc=False):
+    a, b = np.asarray(a), np.asarray(b)
+    if skip_dc:
+        a, b = a[1:], b[1:]
+    return float(np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-300))
+
+
 def draw_case(rng, data: bool = True):
     """One random case, consuming `rng` exactly as this sweep always has (so that a case of an earlier
     run can be drawn again from its seed and position: tests/test_gpu_parity.py promotes two of them).
