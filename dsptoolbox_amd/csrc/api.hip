@@ -2615,10 +2615,14 @@ extern "C" int ds_fir_ola(ds_ctx* c, const float* x, int n_ch, int64_t n_samples
 }
 
 // ---- block-streaming FIR classes, state on the device (kernels_fir_stream.hpp) ----------
-static int stream_ones(ds_ctx* c, float* dst, int n) {  // n_call unit impulses of length 1
-    std::vector<float> h((size_t)n, 1.0f);
-    HIPCHK(c, hipMemcpyAsync(dst, h.data(), sizeof(float) * (size_t)n, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));  // h goes out of scope
+__global__ void k_stream_ones(float* dst, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = 1.f;
+}
+static int stream_ones(ds_ctx* c, float* dst, int n) {  // n_call unit impulses of length 1, written on the
+                                                         // stream: a block step carries no host synchronisation
+    hipLaunchKernelGGL(k_stream_ones, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, dst, n);
+    HIPCHK(c, hipGetLastError());
     return DS_OK;
 }
 

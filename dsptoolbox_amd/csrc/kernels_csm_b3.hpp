@@ -341,9 +341,8 @@ __global__ __launch_bounds__(256, 2) void k_csm_offdiag_b3(CsmArgs p) {
             const float gy = (red[0][1][rg][l] + red[1][1][rg][l]) + (red[2][1][rg][l] + red[3][1][rg][l]);
             const int i = (rg & 3) + 8 * (rg >> 2) + 4 * (l >> 5), j = l & 31;
             const int gi = a0 + 2 * i + T, gj = b0c + 2 * j + U;
-            // one frame at a purely real bin: see csm_tile_reduce_store (keep_sign)
-            const bool keep = F == 1 && gy == 0.f;
-            double vx = (double)gx * p.fin.inv * e, vy = (keep ? 0.0 : (double)gy) * p.fin.inv * e;
+            // (the dispatch requires >= 8 frames: the one-frame sign rule of csm_tile_reduce_store never applies)
+            double vx = (double)gx * p.fin.inv * e, vy = (double)gy * p.fin.inv * e;
             if (p.fin.amp_sqrt) {
                 const double x = vx, y = vy;
                 const double rad = sqrt(x * x + y * y);
@@ -356,7 +355,7 @@ __global__ __launch_bounds__(256, 2) void k_csm_offdiag_b3(CsmArgs p) {
             if (2 * i + T < ca) {
                 const float fx = (float)vx, fy = (float)vy;
                 out[(int64_t)gi * C + gj] = make_float2(fx, fy);
-                out[(int64_t)gj * C + gi] = make_float2(fx, keep ? fy : -fy);
+                out[(int64_t)gj * C + gi] = make_float2(fx, -fy);
             }
         }
     }
