@@ -166,7 +166,7 @@ def _welch(x, y, fs_hz: int, window_type, window_length_samples: int, overlap_pe
 # Arithmetic of the transfer-function estimate behind the reference-shaped API
 # (transfer_functions.compute_transfer_function): "auto" takes the float64 route
 # (ds_welch_tf_x64: float64 transforms, sums and finish, the reference's own precision) when the
-# problem is small -- frame spectra of all channels <= 64 MB, window <= 8192 (median averaging: at
+# problem is small -- frame spectra of all channels <= 64 MB, window <= 16384 (median averaging: at
 # most 4096 frames) -- or when it is SHORT: fewer than 128 frames (and <= 1 GB of frame spectra), where
 # an fp32 estimate has too few frames to average its transform rounding down (the two sweep cases of
 # round 2 that reached 1.1e-6 / 1.8e-6 in the coherence had 98 and 110 frames of 8192 samples: they are
@@ -179,10 +179,10 @@ _X64_SHORT_BYTES = 1 << 30
 
 
 def _tf_x64_applies(precision, n_cx: int, n_cy: int, n_frames: int, W: int, average: str) -> bool:
-    ok = W <= 8192 and (average == "mean" or n_frames <= 4096)
+    ok = W <= 16384 and (average == "mean" or n_frames <= 4096)
     if precision == "f64":
         if not ok:
-            raise NotImplementedError("the float64 route covers windows up to 8192 (median: up to 4096 frames)")
+            raise NotImplementedError("the float64 route covers windows up to 16384 (median: up to 4096 frames)")
         return True
     if precision == "auto":
         nbytes = (n_cx + n_cy) * n_frames * (W // 2 + 1) * 16

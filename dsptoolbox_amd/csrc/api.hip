@@ -1296,8 +1296,8 @@ extern "C" int ds_welch_tf_x64(ds_ctx* c, const double* x, int n_cx, const doubl
         return fail(c, DS_ERR_UNSUP, "ds_welch_tf_x64: median averaging over more than 4096 frames (use ds_welch_tf)");
     if (n_cy <= 0 || (n_cx != 1 && n_cx != n_cy) || n_samples <= 0 || hop <= 0 || hop > W || n_frames <= 0)
         return fail(c, DS_ERR_ARG, "ds_welch_tf_x64: bad shape");
-    if (!is_pow2(W) || W < 8 || W > 8192)
-        return fail(c, DS_ERR_UNSUP, "ds_welch_tf_x64: window length must be a power of two in [8, 8192]");
+    if (!is_pow2(W) || W < 8 || W > 16384)
+        return fail(c, DS_ERR_UNSUP, "ds_welch_tf_x64: window length must be a power of two in [8, 16384]");
     if (mode < DS_TF_H1 || mode > DS_TF_H3) return fail(c, DS_ERR_ARG, "welch: unsupported transfer function type");
     const int nb = W / 2 + 1;
     const size_t spec_x = (size_t)n_cx * n_frames * nb, spec_y = (size_t)n_cy * n_frames * nb;
@@ -1325,11 +1325,13 @@ extern "C" int ds_welch_tf_x64(ds_ctx* c, const double* x, int n_cx, const doubl
     HIPCHK(c, hipGetLastError());
     int lg = 0;
     while ((1 << lg) < W) ++lg;
-    const size_t lds = (size_t)W * 16 + 256 * 8;
+    const bool packed = W > 8192;  // the real frame as a W/2-point complex sequence: 128 KB of LDS either way
+    const size_t lds = (size_t)(packed ? W / 2 : W) * 16 + 256 * 8;
+    auto frames = packed ? w64::k_frames<true> : w64::k_frames<false>;
     w64::FrameArgs fx{dx, n_samples, n_cx, W, lg, hop, n_frames, detrend, dw, tw, xs};
-    CHK(launch(c, "welch_f64_frames", w64::k_frames, dim3(n_frames, n_cx), 256, lds, fx));
+    CHK(launch(c, "welch_f64_frames", frames, dim3(n_frames, n_cx), 256, lds, fx));
     w64::FrameArgs fy{dy, n_samples, n_cy, W, lg, hop, n_frames, detrend, dw, tw, ys};
-    CHK(launch(c, "welch_f64_frames", w64::k_frames, dim3(n_frames, n_cy), 256, lds, fy));
+    CHK(launch(c, "welch_f64_frames", frames, dim3(n_frames, n_cy), 256, lds, fy));
     if (average == DS_AVG_MEDIAN) {
         const int nbias = (n_frames & 1) ? n_frames : n_frames - 1;
         w64::TfArgs ta{xs, ys, n_cx, n_cy, n_frames, mode,

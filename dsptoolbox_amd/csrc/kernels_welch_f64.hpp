@@ -7,7 +7,8 @@
 // BASELINE config 1 -- are only good to 1e-4 (single-precision pocketfft gives the same).  MI355X
 // has a 78 TFLOP/s fp64 vector pipe and such problems are a few hundred transforms: one
 // workgroup per (frame, channel) runs a plain radix-2 transform in LDS on double2 values
-// (W <= 8192: 128 KB), the frame spectra go to HBM as complex128, and a second kernel sums them
+// (W <= 8192: 128 KB; W = 16384 as the 8192-point complex transform of the even / odd samples plus the
+// real-input split), the frame spectra go to HBM as complex128, and a second kernel sums them
 // per (bin, channel) in fp64 and applies the same finish() as the fp32 path.
 //   inputs: float64 (samples, channels) C-order arrays exactly as the reference holds them
 //   (the stride between samples is n_ch), float64 window, mean averaging.
@@ -39,19 +40,31 @@ __global__ __launch_bounds__(256) void k_twiddles(double2* tw, int half) {
 }
 
 // grid = (n_frames, n_ch); dynamic LDS = W * 16 bytes (+ 256 * 8 for the mean)
+// PACKED (W = 16384: 256 KB of double2 would not fit): the real frame travels as the W/2-point complex
+// sequence z[n] = v[2n] + i v[2n+1] (128 KB), one W/2-point transform, and the split
+// X[k] = (Z[k] + conj Z[M-k]) / 2 + W^k (Z[k] - conj Z[M-k]) / (2i), M = W/2, k = 0..M.
+template <bool PACKED>
 __global__ __launch_bounds__(256) void k_frames(FrameArgs p) {
     extern __shared__ __align__(16) double2 buf[];
-    double* red = reinterpret_cast<double*>(buf + p.W);
     const int tid = threadIdx.x, f = blockIdx.x, c = blockIdx.y;
-    const int W = p.W, lg = p.lgW;
+    const int W = p.W;
+    const int M = PACKED ? W / 2 : W, lg = PACKED ? p.lgW - 1 : p.lgW;  // the transform that runs in LDS
+    double* red = reinterpret_cast<double*>(buf + M);
     const int64_t start = (int64_t)f * p.hop;
     // windowed frame, zero past the end of the signal (helpers/other.py:207-209)
     double part = 0.0;
-    for (int n = tid; n < W; n += 256) {
-        const int64_t s = start + n;
-        const double v = s < p.n_samples ? p.sig[s * p.n_ch + c] * p.window[n] : 0.0;
-        part += v;
-        buf[__brev((unsigned)n) >> (32 - lg)] = make_double2(v, 0.0);  // bit-reversed order in
+    for (int n = tid; n < M; n += 256) {
+        double2 z;
+        if (PACKED) {
+            const int64_t s = start + 2 * n;
+            z.x = s < p.n_samples ? p.sig[s * p.n_ch + c] * p.window[2 * n] : 0.0;
+            z.y = s + 1 < p.n_samples ? p.sig[(s + 1) * p.n_ch + c] * p.window[2 * n + 1] : 0.0;
+        } else {
+            const int64_t s = start + n;
+            z = make_double2(s < p.n_samples ? p.sig[s * p.n_ch + c] * p.window[n] : 0.0, 0.0);
+        }
+        part += z.x + z.y;
+        buf[__brev((unsigned)n) >> (32 - lg)] = z;  // bit-reversed order in
     }
     if (p.detrend) {  // mean of the WINDOWED frame (_spectral_methods.py:136-139)
         red[tid] = part;
@@ -62,15 +75,19 @@ __global__ __launch_bounds__(256) void k_frames(FrameArgs p) {
         }
         const double mean = red[0] / (double)W;
         __syncthreads();
-        for (int n = tid; n < W; n += 256) buf[n].x -= mean;  // every slot holds one sample
+        for (int n = tid; n < M; n += 256) {  // every slot holds one sample (PACKED: two)
+            buf[n].x -= mean;
+            if (PACKED) buf[n].y -= mean;
+        }
     }
     __syncthreads();
-    // radix-2 decimation in time, natural order out
+    // radix-2 decimation in time, natural order out; tw[k] = exp(-2 pi i k / W): the M-point transform of
+    // the packed form uses every second entry
     for (int s = 0; s < lg; ++s) {
         const int half = 1 << s;
-        for (int i = tid; i < W / 2; i += 256) {
+        for (int i = tid; i < M / 2; i += 256) {
             const int j = i & (half - 1), a = ((i >> s) << (s + 1)) + j, b = a + half;
-            const double2 w = p.tw[(size_t)j << (lg - 1 - s)];
+            const double2 w = p.tw[((size_t)j << (lg - 1 - s)) << (PACKED ? 1 : 0)];
             const double2 u = buf[a], v = buf[b];
             const double2 t = make_double2(v.x * w.x - v.y * w.y, v.x * w.y + v.y * w.x);
             buf[a] = make_double2(u.x + t.x, u.y + t.y);
@@ -79,7 +96,17 @@ __global__ __launch_bounds__(256) void k_frames(FrameArgs p) {
         __syncthreads();
     }
     double2* out = p.spec + ((size_t)c * p.n_frames + f) * (W / 2 + 1);
-    for (int k = tid; k <= W / 2; k += 256) out[k] = buf[k];
+    if (!PACKED) {
+        for (int k = tid; k <= W / 2; k += 256) out[k] = buf[k];
+        return;
+    }
+    for (int k = tid; k <= M; k += 256) {
+        const double2 zk = buf[k & (M - 1)], zm = buf[(M - k) & (M - 1)];
+        const double2 e = make_double2(0.5 * (zk.x + zm.x), 0.5 * (zk.y - zm.y));   // (Z[k] + conj Z[M-k]) / 2
+        const double2 o = make_double2(0.5 * (zk.y + zm.y), -0.5 * (zk.x - zm.x));  // (Z[k] - conj Z[M-k]) / (2i)
+        const double2 w = k < M ? p.tw[k] : make_double2(-1.0, 0.0);
+        out[k] = make_double2(e.x + o.x * w.x - o.y * w.y, e.y + o.x * w.y + o.y * w.x);
+    }
 }
 
 struct TfArgs {

@@ -356,6 +356,8 @@ def test_welch_long_windows_golden():
 @pytest.mark.parametrize("case", [
     dict(W=8192, n=199273, n_ch=16, ov=75.0, det=True, sc="AmplitudeSpectralDensity", mode="H3", seed=8192),
     dict(W=8192, n=674937, n_ch=33, ov=25.0, det=False, sc="AmplitudeSpectrum", mode="H3", seed=8193),
+    # round 3's sweep (fuzz_parity 200 31, case 121): 61 frames of 16384 samples, coherence 1.13e-6 at the Nyquist bin
+    dict(W=16384, n=988985, n_ch=16, ov=0.0, det=True, sc="FFTOrthogonal", mode="H2", seed=16384),
 ])
 def test_short_long_window_estimates_from_the_round2_sweep(case):
     """The two shapes of gpurun_out/sweeps_r02.log whose coherence reached 1.8e-6 / 1.1e-6 on the fp32 kernels
@@ -382,6 +384,10 @@ def test_short_long_window_estimates_from_the_round2_sweep(case):
         assert e_tf < tol and e_coh < tol, (precision, e_tf, e_coh)
     hop = case["W"] - int(case["ov"] / 100 * case["W"])
     assert backend._tf_x64_applies("auto", 1, n_ch, -(-n // hop), case["W"], "mean")
+    # the float64 route itself is the reference's arithmetic (16384: the packed half-length transform + split)
+    tf, coh = backend.welch_transfer_function(y[:, :3], x, 48000, case["W"], case["mode"], overlap_percent=case["ov"],
+                                              detrend=case["det"], scaling=sc, precision="f64")
+    assert relmax(tf, rt[:, :3], case["det"]) < 1e-10 and relmax(coh, rc[:, :3], case["det"]) < 1e-10
 
 
 def test_das_beamformer_device_chain_golden():
