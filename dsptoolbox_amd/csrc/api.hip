@@ -24,6 +24,7 @@
 #include "kernels_welch4096f.hpp"
 #include "kernels_fir16k.hpp"
 #include "kernels_fir4k.hpp"
+#include "kernels_stft4096.hpp"
 #include "kernels_deconv8k.hpp"
 #include "kernels_stft1024.hpp"
 #include "kernels_welch1024.hpp"
@@ -557,6 +558,24 @@ extern "C" int ds_stft_r2c_dev(ds_ctx* c, const float* x, int64_t n_samples, int
                          : launch(c, "stft", stft1k::k_stft_wave<512, false>, grid, threads, lds, a);
         return power ? launch(c, "stft", stft1k::k_stft_wave<256, true>, grid, threads, lds, a)
                      : launch(c, "stft", stft1k::k_stft_wave<256, false>, grid, threads, lds, a);
+    }
+    // 4096-point transforms: the register-resident transform of the Welch path, four teams of two neighbouring
+    // channels per workgroup and frame (kernels_stft4096.hpp)
+    if (nfft == 4096 && W <= nfft && (W == nfft || !detrend) && !stft_generic && stft4k::fits(n_samples, pad_front)) {
+        if (!c->w4_tables) {
+            std::vector<float2> h;
+            welch4096::host_tables(h);
+            CHK(upload_table_fwd(c, &c->w4_tables, h));
+        }
+        const int n_groups = (n_ch + 15) / 16;
+        // chunks of frames: as many as put one workgroup (8 channels) on each of the 256 CUs
+        int n_chunks = std::max(1, std::min(n_frames, 128 / std::max(1, std::min(128, n_groups))));
+        if (const char* e = getenv("DSPTOOLBOX_AMD_STFT4K_CHUNKS")) n_chunks = std::max(1, std::min(n_frames, atoi(e)));
+        stft4k::Args a{x, n_samples, ld, pad_front, n_ch, W, hop, n_frames, detrend, n_chunks, n_groups, window,
+                       c->w4_tables, scale, edge_scale, (float2*)out};
+        const dim3 grid((unsigned)stft4k::grid_size(n_groups, n_chunks));
+        return power ? launch(c, "stft", stft4k::k_stft<true>, grid, stft4k::NT, stft4k::LDS_BYTES, a)
+                     : launch(c, "stft", stft4k::k_stft<false>, grid, stft4k::NT, stft4k::LDS_BYTES, a);
     }
     const float2* tw;
     CHK(get_twiddles(c, nfft, &tw));
