@@ -577,6 +577,34 @@ extern "C" int ds_stft_r2c_dev(ds_ctx* c, const float* x, int64_t n_samples, int
         return power ? launch(c, "stft", stft4k::k_stft<true>, grid, stft4k::NT, stft4k::LDS_BYTES, a)
                      : launch(c, "stft", stft4k::k_stft<false>, grid, stft4k::NT, stft4k::LDS_BYTES, a);
     }
+    // 8192 / 16384 points: two / four decimated 4096-point transforms per channel pair, combined at the read-out
+    if ((nfft == 8192 || nfft == 16384) && W <= nfft && (W == nfft || !detrend) && !stft_generic &&
+        stft4k::fits_long(n_samples, pad_front, nfft)) {
+        if (!c->w4_tables) {
+            std::vector<float2> h;
+            welch4096::host_tables(h);
+            CHK(upload_table_fwd(c, &c->w4_tables, h));
+        }
+        const int n_groups = (n_ch + 15) / 16;
+        const int wpg = nfft == 8192 ? stft4k::Long<2>::WPG : stft4k::Long<4>::WPG;
+        // one workgroup per CU at a time (142 KB of LDS); 8192 points: four rounds of short chunks measured faster than
+        // one round of long ones (64 x 512 000 samples: 0.254 against 0.311 ms), 16384 points: no difference
+        const int target = nfft == 8192 ? 1024 : 256;
+        int n_chunks = std::max(1, std::min(n_frames, target / std::max(1, std::min(target, wpg * n_groups))));
+        if (const char* e = getenv("DSPTOOLBOX_AMD_STFT4K_CHUNKS")) n_chunks = std::max(1, std::min(n_frames, atoi(e)));
+        stft4k::Args a{x, n_samples, ld, pad_front, n_ch, W, hop, n_frames, detrend, n_chunks, n_groups, window,
+                       c->w4_tables, scale, edge_scale, (float2*)out};
+        if (nfft == 8192) {
+            using G = stft4k::Long<2>;
+            const dim3 grid((unsigned)G::grid_size(n_groups, n_chunks));
+            return power ? launch(c, "stft", stft4k::k_stft_long<2, true>, grid, G::NT, G::LDS_BYTES, a)
+                         : launch(c, "stft", stft4k::k_stft_long<2, false>, grid, G::NT, G::LDS_BYTES, a);
+        }
+        using G = stft4k::Long<4>;
+        const dim3 grid((unsigned)G::grid_size(n_groups, n_chunks));
+        return power ? launch(c, "stft", stft4k::k_stft_long<4, true>, grid, G::NT, G::LDS_BYTES, a)
+                     : launch(c, "stft", stft4k::k_stft_long<4, false>, grid, G::NT, G::LDS_BYTES, a);
+    }
     const float2* tw;
     CHK(get_twiddles(c, nfft, &tw));
     // channel tile: ct teams of NT threads (<= 1024 threads, <= 74 KB of LDS so two

@@ -1,4 +1,4 @@
-// STFT with 4096-point transforms on the register-resident transform of kernels_welch4096w.hpp
+// STFT with 4096-, 8192- and 16384-point frames on the register-resident transform of kernels_welch4096w.hpp
 // (reference: _stft, standard/_spectral_methods.py:196-283; output X[bin][frame][channel] complex64,
 // the reference's own layout).  gfx950.
 //
@@ -155,6 +155,140 @@ __global__ __launch_bounds__(NT) void k_stft(Args p) {
                 oe[0] = A;
                 if (r_two) oe[1] = B;
             }
+        }
+        // (the next transform's first barrier stands between these reads and its image stores)
+    }
+}
+
+// ---- 8192 and 16384 points ------------------------------------------------------------------------------
+// nfft = SUB x 4096 (SUB = 2, 4): a team transforms the SUB decimated sequences z_r[m] = z[r + SUB m] of its
+// channel pair one after the other, each into its own image (the image is the transform's exchange area
+// first and holds its packed spectrum S_r in padded natural order afterwards), and the read-out combines
+//   Z[k] = sum_r w^r S_r[k mod 4096],   Z[N-k] = sum_r conj(w)^r S_r[(4096 - k) mod 4096],   w = exp(-2 pi i k / N)
+// per output bin (w from sincospi, its powers by multiplication) before the same separation as above.
+// A team's images are SUB x 34 KB: two teams (4 channels, 32-byte runs) at 8192 points, one team (16-byte
+// runs) at 16384; the 16 / (2 TEAMS) workgroups of a 16-channel group are neighbouring slots of one XCD.
+// The window is read from global memory (it would be 32 / 64 KB of LDS).
+template <int SUB>
+struct Long {
+    static constexpr int NFFT = SUB * N, TEAMS = SUB == 2 ? 2 : 1, NT = 256 * TEAMS;
+    static constexpr int TEAM_C = SUB * IMG + (SUB == 2 ? 16 : 0);  // complex per team (teams in different bank halves)
+    static constexpr int LDS_BYTES = TEAMS * TEAM_C * 8 + 256 * 8;
+    static constexpr int WPG = 8 / TEAMS;  // workgroups per group of 16 channels
+    static int grid_size(int n_groups, int n_chunks) { return 8 * WPG * ((n_groups * n_chunks + 7) / 8); }
+};
+inline bool fits_long(int64_t n_samples, int64_t pad_front, int nfft) {
+    return n_samples + pad_front + 4 * (int64_t)nfft < ((int64_t)1 << 29);
+}
+
+template <int SUB, bool POWER>
+__global__ __launch_bounds__(Long<SUB>::NT) void k_stft_long(Args p) {
+    using namespace welch4096;
+    using G = Long<SUB>;
+    constexpr int NFFT = G::NFFT, TEAMS = G::TEAMS;
+    extern __shared__ __align__(16) float2 lds[];
+    float2* tw2 = lds + TEAMS * G::TEAM_C;
+    const int team = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 8), tid = (int)threadIdx.x & 255;
+    float2* img = lds + team * G::TEAM_C;
+    const int x = (int)blockIdx.x & 7, s = (int)blockIdx.x >> 3, sub = s % G::WPG, u = (s / G::WPG) * 8 + x;
+    const int g = u % p.n_groups, q = u / p.n_groups;
+    const int cb = 16 * g + 2 * TEAMS * sub;  // first of the workgroup's 2 TEAMS channels
+    if (q >= p.n_chunks || cb >= p.n_ch) return;
+    const int per = (p.n_frames + p.n_chunks - 1) / p.n_chunks;
+    const int f0 = q * per, f1 = min(f0 + per, p.n_frames);
+    if (f0 >= f1) return;
+    const int c0 = cb + 2 * team;
+    const bool one = c0 < p.n_ch, two = c0 + 1 < p.n_ch;
+
+    Tw6 tw;
+    load_tw6(tw, p.twt, tid);
+    if (team == 0) tw2[tid] = p.twt[15 * 256 + tid];
+    const __amdgpu_buffer_rsrc_t ra = channel_rsrc(p.x + (int64_t)(one ? c0 : 0) * p.ld, one ? p.n_samples : 0);
+    const __amdgpu_buffer_rsrc_t rb = channel_rsrc(p.x + (int64_t)(two ? c0 + 1 : 0) * p.ld, two ? p.n_samples : 0);
+    const __amdgpu_buffer_rsrc_t rw = channel_rsrc(p.window, p.W);  // zero past the window: zero-padded frames
+    float sa[16], sb[16], sw[16];
+    auto load = [&](int f, int r) {  // z_r[m], m = tid + 256 n1: sample r + SUB m of the frame
+        const int i0 = r + SUB * tid;
+        const int off = 4 * ((int)((int64_t)f * p.hop - p.pad_front) + i0);
+#pragma unroll
+        for (int n1 = 0; n1 < 16; ++n1) {
+            sa[n1] = ld_sample(ra, off + 1024 * SUB * n1);
+            sb[n1] = ld_sample(rb, off + 1024 * SUB * n1);
+            sw[n1] = ld_sample(rw, 4 * i0 + 1024 * SUB * n1);
+        }
+    };
+    load(f0, 0);
+    __syncthreads();  // table
+
+    const float sc = p.scale, sce = p.scale * p.edge_scale;
+    const float pe = p.scale, pee = p.scale * p.edge_scale * p.edge_scale;
+    const float dc = p.detrend ? 0.f : 1.f;  // W == nfft: removing the frame mean only clears bin 0
+    const int bt = bin_thread(tid);
+    const int64_t F = p.n_frames, C = p.n_ch;
+    const bool wide = !(p.n_ch & 1);
+    // read-out: thread -> (pair rp, bin row rk): TEAMS neighbouring lanes write 16 TEAMS bytes
+    const int rp = (int)threadIdx.x & (TEAMS - 1), rk = (int)threadIdx.x / TEAMS;
+    const float2* rimg = lds + rp * G::TEAM_C;
+    const int rc = cb + 2 * rp;
+    const bool r_one = rc < p.n_ch, r_two = rc + 1 < p.n_ch;
+
+    for (int f = f0; f < f1; ++f) {
+#pragma unroll
+        for (int r = 0; r < SUB; ++r) {
+            float2 v[16];
+#pragma unroll
+            for (int n1 = 0; n1 < 16; ++n1) v[n1] = make_float2(sa[n1] * sw[n1], sb[n1] * sw[n1]);
+            const bool more = r + 1 < SUB || f + 1 < f1;
+            float2* buf = img + r * IMG;
+            fft4096_w(v, tw, buf, tw2, tid, NoHook(), [&]() {
+                if (more) load(r + 1 < SUB ? f : f + 1, r + 1 < SUB ? r + 1 : 0);
+            });
+            __syncthreads();  // every wave has read its rows of the image
+#pragma unroll
+            for (int k3 = 0; k3 < 16; ++k3) buf[fold_pos(bt + 256 * k3)] = v[pos16(k3)];
+        }
+        __syncthreads();
+        if (r_one) {
+            auto put = [&](int k, float2 A, float2 B, bool edge) {
+                if (POWER) {
+                    const float e = edge ? (k == 0 ? pee * dc : pee) : pe;
+                    A = make_float2((A.x * A.x + A.y * A.y) * e, 0.f);
+                    B = make_float2((B.x * B.x + B.y * B.y) * e, 0.f);
+                } else {
+                    const float e = edge ? (k == 0 ? sce * dc : sce) : sc;
+                    A = make_float2(A.x * e, A.y * e);
+                    B = make_float2(B.x * e, B.y * e);
+                }
+                float2* o = p.out + ((int64_t)k * F + f) * C + rc;
+                if (wide) {
+                    *reinterpret_cast<float4*>(o) = make_float4(A.x, A.y, B.x, B.y);
+                } else {
+                    o[0] = A;
+                    if (r_two) o[1] = B;
+                }
+            };
+            auto bin = [&](int k) {
+                const int km = k & (N - 1), kmm = (N - km) & (N - 1);
+                float sn, cs;
+                sincospif(-2.0f * (float)k / (float)NFFT, &sn, &cs);
+                const float2 w = make_float2(cs, sn);
+                float2 P = rimg[fold_pos(km)], Q = rimg[fold_pos(kmm)];
+                float2 wr = w;
+#pragma unroll
+                for (int r = 1; r < SUB; ++r) {
+                    const float2 a = rimg[r * IMG + fold_pos(km)], b = rimg[r * IMG + fold_pos(kmm)];
+                    P.x += wr.x * a.x - wr.y * a.y;  // + w^r S_r[km]
+                    P.y += wr.x * a.y + wr.y * a.x;
+                    Q.x += wr.x * b.x + wr.y * b.y;  // + conj(w)^r S_r[kmm]
+                    Q.y += wr.x * b.y - wr.y * b.x;
+                    if (r + 1 < SUB) wr = cmul(wr, w);
+                }
+                const float2 A = make_float2(0.5f * (P.x + Q.x), 0.5f * (P.y - Q.y));
+                const float2 B = make_float2(0.5f * (P.y + Q.y), -0.5f * (P.x - Q.x));
+                put(k, A, B, k == 0 || k == NFFT / 2);
+            };
+            for (int j = 0; j < NFFT / 512; ++j) bin(rk + 256 * j);
+            if (rk == 0) bin(NFFT / 2);
         }
         // (the next transform's first barrier stands between these reads and its image stores)
     }

@@ -65,9 +65,19 @@ def main():
     for it in range(n_cases):
         cs = draw_case(rng)
         kind, W, ov, n, n_ch, det, sc, x, y = (cs[k] for k in ("kind", "W", "ov", "n", "n_ch", "det", "sc", "x", "y"))
+        limit = 1e-6
         try:
             if kind == "tf":
                 mode = cs["mode"]
+                # a SHORT estimate (fewer than 128 frames) has too few frames to average the fp32 transform rounding
+                # down: the API's "auto" arithmetic sends it through the float64 route --
+                # held to 1e-6 here -- and the fp32 kernels are held to 3e-6 (as tests/test_gpu_parity.py does)
+                hop_ = W - int(ov / 100 * W)
+                short = -(-n // hop_) < 128
+                if short:
+                    limit = 3e-6
+                    tfa, coha = backend.welch_transfer_function(y, x, 48000, W, mode, overlap_percent=ov, detrend=det, scaling=sc,
+                                                                precision="auto")
                 tf, coh = backend.welch_transfer_function(y, x, 48000, W, mode, overlap_percent=ov, detrend=det, scaling=sc)
                 rt, rc = orc.compute_transfer_function_batched(y, x, 48000, W, mode, overlap_percent=ov, detrend=det,
                                                                scaling=sc.name)
@@ -76,7 +86,14 @@ def main():
                     tf = np.where(good, tf, rt)
                 e_tf, e_coh = relmax(tf, rt, det), relmax(coh, rc, det)
                 e = max(e_tf, e_coh)
-                if e > 1e-6:
+                if short:
+                    if mode == "H2":
+                        tfa = np.where(good, tfa, rt)
+                    ea = max(relmax(tfa, rt, det), relmax(coha, rc, det))
+                    worst["tf (auto, short)"] = max(worst.get("tf (auto, short)", 0.0), ea)
+                    if not ea <= 1e-6:
+                        fails.append(("tf auto", W, n, n_ch, ov, det, sc.name, ea))
+                if e > limit:
                     d = np.abs(np.asarray(tf) - rt)[1 if det else 0:]
                     b, c_ = np.unravel_index(np.argmax(d), d.shape)
                     print(f"  tf case #{it} W={W} n={n} ch={n_ch} ov={ov} det={det} {sc.name} mode={mode}: e_tf={e_tf:.2e} e_coh={e_coh:.2e} "
@@ -121,7 +138,7 @@ def main():
             fails.append((kind, W, n, n_ch, ov, det, sc.name, repr(ex)[:200]))
             continue
         worst[kind] = max(worst.get(kind, 0.0), e)
-        if not np.isfinite(e) or e > 1e-6:
+        if not np.isfinite(e) or e > limit:
             fails.append((kind, W, n, n_ch, ov, det, sc.name, e))
     print("worst", worst)
     print("failures", len(fails))

@@ -558,8 +558,8 @@ def test_transfer_function_float64_route_vs_oracle():
         sp = dsp.transfer_functions.compute_transfer_function(out, inp, W, TransferFunctionType.H1)
         rt, rc = orc.compute_transfer_function(out.time_data, inp.time_data, 48000, W, "H1", average=avg)
         assert relmax(sp.spectral_data, rt, True) < TOL and relmax(sp.coherence, rc, True) < TOL, (W, avg)
-    with pytest.raises(NotImplementedError):
-        backend.welch_transfer_function(y, x, 48000, 16384, "H1", precision="f64")
+    with pytest.raises(NotImplementedError):  # the float64 route ends at 16384-sample windows
+        backend.welch_transfer_function(y, x, 48000, 32768, "H1", precision="f64")
 
 
 def test_deconvolve_golden():
@@ -1387,6 +1387,42 @@ def test_stft_default_frame_kernel_vs_oracle():
         worst = max(worst, e)
         assert e < TOL, (W, det, e)
     print("stft 1024-frame kernel worst rel-max", worst)
+
+
+def test_stft_8192_and_16384_frame_kernels_vs_oracle():
+    """Frames of 8192 / 16384 points (kernels_stft4096.hpp, k_stft_long): two / four decimated 4096-point transforms per
+    channel pair, combined at the read-out; two teams (4 channels) / one team (2 channels) per workgroup.  Odd and
+    even channel counts (narrow and wide stores, idle teams), one frame and many, padding, detrend (bin 0),
+    amplitude / power scalings, zero-padded shorter windows (with detrend: the generic kernel)."""
+    rng = np.random.default_rng(8192)
+    worst = 0.0
+    for n_ch, n, ov, pad, det, sc in (
+            (1, 9000, 50, True, False, SpectrumScaling.FFTBackward),
+            (3, 70011, 50, True, True, SpectrumScaling.AmplitudeSpectrum),
+            (4, 40000, 75, False, False, SpectrumScaling.PowerSpectralDensity),
+            (5, 50000, 0, True, True, SpectrumScaling.PowerSpectrum),
+            (18, 33000, 25, False, False, SpectrumScaling.FFTOrthogonal),
+            (64, 20000, 50, True, False, SpectrumScaling.FFTBackward)):
+        x = rng.standard_normal((n, n_ch)) * 0.3 + 0.05
+        for W in (8192, 16384):
+            t, f, st = backend._stft(x, 48000, W, Window.Hann, ov, None, det, pad, sc)
+            rt, rf, rs = orc.stft(x, 48000, W, "hann", ov, None, det, pad, sc.name)
+            assert st.shape == rs.shape and np.allclose(t, rt) and np.array_equal(f, rf)
+            if det:  # the reference's DC bin after mean removal is rounding noise around 0
+                assert np.max(np.abs(st[0])) <= 1e-6 * np.max(np.abs(rs))
+            e = relmax(st, rs)
+            worst = max(worst, e)
+            assert e < TOL, (W, n_ch, n, ov, pad, det, sc, e)
+    for W, nfft, det in ((4096, 8192, False), (1024, 8192, False), (2048, 16384, False), (8192, 16384, False),
+                         (4096, 8192, True), (8192, 16384, True)):
+        x = rng.standard_normal((60000, 3)) * 0.3 + 0.05
+        t, f, st = backend._stft(x, 48000, W, Window.Hann, 50, nfft, det, True, SpectrumScaling.FFTBackward)
+        rt, rf, rs = orc.stft(x, 48000, W, "hann", 50, nfft, det, True, "FFTBackward")
+        assert st.shape == rs.shape
+        e = relmax(st, rs)
+        worst = max(worst, e)
+        assert e < TOL, (W, nfft, det, e)
+    print("stft 8192 / 16384 frame kernels worst rel-max", worst)
 
 
 def test_stft_and_csm_long_windows_vs_oracle():
