@@ -57,6 +57,7 @@ struct ds_ctx {
     size_t blue_bytes = 0;
     uint64_t blue_clock = 0;
     float2* w4_tables = nullptr;  // welch4096::host_tables()
+    float2* stft_dif_tw[2] = {nullptr, nullptr};  // stft4k::host_twiddles(8192 / 16384)
     unsigned* w4_sync = nullptr;  // counters of the one-launch Welch kernel (welch4096::k_h1f), zero between launches
     bool w4_sync_used = false;    // a fused launch since the last check of its timeout word
     int w4_fused_cap = -1;        // workgroups of k_h1f the device holds at once
@@ -171,6 +172,8 @@ extern "C" void ds_destroy(ds_ctx* c) {
     (void)hipStreamSynchronize(c->stream);
     for (auto& kv : c->tw) (void)hipFree(kv.second);
     if (c->w4_tables) (void)hipFree(c->w4_tables);
+    for (float2* t : c->stft_dif_tw)
+        if (t) (void)hipFree(t);
     if (c->w4_sync) (void)hipFree(c->w4_sync);
     if (c->fir16k_tables) (void)hipFree(c->fir16k_tables);
     if (c->deconv8k_tables) (void)hipFree(c->deconv8k_tables);
@@ -572,12 +575,13 @@ extern "C" int ds_stft_r2c_dev(ds_ctx* c, const float* x, int64_t n_samples, int
         int n_chunks = std::max(1, std::min(n_frames, 128 / std::max(1, std::min(128, n_groups))));
         if (const char* e = getenv("DSPTOOLBOX_AMD_STFT4K_CHUNKS")) n_chunks = std::max(1, std::min(n_frames, atoi(e)));
         stft4k::Args a{x, n_samples, ld, pad_front, n_ch, W, hop, n_frames, detrend, n_chunks, n_groups, window,
-                       c->w4_tables, scale, edge_scale, (float2*)out};
+                       c->w4_tables, scale, edge_scale, (float2*)out, nullptr};
         const dim3 grid((unsigned)stft4k::grid_size(n_groups, n_chunks));
         return power ? launch(c, "stft", stft4k::k_stft<true>, grid, stft4k::NT, stft4k::LDS_BYTES, a)
                      : launch(c, "stft", stft4k::k_stft<false>, grid, stft4k::NT, stft4k::LDS_BYTES, a);
     }
-    // 8192 / 16384 points: two / four decimated 4096-point transforms per channel pair, combined at the read-out
+    // 8192 / 16384 points: one radix-2 / radix-4 decimation-in-frequency stage on the windowed samples, then the
+    // 4096-point kernel's structure per residue (kernels_stft4096.hpp, k_stft_dif)
     if ((nfft == 8192 || nfft == 16384) && W <= nfft && (W == nfft || !detrend) && !stft_generic &&
         stft4k::fits_long(n_samples, pad_front, nfft)) {
         if (!c->w4_tables) {
@@ -585,25 +589,25 @@ extern "C" int ds_stft_r2c_dev(ds_ctx* c, const float* x, int64_t n_samples, int
             welch4096::host_tables(h);
             CHK(upload_table_fwd(c, &c->w4_tables, h));
         }
+        float2** twn = &c->stft_dif_tw[nfft == 8192 ? 0 : 1];
+        if (!*twn) {
+            std::vector<float2> h;
+            stft4k::host_twiddles(nfft, h);
+            CHK(upload_table_fwd(c, twn, h));
+        }
         const int n_groups = (n_ch + 15) / 16;
-        const int wpg = nfft == 8192 ? stft4k::Long<2>::WPG : stft4k::Long<4>::WPG;
-        // one workgroup per CU at a time (142 KB of LDS); 8192 points: four rounds of short chunks measured faster than
-        // one round of long ones (64 x 512 000 samples: 0.254 against 0.311 ms), 16384 points: no difference
-        const int target = nfft == 8192 ? 1024 : 256;
-        int n_chunks = std::max(1, std::min(n_frames, target / std::max(1, std::min(target, wpg * n_groups))));
+        // chunks of (frame, phase) units: two rounds of one workgroup (8 channels) per CU (64 x 512 000 samples, 8192
+        // points: 0.182 ms against 0.198 with one round)
+        int n_chunks = std::max(1, std::min(n_frames, 256 / std::max(1, std::min(256, n_groups))));
         if (const char* e = getenv("DSPTOOLBOX_AMD_STFT4K_CHUNKS")) n_chunks = std::max(1, std::min(n_frames, atoi(e)));
         stft4k::Args a{x, n_samples, ld, pad_front, n_ch, W, hop, n_frames, detrend, n_chunks, n_groups, window,
-                       c->w4_tables, scale, edge_scale, (float2*)out};
-        if (nfft == 8192) {
-            using G = stft4k::Long<2>;
-            const dim3 grid((unsigned)G::grid_size(n_groups, n_chunks));
-            return power ? launch(c, "stft", stft4k::k_stft_long<2, true>, grid, G::NT, G::LDS_BYTES, a)
-                         : launch(c, "stft", stft4k::k_stft_long<2, false>, grid, G::NT, G::LDS_BYTES, a);
-        }
-        using G = stft4k::Long<4>;
-        const dim3 grid((unsigned)G::grid_size(n_groups, n_chunks));
-        return power ? launch(c, "stft", stft4k::k_stft_long<4, true>, grid, G::NT, G::LDS_BYTES, a)
-                     : launch(c, "stft", stft4k::k_stft_long<4, false>, grid, G::NT, G::LDS_BYTES, a);
+                       c->w4_tables, scale, edge_scale, (float2*)out, *twn};
+        const dim3 grid((unsigned)stft4k::grid_size(n_groups, n_chunks));
+        if (nfft == 8192)
+            return power ? launch(c, "stft", stft4k::k_stft_dif<2, true>, grid, stft4k::NT, stft4k::Dif<2>::LDS_BYTES, a)
+                         : launch(c, "stft", stft4k::k_stft_dif<2, false>, grid, stft4k::NT, stft4k::Dif<2>::LDS_BYTES, a);
+        return power ? launch(c, "stft", stft4k::k_stft_dif<4, true>, grid, stft4k::NT, stft4k::Dif<4>::LDS_BYTES, a)
+                     : launch(c, "stft", stft4k::k_stft_dif<4, false>, grid, stft4k::NT, stft4k::Dif<4>::LDS_BYTES, a);
     }
     const float2* tw;
     CHK(get_twiddles(c, nfft, &tw));

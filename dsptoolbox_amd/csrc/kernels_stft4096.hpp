@@ -19,6 +19,9 @@
 //     behind the second exchange of the current transform.
 // 157 KB of LDS (4 images, the W256 table, the window), <= 128 registers (four waves per SIMD).
 #pragma once
+#include <cmath>
+#include <vector>
+
 #include "kernels_welch4096w.hpp"
 
 namespace stft4k {
@@ -38,7 +41,8 @@ struct Args {
     const float* window;  // [W], W <= 4096 (shorter windows are zero-padded)
     const float2* twt;    // welch4096::host_tables()
     float scale, edge_scale;
-    float2* out;  // [2049][n_frames][n_ch]
+    float2* out;  // [nfft / 2 + 1][n_frames][n_ch]
+    const float2* twn;  // k_stft_dif: W_nfft^j, j < nfft (host_twiddles)
 };
 
 // workgroups: 2 halves x n_groups x n_chunks, rounded up to whole XCD rows
@@ -160,96 +164,136 @@ __global__ __launch_bounds__(NT) void k_stft(Args p) {
     }
 }
 
-// ---- 8192 and 16384 points ------------------------------------------------------------------------------
-// nfft = SUB x 4096 (SUB = 2, 4): a team transforms the SUB decimated sequences z_r[m] = z[r + SUB m] of its
-// channel pair one after the other, each into its own image (the image is the transform's exchange area
-// first and holds its packed spectrum S_r in padded natural order afterwards), and the read-out combines
-//   Z[k] = sum_r w^r S_r[k mod 4096],   Z[N-k] = sum_r conj(w)^r S_r[(4096 - k) mod 4096],   w = exp(-2 pi i k / N)
-// per output bin (w from sincospi, its powers by multiplication) before the same separation as above.
-// A team's images are SUB x 34 KB: two teams (4 channels, 32-byte runs) at 8192 points, one team (16-byte
-// runs) at 16384; the 16 / (2 TEAMS) workgroups of a 16-channel group are neighbouring slots of one XCD.
-// The window is read from global memory (it would be 32 / 64 KB of LDS).
-template <int SUB>
-struct Long {
-    static constexpr int NFFT = SUB * N, TEAMS = SUB == 2 ? 2 : 1, NT = 256 * TEAMS;
-    static constexpr int TEAM_C = SUB * IMG + (SUB == 2 ? 16 : 0);  // complex per team (teams in different bank halves)
-    static constexpr int LDS_BYTES = TEAMS * TEAM_C * 8 + 256 * 8;
-    static constexpr int WPG = 8 / TEAMS;  // workgroups per group of 16 channels
-    static int grid_size(int n_groups, int n_chunks) { return 8 * WPG * ((n_groups * n_chunks + 7) / 8); }
-};
 inline bool fits_long(int64_t n_samples, int64_t pad_front, int nfft) {
     return n_samples + pad_front + 4 * (int64_t)nfft < ((int64_t)1 << 29);
 }
 
+// ---- 8192 and 16384 points, decimation in frequency -----------------------------------------------------------
+// nfft = SUB x 4096.  One radix-SUB stage on the windowed samples, y_r[m] = (sum_s z[m + 4096 s] (-i)^(r s)) W_nfft^(r m),
+// makes the 4096-point transform of y_r the bins k = SUB k' + r of the frame's spectrum -- final values, and the
+// mirror bin nfft - k lies in residue (SUB - r) mod SUB: residues 0 and SUB/2 pair with THEMSELVES, so a team needs only
+// the one image of the 4096 kernel and the workgroup keeps its FOUR teams = 8 channels = 64-byte runs:
+//   8192:  phase 0: r = 0, phase 1: r = 1, the four teams = the four channel pairs in both;
+//   16384: phases 0, 1: r = 0, 2 as above; phases 2, 3: residues 1 and 3 pair with EACH OTHER: teams (2 j, 2 j + 1)
+//          transform residues 1 and 3 of channel pair j (phase 2) or 2 + j (phase 3): 32-byte runs for that half
+//          of the bins.
+// Every phase is one transform per team and one read-out; the samples (and window values, from global memory: the
+// LDS holds the four images) of a phase are loaded in four batches.  twn = W_nfft^j, j < nfft.
+// (A decimation-in-TIME form -- the SUB sub-spectra of a channel pair kept in SUB images and combined per output
+// bin at the read-out -- needs 70 / 140 KB per team, i.e. two teams / one team per workgroup and 32- / 16-byte runs:
+// 0.252 / 0.279 ms on 64 x 512 000 samples where this form takes 0.182 / 0.263.)
+template <int SUB>
+struct Dif {
+    static constexpr int NFFT = SUB * N, PHASES = SUB;  // 2 -> 2 phases, 4 -> 4 phases
+    static constexpr int LDS_BYTES = TEAMS * IMG * 8 + 256 * 8;
+};
+inline void host_twiddles(int nfft, std::vector<float2>& h) {
+    h.resize((size_t)nfft);
+    for (int j = 0; j < nfft; ++j) {
+        const double a = -2.0 * M_PI * (double)j / (double)nfft;
+        h[(size_t)j] = make_float2((float)std::cos(a), (float)std::sin(a));
+    }
+}
+
 template <int SUB, bool POWER>
-__global__ __launch_bounds__(Long<SUB>::NT) void k_stft_long(Args p) {
+__global__ __launch_bounds__(NT) void k_stft_dif(Args p) {
     using namespace welch4096;
-    using G = Long<SUB>;
-    constexpr int NFFT = G::NFFT, TEAMS = G::TEAMS;
+    constexpr int NFFT = SUB * N;
     extern __shared__ __align__(16) float2 lds[];
-    float2* tw2 = lds + TEAMS * G::TEAM_C;
+    float2* tw2 = lds + TEAMS * IMG;
     const int team = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 8), tid = (int)threadIdx.x & 255;
-    float2* img = lds + team * G::TEAM_C;
-    const int x = (int)blockIdx.x & 7, s = (int)blockIdx.x >> 3, sub = s % G::WPG, u = (s / G::WPG) * 8 + x;
+    float2* buf = lds + team * IMG;
+    const int x = (int)blockIdx.x & 7, s = (int)blockIdx.x >> 3, half = s & 1, u = (s >> 1) * 8 + x;
     const int g = u % p.n_groups, q = u / p.n_groups;
-    const int cb = 16 * g + 2 * TEAMS * sub;  // first of the workgroup's 2 TEAMS channels
+    const int cb = 16 * g + 8 * half;  // first of the workgroup's 8 channels
     if (q >= p.n_chunks || cb >= p.n_ch) return;
-    const int per = (p.n_frames + p.n_chunks - 1) / p.n_chunks;
-    const int f0 = q * per, f1 = min(f0 + per, p.n_frames);
-    if (f0 >= f1) return;
-    const int c0 = cb + 2 * team;
-    const bool one = c0 < p.n_ch, two = c0 + 1 < p.n_ch;
+    // the chunk's share of the (frame, phase) units: 65 frames of 16384 points on 32 chunks are 8 or 9 phases each,
+    // not 2 or 3 frames
+    const int n_units = p.n_frames * SUB;
+    const int u0 = (int)((int64_t)q * n_units / p.n_chunks), u1 = (int)((int64_t)(q + 1) * n_units / p.n_chunks);
+    if (u0 >= u1) return;
 
     Tw6 tw;
     load_tw6(tw, p.twt, tid);
     if (team == 0) tw2[tid] = p.twt[15 * 256 + tid];
-    const __amdgpu_buffer_rsrc_t ra = channel_rsrc(p.x + (int64_t)(one ? c0 : 0) * p.ld, one ? p.n_samples : 0);
-    const __amdgpu_buffer_rsrc_t rb = channel_rsrc(p.x + (int64_t)(two ? c0 + 1 : 0) * p.ld, two ? p.n_samples : 0);
     const __amdgpu_buffer_rsrc_t rw = channel_rsrc(p.window, p.W);  // zero past the window: zero-padded frames
-    float sa[16], sb[16], sw[16];
-    auto load = [&](int f, int r) {  // z_r[m], m = tid + 256 n1: sample r + SUB m of the frame
-        const int i0 = r + SUB * tid;
-        const int off = 4 * ((int)((int64_t)f * p.hop - p.pad_front) + i0);
-#pragma unroll
-        for (int n1 = 0; n1 < 16; ++n1) {
-            sa[n1] = ld_sample(ra, off + 1024 * SUB * n1);
-            sb[n1] = ld_sample(rb, off + 1024 * SUB * n1);
-            sw[n1] = ld_sample(rw, 4 * i0 + 1024 * SUB * n1);
-        }
-    };
-    load(f0, 0);
+    const __amdgpu_buffer_rsrc_t rt = __builtin_amdgcn_make_buffer_rsrc(const_cast<float2*>(p.twn), 0, NFFT * 8, 0x00020000);
     __syncthreads();  // table
 
     const float sc = p.scale, sce = p.scale * p.edge_scale;
     const float pe = p.scale, pee = p.scale * p.edge_scale * p.edge_scale;
     const float dc = p.detrend ? 0.f : 1.f;  // W == nfft: removing the frame mean only clears bin 0
-    const int bt = bin_thread(tid);
     const int64_t F = p.n_frames, C = p.n_ch;
     const bool wide = !(p.n_ch & 1);
-    // read-out: thread -> (pair rp, bin row rk): TEAMS neighbouring lanes write 16 TEAMS bytes
-    const int rp = (int)threadIdx.x & (TEAMS - 1), rk = (int)threadIdx.x / TEAMS;
-    const float2* rimg = lds + rp * G::TEAM_C;
-    const int rc = cb + 2 * rp;
-    const bool r_one = rc < p.n_ch, r_two = rc + 1 < p.n_ch;
 
-    for (int f = f0; f < f1; ++f) {
-#pragma unroll
-        for (int r = 0; r < SUB; ++r) {
+    auto phase = [&](auto phc, const int f) {
+        {
+            constexpr int ph = decltype(phc)::value;
+            // per-thread indices are re-derived per phase (see k_stft)
+            int tx = (int)threadIdx.x;
+            asm volatile("" : "+v"(tx));
+            const int tid_l = tx & 255, bt_l = bin_thread(tid_l);
+            const bool cross = SUB == 4 && ph >= 2;  // residues 1 and 3 on neighbouring teams
+            const int r = cross ? ((team & 1) ? 3 : 1) : (SUB == 4 ? 2 * ph : ph);
+            const int pair = cross ? 2 * (ph - 2) + (team >> 1) : team;
+            const int c0 = cb + 2 * pair;
+            const bool one = c0 < p.n_ch, two = c0 + 1 < p.n_ch;
+            const __amdgpu_buffer_rsrc_t ra = channel_rsrc(p.x + (int64_t)(one ? c0 : 0) * p.ld, one ? p.n_samples : 0);
+            const __amdgpu_buffer_rsrc_t rb = channel_rsrc(p.x + (int64_t)(two ? c0 + 1 : 0) * p.ld, two ? p.n_samples : 0);
+            const int off0 = 4 * ((int)((int64_t)f * p.hop - p.pad_front) + tid_l);
             float2 v[16];
 #pragma unroll
-            for (int n1 = 0; n1 < 16; ++n1) v[n1] = make_float2(sa[n1] * sw[n1], sb[n1] * sw[n1]);
-            const bool more = r + 1 < SUB || f + 1 < f1;
-            float2* buf = img + r * IMG;
-            fft4096_w(v, tw, buf, tw2, tid, NoHook(), [&]() {
-                if (more) load(r + 1 < SUB ? f : f + 1, r + 1 < SUB ? r + 1 : 0);
-            });
-            __syncthreads();  // every wave has read its rows of the image
+            for (int b4 = 0; b4 < 4; ++b4) {  // four batches of four values: the loads of a batch in flight together
+                float za[4][SUB], zb[4][SUB], zw[4][SUB];
+                float2 wn[4];
 #pragma unroll
-            for (int k3 = 0; k3 < 16; ++k3) buf[fold_pos(bt + 256 * k3)] = v[pos16(k3)];
-        }
-        __syncthreads();
-        if (r_one) {
-            auto put = [&](int k, float2 A, float2 B, bool edge) {
+                for (int i = 0; i < 4; ++i) {
+                    const int n1 = 4 * b4 + i;
+#pragma unroll
+                    for (int sI = 0; sI < SUB; ++sI) {
+                        const int o = 1024 * n1 + 4 * N * sI;
+                        za[i][sI] = ld_sample(ra, off0 + o);
+                        zb[i][sI] = ld_sample(rb, off0 + o);
+                        zw[i][sI] = ld_sample(rw, 4 * tid_l + o);
+                    }
+                    if (r) {
+                        const int ot = 8 * r * (tid_l + 256 * n1);
+                        wn[i] = make_float2(ld_sample(rt, ot), ld_sample(rt, ot + 4));
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float2 z[SUB];
+#pragma unroll
+                    for (int sI = 0; sI < SUB; ++sI) z[sI] = make_float2(za[i][sI] * zw[i][sI], zb[i][sI] * zw[i][sI]);
+                    float2 y;
+                    if (SUB == 2) {
+                        y = r ? make_float2(z[0].x - z[1].x, z[0].y - z[1].y) : make_float2(z[0].x + z[1].x, z[0].y + z[1].y);
+                    } else {
+                        const int S2 = SUB == 4 ? 2 : 0, S3 = SUB == 4 ? 3 : 0;  // (indices valid for SUB == 2 too)
+                        if (!(r & 1)) {  // r = 0: (z0 + z2) + (z1 + z3);  r = 2: (z0 + z2) - (z1 + z3)
+                            const float2 e0 = make_float2(z[0].x + z[S2].x, z[0].y + z[S2].y);
+                            const float2 e1 = make_float2(z[1].x + z[S3].x, z[1].y + z[S3].y);
+                            y = r ? make_float2(e0.x - e1.x, e0.y - e1.y) : make_float2(e0.x + e1.x, e0.y + e1.y);
+                        } else {  // r = 1: (z0 - z2) - i (z1 - z3);  r = 3: (z0 - z2) + i (z1 - z3)
+                            const float2 d0 = make_float2(z[0].x - z[S2].x, z[0].y - z[S2].y);
+                            const float2 d1 = make_float2(z[1].x - z[S3].x, z[1].y - z[S3].y);
+                            y = r == 1 ? make_float2(d0.x + d1.y, d0.y - d1.x) : make_float2(d0.x - d1.y, d0.y + d1.x);
+                        }
+                    }
+                    if (r) y = cmul(y, wn[i]);
+                    v[4 * b4 + i] = y;
+                }
+            }
+            fft4096_w(v, tw, buf, tw2, tid_l);
+            __syncthreads();  // every wave has read its rows of the images
+#pragma unroll
+            for (int k3 = 0; k3 < 16; ++k3) buf[fold_pos(bt_l + 256 * k3)] = v[pos16(k3)];
+            __syncthreads();
+            // ---- read-out
+            auto put = [&](int k, int rc, bool r_two, float2 P, float2 Q, bool edge) {
+                float2 A = make_float2(0.5f * (P.x + Q.x), 0.5f * (P.y - Q.y));
+                float2 B = make_float2(0.5f * (P.y + Q.y), -0.5f * (P.x - Q.x));
                 if (POWER) {
                     const float e = edge ? (k == 0 ? pee * dc : pee) : pe;
                     A = make_float2((A.x * A.x + A.y * A.y) * e, 0.f);
@@ -267,30 +311,49 @@ __global__ __launch_bounds__(Long<SUB>::NT) void k_stft_long(Args p) {
                     if (r_two) o[1] = B;
                 }
             };
-            auto bin = [&](int k) {
-                const int km = k & (N - 1), kmm = (N - km) & (N - 1);
-                float sn, cs;
-                sincospif(-2.0f * (float)k / (float)NFFT, &sn, &cs);
-                const float2 w = make_float2(cs, sn);
-                float2 P = rimg[fold_pos(km)], Q = rimg[fold_pos(kmm)];
-                float2 wr = w;
+            const int rk = tx >> 2;
+            if (!cross) {  // four pairs, residue rr pairs with itself
+                const int rr = SUB == 4 ? 2 * ph : ph;
+                const int rp = tx & 3;
+                const float2* im = lds + rp * IMG;
+                const int rc = cb + 2 * rp;
+                if (rc < p.n_ch) {
+                    const bool r_two = rc + 1 < p.n_ch;
 #pragma unroll
-                for (int r = 1; r < SUB; ++r) {
-                    const float2 a = rimg[r * IMG + fold_pos(km)], b = rimg[r * IMG + fold_pos(kmm)];
-                    P.x += wr.x * a.x - wr.y * a.y;  // + w^r S_r[km]
-                    P.y += wr.x * a.y + wr.y * a.x;
-                    Q.x += wr.x * b.x + wr.y * b.y;  // + conj(w)^r S_r[kmm]
-                    Q.y += wr.x * b.y - wr.y * b.x;
-                    if (r + 1 < SUB) wr = cmul(wr, w);
+                    for (int j = 0; j < 8; ++j) {
+                        const int kk = rk + 256 * j;  // k' < 2048
+                        const int km = rr ? N - 1 - kk : (N - kk) & (N - 1);
+                        put(SUB * kk + rr, rc, r_two, im[fold_pos(kk)], im[fold_pos(km)], rr == 0 && kk == 0);
+                    }
+                    if (rr == 0 && rk == 0) put(NFFT / 2, rc, r_two, im[fold_pos(N / 2)], im[fold_pos(N / 2)], true);
                 }
-                const float2 A = make_float2(0.5f * (P.x + Q.x), 0.5f * (P.y - Q.y));
-                const float2 B = make_float2(0.5f * (P.y + Q.y), -0.5f * (P.x - Q.x));
-                put(k, A, B, k == 0 || k == NFFT / 2);
-            };
-            for (int j = 0; j < NFFT / 512; ++j) bin(rk + 256 * j);
-            if (rk == 0) bin(NFFT / 2);
+            } else {  // two pairs x residues 1 and 3, which pair with each other
+                const int rp2 = tx & 1, res3 = (tx >> 1) & 1;
+                const float2* own = lds + (2 * rp2 + res3) * IMG;
+                const float2* oth = lds + (2 * rp2 + 1 - res3) * IMG;
+                const int rc = cb + 2 * (2 * (ph - 2) + rp2);
+                if (rc < p.n_ch) {
+                    const bool r_two = rc + 1 < p.n_ch;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int kk = rk + 256 * j;
+                        put(SUB * kk + (res3 ? 3 : 1), rc, r_two, own[fold_pos(kk)], oth[fold_pos(N - 1 - kk)], false);
+                    }
+                }
+            }
+            // (the next transform's first barrier stands between these reads and its image stores)
         }
-        // (the next transform's first barrier stands between these reads and its image stores)
+    };
+    for (int un = u0; un < u1; ++un) {
+        const int f = un / SUB, ph = un - f * SUB;
+        if (ph == 0)
+            phase(std::integral_constant<int, 0>{}, f);
+        else if (ph == 1)
+            phase(std::integral_constant<int, 1>{}, f);
+        else if (SUB == 4 && ph == 2)
+            phase(std::integral_constant<int, SUB == 4 ? 2 : 0>{}, f);
+        else if (SUB == 4)
+            phase(std::integral_constant<int, SUB == 4 ? 3 : 0>{}, f);
     }
 }
 
