@@ -91,19 +91,25 @@ def _without_remarks(text: str) -> str:
     return "".join(keep)
 
 
+LAST_BUILD = None  # "compiled" or "reused" (the library's source hash matched): what build_library last did
+
+
 def build_library(force: bool = False, verbose: bool = True) -> str:
     """hipcc --offload-arch=gfx950 -> dsptoolbox_amd/lib/libdsptoolbox_amd.so
 
     Safe to call from several ranks at once: one process compiles (file lock) into a
     temporary name and renames it into place, the others wait and reuse the result."""
+    global LAST_BUILD
     os.makedirs(LIB_DIR, exist_ok=True)
     if not force and _up_to_date():
+        LAST_BUILD = "reused"
         return LIB_PATH
     import fcntl
     with open(os.path.join(LIB_DIR, ".build.lock"), "w") as lock:
         fcntl.flock(lock, fcntl.LOCK_EX)
         try:
             if not force and _up_to_date():  # another rank built it while we waited
+                LAST_BUILD = "reused"
                 return LIB_PATH
             hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
             tmp = LIB_PATH + f".tmp{os.getpid()}"
@@ -143,6 +149,7 @@ def build_library(force: bool = False, verbose: bool = True) -> str:
                 os.replace(tmp, LIB_PATH)
                 with open(HASH_PATH, "w") as fh:
                     fh.write(_source_hash() + "\n")
+                LAST_BUILD = "compiled"
             finally:
                 if os.path.exists(tmp):
                     os.remove(tmp)
