@@ -110,6 +110,34 @@ def gen_stft_manych(dsp):
     save("stft_manych", dict(cases=cases, fs=fs), arrs)
 
 
+def gen_stft_long(dsp):
+    """Signal.get_spectrogram with windows of 4096, 8192 and 16384 samples (the frame kernels of
+    dsptoolbox_amd/csrc/kernels_stft4096.hpp: four teams of two neighbouring channels per workgroup; 8192 / 16384 by
+    decimation in frequency, residues 1 and 3 of the 16384-point frames on neighbouring teams) of a 10-channel
+    signal: one workgroup with 8 channels, one with 2 (idle teams).  Every 11th bin (all residues modulo 2 and 4)
+    and the edge bins, stored as complex64."""
+    from dsptoolbox.standard.enums import SpectrumScaling as S, Window
+    fs = 48000
+    rng = np.random.default_rng(47)
+    xs = (rng.standard_normal((24000, 10)) * 0.4 + 0.1).astype(np.float32)
+    cases, arrs = [], {"x": xs}
+    for i, (W, ov, det, pad, sc) in enumerate(((4096, 50, True, False, S.FFTBackward),
+                                               (4096, 25, False, True, S.PowerSpectralDensity),
+                                               (8192, 50, False, True, S.AmplitudeSpectrum),
+                                               (8192, 25, True, False, S.FFTOrthogonal),
+                                               (16384, 50, True, True, S.FFTBackward),
+                                               (16384, 0, False, False, S.PowerSpectrum))):
+        s = dsp.Signal(None, xs.astype(np.float64), fs)
+        s.set_spectrogram_parameters(window_length_samples=W, window_type=Window.Hann, overlap_percent=ov,
+                                     detrend=det, padding=pad, scaling=sc)
+        t, f, st = s.get_spectrogram()
+        nb = W // 2 + 1
+        bins = np.unique(np.r_[0:4, 0:nb:11, nb - 4:nb])
+        cases.append(dict(W=W, overlap=ov, detrend=det, padding=pad, scaling=sc.name, shape=list(st.shape)))
+        arrs[f"bins_{i}"], arrs[f"stft_{i}"] = bins, st[bins].astype(np.complex64)
+    save("stft_long", dict(cases=cases, fs=fs), arrs)
+
+
 def gen_fir_state(dsp):
     """Filter state (zi), zero-phase and long FIR filters: Filter / FilterBank.filter_signal with
     activate_zi / zero_phase (classes/filter.py:648-743, filter_helpers.py:288-382, 454-503)."""
@@ -614,6 +642,10 @@ def gen_csm_coherent(dsp):
 
 def main():
     dsp = import_reference()
+    if "--only-stft-long" in sys.argv:
+        import warnings
+        warnings.simplefilter("ignore")
+        return gen_stft_long(dsp)
     if "--only-stft-manych" in sys.argv:
         import warnings
         warnings.simplefilter("ignore")
@@ -953,6 +985,7 @@ def main():
     gen_das_signal(dsp)
     gen_csm_coherent(dsp)
     gen_stft_manych(dsp)
+    gen_stft_long(dsp)
     gen_fir_state(dsp)
     gen_istft(dsp)
     gen_istft_anylen(dsp)

@@ -1663,10 +1663,13 @@ def test_csm_negative_real_elements_at_the_real_bins(n_ch):
         assert relmax(part, r[W // 2 - 2:]) < TOL
 
 
-def test_stft_many_channels_golden():
+@pytest.mark.parametrize("fixture", ["stft_manych", "stft_long"])
+def test_stft_many_channels_golden(fixture):
     """tests/golden/stft_manych.npz: the reference's spectrograms of a 20-channel signal (one full tile of
-    16 channels and a ragged one of 4 in the wave-level kernels) at windows 256 ... 2048."""
-    meta, z = load_golden("stft_manych")
+    16 channels and a ragged one of 4 in the wave-level kernels) at windows 256 ... 2048;
+    tests/golden/stft_long.npz: 10 channels (one workgroup of 8, one of 2 with idle teams) at windows of 4096, 8192
+    and 16384 samples -- kernels_stft4096.hpp: every residue class of the decimation in frequency is in the stored bins."""
+    meta, z = load_golden(fixture)
     x = z["x"].astype(np.float64)
     for i, c in enumerate(meta["cases"]):
         t, f, st = backend._stft(x, meta["fs"], c["W"], Window.Hann, c["overlap"], None, c["detrend"], c["padding"],

@@ -178,8 +178,10 @@ def test_stft_any_fft_length():
         assert s.dtype == z[f"stft_{i}"].dtype
 
 
-def test_stft_many_channels():
-    meta, z = load_golden("stft_manych")
+@pytest.mark.parametrize("fixture", ["stft_manych", "stft_long"])
+def test_stft_many_channels(fixture):
+    """stft_manych: 20 channels, windows 256 ... 2048; stft_long: 10 channels, windows 4096 / 8192 / 16384."""
+    meta, z = load_golden(fixture)
     x = z["x"].astype(np.float64)
     for i, c in enumerate(meta["cases"]):
         t, f, s = orc.stft(x, meta["fs"], c["W"], "hann", c["overlap"], None, c["detrend"], c["padding"], c["scaling"])
