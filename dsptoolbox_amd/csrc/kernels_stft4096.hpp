@@ -178,13 +178,14 @@ inline bool fits_long(int64_t n_samples, int64_t pad_front, int nfft) {
 //          transform residues 1 and 3 of channel pair j (phase 2) or 2 + j (phase 3): 32-byte runs for that half
 //          of the bins.
 // Every phase is one transform per team and one read-out; the samples (and window values, from global memory: the
-// LDS holds the four images) of a phase are loaded in four batches.  twn = W_nfft^j, j < nfft.
+// LDS holds the four images) of a phase are loaded in eight batches, one batch ahead of their use.  twn = W_nfft^j, j < nfft.
 // (A decimation-in-TIME form -- the SUB sub-spectra of a channel pair kept in SUB images and combined per output
 // bin at the read-out -- needs 70 / 140 KB per team, i.e. two teams / one team per workgroup and 32- / 16-byte runs:
 // 0.252 / 0.279 ms on 64 x 512 000 samples where this form takes 0.182 / 0.263.)
 template <int SUB>
 struct Dif {
-    static constexpr int NFFT = SUB * N, PHASES = SUB;  // 2 -> 2 phases, 4 -> 4 phases
+    static constexpr int NFFT = SUB * N;
+    static constexpr int KINDS = SUB == 2 ? 1 : 3;  // work units per frame (k_stft_dif)
     static constexpr int LDS_BYTES = TEAMS * IMG * 8 + 256 * 8;
 };
 inline void host_twiddles(int nfft, std::vector<float2>& h) {
@@ -199,6 +200,7 @@ template <int SUB, bool POWER>
 __global__ __launch_bounds__(NT) void k_stft_dif(Args p) {
     using namespace welch4096;
     constexpr int NFFT = SUB * N;
+    constexpr int KINDS = Dif<SUB>::KINDS;  // units per frame: the self-mirroring residues, then the cross phases
     extern __shared__ __align__(16) float2 lds[];
     float2* tw2 = lds + TEAMS * IMG;
     const int team = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 8), tid = (int)threadIdx.x & 255;
@@ -207,14 +209,11 @@ __global__ __launch_bounds__(NT) void k_stft_dif(Args p) {
     const int g = u % p.n_groups, q = u / p.n_groups;
     const int cb = 16 * g + 8 * half;  // first of the workgroup's 8 channels
     if (q >= p.n_chunks || cb >= p.n_ch) return;
-    // the chunk's share of the (frame, phase) units: 65 frames of 16384 points on 32 chunks are 8 or 9 phases each,
-    // not 2 or 3 frames
-    const int n_units = p.n_frames * SUB;
+    // the chunk's share of the (frame, kind) units
+    const int n_units = p.n_frames * KINDS;
     const int u0 = (int)((int64_t)q * n_units / p.n_chunks), u1 = (int)((int64_t)(q + 1) * n_units / p.n_chunks);
     if (u0 >= u1) return;
 
-    Tw6 tw;
-    load_tw6(tw, p.twt, tid);
     if (team == 0) tw2[tid] = p.twt[15 * 256 + tid];
     const __amdgpu_buffer_rsrc_t rw = channel_rsrc(p.window, p.W);  // zero past the window: zero-padded frames
     const __amdgpu_buffer_rsrc_t rt = __builtin_amdgcn_make_buffer_rsrc(const_cast<float2*>(p.twn), 0, NFFT * 8, 0x00020000);
@@ -226,95 +225,122 @@ __global__ __launch_bounds__(NT) void k_stft_dif(Args p) {
     const int64_t F = p.n_frames, C = p.n_ch;
     const bool wide = !(p.n_ch & 1);
 
-    auto phase = [&](auto phc, const int f) {
-        {
-            constexpr int ph = decltype(phc)::value;
-            // per-thread indices are re-derived per phase (see k_stft)
-            int tx = (int)threadIdx.x;
-            asm volatile("" : "+v"(tx));
-            const int tid_l = tx & 255, bt_l = bin_thread(tid_l);
-            const bool cross = SUB == 4 && ph >= 2;  // residues 1 and 3 on neighbouring teams
-            const int r = cross ? ((team & 1) ? 3 : 1) : (SUB == 4 ? 2 * ph : ph);
-            const int pair = cross ? 2 * (ph - 2) + (team >> 1) : team;
-            const int c0 = cb + 2 * pair;
-            const bool one = c0 < p.n_ch, two = c0 + 1 < p.n_ch;
-            const __amdgpu_buffer_rsrc_t ra = channel_rsrc(p.x + (int64_t)(one ? c0 : 0) * p.ld, one ? p.n_samples : 0);
-            const __amdgpu_buffer_rsrc_t rb = channel_rsrc(p.x + (int64_t)(two ? c0 + 1 : 0) * p.ld, two ? p.n_samples : 0);
-            const int off0 = 4 * ((int)((int64_t)f * p.hop - p.pad_front) + tid_l);
-            float2 v[16];
+    // kind 0: residues 0 and SUB/2 of the team's own channel pair from ONE pass over the samples (a sample load
+    // costs more than its share of the arithmetic: with half of them removed a phase took 30 % less), two transforms;
+    // kinds 1, 2 (16384 points): residue 1 (even teams) or 3 (odd teams) of channel pair (team >> 1) + 2 (kind - 1)
+    auto unit = [&](auto kc, const int f) {
+        constexpr int kind = decltype(kc)::value;
+        constexpr bool cross = kind > 0;
+        // per-thread indices are re-derived per unit (see k_stft)
+        int tx = (int)threadIdx.x;
+        asm volatile("" : "+v"(tx));
+        const int tid_l = tx & 255;
+        const int r = cross ? ((team & 1) ? 3 : 1) : 0;
+        const int pair = cross ? 2 * (kind - 1) + (team >> 1) : team;
+        const int c0 = cb + 2 * pair;
+        const bool one = c0 < p.n_ch, two = c0 + 1 < p.n_ch;
+        const __amdgpu_buffer_rsrc_t ra = channel_rsrc(p.x + (int64_t)(one ? c0 : 0) * p.ld, one ? p.n_samples : 0);
+        const __amdgpu_buffer_rsrc_t rb = channel_rsrc(p.x + (int64_t)(two ? c0 + 1 : 0) * p.ld, two ? p.n_samples : 0);
+        const int off0 = 4 * ((int)((int64_t)f * p.hop - p.pad_front) + tid_l);
+        constexpr int RT = cross ? 0 : SUB / 2;  // the second residue of kind 0 (its twiddle W^(RT m))
+        float2 v[16], v2[cross ? 1 : 16];
+        // eight batches of two values, the loads of batch b + 1 requested before batch b is combined
+        struct Batch {
+            float za[2][SUB], zb[2][SUB], zw[2][SUB];
+            float2 wn[2];
+        };
+        auto load = [&](Batch& qb, int b2) {
 #pragma unroll
-            for (int b4 = 0; b4 < 4; ++b4) {  // four batches of four values: the loads of a batch in flight together
-                float za[4][SUB], zb[4][SUB], zw[4][SUB];
-                float2 wn[4];
+            for (int i = 0; i < 2; ++i) {
+                const int n1 = 2 * b2 + i;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int n1 = 4 * b4 + i;
-#pragma unroll
-                    for (int sI = 0; sI < SUB; ++sI) {
-                        const int o = 1024 * n1 + 4 * N * sI;
-                        za[i][sI] = ld_sample(ra, off0 + o);
-                        zb[i][sI] = ld_sample(rb, off0 + o);
-                        zw[i][sI] = ld_sample(rw, 4 * tid_l + o);
-                    }
-                    if (r) {
-                        const int ot = 8 * r * (tid_l + 256 * n1);
-                        wn[i] = make_float2(ld_sample(rt, ot), ld_sample(rt, ot + 4));
-                    }
+                for (int sI = 0; sI < SUB; ++sI) {
+                    const int o = 1024 * n1 + 4 * N * sI;
+                    qb.za[i][sI] = ld_sample(ra, off0 + o);
+                    qb.zb[i][sI] = ld_sample(rb, off0 + o);
+                    qb.zw[i][sI] = ld_sample(rw, 4 * tid_l + o);
                 }
+                const int ot = 8 * (cross ? r : RT) * (tid_l + 256 * n1);
+                qb.wn[i] = make_float2(ld_sample(rt, ot), ld_sample(rt, ot + 4));
+            }
+        };
+        auto combine = [&](const Batch& qb, int b2) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    float2 z[SUB];
+            for (int i = 0; i < 2; ++i) {
+                float2 z[SUB];
 #pragma unroll
-                    for (int sI = 0; sI < SUB; ++sI) z[sI] = make_float2(za[i][sI] * zw[i][sI], zb[i][sI] * zw[i][sI]);
-                    float2 y;
+                for (int sI = 0; sI < SUB; ++sI) z[sI] = make_float2(qb.za[i][sI] * qb.zw[i][sI], qb.zb[i][sI] * qb.zw[i][sI]);
+                constexpr int S2 = SUB == 4 ? 2 : 0, S3 = SUB == 4 ? 3 : 0;  // (indices valid for SUB == 2 too)
+                if (!cross) {
+                    float2 e0, e1;
                     if (SUB == 2) {
-                        y = r ? make_float2(z[0].x - z[1].x, z[0].y - z[1].y) : make_float2(z[0].x + z[1].x, z[0].y + z[1].y);
+                        e0 = z[0], e1 = z[1];
                     } else {
-                        const int S2 = SUB == 4 ? 2 : 0, S3 = SUB == 4 ? 3 : 0;  // (indices valid for SUB == 2 too)
-                        if (!(r & 1)) {  // r = 0: (z0 + z2) + (z1 + z3);  r = 2: (z0 + z2) - (z1 + z3)
-                            const float2 e0 = make_float2(z[0].x + z[S2].x, z[0].y + z[S2].y);
-                            const float2 e1 = make_float2(z[1].x + z[S3].x, z[1].y + z[S3].y);
-                            y = r ? make_float2(e0.x - e1.x, e0.y - e1.y) : make_float2(e0.x + e1.x, e0.y + e1.y);
-                        } else {  // r = 1: (z0 - z2) - i (z1 - z3);  r = 3: (z0 - z2) + i (z1 - z3)
-                            const float2 d0 = make_float2(z[0].x - z[S2].x, z[0].y - z[S2].y);
-                            const float2 d1 = make_float2(z[1].x - z[S3].x, z[1].y - z[S3].y);
-                            y = r == 1 ? make_float2(d0.x + d1.y, d0.y - d1.x) : make_float2(d0.x - d1.y, d0.y + d1.x);
-                        }
+                        e0 = make_float2(z[0].x + z[S2].x, z[0].y + z[S2].y);
+                        e1 = make_float2(z[1].x + z[S3].x, z[1].y + z[S3].y);
                     }
-                    if (r) y = cmul(y, wn[i]);
-                    v[4 * b4 + i] = y;
+                    v[2 * b2 + i] = make_float2(e0.x + e1.x, e0.y + e1.y);                               // residue 0
+                    float2 y2 = cmul(make_float2(e0.x - e1.x, e0.y - e1.y), qb.wn[i]);  // residue SUB/2
+                    asm volatile("" : "+v"(y2.x), "+v"(y2.y));  // parked as the product, not as its two factors
+                    v2[cross ? 0 : 2 * b2 + i] = y2;
+                } else {  // r = 1: (z0 - z2) - i (z1 - z3);  r = 3: (z0 - z2) + i (z1 - z3)
+                    const float2 d0 = make_float2(z[0].x - z[S2].x, z[0].y - z[S2].y);
+                    const float2 d1 = make_float2(z[1].x - z[S3].x, z[1].y - z[S3].y);
+                    const float2 y = r == 1 ? make_float2(d0.x + d1.y, d0.y - d1.x) : make_float2(d0.x - d1.y, d0.y + d1.x);
+                    v[2 * b2 + i] = cmul(y, qb.wn[i]);
                 }
             }
-            fft4096_w(v, tw, buf, tw2, tid_l);
+        };
+        {
+            Batch cur;
+#pragma unroll
+            for (int b2 = 0; b2 < 8; ++b2) {
+                load(cur, b2);
+                __builtin_amdgcn_sched_barrier(0);
+                combine(cur, b2);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        auto put = [&](int k, int rc, bool r_two, float2 P, float2 Q, bool edge) {
+            float2 A = make_float2(0.5f * (P.x + Q.x), 0.5f * (P.y - Q.y));
+            float2 B = make_float2(0.5f * (P.y + Q.y), -0.5f * (P.x - Q.x));
+            if (POWER) {
+                const float e = edge ? (k == 0 ? pee * dc : pee) : pe;
+                A = make_float2((A.x * A.x + A.y * A.y) * e, 0.f);
+                B = make_float2((B.x * B.x + B.y * B.y) * e, 0.f);
+            } else {
+                const float e = edge ? (k == 0 ? sce * dc : sce) : sc;
+                A = make_float2(A.x * e, A.y * e);
+                B = make_float2(B.x * e, B.y * e);
+            }
+            float2* o = p.out + ((int64_t)k * F + f) * C + rc;
+            if (wide) {
+                *reinterpret_cast<float4*>(o) = make_float4(A.x, A.y, B.x, B.y);
+            } else {
+                o[0] = A;
+                if (r_two) o[1] = B;
+            }
+        };
+        // one transform of the team's 16 values and the workgroup's read-out of the four images
+        auto pass = [&](auto rrc) {  // (transforms v: handed over as an argument, the arrays ended up in scratch)
+            constexpr int rr = decltype(rrc)::value;  // kind 0: the residue (0 or SUB/2); cross: unused
+            int ty = (int)threadIdx.x;
+            asm volatile("" : "+v"(ty));
+            const int tl = ty & 255, bt_l = bin_thread(tl);
+            Tw6 tw;  // six 8-byte loads per transform: held across the unit they are 12 registers this kernel does not have
+            load_tw6(tw, p.twt, tl);
+            fft4096_w(v, tw, buf, tw2, tl);
             __syncthreads();  // every wave has read its rows of the images
 #pragma unroll
             for (int k3 = 0; k3 < 16; ++k3) buf[fold_pos(bt_l + 256 * k3)] = v[pos16(k3)];
             __syncthreads();
-            // ---- read-out
-            auto put = [&](int k, int rc, bool r_two, float2 P, float2 Q, bool edge) {
-                float2 A = make_float2(0.5f * (P.x + Q.x), 0.5f * (P.y - Q.y));
-                float2 B = make_float2(0.5f * (P.y + Q.y), -0.5f * (P.x - Q.x));
-                if (POWER) {
-                    const float e = edge ? (k == 0 ? pee * dc : pee) : pe;
-                    A = make_float2((A.x * A.x + A.y * A.y) * e, 0.f);
-                    B = make_float2((B.x * B.x + B.y * B.y) * e, 0.f);
-                } else {
-                    const float e = edge ? (k == 0 ? sce * dc : sce) : sc;
-                    A = make_float2(A.x * e, A.y * e);
-                    B = make_float2(B.x * e, B.y * e);
-                }
-                float2* o = p.out + ((int64_t)k * F + f) * C + rc;
-                if (wide) {
-                    *reinterpret_cast<float4*>(o) = make_float4(A.x, A.y, B.x, B.y);
-                } else {
-                    o[0] = A;
-                    if (r_two) o[1] = B;
-                }
-            };
-            const int rk = tx >> 2;
-            if (!cross) {  // four pairs, residue rr pairs with itself
-                const int rr = SUB == 4 ? 2 * ph : ph;
-                const int rp = tx & 3;
+            // the read-out's indices and output addresses are derived HERE: from a value known before the transform
+            // they are computed before it and held through it (70 dwords of scratch)
+            ty = (int)threadIdx.x;
+            asm volatile("" : "+v"(ty));
+            const int rk = ty >> 2;
+            if (!cross) {  // four pairs, residue rr mirrors into itself
+                const int rp = ty & 3;
                 const float2* im = lds + rp * IMG;
                 const int rc = cb + 2 * rp;
                 if (rc < p.n_ch) {
@@ -327,11 +353,11 @@ __global__ __launch_bounds__(NT) void k_stft_dif(Args p) {
                     }
                     if (rr == 0 && rk == 0) put(NFFT / 2, rc, r_two, im[fold_pos(N / 2)], im[fold_pos(N / 2)], true);
                 }
-            } else {  // two pairs x residues 1 and 3, which pair with each other
-                const int rp2 = tx & 1, res3 = (tx >> 1) & 1;
+            } else {  // two pairs x residues 1 and 3, which mirror into each other
+                const int rp2 = ty & 1, res3 = (ty >> 1) & 1;
                 const float2* own = lds + (2 * rp2 + res3) * IMG;
                 const float2* oth = lds + (2 * rp2 + 1 - res3) * IMG;
-                const int rc = cb + 2 * (2 * (ph - 2) + rp2);
+                const int rc = cb + 2 * (2 * (kind - 1) + rp2);
                 if (rc < p.n_ch) {
                     const bool r_two = rc + 1 < p.n_ch;
 #pragma unroll
@@ -342,18 +368,22 @@ __global__ __launch_bounds__(NT) void k_stft_dif(Args p) {
                 }
             }
             // (the next transform's first barrier stands between these reads and its image stores)
+        };
+        pass(std::integral_constant<int, 0>{});
+        if constexpr (!cross) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) v[i] = v2[i];
+            pass(std::integral_constant<int, SUB / 2>{});
         }
     };
     for (int un = u0; un < u1; ++un) {
-        const int f = un / SUB, ph = un - f * SUB;
-        if (ph == 0)
-            phase(std::integral_constant<int, 0>{}, f);
-        else if (ph == 1)
-            phase(std::integral_constant<int, 1>{}, f);
-        else if (SUB == 4 && ph == 2)
-            phase(std::integral_constant<int, SUB == 4 ? 2 : 0>{}, f);
-        else if (SUB == 4)
-            phase(std::integral_constant<int, SUB == 4 ? 3 : 0>{}, f);
+        const int f = un / KINDS, kind = un - f * KINDS;
+        if (kind == 0)
+            unit(std::integral_constant<int, 0>{}, f);
+        else if (KINDS > 1 && kind == 1)
+            unit(std::integral_constant<int, (KINDS > 1 ? 1 : 0)>{}, f);
+        else if (KINDS > 2)
+            unit(std::integral_constant<int, (KINDS > 2 ? 2 : 0)>{}, f);
     }
 }
 
