@@ -220,7 +220,7 @@ __device__ __forceinline__ void ifft4096_wi(float2 (&v)[16], const w4::Tw6& tw, 
 #pragma unroll
             for (int b = 0; b < 4; ++b) {
                 float2 z = v[4 * g + b];
-                if (g) z = cmulc(z, tw.a[g - 1]);  // k1 = g + 4 b: lo = g, hi = b
+                if constexpr (g > 0) z = cmulc(z, tw.a[g - 1]);  // k1 = g + 4 b: lo = g, hi = b
                 if (b) z = cmulc(z, tw.b[b - 1]);
                 v[4 * g + b] = z;
             }
