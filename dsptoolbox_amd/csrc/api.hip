@@ -1996,6 +1996,12 @@ extern "C" int ds_deconv_dev(ds_ctx* c, const float* y, int n_items, int n_ch, i
         // one 256-thread group per channel pair, its two sub-spectra one after the other: three independent
         // workgroups per CU (k_deconv3); DSPTOOLBOX_AMD_DECONV_2PERCU=1 keeps the 512-thread kernel (A/B)
         static const bool two = getenv("DSPTOOLBOX_AMD_DECONV_2PERCU") != nullptr;
+        // four workgroups per CU (k_deconv3q: all 1024 pairs of the benchmark resident at once) unless
+        // DSPTOOLBOX_AMD_DECONV_4PERCU=0 (k_deconv3: three, 168 registers)
+        static const bool four = !(getenv("DSPTOOLBOX_AMD_DECONV_4PERCU") && atoi(getenv("DSPTOOLBOX_AMD_DECONV_4PERCU")) == 0);
+        if (!two && four && (int64_t)((n_ch + 1) / 2) * n_items < ((int64_t)1 << 31))
+            return launch(c, "deconv", deconv8k::k_deconv3q, dim3((unsigned)(((n_ch + 1) / 2) * n_items)), 256,
+                          deconv8k::LDS_BYTES_3, a8);
         if (!two && (int64_t)((n_ch + 1) / 2) * n_items < ((int64_t)1 << 31))
             return launch(c, "deconv", deconv8k::k_deconv3, dim3((unsigned)(((n_ch + 1) / 2) * n_items)), 256,
                           deconv8k::LDS_BYTES_3, a8);

@@ -265,4 +265,96 @@ __global__ __launch_bounds__(256, 3) void k_deconv3(Args p) {
     }
 }
 
+// The same with FOUR workgroups per CU (<= 128 registers: the shared spectrum of a sub-problem is gathered behind its
+// forward transform instead of being held through it, the second half block waits as 32 finished values): all 1024
+// channel pairs of the benchmark are resident at once, as independent 256-thread workgroups (four channel pairs as
+// four TEAMS of one 1024-thread workgroup were slower: 54.5 against 46.7 us).
+// grid = ceil(n_ch / 2) * n_items
+__global__ __launch_bounds__(256, 4) void k_deconv3q(Args p) {
+    extern __shared__ __align__(16) float2 lds[];
+    float2* buf = lds;
+    float2* tw2 = lds + 16 * w4::L1S;
+    const int tid = threadIdx.x;
+    const int pairs = (p.n_ch + 1) / 2;
+    const int64_t item = (int)blockIdx.x / pairs;
+    const int ca = 2 * ((int)blockIdx.x - (int)item * pairs), cb = ca + 1;
+    const bool vb = cb < p.n_ch;
+    const uint32_t in_bytes = (uint32_t)(p.n_samples < (int64_t)N ? p.n_samples : (int64_t)N) * 4u;
+    const float* ya = p.y + (item * p.n_ch + ca) * p.ld;
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ya), 0, (int)in_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ya + (vb ? p.ld : 0)), 0, vb ? (int)in_bytes : 0, 0x00020000);
+    w4::Tw6 tw;
+    w4::load_tw6(tw, p.twt, tid);
+    tw2[tid] = p.twt[15 * 256 + tid];
+    const float2 wt = p.twn[tid];           // W8192^tid
+    const float2* c32 = p.twn + 256;        // W32^n1 (wave-uniform)
+    // b_0 = z[n'] + z[n' + 4096] ,  b_1 = (z[n'] - z[n' + 4096]) W8192^n' ,  n' = tid + 256 n1
+    float2 v[16], b1[16];
+#pragma unroll
+    for (int n1 = 0; n1 < 16; ++n1) {
+        const int off = 4 * (tid + 256 * n1);
+        const float2 z0 = make_float2(w4::ld_sample(ra, off), w4::ld_sample(rb, off));
+        const float2 z1 = make_float2(w4::ld_sample(ra, off + 4 * M), w4::ld_sample(rb, off + 4 * M));
+        v[n1] = make_float2(z0.x + z1.x, z0.y + z1.y);
+        float2 y1 = cmul(make_float2(z0.x - z1.x, z0.y - z1.y), cmul(wt, c32[n1]));
+        asm volatile("" : "+v"(y1.x), "+v"(y1.y));  // parked as the product, not as its factors
+        b1[n1] = y1;
+    }
+    // The shared inverse spectrum of sub-spectrum q in the transform's register layout: slot
+    // s = pos16(k3) <-> bin k = 2 (bt + 256 k3) + q;  Rf[k] = R[k], Rf[N - k] = conj R[k], real at 0 and
+    // N / 2 (numpy's irfft ignores the imaginary parts there); 1 / N folded in.  Branch-free.
+    const int bt = w4::bin_thread(tid);
+    const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float2*>(p.r), 0, (N / 2 + 1) * 8, 0x00020000);
+    auto gather = [&](float2 (&rf)[16], int q) {
+        const float inv = 1.0f / (float)N;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const int k3 = (s >> 2) + 4 * (s & 3);
+            const int k = 2 * (bt + 256 * k3) + q;
+            const float2 r = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(rr, 8 * min(k, N - k), 0, 0));
+            const float sg = (k == 0 || k == N / 2) ? 0.f : (k < N / 2 ? inv : -inv);
+            rf[s] = make_float2(r.x * inv, r.y * sg);
+        }
+    };
+    // (the transforms with their LDS traffic spread between the butterflies: the plain forms, whose
+    // exchanges hipcc issues in bursts, made this kernel SLOWER than the 512-thread one -- 58 against 45 us)
+    float2* tw2p = lds + 16 * w4::L1S + 256;
+    fir4k::fill_tw2p(tw2p, p.twt, tid);
+    float2 rf[16];
+    w4::Stamp ts;
+    auto none = [](int) {};
+    __syncthreads();  // the tables
+    w4::fft4096_wi(v, tw, buf, tw2, tid, none, none, ts, 0);
+    gather(rf, 0);
+#pragma unroll
+    for (int s = 0; s < 16; ++s) v[s] = cmul(v[s], rf[s]);
+    fir4k::ifft4096_wi(v, tw, buf, tw2p, tid, none, none);
+    float2 g0[16];
+#pragma unroll
+    for (int n1 = 0; n1 < 16; ++n1) {
+        g0[n1] = v[n1];
+        v[n1] = b1[n1];
+    }
+    __syncthreads();  // the column reads of the transform back: the forward transform stores into the image at once
+    w4::fft4096_wi(v, tw, buf, tw2, tid, none, none, ts, 0);
+    gather(rf, 1);
+#pragma unroll
+    for (int s = 0; s < 16; ++s) v[s] = cmul(v[s], rf[s]);
+    fir4k::ifft4096_wi(v, tw, buf, tw2p, tid, none, none);
+    // y[n'] = g_0 + W8192^(-n') g_1 ,  y[n' + 4096] = g_0 - W8192^(-n') g_1
+    float* oa = p.ir + (item * p.n_ch + ca) * p.ld_out;
+    const uint32_t out_bytes = (uint32_t)(p.n_out < (int64_t)N ? p.n_out : (int64_t)N) * 4u;
+    const __amdgpu_buffer_rsrc_t sa = __builtin_amdgcn_make_buffer_rsrc(oa, 0, (int)out_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t sb = __builtin_amdgcn_make_buffer_rsrc(oa + (vb ? p.ld_out : 0), 0, vb ? (int)out_bytes : 0, 0x00020000);
+#pragma unroll
+    for (int n1 = 0; n1 < 16; ++n1) {
+        const float2 u = cmulc(v[n1], cmul(wt, c32[n1]));
+        const int off = 4 * (tid + 256 * n1);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, g0[n1].x + u.x), sa, off, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, g0[n1].y + u.y), sb, off, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, g0[n1].x - u.x), sa, off + 4 * M, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, g0[n1].y - u.y), sb, off + 4 * M, 0, 0);
+    }
+}
+
 }  // namespace deconv8k
