@@ -727,13 +727,64 @@ extern "C" int ds_istft_dev(ds_ctx* c, const ds_c32* stft, int n_bins, int n_fra
     CHK(check_fft_len(c, nfft, "ds_istft nfft"));
     const float2* tw;
     CHK(get_twiddles(c, nfft, &tw));
+    // 50 % overlap of full-length frames: transform and overlap-add in one kernel, no frames in memory
+    static const bool no_fuse = getenv("DSPTOOLBOX_AMD_ISTFT_FUSED") && atoi(getenv("DSPTOOLBOX_AMD_ISTFT_FUSED")) == 0;
+    if (W == nfft && 2 * step == nfft && n_ch > 1 && !no_fuse) {
+        int ct = 1;
+        size_t lds = 0;
+        int threads = 0, nt = 64;
+        DISPATCH_N(nfft, {
+            ct = std::min<int>(stft_max_teams<NN>(), n_ch);
+            while (ct & (ct - 1)) ct &= ct - 1;
+            lds = (size_t)stft_ch_stride<NN>() * sizeof(float2) * ct + sizeof(float) * (size_t)(NN / 2);  // + 1 / envelope
+            threads = ct * Cfg<NN>::NT;
+            nt = Cfg<NN>::NT;
+        });
+        if (ct > 1 && nfft % (2 * nt) == 0) {
+            const int n_fp = (n_frames + 1) / 2, n_ct = (n_ch + ct - 1) / ct;
+            // frame pairs per workgroup: every workgroup transforms one more pair (the carry in front of its range)
+            // (64 x 512 000 samples, windows of 256 / 1024 / 4096: ~250 workgroups measured best: 0.21 / 0.21 / 0.29 ms)
+            int fpw = std::max(4, std::min(64, (int)(((int64_t)n_fp * n_ct + 255) / 256)));
+            if (const char* e = getenv("DSPTOOLBOX_AMD_ISTFT_FPW")) fpw = std::max(1, atoi(e));
+            IstftFusedArgs fa{IstftArgs{(const float2*)stft, n_bins, n_frames, n_ch, W, window, tw, scale, nullptr, ct, fpw},
+                              frame_offset, n_frames_total, total_length, ld_out, out};
+            DISPATCH_N(nfft, CHK(launch(c, "istft", k_istft_fused<NN>,
+                                        dim3((unsigned)((n_fp + fpw - 1) / fpw), (unsigned)n_ct), threads, lds, fa)));
+            return DS_OK;
+        }
+    }
     CHK(reserve(c, &c->ws, &c->ws_bytes, sizeof(float) * (size_t)n_ch * n_frames * W));
     float* frames = (float*)c->ws;
     IstftArgs a{(const float2*)stft, n_bins, n_frames, n_ch, W, window, tw, scale, frames};
-    DISPATCH_N(nfft, CHK(launch(c, "istft", k_istft<NN>, dim3((n_frames + 1) / 2, n_ch), Cfg<NN>::NT,
-                                Cfg<NN>::LDS_BYTES, a)));
+    // ct neighbouring channels per workgroup (runs of 8 ct bytes of the channel-fastest spectrogram) wherever more
+    // than one image fits; DSPTOOLBOX_AMD_ISTFT_CT=1 keeps one channel per workgroup
+    static const bool one_ch = getenv("DSPTOOLBOX_AMD_ISTFT_CT") && atoi(getenv("DSPTOOLBOX_AMD_ISTFT_CT")) == 1;
+    int ct = 1;
+    size_t lds = 0;
+    int threads = 0;
+    DISPATCH_N(nfft, {
+        ct = std::min<int>(stft_max_teams<NN>(), n_ch);
+        while (ct & (ct - 1)) ct &= ct - 1;
+        lds = (size_t)stft_ch_stride<NN>() * sizeof(float2) * ct;
+        threads = ct * Cfg<NN>::NT;
+    });
+    if (ct > 1 && !one_ch) {
+        const int n_fp = (n_frames + 1) / 2, n_ct = (n_ch + ct - 1) / ct;
+        a.ct = ct;
+        a.fpw = std::max(1, std::min(16, (int)(((int64_t)n_fp * n_ct + 511) / 512)));
+        DISPATCH_N(nfft, CHK(launch(c, "istft", k_istft_ct<NN>, dim3((unsigned)((n_fp + a.fpw - 1) / a.fpw), (unsigned)n_ct),
+                                    threads, lds, a)));
+    } else {
+        DISPATCH_N(nfft, CHK(launch(c, "istft", k_istft<NN>, dim3((n_frames + 1) / 2, n_ch), Cfg<NN>::NT,
+                                    Cfg<NN>::LDS_BYTES, a)));
+    }
     IstftOlaArgs o{frames, n_frames, n_ch, W, step, frame_offset, n_frames_total, window, total_length, ld_out, out};
-    CHK(launch(c, "istft_ola", k_istft_ola, dim3((unsigned)((total_length + 255) / 256), n_ch), 256, 0, o));
+    // four samples per thread where every row and frame boundary is a multiple of four samples (and 16-byte aligned)
+    if (W % 4 == 0 && step % 4 == 0 && total_length % 4 == 0 && ld_out % 4 == 0 && ((uintptr_t)out & 15) == 0 &&
+        ((uintptr_t)window & 15) == 0)
+        CHK(launch(c, "istft_ola", k_istft_ola4, dim3((unsigned)((total_length / 4 + 255) / 256), n_ch), 256, 0, o));
+    else
+        CHK(launch(c, "istft_ola", k_istft_ola, dim3((unsigned)((total_length + 255) / 256), n_ch), 256, 0, o));
     return DS_OK;
 }
 

@@ -499,7 +499,185 @@ struct IstftArgs {
     const float2* tw;
     float scale;
     float* frames;
+    int ct = 1, fpw = 1;  // k_istft_ct: channels (teams) per workgroup, frame pairs per workgroup
 };
+
+// The same with ct channels per workgroup (the mirror image of k_stft's tile): the spectrogram is
+// channel-fastest, so ONE channel per workgroup reads 8 bytes out of every 128-byte line it touches
+// (64 channels x 512 000 samples: 0.79 ms at every window length, 0.5 TB/s).  Here the workgroup reads the
+// bins of ct neighbouring channels together -- runs of 8 ct bytes -- straight into the ct LDS images
+// (Z = A + i B and its mirror half), every team transforms its own image back and writes its two frames,
+// which are contiguous per channel.  grid = (ceil(ceil(F/2) / fpw), ceil(C / ct)), block = ct * NT.
+template <int N>
+__global__ __launch_bounds__(stft_max_teams<N>() * Cfg<N>::NT) void k_istft_ct(IstftArgs p) {
+    using C = Cfg<N>;
+    constexpr int CHS = stft_ch_stride<N>();
+    extern __shared__ __align__(16) float2 lds[];
+    const int team = threadIdx.x / C::NT, tid = threadIdx.x % C::NT;
+    float2* buf = lds + (int64_t)team * CHS;
+    const int c0 = blockIdx.y * p.ct;
+    const int ctv = min(p.ct, p.n_ch - c0);
+    const int c = c0 + team;
+    const int64_t F = p.n_frames, Cn = p.n_ch;
+    const int lct = __ffs(p.ct) - 1;  // ct is a power of two
+    const int cl = threadIdx.x & (p.ct - 1);
+    float2* img = lds + (int64_t)cl * CHS;
+    const int n_fp = (p.n_frames + 1) >> 1;
+    const int fp0 = blockIdx.x * p.fpw, fp1 = min(fp0 + p.fpw, n_fp);
+    for (int fp = fp0; fp < fp1; ++fp) {
+        const int f0 = 2 * fp;
+        const bool v1 = f0 + 1 < p.n_frames;
+        __syncthreads();  // the frames of the previous pair have been read out of the images
+        for (int k = threadIdx.x >> lct; k <= N / 2; k += blockDim.x >> lct) {
+            float2 A = make_float2(0.f, 0.f), B = make_float2(0.f, 0.f);
+            if (cl < ctv && k < p.n_bins) {
+                const float2* s = p.stft + ((int64_t)k * F + f0) * Cn + c0 + cl;
+                A = s[0];
+                if (v1) B = s[Cn];
+            }
+            if (k == 0 || k == N / 2) {
+                img[lidx(k)] = make_float2(A.x, B.x);
+            } else {
+                img[lidx(k)] = make_float2(A.x - B.y, A.y + B.x);      // A + i B
+                img[lidx(N - k)] = make_float2(A.x + B.y, B.x - A.y);  // conj(A) + i conj(B)
+            }
+        }
+        __syncthreads();
+        float2 v[C::VMAX];
+        fft<N, true, false, false>(v, buf, p.tw, tid);
+        if (c < p.n_ch) {
+            float* oa = p.frames + ((int64_t)c * F + f0) * p.W;
+            float* ob = oa + p.W;
+            for (int n = tid; n < p.W && n < N; n += C::NT) {
+                const float2 z = buf[lidx(n)];
+                const float w = p.window[n] * p.scale;
+                oa[n] = z.x * w;
+                if (v1) ob[n] = z.y * w;
+            }
+        }
+    }
+}
+
+// k_istft_ct with the overlap-add folded in, for THE common case W == N, step == N / 2 (50 % overlap): a frame's first
+// half completes the second half of the frame before it, so a team thread carries N / (2 NT) sums in registers from
+// one frame pair to the next and writes finished output samples -- the frames never go to memory (263 MB written and
+// read back for 64 channels x 512 000 samples) and the separate overlap-add launch disappears.  A workgroup owns the
+// output from the start of its first frame to the start of the next workgroup's; it first transforms the frame
+// pair in front of its range to obtain the carry (the last one also writes what follows the last frame).
+// out[c * ld + n] = sum / max(sum of w^2 over the frame slots [0, n_total) that cover n, 1e-4)  (k_istft_ola).
+struct IstftFusedArgs {
+    IstftArgs a;
+    int off, n_total;
+    int64_t total_length, ld;
+    float* out;
+};
+template <int N>
+__global__ __launch_bounds__(stft_max_teams<N>() * Cfg<N>::NT) void k_istft_fused(IstftFusedArgs q) {
+    using C = Cfg<N>;
+    const IstftArgs& p = q.a;
+    // (the host launches it only where half a frame is a whole number of values per thread: N % (2 NT) == 0)
+    constexpr int CHS = stft_ch_stride<N>(), NT = C::NT, H = N / (2 * NT) > 0 ? N / (2 * NT) : 1, STEP = N / 2;
+    extern __shared__ __align__(16) float2 lds[];
+    const int team = threadIdx.x / NT, tid = threadIdx.x % NT;
+    float2* buf = lds + (int64_t)team * CHS;
+    const int c0 = blockIdx.y * p.ct;
+    const int ctv = min(p.ct, p.n_ch - c0);
+    const int c = c0 + team;
+    const int64_t F = p.n_frames, Cn = p.n_ch;
+    const int lct = __ffs(p.ct) - 1;
+    const int cl = threadIdx.x & (p.ct - 1);
+    float2* img = lds + (int64_t)cl * CHS;
+    const int n_fp = (p.n_frames + 1) >> 1;
+    const int fp0 = blockIdx.x * p.fpw, fp1 = min(fp0 + p.fpw, n_fp);
+    if (fp0 >= fp1) return;
+    float* oc = q.out + (int64_t)(c < p.n_ch ? c : 0) * q.ld;
+    // 1 / envelope wherever two frame slots cover a position (everywhere but at the ends of the signal): it depends
+    // on the position within the step only (a per-sample float64 division tripled the vector work of a team)
+    float* inv_env = reinterpret_cast<float*>(lds + (int64_t)p.ct * CHS);
+    for (int m = threadIdx.x; m < STEP; m += blockDim.x) {
+        const double w0 = (double)p.window[m], w1 = (double)p.window[m + STEP];
+        const double e = w0 * w0 + w1 * w1;
+        inv_env[m] = (float)(1.0 / (e < 1e-4 ? 1e-4 : e));
+    }
+    // envelope of the window at output position pos: the frame slots fs = pos / STEP and fs - 1 (both within [0, n_total))
+    auto emit = [&](int64_t pos, float sum) {
+        if (pos < 0 || pos >= q.total_length) return;
+        const int64_t fs = pos / STEP;
+        const int m = (int)(pos - fs * STEP);
+        double env = 0.0;
+        if (fs < q.n_total) {
+            const float w = p.window[m];
+            env += (double)w * (double)w;
+        }
+        if (fs >= 1 && fs - 1 < q.n_total) {
+            const float w = p.window[m + STEP];
+            env += (double)w * (double)w;
+        }
+        oc[pos] = (float)((double)sum / (env < 1e-4 ? 1e-4 : env));
+    };
+    float carry[H];
+#pragma unroll
+    for (int j = 0; j < H; ++j) carry[j] = 0.f;
+    // positions in front of the first frame slot (off = 1: the reference's empty frame in front) are written by the
+    // first workgroup
+    if (fp0 == 0 && c < p.n_ch)
+        for (int64_t n = tid; n < (int64_t)q.off * STEP; n += NT) emit(n, 0.f);
+    for (int fp = fp0 > 0 ? fp0 - 1 : 0; fp < fp1; ++fp) {
+        const int f0 = 2 * fp;
+        const bool v1 = f0 + 1 < p.n_frames;
+        const bool owned = fp >= fp0;  // the pair in front of the range only yields the carry
+        __syncthreads();  // the previous pair has been read out of the images
+        for (int k = threadIdx.x >> lct; k <= N / 2; k += blockDim.x >> lct) {
+            float2 A = make_float2(0.f, 0.f), B = make_float2(0.f, 0.f);
+            if (cl < ctv && k < p.n_bins) {
+                const float2* s = p.stft + ((int64_t)k * F + f0) * Cn + c0 + cl;
+                A = s[0];
+                if (v1) B = s[Cn];
+            }
+            if (k == 0 || k == N / 2) {
+                img[lidx(k)] = make_float2(A.x, B.x);
+            } else {
+                img[lidx(k)] = make_float2(A.x - B.y, A.y + B.x);      // A + i B
+                img[lidx(N - k)] = make_float2(A.x + B.y, B.x - A.y);  // conj(A) + i conj(B)
+            }
+        }
+        __syncthreads();
+        float2 v[C::VMAX];
+        fft<N, true, false, false>(v, buf, p.tw, tid);
+        if (c < p.n_ch) {
+            const int64_t P0 = (int64_t)(f0 + q.off) * STEP;
+            // both covering frame slots exist: fs - 1 >= 0 and fs < n_total (uniform per segment)
+            const bool fast0 = f0 + q.off >= 1 && f0 + q.off < q.n_total;
+            const bool fast1 = f0 + q.off + 1 < q.n_total;
+#pragma unroll
+            for (int j = 0; j < H; ++j) {
+                const int n = tid + NT * j;
+                const float2 lo = buf[lidx(n)], hi = buf[lidx(n + STEP)];
+                const float wl = p.window[n] * p.scale, wh = p.window[n + STEP] * p.scale;
+                if (owned) {
+                    const float s0 = carry[j] + lo.x * wl;       // second half of the frame before + first half of f0
+                    const float s1 = hi.x * wh + lo.y * wl;      // second half of f0 + first half of f0 + 1
+                    if (fast0 && P0 + n < q.total_length)
+                        oc[P0 + n] = s0 * inv_env[n];
+                    else
+                        emit(P0 + n, s0);
+                    if (fast1 && P0 + STEP + n < q.total_length)
+                        oc[P0 + STEP + n] = s1 * inv_env[n];
+                    else
+                        emit(P0 + STEP + n, s1);
+                }
+                carry[j] = hi.y * wh;                                // second half of f0 + 1 (zero if it does not exist)
+            }
+        }
+    }
+    // behind the last frame: its second half, then nothing but the envelope's floor
+    if (fp1 == n_fp && c < p.n_ch) {
+        const int64_t P = (int64_t)(2 * n_fp + q.off) * STEP;
+#pragma unroll
+        for (int j = 0; j < H; ++j) emit(P + tid + NT * j, carry[j]);
+        for (int64_t n = P + STEP + tid; n < q.total_length; n += NT) emit(n, 0.f);
+    }
+}
 
 template <int N>
 __global__ __launch_bounds__(Cfg<N>::NT) void k_istft(IstftArgs p) {
@@ -549,9 +727,17 @@ __global__ void k_istft_ola(IstftOlaArgs p) {
     const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int c = blockIdx.y;
     if (n >= p.total_length) return;
-    int64_t lo = (n - p.W + p.step) / p.step;  // ceil((n - W + 1) / step) for n - W + 1 > 0
-    if (n - p.W + 1 <= 0) lo = 0;
-    int64_t hi = n / p.step;
+    // (32-bit quotients wherever the signal is shorter than 2^31 samples: the two 64-bit integer divisions were
+    // most of this kernel's time)
+    int64_t lo, hi;
+    if (p.total_length < ((int64_t)1 << 31)) {
+        const unsigned nn = (unsigned)n, st = (unsigned)p.step;
+        lo = n - p.W + 1 <= 0 ? 0 : (int64_t)((nn - (unsigned)p.W + st) / st);  // ceil((n - W + 1) / step)
+        hi = (int64_t)(nn / st);
+    } else {
+        lo = n - p.W + 1 <= 0 ? 0 : (n - p.W + p.step) / p.step;
+        hi = n / p.step;
+    }
     if (hi > p.n_total - 1) hi = p.n_total - 1;
     double acc = 0.0, env = 0.0;
     for (int64_t fs = lo; fs <= hi; ++fs) {
@@ -563,6 +749,48 @@ __global__ void k_istft_ola(IstftOlaArgs p) {
     }
     if (env < 1e-4) env = 1e-4;
     p.out[(int64_t)c * p.ld + n] = (float)(acc / env);
+}
+
+// Four neighbouring samples per thread, 16-byte loads and stores: when the window length, the step, the row pitch
+// and the total length are multiples of 4 the four samples are covered by the same frames (frame boundaries fall
+// on multiples of the step).  grid = (ceil(total_length / 4 / 256), n_ch).
+__global__ void k_istft_ola4(IstftOlaArgs p) {
+    const int64_t n = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    const int c = blockIdx.y;
+    if (n >= p.total_length) return;
+    int64_t lo, hi;
+    if (p.total_length < ((int64_t)1 << 31)) {
+        const unsigned nn = (unsigned)n, st = (unsigned)p.step;
+        lo = n + 3 - p.W + 1 <= 0 ? 0 : (int64_t)((nn + 3u - (unsigned)p.W + st) / st);
+        hi = (int64_t)(nn / st);
+    } else {
+        lo = n + 3 - p.W + 1 <= 0 ? 0 : (n + 3 - p.W + p.step) / p.step;
+        hi = n / p.step;
+    }
+    if (hi > p.n_total - 1) hi = p.n_total - 1;
+    double acc[4] = {0.0, 0.0, 0.0, 0.0}, env[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int64_t fs = lo; fs <= hi; ++fs) {
+        const int m = (int)(n - fs * p.step);  // multiple of 4, 0 <= m <= W - 4
+        const float4 w = *reinterpret_cast<const float4*>(p.window + m);
+        env[0] += (double)w.x * (double)w.x;
+        env[1] += (double)w.y * (double)w.y;
+        env[2] += (double)w.z * (double)w.z;
+        env[3] += (double)w.w * (double)w.w;
+        const int64_t f = fs - p.off;
+        if (f >= 0 && f < p.n_frames) {
+            const float4 v = *reinterpret_cast<const float4*>(p.frames + ((int64_t)c * p.n_frames + f) * p.W + m);
+            acc[0] += (double)v.x;
+            acc[1] += (double)v.y;
+            acc[2] += (double)v.z;
+            acc[3] += (double)v.w;
+        }
+    }
+    float4 o;
+    o.x = (float)(acc[0] / (env[0] < 1e-4 ? 1e-4 : env[0]));
+    o.y = (float)(acc[1] / (env[1] < 1e-4 ? 1e-4 : env[1]));
+    o.z = (float)(acc[2] / (env[2] < 1e-4 ? 1e-4 : env[2]));
+    o.w = (float)(acc[3] / (env[3] < 1e-4 ? 1e-4 : env[3]));
+    *reinterpret_cast<float4*>(p.out + (int64_t)c * p.ld + n) = o;
 }
 
 // ---------------------------------------------------------------- band powers of a spectrogram

@@ -1389,6 +1389,33 @@ def test_stft_default_frame_kernel_vs_oracle():
     print("stft 1024-frame kernel worst rel-max", worst)
 
 
+@pytest.mark.parametrize("n_ch", [2, 5, 20])
+def test_istft_channel_tiles_and_fused_overlap_add_vs_oracle(n_ch):
+    """The inverse STFT reads ct neighbouring channels per workgroup (k_istft_ct) and, for full-length frames at 50 %
+    overlap, adds the overlapping halves in registers and writes finished samples (k_istft_fused): random spectrograms
+    (not the transform of any signal: every frame half matters), odd and even frame counts, with and without the
+    reference's padding (frame offset 0 / 1 and the empty frame slots at both ends), channel tiles with idle teams,
+    several workgroups per channel tile; other overlaps and shorter windows take the two-kernel path."""
+    rng = np.random.default_rng(100 + n_ch)
+    worst = 0.0
+    for W, nfft, ov, pad, n_frames in ((256, None, 50, True, 37), (256, None, 50, False, 300), (1024, None, 50, False, 41),
+                                        (1024, None, 50, True, 200), (4096, None, 50, True, 9), (2048, None, 50, False, 130),
+                                        (1024, None, 75, True, 40), (512, 1024, 50, False, 30), (1024, None, 25, False, 33)):
+        nb = (nfft or W) // 2 + 1
+        sp = rng.standard_normal((nb, n_frames, n_ch)) + 1j * rng.standard_normal((nb, n_frames, n_ch))
+        sp[0].imag = 0
+        sp[-1].imag = 0
+        got = dsp.transforms.istft(sp, sampling_rate_hz=48000, window_length_samples=W, window_type=Window.Hann,
+                                   overlap_percent=ov, fft_length_samples=nfft, padding=pad,
+                                   scaling=SpectrumScaling.FFTBackward)
+        ref = orc.istft(sp, 48000, W, "hann", ov, nfft, pad, "FFTBackward")
+        assert got.time_data.shape == ref.shape, (W, nfft, ov, pad, got.time_data.shape, ref.shape)
+        e = relmax(got.time_data, ref)
+        worst = max(worst, e)
+        assert e < TOL, (W, nfft, ov, pad, n_frames, e)
+    print("istft worst rel-max", worst)
+
+
 def test_stft_8192_and_16384_frame_kernels_vs_oracle():
     """Frames of 8192 / 16384 points (kernels_stft4096.hpp, k_stft_long): two / four decimated 4096-point transforms per
     channel pair, combined at the read-out; two teams (4 channels) / one team (2 channels) per workgroup.  Odd and
