@@ -748,8 +748,11 @@ extern "C" int ds_istft_dev(ds_ctx* c, const ds_c32* stft, int n_bins, int n_fra
             if (const char* e = getenv("DSPTOOLBOX_AMD_ISTFT_FPW")) fpw = std::max(1, atoi(e));
             IstftFusedArgs fa{IstftArgs{(const float2*)stft, n_bins, n_frames, n_ch, W, window, tw, scale, nullptr, ct, fpw},
                               frame_offset, n_frames_total, total_length, ld_out, out};
-            DISPATCH_N(nfft, CHK(launch(c, "istft", k_istft_fused<NN>,
-                                        dim3((unsigned)((n_fp + fpw - 1) / fpw), (unsigned)n_ct), threads, lds, fa)));
+            DISPATCH_N(nfft, {
+                if constexpr (stft_max_teams<NN>() > 1 && NN % (2 * Cfg<NN>::NT) == 0)  // (ct > 1 never holds otherwise)
+                    CHK(launch(c, "istft", k_istft_fused<NN>, dim3((unsigned)((n_fp + fpw - 1) / fpw), (unsigned)n_ct),
+                               threads, lds, fa));
+            });
             return DS_OK;
         }
     }
@@ -772,8 +775,11 @@ extern "C" int ds_istft_dev(ds_ctx* c, const ds_c32* stft, int n_bins, int n_fra
         const int n_fp = (n_frames + 1) / 2, n_ct = (n_ch + ct - 1) / ct;
         a.ct = ct;
         a.fpw = std::max(1, std::min(16, (int)(((int64_t)n_fp * n_ct + 511) / 512)));
-        DISPATCH_N(nfft, CHK(launch(c, "istft", k_istft_ct<NN>, dim3((unsigned)((n_fp + a.fpw - 1) / a.fpw), (unsigned)n_ct),
-                                    threads, lds, a)));
+        DISPATCH_N(nfft, {
+            if constexpr (stft_max_teams<NN>() > 1)
+                CHK(launch(c, "istft", k_istft_ct<NN>, dim3((unsigned)((n_fp + a.fpw - 1) / a.fpw), (unsigned)n_ct), threads,
+                           lds, a));
+        });
     } else {
         DISPATCH_N(nfft, CHK(launch(c, "istft", k_istft<NN>, dim3((n_frames + 1) / 2, n_ch), Cfg<NN>::NT,
                                     Cfg<NN>::LDS_BYTES, a)));
