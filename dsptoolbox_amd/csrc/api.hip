@@ -857,11 +857,11 @@ static WelchPlan plan_welch(int n_frames, int units) {
 }
 
 // kind 0: tf+coh, 1: psd of x, 2: csd of (x[c], y[c])
-// Median kernels keep `series` float series of n_frames values per bin in LDS: the number of bins
+// Median kernels keep `series` float series of n_frames values (padded to a power of two) per bin in LDS: the number of bins
 // per workgroup (8, 4, 2 or 1) that fits 150 KB; 0 if not even one does.
 static int median_bins_per_block(int series, int n_frames, size_t* lds) {
     for (int bpb = 8; bpb >= 1; bpb >>= 1) {
-        const size_t need = ((size_t)bpb * series * n_frames + (size_t)bpb * series * 2) * sizeof(float);
+        const size_t need = ((size_t)bpb * series * median_stride(n_frames) + (size_t)bpb * series * 2) * sizeof(float);
         if (need <= 150 * 1024) {
             *lds = need;
             return bpb;

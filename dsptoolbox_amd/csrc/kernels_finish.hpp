@@ -148,8 +148,8 @@ __global__ __launch_bounds__(256) void k_welch_finish(WelchFinArgs p) {
 // Median over frames (average="median", standard/_spectral_methods.py:153-162): per (channel, bin)
 // the median of the per-frame auto power |X_f|^2, or of the real and imaginary parts of the cross
 // power conj(X_f) Y_f, from the stored frame spectra xs[cx][f][b], ys[c][f][b].  One block = one
-// channel x 8 bins; the series sit in LDS and every element is ranked against all others (ties
-// by index), O(F^2) -- frame counts are a few hundred to a few thousand.  Results go into the
+// channel x 8 bins; the series sit in LDS and are sorted there (one bitonic network over all series of the
+// workgroup).  Results go into the
 // one-chunk partial layout k_welch_finish reads.
 struct MedianArgs {
     const float2* xs;  // [n_cx][F][nb]
@@ -161,50 +161,77 @@ struct MedianArgs {
     float* pyy;   // [n_cy][nb]
 };
 
-__device__ __forceinline__ float median_of(const float* s, int F, int tid, int nt, float* out2) {
-    // rank every element; the elements of rank (F-1)/2 and F/2 are the two middle ones
-    const int r0 = (F - 1) / 2, r1 = F / 2;
-    for (int i = tid; i < F; i += nt) {
-        const float v = s[i];
-        int rank = 0;
-        for (int j = 0; j < F; ++j) {
-            const float u = s[j];
-            rank += (u < v || (u == v && j < i)) ? 1 : 0;
+// All `nser` series of the workgroup (stride P = the frame count rounded up to a power of two, the tail filled with
+// +inf) are sorted at once by one bitonic network in LDS: P log2(P) (log2(P) + 1) / 4 compare-exchanges per series
+// instead of the F^2 comparisons of ranking every element against all others (2048 frames: 68 k against 4.2 M).
+// The two middle elements of the F sorted values go to out2[2 q], out2[2 q + 1].
+__host__ __device__ inline int median_stride(int F) {
+    int P = 1;
+    while (P < F) P <<= 1;
+    return P < 2 ? 2 : P;
+}
+__device__ __forceinline__ void sort_series(float* ser, int nser, int P, int tid, int nt) {
+    const int half = P >> 1, lh = __ffs(half) - 1;
+    for (int k = 2; k <= P; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int idx = tid; idx < nser * half; idx += nt) {
+                const int q = idx >> lh, t = idx & (half - 1);
+                const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), l = i | j;
+                float* s = ser + (size_t)q * P;
+                const float a = s[i], b = s[l];
+                const bool up = (i & k) == 0;
+                if ((a > b) == up) {
+                    s[i] = b;
+                    s[l] = a;
+                }
+            }
+            __syncthreads();
         }
-        if (rank == r0) out2[0] = v;
-        if (rank == r1) out2[1] = v;
     }
-    return 0.f;
+}
+__device__ __forceinline__ void middle_of_sorted(const float* ser, int nser, int P, int F, int tid, float* out2) {
+    if (tid < nser) {
+        out2[2 * tid] = ser[(size_t)tid * P + (F - 1) / 2];
+        out2[2 * tid + 1] = ser[(size_t)tid * P + F / 2];
+    }
 }
 
 __global__ __launch_bounds__(256) void k_welch_median(MedianArgs p) {
-    extern __shared__ float ser[];  // [bpb bins][3 series][F]  (+ bpb*3*2 results)
-    const int F = p.n_frames, nb = p.nb;
+    extern __shared__ float ser[];  // [bpb bins][3 series][P]  (+ bpb*3*2 results)
+    const int F = p.n_frames, nb = p.nb, P = median_stride(F);
     const int BP = p.bpb, lb = __ffs(BP) - 1;
     const int b0 = blockIdx.x * BP, c = blockIdx.y;
     const int tid = threadIdx.x;
     const bool have_y = p.ys != nullptr;
     const int cx = p.n_cx == 1 ? 0 : c;
-    float* res = ser + (size_t)BP * 3 * F;  // [bpb][3][2]
+    float* res = ser + (size_t)BP * 3 * P;  // [bpb][3][2]
     // series 0: |X|^2 (kind 0: of xs[cx]; kind 1: of xs[c]); 1: Re conj(X) Y; 2: Im conj(X) Y; for kind 0
     // |Y|^2 replaces series 0 in a second sweep below
     const float2* X = p.xs + (size_t)(p.kind == 1 ? c : cx) * F * nb;
     const float2* Y = have_y ? p.ys + (size_t)c * F * nb : nullptr;
-    for (int i = tid; i < BP * F; i += 256) {
+    const float inf = __builtin_inff();
+    for (int i = tid; i < BP * P; i += 256) {
         const int bl = i & (BP - 1), f = i >> lb, b = b0 + bl;
-        float2 xv = make_float2(0.f, 0.f), yv = make_float2(0.f, 0.f);
-        if (b < nb) {
-            xv = X[(size_t)f * nb + b];
-            if (have_y) yv = Y[(size_t)f * nb + b];
+        float s0 = inf, s1 = inf, s2 = inf;
+        if (f < F) {
+            float2 xv = make_float2(0.f, 0.f), yv = make_float2(0.f, 0.f);
+            if (b < nb) {
+                xv = X[(size_t)f * nb + b];
+                if (have_y) yv = Y[(size_t)f * nb + b];
+            }
+            s0 = xv.x * xv.x + xv.y * xv.y;
+            s1 = xv.x * yv.x + xv.y * yv.y;  // Re conj(x) y
+            s2 = xv.x * yv.y - xv.y * yv.x;  // Im conj(x) y
         }
-        ser[(bl * 3 + 0) * F + f] = xv.x * xv.x + xv.y * xv.y;
-        ser[(bl * 3 + 1) * F + f] = xv.x * yv.x + xv.y * yv.y;  // Re conj(x) y
-        ser[(bl * 3 + 2) * F + f] = xv.x * yv.y - xv.y * yv.x;  // Im conj(x) y
+        ser[(bl * 3 + 0) * P + f] = s0;
+        ser[(bl * 3 + 1) * P + f] = s1;
+        ser[(bl * 3 + 2) * P + f] = s2;
     }
     __syncthreads();
-    const int ns = have_y ? 3 : 1;
-    for (int bl = 0; bl < BP; ++bl)
-        for (int q = 0; q < ns; ++q) median_of(ser + (bl * 3 + q) * F, F, tid, 256, res + (bl * 3 + q) * 2);
+    // (without an output channel only the first of the three series of a bin is used: sorting all three keeps the
+    // layout uniform and the other two are constant)
+    sort_series(ser, BP * 3, P, tid, 256);
+    middle_of_sorted(ser, BP * 3, P, F, tid, res);
     __syncthreads();
     if (tid < BP && b0 + tid < nb) {
         const int b = b0 + tid;
@@ -219,22 +246,23 @@ __global__ __launch_bounds__(256) void k_welch_median(MedianArgs p) {
     }
     if (p.kind == 0) {  // |Y|^2 series
         __syncthreads();
-        for (int i = tid; i < BP * F; i += 256) {  // BP bins per workgroup here too (LDS holds BP series)
+        for (int i = tid; i < BP * P; i += 256) {  // BP bins per workgroup here too (LDS holds BP series)
             const int bl = i & (BP - 1), f = i >> lb, b = b0 + bl;
-            float2 yv = b < nb ? Y[(size_t)f * nb + b] : make_float2(0.f, 0.f);
-            ser[(bl * 3 + 0) * F + f] = yv.x * yv.x + yv.y * yv.y;
+            float s0 = inf;
+            if (f < F) {
+                const float2 yv = b < nb ? Y[(size_t)f * nb + b] : make_float2(0.f, 0.f);
+                s0 = yv.x * yv.x + yv.y * yv.y;
+            }
+            ser[(size_t)bl * P + f] = s0;
         }
         __syncthreads();
-        for (int bl = 0; bl < BP; ++bl) median_of(ser + (bl * 3) * F, F, tid, 256, res + (bl * 3) * 2);
+        sort_series(ser, BP, P, tid, 256);
+        middle_of_sorted(ser, BP, P, F, tid, res);
         __syncthreads();
-        if (tid < BP && b0 + tid < nb) p.pyy[(size_t)c * nb + b0 + tid] = 0.5f * (res[tid * 6] + res[tid * 6 + 1]);
+        if (tid < BP && b0 + tid < nb) p.pyy[(size_t)c * nb + b0 + tid] = 0.5f * (res[tid * 2] + res[tid * 2 + 1]);
     }
 }
 
-// Median-averaged cross-spectral matrix (reference: _csm_welch's pair loop of _welch(...,
-// average="median"), _spectral_methods.py:153-162 + :351-369).  grid = (ceil(nb/8), C(C+1)/2);
-// pair (i1 <= i2): per-bin medians over the frames of Re / Im conj(X_i1) X_i2 from the stored
-// spectra xs[c][F][nb], then the Welch finish; csm[b][i2][i1] = g, csm[b][i1][i2] = conj(g).
 struct CsmMedianArgs {
     const float2* xs;
     int n_ch, n_frames;
@@ -243,8 +271,8 @@ struct CsmMedianArgs {
     float2* csm;    // [nb][C][C]
 };
 __global__ __launch_bounds__(256) void k_csm_median(CsmMedianArgs p) {
-    extern __shared__ float ser[];  // [bpb bins][2 series][F] (+ bpb*2*2 results)
-    const int F = p.n_frames, nb = p.fin.nb, C = p.n_ch;
+    extern __shared__ float ser[];  // [bpb bins][2 series][P] (+ bpb*2*2 results)
+    const int F = p.n_frames, nb = p.fin.nb, C = p.n_ch, P = median_stride(F);
     const int BP = p.bpb, lb = __ffs(BP) - 1;
     const int b0 = blockIdx.x * BP, tid = threadIdx.x;
     // triangular decode: pair index -> (i1 <= i2), rows of length C, C-1, ...
@@ -254,21 +282,28 @@ __global__ __launch_bounds__(256) void k_csm_median(CsmMedianArgs p) {
         ++i1;
     }
     const int i2 = i1 + rem;
-    float* res = ser + (size_t)BP * 2 * F;
+    float* res = ser + (size_t)BP * 2 * P;
     const float2* X = p.xs + (size_t)i1 * F * nb;
     const float2* Y = p.xs + (size_t)i2 * F * nb;
-    for (int i = tid; i < BP * F; i += 256) {
+    const float inf = __builtin_inff();
+    for (int i = tid; i < BP * P; i += 256) {
         const int bl = i & (BP - 1), f = i >> lb, b = b0 + bl;
-        float2 xv = make_float2(0.f, 0.f), yv = make_float2(0.f, 0.f);
-        if (b < nb) {
-            xv = X[(size_t)f * nb + b];
-            yv = Y[(size_t)f * nb + b];
+        float s0 = inf, s1 = inf;
+        if (f < F) {
+            float2 xv = make_float2(0.f, 0.f), yv = make_float2(0.f, 0.f);
+            if (b < nb) {
+                xv = X[(size_t)f * nb + b];
+                yv = Y[(size_t)f * nb + b];
+            }
+            s0 = xv.x * yv.x + xv.y * yv.y;
+            s1 = xv.x * yv.y - xv.y * yv.x;
         }
-        ser[(bl * 2 + 0) * F + f] = xv.x * yv.x + xv.y * yv.y;
-        ser[(bl * 2 + 1) * F + f] = xv.x * yv.y - xv.y * yv.x;
+        ser[(bl * 2 + 0) * P + f] = s0;
+        ser[(bl * 2 + 1) * P + f] = s1;
     }
     __syncthreads();
-    for (int q = 0; q < 2 * BP; ++q) median_of(ser + (size_t)q * F, F, tid, 256, res + q * 2);
+    sort_series(ser, 2 * BP, P, tid, 256);
+    middle_of_sorted(ser, 2 * BP, P, F, tid, res);
     __syncthreads();
     if (tid < BP && b0 + tid < nb) {
         const int b = b0 + tid;
