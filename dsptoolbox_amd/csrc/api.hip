@@ -729,6 +729,40 @@ extern "C" int ds_istft_dev(ds_ctx* c, const ds_c32* stft, int n_bins, int n_fra
     CHK(get_twiddles(c, nfft, &tw));
     // 50 % overlap of full-length frames: transform and overlap-add in one kernel, no frames in memory
     static const bool no_fuse = getenv("DSPTOOLBOX_AMD_ISTFT_FUSED") && atoi(getenv("DSPTOOLBOX_AMD_ISTFT_FUSED")) == 0;
+    // ... on the wave-level transform for 256 ... 2048 points (kernels_stft1024.hpp, k_istft_wave)
+    static const bool no_wave = getenv("DSPTOOLBOX_AMD_ISTFT_WAVE") && atoi(getenv("DSPTOOLBOX_AMD_ISTFT_WAVE")) == 0;
+    if (W == nfft && 2 * step == nfft && n_ch > 1 && !no_fuse && !no_wave &&
+        (nfft == 1024 || nfft == 512 || nfft == 256)) {  // (2048 points: 45 registers over the 128 of a 1024-thread workgroup)
+        const int slot = nfft == 1024 ? 0 : (nfft == 512 ? 1 : 2);
+        float2** tab = slot == 0 ? &c->stft1k_tables : &c->stft_wave_tables[slot - 1];
+        if (!*tab) {
+            std::vector<float2> h;
+            if (nfft == 1024) stft1k::host_tables<1024>(h);
+            else if (nfft == 512) stft1k::host_tables<512>(h);
+            else stft1k::host_tables<256>(h);
+            CHK(upload_table_fwd(c, tab, h));
+        }
+        const int lanes = nfft / 16;
+        int ct = std::min(16, n_ch);
+        while (ct & (ct - 1)) ct &= ct - 1;
+        if (ct > 1) {
+            const size_t lds = nfft == 1024 ? stft1k::istft_lds_bytes<1024>(ct)
+                                            : (nfft == 512 ? stft1k::istft_lds_bytes<512>(ct) : stft1k::istft_lds_bytes<256>(ct));
+            const int threads = lanes * ct;
+            const int n_fp = (n_frames + 1) / 2, n_ct = (n_ch + ct - 1) / ct;
+            const int per_cu = std::max(1, std::min<int>((int)((160 * 1024) / lds), 2048 / std::max(64, threads)));
+            // frame pairs per workgroup (+ 1 for the carry): two rounds of resident workgroups, at least 4 (1024 points: 8)
+            // -- 64 x 512 000 samples: 0.154 / 0.130 / 0.135 ms at 256 / 512 / 1024 points, 0.18 / 0.13 / 0.145 one step off
+            int fpw = std::max(nfft >= 1024 ? 8 : 4, std::min(64, (int)(((int64_t)n_fp * n_ct + 512 * per_cu - 1) / (512 * per_cu))));
+            if (const char* e = getenv("DSPTOOLBOX_AMD_ISTFT_FPW")) fpw = std::max(1, atoi(e));
+            IstftFusedArgs fa{IstftArgs{(const float2*)stft, n_bins, n_frames, n_ch, W, window, *tab, scale, nullptr, ct, fpw},
+                              frame_offset, n_frames_total, total_length, ld_out, out};
+            const dim3 grid((unsigned)((n_fp + fpw - 1) / fpw), (unsigned)n_ct);
+            if (nfft == 1024) return launch(c, "istft", stft1k::k_istft_wave<1024>, grid, threads, lds, fa);
+            if (nfft == 512) return launch(c, "istft", stft1k::k_istft_wave<512>, grid, threads, lds, fa);
+            return launch(c, "istft", stft1k::k_istft_wave<256>, grid, threads, lds, fa);
+        }
+    }
     if (W == nfft && 2 * step == nfft && n_ch > 1 && !no_fuse) {
         int ct = 1;
         size_t lds = 0;

@@ -372,4 +372,142 @@ __global__ __launch_bounds__(1024) void k_stft_wave(StftArgs p) {
     }
 }
 
+// ---- inverse STFT on the same wave-level transform ------------------------------------------------------
+// (reference: transforms.istft, transforms/transforms.py:444-586; the generic kernels and the semantics of the
+// overlap-add are in kernels_generic.hpp: k_istft_fused.)  Full-length frames at 50 % overlap, NN = 256 ... 2048.
+// The inverse transform is the forward one between two conjugations: ifft(Z) = conj(fft(conj Z)) (unnormalised; the
+// caller's scale carries 1 / N), so fft_wave serves unchanged.  A workgroup = ct teams (channels); per frame pair
+//   * all threads read the bins of the ct channels together (runs of 8 ct bytes of the channel-fastest spectrogram)
+//     and lay conj(Z) = conj(A + i B) and its mirror half into the ct images in natural order;
+//   * every team takes its 16 values per lane out of its image (z[t + L n1]), transforms, and holds the two frames'
+//     samples n = t + L m: frame f0 = Re / frame f0 + 1 = -Im; m < 8 is the first half of a frame, m >= 8 the second:
+//     the overlap-add is lane-local -- 8 sums travel in registers to the next pair -- and finished samples leave
+//     as 4 L-byte runs per channel; 1 / envelope from an LDS table wherever two frame slots cover a sample.
+// A workgroup owns the output from the start of its first frame to the start of the next workgroup's and transforms
+// the pair in front of its range once more for the carry (k_istft_fused).
+template <int NN>
+inline size_t istft_lds_bytes(int ct) {
+    return ((size_t)ct * ch_stride<NN>(ct) + Geo<NN>::TW_LEN) * sizeof(float2) + (size_t)(NN / 2) * sizeof(float);
+}
+template <int NN>
+__global__ __launch_bounds__(NN >= 1024 ? 1024 : NN) void k_istft_wave(dsk::IstftFusedArgs q) {
+    using G = Geo<NN>;
+    constexpr int L = G::L, STEP = NN / 2;
+    const dsk::IstftArgs& p = q.a;
+    extern __shared__ __align__(16) float2 lds[];
+    const int team = L == 64 ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : (int)threadIdx.x / L;
+    const int t = threadIdx.x % L;
+    const int CHS = ch_stride<NN>(p.ct);
+    float2* buf = lds + team * CHS;
+    float2* tw1 = lds + p.ct * CHS;
+    const float2* tw2 = tw1 + G::TW1;
+    float* inv_env = reinterpret_cast<float*>(tw1 + G::TW_LEN);
+    for (int i = threadIdx.x; i < G::TW_LEN; i += blockDim.x) tw1[i] = p.tw[i];
+    for (int m = threadIdx.x; m < STEP; m += blockDim.x) {
+        const double w0 = (double)p.window[m], w1 = (double)p.window[m + STEP];
+        const double e = w0 * w0 + w1 * w1;
+        inv_env[m] = (float)(1.0 / (e < 1e-4 ? 1e-4 : e));
+    }
+    // window[t + L m] * scale: in registers, except at 2048 points (128 registers: they are read again per pair)
+    constexpr bool WIN_REG = NN < 2048;
+    float win[WIN_REG ? 16 : 1];
+    if constexpr (WIN_REG) {
+#pragma unroll
+        for (int m = 0; m < 16; ++m) win[m] = p.window[t + L * m] * p.scale;
+    }
+    auto wv = [&](int m) { return WIN_REG ? win[WIN_REG ? m : 0] : p.window[t + L * m] * p.scale; };
+    const int c0 = blockIdx.y * p.ct;
+    const int ctv = min(p.ct, p.n_ch - c0);
+    const int c = c0 + team;
+    const bool live = c < p.n_ch;
+    const int64_t F = p.n_frames, Cn = p.n_ch;
+    const int lct = __ffs(p.ct) - 1;
+    const int cl = threadIdx.x & (p.ct - 1);
+    float2* img = lds + cl * CHS;
+    const int n_fp = (p.n_frames + 1) >> 1;
+    const int fp0 = blockIdx.x * p.fpw, fp1 = min(fp0 + p.fpw, n_fp);
+    if (fp0 >= fp1) return;
+    float* oc = q.out + (int64_t)(live ? c : 0) * q.ld;
+    auto emit = [&](int64_t pos, float sum) {  // the ends of the signal: one frame slot, or none
+        if (pos < 0 || pos >= q.total_length) return;
+        const int64_t fs = pos / STEP;
+        const int m = (int)(pos - fs * STEP);
+        double env = 0.0;
+        if (fs < q.n_total) {
+            const float w = p.window[m];
+            env += (double)w * (double)w;
+        }
+        if (fs >= 1 && fs - 1 < q.n_total) {
+            const float w = p.window[m + STEP];
+            env += (double)w * (double)w;
+        }
+        oc[pos] = (float)((double)sum / (env < 1e-4 ? 1e-4 : env));
+    };
+    float carry[8];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) carry[m] = 0.f;
+    if (fp0 == 0 && live)
+        for (int64_t n = t; n < (int64_t)q.off * STEP; n += L) emit(n, 0.f);
+    for (int fp = fp0 > 0 ? fp0 - 1 : 0; fp < fp1; ++fp) {
+        const int f0 = 2 * fp;
+        const bool v1 = f0 + 1 < p.n_frames;
+        const bool owned = fp >= fp0;  // the pair in front of the range only yields the carry
+        __syncthreads();  // tables written / the previous pair's images have been consumed
+        for (int k = threadIdx.x >> lct; k <= NN / 2; k += blockDim.x >> lct) {
+            float2 A = make_float2(0.f, 0.f), B = make_float2(0.f, 0.f);
+            if (cl < ctv && k < p.n_bins) {
+                const float2* s = p.stft + ((int64_t)k * F + f0) * Cn + c0 + cl;
+                A = s[0];
+                if (v1) B = s[Cn];
+            }
+            if (k == 0 || k == NN / 2) {
+                img[k] = make_float2(A.x, -B.x);  // conj(A.x + i B.x)
+            } else {
+                img[k] = make_float2(A.x - B.y, -A.y - B.x);      // conj(A + i B)
+                img[NN - k] = make_float2(A.x + B.y, A.y - B.x);  // conj(conj A + i conj B)
+            }
+        }
+        __syncthreads();
+        float2 v[16], z[16];
+#pragma unroll
+        for (int n1 = 0; n1 < 16; ++n1) v[n1] = buf[t + L * n1];
+        team_sync<NN>();  // the image is in registers: the transform may use the region
+        fft_wave<NN>(v, z, buf, tw1, tw2, t);
+        if (live) {
+            const int64_t P0 = (int64_t)(f0 + q.off) * STEP;
+            // both covering frame slots exist: fs - 1 >= 0 and fs < n_total (uniform per segment)
+            const bool fast0 = f0 + q.off >= 1 && f0 + q.off < q.n_total;
+            const bool fast1 = f0 + q.off + 1 < q.n_total;
+#pragma unroll
+            for (int m = 0; m < 8; ++m) {
+                const int n = t + L * m;
+                // frame f0: Re, frame f0 + 1: -Im (the result is the conjugate of a + i b)
+                const float wl = wv(m), wh = wv(m + 8);
+                const float a_lo = z[m].x * wl, b_lo = -z[m].y * wl;
+                const float a_hi = z[m + 8].x * wh, b_hi = -z[m + 8].y * wh;
+                if (owned) {
+                    const float s0 = carry[m] + a_lo;  // second half of the frame before + first half of f0
+                    const float s1 = a_hi + b_lo;      // second half of f0 + first half of f0 + 1
+                    if (fast0 && P0 + n < q.total_length)
+                        oc[P0 + n] = s0 * inv_env[n];
+                    else
+                        emit(P0 + n, s0);
+                    if (fast1 && P0 + STEP + n < q.total_length)
+                        oc[P0 + STEP + n] = s1 * inv_env[n];
+                    else
+                        emit(P0 + STEP + n, s1);
+                }
+                carry[m] = b_hi;  // second half of f0 + 1 (zero if it does not exist)
+            }
+        }
+    }
+    // behind the last frame: its second half, then nothing but the envelope's floor
+    if (fp1 == n_fp && live) {
+        const int64_t P = (int64_t)(2 * n_fp + q.off) * STEP;
+#pragma unroll
+        for (int m = 0; m < 8; ++m) emit(P + t + L * m, carry[m]);
+        for (int64_t n = P + STEP + t; n < q.total_length; n += L) emit(n, 0.f);
+    }
+}
+
 }  // namespace stft1k
