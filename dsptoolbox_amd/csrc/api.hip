@@ -763,6 +763,23 @@ extern "C" int ds_istft_dev(ds_ctx* c, const ds_c32* stft, int n_bins, int n_fra
             return launch(c, "istft", stft1k::k_istft_wave<256>, grid, threads, lds, fa);
         }
     }
+    // ... and on the 4096-point register transform, two neighbouring channels per team (kernels_stft4096.hpp, k_istft)
+    if (W == nfft && nfft == 4096 && 2 * step == nfft && n_ch > 1 && !no_fuse && !no_wave &&
+        total_length < ((int64_t)1 << 31)) {
+        if (!c->w4_tables) {
+            std::vector<float2> h;
+            welch4096::host_tables(h);
+            CHK(upload_table_fwd(c, &c->w4_tables, h));
+        }
+        const int n_groups = (n_ch + 15) / 16;
+        // chunks of frames (+ 1 frame each for the carry): two rounds of one workgroup (8 channels) per CU
+        int n_chunks = std::max(1, std::min((n_frames + 3) / 4, 256 / std::max(1, std::min(256, n_groups))));
+        if (const char* e = getenv("DSPTOOLBOX_AMD_ISTFT_FPW")) n_chunks = std::max(1, std::min(n_frames, atoi(e)));
+        IstftFusedArgs fa{IstftArgs{(const float2*)stft, n_bins, n_frames, n_ch, W, window, c->w4_tables, scale, nullptr, 1, n_chunks},
+                          frame_offset, n_frames_total, total_length, ld_out, out};
+        return launch(c, "istft", stft4k::k_istft, dim3((unsigned)stft4k::grid_size(n_groups, n_chunks)), stft4k::NT,
+                      stft4k::ISTFT_LDS_BYTES, fa);
+    }
     if (W == nfft && 2 * step == nfft && n_ch > 1 && !no_fuse) {
         int ct = 1;
         size_t lds = 0;

@@ -387,4 +387,167 @@ __global__ __launch_bounds__(NT) void k_stft_dif(Args p) {
     }
 }
 
+// ---- inverse STFT, 4096-point frames at 50 % overlap -----------------------------------------------------------
+// (reference: transforms.istft, transforms/transforms.py:444-586; the overlap-add's semantics: dsk::k_istft_fused.)
+// The mirror image of k_stft: a team handles TWO NEIGHBOURING CHANNELS of ONE frame -- Z = X_c + i X_{c+1} built from
+// the one-sided spectra, x_c + i x_{c+1} = ifft(Z) = conj(fft(conj Z)) on fft4096_w --, the workgroup's four teams read
+// the bins of 8 channels together (64-byte runs of the channel-fastest spectrogram) into the four images.  A thread
+// ends with samples n = bt + 256 k3 of both channels; k3 < 8 is the first half of the frame, so the overlap-add with
+// the frame before is thread-local (8 + 8 carried sums); the finished half frame goes through the image once more
+// (as (c, c + 1) pairs in padded natural order) and leaves as 1 KB runs per channel.  A workgroup walks a chunk of
+// frames, after the frame in front of it (for the carry).
+constexpr int ISTFT_LDS_BYTES = TEAMS * IMG * 8 + 256 * 8 + (N / 2) * 4;  // images, W256, 1 / envelope
+
+// (q.a.tw = welch4096::host_tables(), q.a.fpw = the number of frame chunks)
+__global__ __launch_bounds__(NT) void k_istft(dsk::IstftFusedArgs q) {
+    using namespace welch4096;
+    constexpr int STEP = N / 2;
+    const dsk::IstftArgs& p = q.a;
+    extern __shared__ __align__(16) float2 lds[];
+    float2* tw2 = lds + TEAMS * IMG;
+    float* inv_env = reinterpret_cast<float*>(tw2 + 256);
+    const int team = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 8), tid = (int)threadIdx.x & 255;
+    float2* buf = lds + team * IMG;
+    // blockIdx -> (XCD, slot): the two halves of a 16-channel group are neighbouring slots of one XCD (k_stft)
+    const int x = (int)blockIdx.x & 7, s = (int)blockIdx.x >> 3, half = s & 1, u = (s >> 1) * 8 + x;
+    const int n_groups = (p.n_ch + 15) / 16;
+    const int g = u % n_groups, qc = u / n_groups;  // qc: chunk of frames
+    const int cb = 16 * g + 8 * half;
+    const int n_chunks = p.fpw;  // (the host passes the number of chunks here)
+    if (qc >= n_chunks || cb >= p.n_ch) return;
+    const int per = (p.n_frames + n_chunks - 1) / n_chunks;
+    const int fa = qc * per, fb = min(fa + per, p.n_frames);
+    if (fa >= fb) return;
+    const int c0 = cb + 2 * team;
+    const bool one = c0 < p.n_ch, two = c0 + 1 < p.n_ch;
+
+    if (team == 0) tw2[tid] = p.tw[15 * 256 + tid];
+    for (int m = (int)threadIdx.x; m < STEP; m += NT) {
+        const double w0 = (double)p.window[m], w1 = (double)p.window[m + STEP];
+        const double e = w0 * w0 + w1 * w1;
+        inv_env[m] = (float)(1.0 / (e < 1e-4 ? 1e-4 : e));
+    }
+    const int bt = bin_thread(tid);
+    const int64_t F = p.n_frames, C = p.n_ch;
+    const bool wide = !(p.n_ch & 1);
+    float ca[8], cbv[8];  // second half of the frame before, channels c0 and c0 + 1
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ca[j] = cbv[j] = 0.f;
+    float* oa = q.out + (int64_t)(one ? c0 : 0) * q.ld;
+    float* ob = q.out + (int64_t)(two ? c0 + 1 : 0) * q.ld;
+    auto emit = [&](float* o, int64_t pos, float sum, bool fast, int n) {
+        if (pos < 0 || pos >= q.total_length) return;
+        if (fast) {
+            o[pos] = sum * inv_env[n];
+            return;
+        }
+        const int64_t fs = pos / STEP;
+        const int m = (int)(pos - fs * STEP);
+        double env = 0.0;
+        if (fs < q.n_total) {
+            const float w = p.window[m];
+            env += (double)w * (double)w;
+        }
+        if (fs >= 1 && fs - 1 < q.n_total) {
+            const float w = p.window[m + STEP];
+            env += (double)w * (double)w;
+        }
+        o[pos] = (float)((double)sum / (env < 1e-4 ? 1e-4 : env));
+    };
+    // positions in front of the first frame slot
+    if (fa == 0)
+        for (int64_t n = tid; n < (int64_t)q.off * STEP; n += 256) {
+            if (one) emit(oa, n, 0.f, false, 0);
+            if (two) emit(ob, n, 0.f, false, 0);
+        }
+    for (int f = fa > 0 ? fa - 1 : 0; f < fb; ++f) {
+        const bool owned = f >= fa;
+        int tx = (int)threadIdx.x;
+        asm volatile("" : "+v"(tx));
+        __syncthreads();  // tables / the previous frame's read-out
+        {   // load: thread -> (pair rp, bin row rk); conj(Z) and its mirror half into image rp, padded natural order
+            const int rp = tx & 3, rk = tx >> 2;
+            float2* im = lds + rp * IMG;
+            const int rc = cb + 2 * rp;
+            const bool r_one = rc < p.n_ch, r_two = rc + 1 < p.n_ch;
+            auto bin = [&](int k) {
+                float2 A = make_float2(0.f, 0.f), B = make_float2(0.f, 0.f);
+                if (r_one && k < p.n_bins) {
+                    const float2* sp = p.stft + ((int64_t)k * F + f) * C + rc;
+                    if (wide) {
+                        const float4 v4 = *reinterpret_cast<const float4*>(sp);
+                        A = make_float2(v4.x, v4.y);
+                        B = make_float2(v4.z, v4.w);
+                    } else {
+                        A = sp[0];
+                        if (r_two) B = sp[1];
+                    }
+                }
+                if (k == 0 || k == N / 2) {
+                    im[fold_pos(k)] = make_float2(A.x, -B.x);  // conj(A.x + i B.x): numpy's irfft drops the imaginary parts
+                } else {
+                    im[fold_pos(k)] = make_float2(A.x - B.y, -A.y - B.x);      // conj(A + i B)
+                    im[fold_pos(N - k)] = make_float2(A.x + B.y, A.y - B.x);  // conj(conj A + i conj B)
+                }
+            };
+#pragma unroll
+            for (int j = 0; j < 8; ++j) bin(rk + 256 * j);
+            if (rk == 0) bin(N / 2);
+        }
+        __syncthreads();
+        const int tl = tx & 255, bt_l = bin_thread(tl);
+        float2 v[16];
+#pragma unroll
+        for (int n1 = 0; n1 < 16; ++n1) v[n1] = buf[fold_pos(tl + 256 * n1)];
+        Tw6 tw;  // six 8-byte loads per frame (L1): held across the loop they are 12 registers too many
+        load_tw6(tw, p.tw, tl);
+        fft4096_w(v, tw, buf, tw2, tl);  // (its first barrier stands behind these reads)
+        // v[pos16(k3)] = N conj(x_c + i x_{c+1})[bt + 256 k3]
+        const int64_t P0 = (int64_t)(f + q.off) * STEP;
+        float2 fin[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            // window[bt + 256 k3] * scale, read per frame (L1): 16 registers this kernel does not have
+            const float wl = p.window[bt_l + 256 * j] * p.scale, wh = p.window[bt_l + 256 * (j + 8)] * p.scale;
+            const float2 lo = v[pos16(j)], hi = v[pos16(j + 8)];
+            fin[j] = make_float2(ca[j] + lo.x * wl, cbv[j] - lo.y * wl);  // the frame before + this frame's first half
+            ca[j] = hi.x * wh;
+            cbv[j] = -hi.y * wh;
+        }
+        __syncthreads();  // every wave has read its rows of the images
+#pragma unroll
+        for (int j = 0; j < 8; ++j) buf[fold_pos(bt_l + 256 * j)] = fin[j];
+        __syncthreads();
+        if (owned) {
+            const bool fast = f + q.off >= 1 && f + q.off < q.n_total;  // both covering frame slots exist
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int n = tl + 256 * j;
+                const float2 sv = buf[fold_pos(n)];
+                if (one) emit(oa, P0 + n, sv.x, fast, n);
+                if (two) emit(ob, P0 + n, sv.y, fast, n);
+            }
+        }
+    }
+    // behind the last frame: its second half, then nothing but the envelope's floor
+    if (fb == p.n_frames) {
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 8; ++j) buf[fold_pos(bt + 256 * j)] = make_float2(ca[j], cbv[j]);
+        __syncthreads();
+        const int64_t P = (int64_t)(p.n_frames + q.off) * STEP;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int n = tid + 256 * j;
+            const float2 sv = buf[fold_pos(n)];
+            if (one) emit(oa, P + n, sv.x, false, n);
+            if (two) emit(ob, P + n, sv.y, false, n);
+        }
+        for (int64_t n = P + STEP + tid; n < q.total_length; n += 256) {
+            if (one) emit(oa, n, 0.f, false, 0);
+            if (two) emit(ob, n, 0.f, false, 0);
+        }
+    }
+}
+
 }  // namespace stft4k
