@@ -732,21 +732,23 @@ extern "C" int ds_istft_dev(ds_ctx* c, const ds_c32* stft, int n_bins, int n_fra
     // ... on the wave-level transform for 256 ... 2048 points (kernels_stft1024.hpp, k_istft_wave)
     static const bool no_wave = getenv("DSPTOOLBOX_AMD_ISTFT_WAVE") && atoi(getenv("DSPTOOLBOX_AMD_ISTFT_WAVE")) == 0;
     if (W == nfft && 2 * step == nfft && n_ch > 1 && !no_fuse && !no_wave &&
-        (nfft == 1024 || nfft == 512 || nfft == 256)) {  // (2048 points: 45 registers over the 128 of a 1024-thread workgroup)
-        const int slot = nfft == 1024 ? 0 : (nfft == 512 ? 1 : 2);
+        (nfft == 2048 || nfft == 1024 || nfft == 512 || nfft == 256)) {
+        // (2048 points: 45 registers over the 128 of a 1024-thread workgroup: four teams = 512 threads there)
+        const int slot = nfft == 1024 ? 0 : (nfft == 512 ? 1 : (nfft == 256 ? 2 : 3));
         float2** tab = slot == 0 ? &c->stft1k_tables : &c->stft_wave_tables[slot - 1];
         if (!*tab) {
             std::vector<float2> h;
-            if (nfft == 1024) stft1k::host_tables<1024>(h);
+            if (nfft == 2048) stft1k::host_tables<2048>(h);
+            else if (nfft == 1024) stft1k::host_tables<1024>(h);
             else if (nfft == 512) stft1k::host_tables<512>(h);
             else stft1k::host_tables<256>(h);
             CHK(upload_table_fwd(c, tab, h));
         }
         const int lanes = nfft / 16;
-        int ct = std::min(16, n_ch);
+        int ct = std::min(nfft == 2048 ? 4 : 16, n_ch);
         while (ct & (ct - 1)) ct &= ct - 1;
         if (ct > 1) {
-            const size_t lds = nfft == 1024 ? stft1k::istft_lds_bytes<1024>(ct)
+            const size_t lds = nfft == 2048 ? stft1k::istft_lds_bytes<2048>(ct) : nfft == 1024 ? stft1k::istft_lds_bytes<1024>(ct)
                                             : (nfft == 512 ? stft1k::istft_lds_bytes<512>(ct) : stft1k::istft_lds_bytes<256>(ct));
             const int threads = lanes * ct;
             const int n_fp = (n_frames + 1) / 2, n_ct = (n_ch + ct - 1) / ct;
@@ -758,6 +760,7 @@ extern "C" int ds_istft_dev(ds_ctx* c, const ds_c32* stft, int n_bins, int n_fra
             IstftFusedArgs fa{IstftArgs{(const float2*)stft, n_bins, n_frames, n_ch, W, window, *tab, scale, nullptr, ct, fpw},
                               frame_offset, n_frames_total, total_length, ld_out, out};
             const dim3 grid((unsigned)((n_fp + fpw - 1) / fpw), (unsigned)n_ct);
+            if (nfft == 2048) return launch(c, "istft", stft1k::k_istft_wave<2048>, grid, threads, lds, fa);
             if (nfft == 1024) return launch(c, "istft", stft1k::k_istft_wave<1024>, grid, threads, lds, fa);
             if (nfft == 512) return launch(c, "istft", stft1k::k_istft_wave<512>, grid, threads, lds, fa);
             return launch(c, "istft", stft1k::k_istft_wave<256>, grid, threads, lds, fa);

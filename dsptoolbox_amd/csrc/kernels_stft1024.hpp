@@ -390,7 +390,7 @@ inline size_t istft_lds_bytes(int ct) {
     return ((size_t)ct * ch_stride<NN>(ct) + Geo<NN>::TW_LEN) * sizeof(float2) + (size_t)(NN / 2) * sizeof(float);
 }
 template <int NN>
-__global__ __launch_bounds__(NN >= 1024 ? 1024 : NN) void k_istft_wave(dsk::IstftFusedArgs q) {
+__global__ __launch_bounds__(NN == 2048 ? 512 : (NN >= 1024 ? 1024 : NN)) void k_istft_wave(dsk::IstftFusedArgs q) {
     using G = Geo<NN>;
     constexpr int L = G::L, STEP = NN / 2;
     const dsk::IstftArgs& p = q.a;
