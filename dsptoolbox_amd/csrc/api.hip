@@ -514,8 +514,15 @@ extern "C" int ds_stft_r2c_dev(ds_ctx* c, const float* x, int64_t n_samples, int
     // 256-, 512- and 1024-point transforms (1024 = the reference's default frame): wave-level
     // register transforms, one frame pair per team of nfft/16 lanes (kernels_stft1024.hpp)
     static const bool stft_generic = getenv("DSPTOOLBOX_AMD_STFT_GENERIC") != nullptr;
-    if ((nfft == 2048 || nfft == 1024 || nfft == 512 || nfft == 256) && (W == nfft || (W < nfft && !detrend)) &&
-        !stft_generic && stft1k::stft_wave_fits(n_samples, n_ch, ld, pad_front, nfft)) {
+    // frames of 128 / 64 / 32 samples: their transform is every 2nd / 4th / 8th bin of the 256-point transform of the
+    // zero-padded frame (the wave kernel with decim; removing the frame mean still only clears bin 0 of the kept bins)
+    const int decim = (nfft == 128 || nfft == 64 || nfft == 32) ? 256 / nfft : 1;
+    const int nfft_k = decim > 1 ? 256 : nfft;  // the transform that runs
+    if ((nfft_k == 2048 || nfft_k == 1024 || nfft_k == 512 || nfft_k == 256) && (W == nfft || (W < nfft && !detrend)) &&
+        !stft_generic && stft1k::stft_wave_fits(n_samples, n_ch, ld, pad_front, nfft_k)) {
+        const int nfft_api = nfft;
+        (void)nfft_api;
+        nfft = nfft_k;
         const int slot = nfft == 1024 ? 0 : (nfft == 512 ? 1 : (nfft == 256 ? 2 : 3));
         float2** tab = slot == 0 ? &c->stft1k_tables : &c->stft_wave_tables[slot - 1];
         if (!*tab) {
@@ -548,7 +555,7 @@ extern "C" int ds_stft_r2c_dev(ds_ctx* c, const float* x, int64_t n_samples, int
         int fpw = std::max(1, std::min(16, (int)(((int64_t)n_fp * n_ct + resident - 1) / resident)));
         if (const char* e = getenv("DSPTOOLBOX_AMD_STFT_FPW")) fpw = std::max(1, atoi(e));
         StftArgs a{x, n_samples, ld, pad_front, n_ch, W, hop, n_frames, detrend, power, ct, fpw, window,
-                   *tab, scale, edge_scale, (float2*)out};
+                   *tab, scale, edge_scale, (float2*)out, decim};
         dim3 grid((unsigned)((n_fp + fpw - 1) / fpw), (unsigned)n_ct);
         if (nfft == 2048)
             return power ? launch(c, "stft", stft1k::k_stft_wave<2048, true>, grid, threads, lds, a)

@@ -170,6 +170,7 @@ struct StftArgs {
     const float2* tw;
     float scale, edge_scale;
     float2* out;
+    int decim = 1;  // stft1k::k_stft_wave only: keep every decim-th bin (frames shorter than the 256-point transform)
 };
 
 // per-channel image: padded transform buffer (+2 spare slots), rounded up to 1 (mod 32) complex

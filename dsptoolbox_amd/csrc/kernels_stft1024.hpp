@@ -358,10 +358,13 @@ __global__ __launch_bounds__(1024) void k_stft_wave(StftArgs p) {
         }
         __syncthreads();
         // ---- read-out: rows r0 + L i of channel cl; row r -> out[((r>>1) F + f0 + (r&1)) C + c]
-        if (cl < ctv && (v1 || !(r0 & 1))) {
+        // (p.decim = D > 1: frames of NN / D samples -- their transform is every D-th bin of the NN-point transform
+        // of the zero-padded frame; only those rows are stored, at bin (r >> 1) / D.  D divides L / 2.)
+        const int D = p.decim;
+        if (cl < ctv && (v1 || !(r0 & 1)) && ((r0 >> 1) & (D - 1)) == 0) {
             const float2* s = lds + cl * CHS + r0;
-            float2* o = p.out + ((int64_t)(r0 >> 1) * F + f0 + (r0 & 1)) * Cn + c0 + cl;
-            const int64_t ostep = (L / 2) * F * Cn;
+            float2* o = p.out + ((int64_t)((r0 >> 1) / D) * F + f0 + (r0 & 1)) * Cn + c0 + cl;
+            const int64_t ostep = (L / 2 / D) * F * Cn;
             float2 g[16];
 #pragma unroll
             for (int i = 0; i < 16; ++i) g[i] = s[L * i];

@@ -1367,7 +1367,8 @@ def test_stft_default_frame_kernel_vs_oracle():
             (2, 1024, 50, True, False, SpectrumScaling.FFTOrthogonal),
             (64, 8192, 50, True, False, SpectrumScaling.FFTBackward)):
         x = rng.standard_normal((n, n_ch)) * 0.3 + 0.05
-        for W in (4096, 2048, 1024, 512, 256):   # 256 threads; 128 (two waves), 64, 32, 16 lanes per transform
+        for W in (4096, 2048, 1024, 512, 256, 128, 64, 32):   # 256 threads; 128 (two waves), 64, 32, 16 lanes per transform;
+            # 128 / 64 / 32 samples: every 2nd / 4th / 8th bin of the 256-point transform of the zero-padded frame
             t, f, st = backend._stft(x, 48000, W, Window.Hann, ov, None, det, pad, sc)
             rt, rf, rs = orc.stft(x, 48000, W, "hann", ov, None, det, pad, sc.name)
             assert st.shape == rs.shape and np.allclose(t, rt) and np.array_equal(f, rf)
@@ -1378,7 +1379,7 @@ def test_stft_default_frame_kernel_vs_oracle():
             assert e < TOL, (W, n_ch, n, ov, pad, det, sc, e)
     # shorter windows zero-padded to 1024 points (no detrend: that case stays on the generic kernel)
     for W, nfft, det in ((512, 1024, False), (256, 1024, False), (512, 1024, True), (128, 256, False),
-                         (256, 512, False), (128, 512, True), (2048, 4096, False), (512, 4096, False), (1024, 4096, True)):
+                         (256, 512, False), (128, 512, True), (2048, 4096, False), (512, 4096, False), (1024, 4096, True), (64, 128, False), (16, 64, False), (32, 128, True)):
         x = rng.standard_normal((20000, 3)) * 0.3 + 0.05
         t, f, st = backend._stft(x, 48000, W, Window.Hann, 50, nfft, det, True, SpectrumScaling.FFTBackward)
         rt, rf, rs = orc.stft(x, 48000, W, "hann", 50, nfft, det, True, "FFTBackward")
