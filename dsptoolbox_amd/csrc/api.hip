@@ -1352,7 +1352,9 @@ template <int NN>
 static int welch_wave_run(ds_ctx* c, const float* x, int n_cx, int64_t ldx, const float* y, int n_cy, int64_t ldy,
                           int64_t n_samples, int hop, int n_frames, const float* window, int detrend,
                           int mode, int amp_sqrt, double norm_scale, double factor, int halve_edges,
-                          float2* tf, float* coh, int kind = 0) {  // kind 2: tf = cross spectra, no coh
+                          float2* tf, float* coh, int kind = 0, int decim = 1) {  // kind 2: tf = cross spectra, no coh
+    // decim = D > 1: windows of NN / D samples (`window` holds that many values): the frames are transformed zero-padded
+    // to NN points and every D-th bin is kept (removing a frame's mean still only clears bin 0 of the kept bins)
     namespace w1 = welch1k;
     using W = w1::WG<NN>;
     if (!x || !y || !window) return fail(c, DS_ERR_ARG, "ds_welch_tf: null argument");
@@ -1365,8 +1367,14 @@ static int welch_wave_run(ds_ctx* c, const float* x, int n_cx, int64_t ldx, cons
     const int nf = frames_to_visit(n_samples, hop, n_frames);
     if (n_cx != 1 && n_cx != n_cy) return fail(c, DS_ERR_ARG, "ds_welch_tf: one input channel, or one per output channel");
     w1::Plan pl = w1::plan<NN>(nf, n_cy, n_cx);
-    CHK(reserve(c, &c->ws, &c->ws_bytes, pl.bytes));
+    CHK(reserve(c, &c->ws, &c->ws_bytes, pl.bytes + Carver::pad(sizeof(float) * NN)));
     Carver cv(c->ws);
+    if (decim > 1) {  // the window, zero-padded to the transform length
+        float* wz = cv.take<float>(NN);
+        HIPCHK(c, hipMemsetAsync(wz, 0, sizeof(float) * NN, c->stream));
+        HIPCHK(c, hipMemcpyAsync(wz, window, sizeof(float) * (NN / decim), hipMemcpyDeviceToDevice, c->stream));
+        window = wz;
+    }
     float2* xs = cv.take<float2>((size_t)n_cx * pl.n_pairs * NN);
     float* px = cv.take<float>((size_t)n_cx * pl.n_pairs * W::NB);
     float* psx = cv.take<float>((size_t)pl.n_chunks * n_cx * W::NB);
@@ -1385,10 +1393,11 @@ static int welch_wave_run(ds_ctx* c, const float* x, int n_cx, int64_t ldx, cons
     ay.n_ch = n_cy;
     const int n_grp = (n_cy + W::TPB - 1) / W::TPB;
     CHK(launch(c, "welch1024_main", ky, dim3(pl.n_chunks * n_grp), w1::NTB, W::LDS_BYTES, ay));
+    const int nb_out = NN / decim / 2 + 1;
     WelchFinArgs f{psx, pxy, pyy, pl.n_chunks, pl.n_chunks, n_cx, n_cy, kind, mode,
-                   FinishPar{norm_scale / (double)n_frames, factor, halve_edges, amp_sqrt, W::NB},
-                   tf, coh};
-    int64_t total = (int64_t)W::NB * n_cy;
+                   FinishPar{norm_scale / (double)n_frames, factor, halve_edges, amp_sqrt, nb_out},
+                   tf, coh, W::NB, decim};
+    int64_t total = (int64_t)nb_out * n_cy;
     CHK(launch(c, "welch_finish", k_welch_finish, dim3((unsigned)((total + 63) / 64)), 256, 0, f));
     return DS_OK;
 }
@@ -1397,7 +1406,7 @@ static int welch_wave_run(ds_ctx* c, const float* x, int n_cx, int64_t ldx, cons
 template <int NN>
 static int welch_wave_psd_run(ds_ctx* c, const float* x, int n_cx, int64_t ldx, int64_t n_samples, int hop,
                               int n_frames, const float* window, int detrend, int amp_sqrt, double norm_scale,
-                              double factor, int halve_edges, float* psd) {
+                              double factor, int halve_edges, float* psd, int decim = 1) {
     namespace w1 = welch1k;
     using W = w1::WG<NN>;
     if (!x || !window) return fail(c, DS_ERR_ARG, "ds_welch_psd: null argument");
@@ -1407,18 +1416,26 @@ static int welch_wave_psd_run(ds_ctx* c, const float* x, int n_cx, int64_t ldx, 
     CHK(wave_tables<NN>(c, &tab));
     const int nf = frames_to_visit(n_samples, hop, n_frames);
     w1::Plan pl = w1::plan<NN>(nf, n_cx);
-    CHK(reserve(c, &c->ws, &c->ws_bytes, Carver::pad(sizeof(float) * (size_t)pl.n_chunks * n_cx * W::NB)));
+    CHK(reserve(c, &c->ws, &c->ws_bytes,
+                Carver::pad(sizeof(float) * (size_t)pl.n_chunks * n_cx * W::NB) + Carver::pad(sizeof(float) * NN)));
     Carver cv(c->ws);
+    if (decim > 1) {  // the window, zero-padded to the transform length (see welch_wave_run)
+        float* wz = cv.take<float>(NN);
+        HIPCHK(c, hipMemsetAsync(wz, 0, sizeof(float) * NN, c->stream));
+        HIPCHK(c, hipMemcpyAsync(wz, window, sizeof(float) * (NN / decim), hipMemcpyDeviceToDevice, c->stream));
+        window = wz;
+    }
     float* pyy = cv.take<float>((size_t)pl.n_chunks * n_cx * W::NB);
     w1::Args a{x, n_samples, ldx, n_cx, hop, nf, pl.n_pairs, detrend, pl.n_chunks, pl.ppc, window,
                tab, nullptr, nullptr, nullptr, pyy, nullptr, 1};
     auto ky = hop == NN / 2 ? w1::k_y<NN, true, true> : w1::k_y<NN, false, true>;
     const int n_grp = (n_cx + W::TPB - 1) / W::TPB;
     CHK(launch(c, "welch1024_main", ky, dim3(pl.n_chunks * n_grp), w1::NTB, W::LDS_BYTES, a));
+    const int nb_out = NN / decim / 2 + 1;
     WelchFinArgs f{pyy, nullptr, nullptr, pl.n_chunks, pl.n_chunks, n_cx, 0, 1, 0,
-                   FinishPar{norm_scale / (double)n_frames, factor, halve_edges, amp_sqrt, W::NB},
-                   nullptr, psd};
-    int64_t total = (int64_t)W::NB * n_cx;
+                   FinishPar{norm_scale / (double)n_frames, factor, halve_edges, amp_sqrt, nb_out},
+                   nullptr, psd, W::NB, decim};
+    int64_t total = (int64_t)nb_out * n_cx;
     CHK(launch(c, "welch_finish", k_welch_finish, dim3((unsigned)((total + 63) / 64)), 256, 0, f));
     return DS_OK;
 }
@@ -1448,8 +1465,13 @@ extern "C" int ds_welch_tf_dev(ds_ctx* c, const float* x, int n_cx, int64_t ldx,
         auto run = W == 2048 ? welch_wave_run<2048>
                              : (W == 1024 ? welch_wave_run<1024> : (W == 512 ? welch_wave_run<512> : welch_wave_run<256>));
         return run(c, x, n_cx, ldx, y, n_cy, ldy, n_samples, hop, n_frames, window, detrend, mode, amp_sqrt,
-                   norm_scale, factor, halve_edges, (float2*)tf, coh, 0);
+                   norm_scale, factor, halve_edges, (float2*)tf, coh, 0, 1);
     }
+    // 128 / 64 / 32-sample windows: every 2nd / 4th / 8th bin of the 256-point kernels on zero-padded frames
+    if (c && (W == 128 || W == 64 || W == 32) && (n_cx == 1 || n_cx == n_cy) && average == DS_AVG_MEAN && !no1k &&
+        welch1k::buf_fits(n_samples, n_cy, ldy))
+        return welch_wave_run<256>(c, x, n_cx, ldx, y, n_cy, ldy, n_samples, hop, n_frames, window, detrend, mode, amp_sqrt,
+                                   norm_scale, factor, halve_edges, (float2*)tf, coh, 0, 256 / W);
     return welch_common(c, 0, x, n_cx, ldx, y, n_cy, ldy, n_samples, W, hop, n_frames, window, detrend,
                         average, mode, amp_sqrt, norm_scale, factor, halve_edges, (float2*)tf, coh);
 }
@@ -1539,8 +1561,11 @@ extern "C" int ds_welch_psd_dev(ds_ctx* c, const float* x, int n_cx, int64_t ldx
                              : (W == 1024 ? welch_wave_psd_run<1024>
                                           : (W == 512 ? welch_wave_psd_run<512> : welch_wave_psd_run<256>));
         return run(c, x, n_cx, ldx, n_samples, hop, n_frames, window, detrend, amp_sqrt, norm_scale, factor,
-                   halve_edges, psd);
+                   halve_edges, psd, 1);
     }
+    if (c && (W == 128 || W == 64 || W == 32) && average == DS_AVG_MEAN && !no1k && welch1k::buf_fits(n_samples, n_cx, ldx))
+        return welch_wave_psd_run<256>(c, x, n_cx, ldx, n_samples, hop, n_frames, window, detrend, amp_sqrt, norm_scale,
+                                       factor, halve_edges, psd, 256 / W);
     return welch_common(c, 1, x, n_cx, ldx, nullptr, 0, 0, n_samples, W, hop, n_frames, window, detrend,
                         average, 0, amp_sqrt, norm_scale, factor, halve_edges, nullptr, psd);
 }
@@ -1566,8 +1591,11 @@ static int welch_csd_dev(ds_ctx* c, const float* x, const float* y, int n_ch, in
             auto run = W == 2048 ? welch_wave_run<2048>
                                  : (W == 1024 ? welch_wave_run<1024> : (W == 512 ? welch_wave_run<512> : welch_wave_run<256>));
             return run(c, x, n_ch, ld, y, n_ch, ld, n_samples, hop, n_frames, window, detrend, DS_TF_H1, amp_sqrt,
-                       norm_scale, factor, halve_edges, (float2*)csd, nullptr, 2);
+                       norm_scale, factor, halve_edges, (float2*)csd, nullptr, 2, 1);
         }
+        if ((W == 128 || W == 64 || W == 32) && welch1k::buf_fits(n_samples, n_ch, ld))
+            return welch_wave_run<256>(c, x, n_ch, ld, y, n_ch, ld, n_samples, hop, n_frames, window, detrend, DS_TF_H1,
+                                       amp_sqrt, norm_scale, factor, halve_edges, (float2*)csd, nullptr, 2, 256 / W);
     }
     return welch_common(c, 2, x, n_ch, ld, y, n_ch, ld, n_samples, W, hop, n_frames, window, detrend,
                         average, 0, amp_sqrt, norm_scale, factor, halve_edges, (float2*)csd, nullptr);

@@ -80,6 +80,9 @@ struct WelchFinArgs {
     FinishPar fin;
     float2* tf;  // [nb][n_cy]   (kind 0: tf, kind 2: csd)
     float* coh;  // [nb][n_cy]   (kind 0: coherence, kind 1: psd [nb][n_cx])
+    // windows shorter than the transform that ran (128 / 64 / 32 samples on the 256-point kernels): the partial rows hold
+    // in_nb bins of which every in_step-th is one of the fin.nb output bins (0: rows of fin.nb bins, every one)
+    int in_nb = 0, in_step = 1;
 };
 
 // block = 256 threads = 64 output values x 4 waves; wave s sums the chunks q = s (mod 4) in fp64,
@@ -103,13 +106,15 @@ __global__ __launch_bounds__(256) void k_welch_finish(WelchFinArgs p) {
     const float* __restrict__ pxx = p.pxx;
     const float2* __restrict__ pxy = p.pxy;
     const float* __restrict__ pyy = p.pyy;
+    const int inb = p.in_nb > 0 ? p.in_nb : nb;  // bins per partial row
+    const int64_t bi = (int64_t)b * p.in_step;    // this output bin within it
     if (live) {
         if (p.kind != 2) {
-            const int64_t sx = (int64_t)p.n_cx * nb, ox = (int64_t)cx * nb + b;
+            const int64_t sx = (int64_t)p.n_cx * inb, ox = (int64_t)cx * inb + bi;
             for (int q = sub; q < p.n_chunks_x; q += 4) sxx += (double)pxx[q * sx + ox];
         }
         if (p.kind != 1) {
-            const int64_t sy = (int64_t)p.n_cy * nb, oy = (int64_t)c * nb + b;
+            const int64_t sy = (int64_t)p.n_cy * inb, oy = (int64_t)c * inb + bi;
             const bool want_yy = p.kind == 0;
             for (int q = sub; q < p.n_chunks; q += 4) {
                 const float2 t = pxy[q * sy + oy];

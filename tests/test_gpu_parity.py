@@ -285,10 +285,11 @@ def test_welch4096_paired_inputs_vs_oracle():
             assert relmax(k, r, det) < TOL, (n, C, ov, "csd")
 
 
-@pytest.mark.parametrize("W", [256, 512, 1024, 2048, 8192, 16384])
+@pytest.mark.parametrize("W", [32, 64, 128, 256, 512, 1024, 2048, 8192, 16384])
 def test_welch_wave_kernels_paired_inputs_vs_oracle(W):
     """One input channel per output channel on the wave-level register kernels (256 ... 2048-sample
-    windows, 1024 being the reference's default) and the 8192-sample ones: k_x over every input
+    windows, 1024 being the reference's default; 32 / 64 / 128-sample windows ride on the 256-point kernels: zero-padded
+    frames, every 8th / 4th / 2nd bin kept) and the 8192-sample ones: k_x over every input
     channel, k_px_sum, k_y with the team's own input spectra.  50 % overlap (carried half frame) and 75 %, ragged tails, more
     channels than teams per workgroup."""
     rng = np.random.default_rng(100 + W)
@@ -308,7 +309,7 @@ def test_welch_wave_kernels_paired_inputs_vs_oracle(W):
                 tf, rt = np.where(weak, 0.0, tf), np.where(weak, 0.0, rt)
             e1, e2 = relmax(tf, rt, det), relmax(coh, rc, det)
             assert e1 < TOL and e2 < TOL, (W, n, C, mode, e1, e2)
-        if W == 16384:  # one input channel for every output channel on the 16384-sample kernels, auto spectra
+        if W == 16384 or W <= 128:  # one input channel for all output channels, auto spectra
             y1 = np.stack([np.convolve(x[:, 0], rng.standard_normal(6))[:n] for _ in range(3)], axis=1)
             y1 += 0.05 * rng.standard_normal(y1.shape)
             for mode in ("H1", "H3"):
