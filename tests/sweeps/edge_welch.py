@@ -11,7 +11,7 @@ worst = 0.0
 def rel(a, b, lo):
     a, b = np.asarray(a)[lo:], np.asarray(b)[lo:]
     return float(np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-300))
-for W in (256, 1024, 2048, 4096, 8192, 16384):
+for W in (32, 64, 128, 256, 1024, 2048, 4096, 8192, 16384):
     for n in (W, W + 1, W + W // 2, 2 * W, 2 * W + 5, 3 * W - 1, 5 * W + 17):
         for C in (1, 2, 3):
             for det in (False, True):
