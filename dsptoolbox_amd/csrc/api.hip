@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "../../include/dsptoolbox_amd.h"
+#include "config.hpp"
 #include "host_marshal.hpp"
 #include "kernels_bigfft.hpp"
 #include "kernels_bluestein.hpp"
@@ -21,7 +22,6 @@
 #include "kernels_generic.hpp"
 #include "kernels_welch4096.hpp"
 #include "kernels_welch4096w.hpp"
-#include "kernels_welch4096f.hpp"
 #include "kernels_fir16k.hpp"
 #include "kernels_fir4k.hpp"
 #include "kernels_stft4096.hpp"
@@ -40,6 +40,7 @@ static thread_local std::string g_err;
 
 struct ds_ctx {
     int device = 0;
+    ds_config cfg;  // every DSPTOOLBOX_AMD_* switch, read once by ds_init (config.hpp)
     hipStream_t stream = nullptr;
     hipStream_t side = nullptr;  // second stream for a kernel that may run beside the main one
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -58,9 +59,6 @@ struct ds_ctx {
     uint64_t blue_clock = 0;
     float2* w4_tables = nullptr;  // welch4096::host_tables()
     float2* stft_dif_tw[2] = {nullptr, nullptr};  // stft4k::host_twiddles(8192 / 16384)
-    unsigned* w4_sync = nullptr;  // counters of the one-launch Welch kernel (welch4096::k_h1f), zero between launches
-    bool w4_sync_used = false;    // a fused launch since the last check of its timeout word
-    int w4_fused_cap = -1;        // workgroups of k_h1f the device holds at once
     float2* fir16k_tables = nullptr;  // fir16k::host_tables()
     float2* deconv8k_tables = nullptr;  // deconv8k::host_tables()
     float2* stft1k_tables = nullptr;  // stft1k::host_tables<1024>()
@@ -152,6 +150,7 @@ extern "C" int ds_init(int device, ds_ctx** out) {
     if (device < 0 || device >= n) return fail(nullptr, DS_ERR_ARG, "ds_init: bad device index");
     ds_ctx* c = new ds_ctx();
     c->device = device;
+    c->cfg = ds_config::from_env();
     HIPCHK(c, hipSetDevice(device));
     HIPCHK(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     HIPCHK(c, hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
@@ -174,7 +173,6 @@ extern "C" void ds_destroy(ds_ctx* c) {
     if (c->w4_tables) (void)hipFree(c->w4_tables);
     for (float2* t : c->stft_dif_tw)
         if (t) (void)hipFree(t);
-    if (c->w4_sync) (void)hipFree(c->w4_sync);
     if (c->fir16k_tables) (void)hipFree(c->fir16k_tables);
     if (c->deconv8k_tables) (void)hipFree(c->deconv8k_tables);
     if (c->stft1k_tables) (void)hipFree(c->stft1k_tables);
@@ -223,23 +221,11 @@ extern "C" int ds_upload(ds_ctx* c, void* dst, const void* src, size_t bytes) {
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return DS_OK;
 }
-// The one-launch Welch kernel bounds its in-kernel waits; a wait that ran out leaves a code in
-// word 0 of its counter block.  Looked at whenever the host has just synchronised with the stream.
-static int check_fused_sync(ds_ctx* c) {
-    if (!c->w4_sync_used || !c->w4_sync) return DS_OK;
-    c->w4_sync_used = false;
-    unsigned code = 0;
-    HIPCHK(c, hipMemcpy(&code, c->w4_sync, sizeof(code), hipMemcpyDeviceToHost));
-    if (code == 0) return DS_OK;
-    HIPCHK(c, hipMemset(c->w4_sync, 0, sizeof(unsigned) * welch4096::F_SYNC_WORDS));
-    return fail(c, DS_ERR_HIP, "welch4096 one-launch kernel: an in-kernel hand-off timed out (code " +
-                                   std::to_string(code) + "); the result of that call is invalid");
-}
 extern "C" int ds_download(ds_ctx* c, void* dst, const void* src, size_t bytes) {
     if (!c || (bytes && (!dst || !src))) return fail(c, DS_ERR_ARG, "ds_download: null argument");
     HIPCHK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    return check_fused_sync(c);
+    return DS_OK;
 }
 extern "C" int ds_memset(ds_ctx* c, void* dst, int value, size_t bytes) {
     if (!c) return fail(c, DS_ERR_ARG, "ds_memset: null ctx");
@@ -249,7 +235,7 @@ extern "C" int ds_memset(ds_ctx* c, void* dst, int value, size_t bytes) {
 extern "C" int ds_sync(ds_ctx* c) {
     if (!c) return fail(c, DS_ERR_ARG, "ds_sync: null ctx");
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    return check_fused_sync(c);
+    return DS_OK;
 }
 extern "C" int ds_timer_start(ds_ctx* c) {
     if (!c) return fail(c, DS_ERR_ARG, "ds_timer_start: null ctx");
@@ -513,7 +499,7 @@ extern "C" int ds_stft_r2c_dev(ds_ctx* c, const float* x, int64_t n_samples, int
     CHK(check_fft_len(c, nfft, "ds_stft_r2c nfft"));
     // 256-, 512- and 1024-point transforms (1024 = the reference's default frame): wave-level
     // register transforms, one frame pair per team of nfft/16 lanes (kernels_stft1024.hpp)
-    static const bool stft_generic = getenv("DSPTOOLBOX_AMD_STFT_GENERIC") != nullptr;
+    const bool stft_generic = c->cfg.stft_generic;
     // frames of 128 / 64 / 32 samples: their transform is every 2nd / 4th / 8th bin of the 256-point transform of the
     // zero-padded frame (the wave kernel with decim; removing the frame mean still only clears bin 0 of the kept bins)
     const int decim = (nfft == 128 || nfft == 64 || nfft == 32) ? 256 / nfft : 1;
@@ -540,10 +526,7 @@ extern "C" int ds_stft_r2c_dev(ds_ctx* c, const float* x, int64_t n_samples, int
         // two per CU: 0.20 ms against 0.16)
         const int lanes = nfft / 16;
         int ct = std::min(nfft >= 2048 ? 8 : 16, n_ch);
-        if (const char* e = getenv("DSPTOOLBOX_AMD_STFT_CT")) {
-            int v = atoi(e);
-            if (v >= 1 && v <= 16 && v * lanes <= 1024) ct = std::min(v, n_ch);
-        }
+        if (const int v = c->cfg.stft_ct; v >= 1 && v <= 16 && v * lanes <= 1024) ct = std::min(v, n_ch);
         while (ct & (ct - 1)) ct &= ct - 1;
         const size_t lds = nfft == 2048 ? stft1k::lds_bytes<2048>(ct) : nfft == 1024 ? stft1k::lds_bytes<1024>(ct)
                                         : (nfft == 512 ? stft1k::lds_bytes<512>(ct) : stft1k::lds_bytes<256>(ct));
@@ -553,7 +536,7 @@ extern "C" int ds_stft_r2c_dev(ds_ctx* c, const float* x, int64_t n_samples, int
         const int n_fp = (n_frames + 1) / 2, n_ct = (n_ch + ct - 1) / ct;
         const int64_t resident = 256 * (int64_t)per_cu;
         int fpw = std::max(1, std::min(16, (int)(((int64_t)n_fp * n_ct + resident - 1) / resident)));
-        if (const char* e = getenv("DSPTOOLBOX_AMD_STFT_FPW")) fpw = std::max(1, atoi(e));
+        if (c->cfg.stft_fpw > 0) fpw = c->cfg.stft_fpw;
         StftArgs a{x, n_samples, ld, pad_front, n_ch, W, hop, n_frames, detrend, power, ct, fpw, window,
                    *tab, scale, edge_scale, (float2*)out, decim};
         dim3 grid((unsigned)((n_fp + fpw - 1) / fpw), (unsigned)n_ct);
@@ -580,7 +563,7 @@ extern "C" int ds_stft_r2c_dev(ds_ctx* c, const float* x, int64_t n_samples, int
         const int n_groups = (n_ch + 15) / 16;
         // chunks of frames: as many as put one workgroup (8 channels) on each of the 256 CUs
         int n_chunks = std::max(1, std::min(n_frames, 128 / std::max(1, std::min(128, n_groups))));
-        if (const char* e = getenv("DSPTOOLBOX_AMD_STFT4K_CHUNKS")) n_chunks = std::max(1, std::min(n_frames, atoi(e)));
+        if (c->cfg.stft4k_chunks > 0) n_chunks = std::min(n_frames, c->cfg.stft4k_chunks);
         stft4k::Args a{x, n_samples, ld, pad_front, n_ch, W, hop, n_frames, detrend, n_chunks, n_groups, window,
                        c->w4_tables, scale, edge_scale, (float2*)out, nullptr};
         const dim3 grid((unsigned)stft4k::grid_size(n_groups, n_chunks));
@@ -606,7 +589,7 @@ extern "C" int ds_stft_r2c_dev(ds_ctx* c, const float* x, int64_t n_samples, int
         // chunks of (frame, phase) units: two rounds of one workgroup (8 channels) per CU (64 x 512 000 samples, 8192
         // points: 0.182 ms against 0.198 with one round)
         int n_chunks = std::max(1, std::min(n_frames, 256 / std::max(1, std::min(256, n_groups))));
-        if (const char* e = getenv("DSPTOOLBOX_AMD_STFT4K_CHUNKS")) n_chunks = std::max(1, std::min(n_frames, atoi(e)));
+        if (c->cfg.stft4k_chunks > 0) n_chunks = std::min(n_frames, c->cfg.stft4k_chunks);
         stft4k::Args a{x, n_samples, ld, pad_front, n_ch, W, hop, n_frames, detrend, n_chunks, n_groups, window,
                        c->w4_tables, scale, edge_scale, (float2*)out, *twn};
         const dim3 grid((unsigned)stft4k::grid_size(n_groups, n_chunks));
@@ -627,10 +610,8 @@ extern "C" int ds_stft_r2c_dev(ds_ctx* c, const float* x, int64_t n_samples, int
     DISPATCH_N(nfft, {
         const size_t per = (size_t)stft_ch_stride<NN>() * sizeof(float2);
         ct = std::min<int>(stft_max_teams<NN>(), n_ch);
-        if (const char* e = getenv("DSPTOOLBOX_AMD_STFT_CT")) {  // fewer teams only: the kernel is compiled for the maximum
-            int v = atoi(e);
-            if (v >= 1 && v <= stft_max_teams<NN>()) ct = std::min(v, std::max(1, n_ch));
-        }
+        // (override: fewer teams only, the kernel is compiled for the maximum)
+        if (const int v = c->cfg.stft_ct; v >= 1 && v <= stft_max_teams<NN>()) ct = std::min(v, std::max(1, n_ch));
         while (ct & (ct - 1)) ct &= ct - 1;  // power of two (shift-only index math in the kernel)
         lds = per * ct;
         threads = ct * Cfg<NN>::NT;
@@ -639,7 +620,7 @@ extern "C" int ds_stft_r2c_dev(ds_ctx* c, const float* x, int64_t n_samples, int
     // on each of the 256 CUs: no second, partly filled round), at most 16
     const int n_fp = (n_frames + 1) / 2, n_ct = (n_ch + ct - 1) / ct;
     int fpw = std::max(1, std::min(16, (int)(((int64_t)n_fp * n_ct + 511) / 512)));
-    if (const char* e = getenv("DSPTOOLBOX_AMD_STFT_FPW")) fpw = std::max(1, atoi(e));
+    if (c->cfg.stft_fpw > 0) fpw = c->cfg.stft_fpw;
     StftArgs a{x, n_samples, ld, pad_front, n_ch, W, hop, n_frames, detrend, power, ct, fpw, window, tw,
                scale, edge_scale, (float2*)out};
     dim3 grid((unsigned)((n_fp + fpw - 1) / fpw), (unsigned)n_ct);
@@ -735,9 +716,9 @@ extern "C" int ds_istft_dev(ds_ctx* c, const ds_c32* stft, int n_bins, int n_fra
     const float2* tw;
     CHK(get_twiddles(c, nfft, &tw));
     // 50 % overlap of full-length frames: transform and overlap-add in one kernel, no frames in memory
-    static const bool no_fuse = getenv("DSPTOOLBOX_AMD_ISTFT_FUSED") && atoi(getenv("DSPTOOLBOX_AMD_ISTFT_FUSED")) == 0;
+    const bool no_fuse = !c->cfg.istft_fused;
     // ... on the wave-level transform for 256 ... 2048 points (kernels_stft1024.hpp, k_istft_wave)
-    static const bool no_wave = getenv("DSPTOOLBOX_AMD_ISTFT_WAVE") && atoi(getenv("DSPTOOLBOX_AMD_ISTFT_WAVE")) == 0;
+    const bool no_wave = !c->cfg.istft_wave;
     if (W == nfft && 2 * step == nfft && n_ch > 1 && !no_fuse && !no_wave &&
         (nfft == 2048 || nfft == 1024 || nfft == 512 || nfft == 256)) {
         // (2048 points: 45 registers over the 128 of a 1024-thread workgroup: four teams = 512 threads there)
@@ -763,7 +744,7 @@ extern "C" int ds_istft_dev(ds_ctx* c, const ds_c32* stft, int n_bins, int n_fra
             // frame pairs per workgroup (+ 1 for the carry): two rounds of resident workgroups, at least 4 (1024 points: 8)
             // -- 64 x 512 000 samples: 0.154 / 0.130 / 0.135 ms at 256 / 512 / 1024 points, 0.18 / 0.13 / 0.145 one step off
             int fpw = std::max(nfft >= 1024 ? 8 : 4, std::min(64, (int)(((int64_t)n_fp * n_ct + 512 * per_cu - 1) / (512 * per_cu))));
-            if (const char* e = getenv("DSPTOOLBOX_AMD_ISTFT_FPW")) fpw = std::max(1, atoi(e));
+            if (c->cfg.istft_fpw > 0) fpw = c->cfg.istft_fpw;
             IstftFusedArgs fa{IstftArgs{(const float2*)stft, n_bins, n_frames, n_ch, W, window, *tab, scale, nullptr, ct, fpw},
                               frame_offset, n_frames_total, total_length, ld_out, out};
             const dim3 grid((unsigned)((n_fp + fpw - 1) / fpw), (unsigned)n_ct);
@@ -784,7 +765,7 @@ extern "C" int ds_istft_dev(ds_ctx* c, const ds_c32* stft, int n_bins, int n_fra
         const int n_groups = (n_ch + 15) / 16;
         // chunks of frames (+ 1 frame each for the carry): two rounds of one workgroup (8 channels) per CU
         int n_chunks = std::max(1, std::min((n_frames + 3) / 4, 256 / std::max(1, std::min(256, n_groups))));
-        if (const char* e = getenv("DSPTOOLBOX_AMD_ISTFT_FPW")) n_chunks = std::max(1, std::min(n_frames, atoi(e)));
+        if (c->cfg.istft_fpw > 0) n_chunks = std::min(n_frames, c->cfg.istft_fpw);
         IstftFusedArgs fa{IstftArgs{(const float2*)stft, n_bins, n_frames, n_ch, W, window, c->w4_tables, scale, nullptr, 1, n_chunks},
                           frame_offset, n_frames_total, total_length, ld_out, out};
         return launch(c, "istft", stft4k::k_istft, dim3((unsigned)stft4k::grid_size(n_groups, n_chunks)), stft4k::NT,
@@ -806,7 +787,7 @@ extern "C" int ds_istft_dev(ds_ctx* c, const ds_c32* stft, int n_bins, int n_fra
             // frame pairs per workgroup: every workgroup transforms one more pair (the carry in front of its range)
             // (64 x 512 000 samples, windows of 256 / 1024 / 4096: ~250 workgroups measured best: 0.21 / 0.21 / 0.29 ms)
             int fpw = std::max(4, std::min(64, (int)(((int64_t)n_fp * n_ct + 255) / 256)));
-            if (const char* e = getenv("DSPTOOLBOX_AMD_ISTFT_FPW")) fpw = std::max(1, atoi(e));
+            if (c->cfg.istft_fpw > 0) fpw = c->cfg.istft_fpw;
             IstftFusedArgs fa{IstftArgs{(const float2*)stft, n_bins, n_frames, n_ch, W, window, tw, scale, nullptr, ct, fpw},
                               frame_offset, n_frames_total, total_length, ld_out, out};
             DISPATCH_N(nfft, {
@@ -822,7 +803,7 @@ extern "C" int ds_istft_dev(ds_ctx* c, const ds_c32* stft, int n_bins, int n_fra
     IstftArgs a{(const float2*)stft, n_bins, n_frames, n_ch, W, window, tw, scale, frames};
     // ct neighbouring channels per workgroup (runs of 8 ct bytes of the channel-fastest spectrogram) wherever more
     // than one image fits; DSPTOOLBOX_AMD_ISTFT_CT=1 keeps one channel per workgroup
-    static const bool one_ch = getenv("DSPTOOLBOX_AMD_ISTFT_CT") && atoi(getenv("DSPTOOLBOX_AMD_ISTFT_CT")) == 1;
+    const bool one_ch = c->cfg.istft_one_ch;
     int ct = 1;
     size_t lds = 0;
     int threads = 0;
@@ -1061,8 +1042,8 @@ static int welch4096_run(ds_ctx* c, const float* x, int n_cx, int64_t ldx, const
     const int nf = frames_to_visit(n_samples, hop, n_frames);
     // 50 % overlap: three workgroups per CU (kernels_welch4096w.hpp); any other hop: two
     const bool half = hop == 2048;
-    const bool three = half && w4::enabled3() && w4::fits3(n_samples, nf);
-    w4::Plan pl = three ? w4::plan3(nf, n_cy) : w4::plan(nf, n_cy);
+    const bool three = half && !c->cfg.w4_two_per_cu && w4::fits3(n_samples, nf);
+    w4::Plan pl = three ? w4::plan3(nf, n_cy, c->cfg.welch_chunks) : w4::plan(nf, n_cy, c->cfg.welch_chunks);
     CHK(reserve(c, &c->ws, &c->ws_bytes, pl.bytes + (size_t)(n_cx - 1) * (Carver::pad(sizeof(float2) * (size_t)pl.n_pairs * w4::N) +
                                                                   Carver::pad(sizeof(float) * (size_t)pl.n_pairs * w4::NB) +
                                                                   Carver::pad(sizeof(float) * (size_t)pl.n_chunks * w4::NB)) + 4096));
@@ -1080,31 +1061,6 @@ static int welch4096_run(ds_ctx* c, const float* x, int n_cx, int64_t ldx, const
     ay.ld = ldy;
     ay.n_ch = n_cy;
     if (three) w4::place_remainder(ay, n_cy);
-    // one input channel, transfer function: the whole step in one launch when its grid is resident at once
-    if (three && n_cx == 1 && kind == 0 && w4::fused_enabled() && pl.n_chunks <= w4::F_MAX_UNITS && n_cy <= w4::F_MAX_UNITS) {
-        if (c->w4_fused_cap < 0) {
-            int per_cu = 0, cus = 0;
-            HIPCHK(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, w4::k_h1f, w4::NT, w4::LDS3_BYTES));
-            HIPCHK(c, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device));
-            c->w4_fused_cap = std::min(per_cu, 3) * cus;
-        }
-        if (pl.n_chunks * n_cy <= c->w4_fused_cap) {
-            if (!c->w4_sync) {
-                HIPCHK(c, hipMalloc((void**)&c->w4_sync, sizeof(unsigned) * w4::F_SYNC_WORDS));
-                HIPCHK(c, hipMemsetAsync(c->w4_sync, 0, sizeof(unsigned) * w4::F_SYNC_WORDS, c->stream));
-            }
-            w4::FusedArgs fa;
-            fa.a = ay;
-            fa.a.xsig = x;
-            fa.sync = c->w4_sync;
-            fa.mode = mode;
-            fa.fin = FinishPar{norm_scale / (double)n_frames, factor, halve_edges, amp_sqrt, w4::NB};
-            fa.tf = tf;
-            fa.coh = coh;
-            c->w4_sync_used = true;
-            return launch(c, "welch4096_fused", w4::k_h1f, dim3(pl.n_chunks * n_cy), w4::NT, w4::LDS3_BYTES, fa);
-        }
-    }
     if (three) {
         CHK(launch(c, "welch4096_x", w4::k_x3, dim3(pl.n_pairs * n_cx), w4::NT, w4::LDS3_BYTES, ax));
         if (n_cx > 1) CHK(launch(c, "welch4096_pxsum", w4::k_px_sum, dim3(pl.n_chunks, n_cx), 256, 0, ay));
@@ -1311,8 +1267,8 @@ static int welch4096_psd_run(ds_ctx* c, const float* x, int n_cx, int64_t ldx, i
         CHK(upload_table_fwd(c, &c->w4_tables, h));
     }
     const int nf = frames_to_visit(n_samples, hop, n_frames);
-    const bool three = hop == 2048 && w4::enabled3() && w4::fits3(n_samples, nf);
-    w4::Plan pl = three ? w4::plan3(nf, n_cx) : w4::plan(nf, n_cx);
+    const bool three = hop == 2048 && !c->cfg.w4_two_per_cu && w4::fits3(n_samples, nf);
+    w4::Plan pl = three ? w4::plan3(nf, n_cx, c->cfg.welch_chunks) : w4::plan(nf, n_cx, c->cfg.welch_chunks);
     CHK(reserve(c, &c->ws, &c->ws_bytes, Carver::pad(sizeof(float) * (size_t)pl.n_chunks * n_cx * w4::NB)));
     Carver cv(c->ws);
     float* pyy = cv.take<float>((size_t)pl.n_chunks * n_cx * w4::NB);
@@ -1366,7 +1322,7 @@ static int welch_wave_run(ds_ctx* c, const float* x, int n_cx, int64_t ldx, cons
     CHK(wave_tables<NN>(c, &tab));
     const int nf = frames_to_visit(n_samples, hop, n_frames);
     if (n_cx != 1 && n_cx != n_cy) return fail(c, DS_ERR_ARG, "ds_welch_tf: one input channel, or one per output channel");
-    w1::Plan pl = w1::plan<NN>(nf, n_cy, n_cx);
+    w1::Plan pl = w1::plan<NN>(nf, n_cy, n_cx, c->cfg.welch1k_chunks);
     CHK(reserve(c, &c->ws, &c->ws_bytes, pl.bytes + Carver::pad(sizeof(float) * NN)));
     Carver cv(c->ws);
     if (decim > 1) {  // the window, zero-padded to the transform length
@@ -1415,7 +1371,7 @@ static int welch_wave_psd_run(ds_ctx* c, const float* x, int n_cx, int64_t ldx, 
     const float2* tab;
     CHK(wave_tables<NN>(c, &tab));
     const int nf = frames_to_visit(n_samples, hop, n_frames);
-    w1::Plan pl = w1::plan<NN>(nf, n_cx);
+    w1::Plan pl = w1::plan<NN>(nf, n_cx, 1, c->cfg.welch1k_chunks);
     CHK(reserve(c, &c->ws, &c->ws_bytes,
                 Carver::pad(sizeof(float) * (size_t)pl.n_chunks * n_cx * W::NB) + Carver::pad(sizeof(float) * NN)));
     Carver cv(c->ws);
@@ -1447,10 +1403,10 @@ extern "C" int ds_welch_tf_dev(ds_ctx* c, const float* x, int n_cx, int64_t ldx,
                                float* coh) {
     if (!tf || !coh) return fail(c, DS_ERR_ARG, "ds_welch_tf: null output");
     // one input channel, or one per output channel (three-per-CU kernels at 50 % overlap, two-per-CU otherwise)
-    if (c && W == 4096 && average == DS_AVG_MEAN && welch4096::enabled() && (n_cx == 1 || n_cx == n_cy))
+    if (c && W == 4096 && average == DS_AVG_MEAN && !c->cfg.no_welch4096 && (n_cx == 1 || n_cx == n_cy))
         return welch4096_run(c, x, n_cx, ldx, y, n_cy, ldy, n_samples, hop, n_frames, window, detrend, mode,
                              amp_sqrt, norm_scale, factor, halve_edges, (float2*)tf, coh);
-    static const bool no1k = getenv("DSPTOOLBOX_AMD_WELCH_GENERIC") != nullptr;
+    const bool no1k = c && c->cfg.welch_generic;
     if (c && W == 16384 && (n_cx == 1 || n_cx == n_cy) && average == DS_AVG_MEAN && !no1k &&
         welch16k::buf_fits(n_samples, n_frames, hop))
         return welch16384_run(c, x, n_cx, ldx, y, n_cy, ldy, n_samples, hop, n_frames, window, detrend, mode,
@@ -1545,14 +1501,14 @@ extern "C" int ds_welch_psd_dev(ds_ctx* c, const float* x, int n_cx, int64_t ldx
                                 int average, int amp_sqrt, double norm_scale, double factor,
                                 int halve_edges, float* psd) {
     if (!psd) return fail(c, DS_ERR_ARG, "ds_welch_psd: null output");
-    static const bool no1k = getenv("DSPTOOLBOX_AMD_WELCH_GENERIC") != nullptr;
+    const bool no1k = c && c->cfg.welch_generic;
     if (c && W == 16384 && average == DS_AVG_MEAN && !no1k && welch16k::buf_fits(n_samples, n_frames, hop))
         return welch16384_psd_run(c, x, n_cx, ldx, n_samples, hop, n_frames, window, detrend, amp_sqrt,
                                   norm_scale, factor, halve_edges, psd);
     if (c && W == 8192 && average == DS_AVG_MEAN && !no1k && welch8k::buf_fits(n_samples, n_frames, hop))
         return welch8192_psd_run(c, x, n_cx, ldx, n_samples, hop, n_frames, window, detrend, amp_sqrt,
                                  norm_scale, factor, halve_edges, psd);
-    if (c && W == 4096 && average == DS_AVG_MEAN && welch4096::enabled() && !no1k)
+    if (c && W == 4096 && average == DS_AVG_MEAN && !c->cfg.no_welch4096 && !no1k)
         return welch4096_psd_run(c, x, n_cx, ldx, n_samples, hop, n_frames, window, detrend, amp_sqrt,
                                  norm_scale, factor, halve_edges, psd);
     if (c && (W == 2048 || W == 1024 || W == 512 || W == 256) && average == DS_AVG_MEAN && !no1k &&
@@ -1575,10 +1531,10 @@ static int welch_csd_dev(ds_ctx* c, const float* x, const float* y, int n_ch, in
                          int halve_edges, ds_c32* csd) {
     // csd_i = mean_f conj(X_i) Y_i is the cross sum a transfer function with one input channel per
     // output channel accumulates: the register kernels with the finish of kind 2
-    static const bool generic = getenv("DSPTOOLBOX_AMD_WELCH_GENERIC") != nullptr;
+    const bool generic = c && c->cfg.welch_generic;
     if (c && x && y && window && csd && average == DS_AVG_MEAN && !generic && n_ch > 0 && n_samples > 0 &&
         n_frames > 0 && hop > 0 && hop <= W && ld >= n_samples) {
-        if (W == 4096 && welch4096::enabled())
+        if (W == 4096 && !c->cfg.no_welch4096)
             return welch4096_run(c, x, n_ch, ld, y, n_ch, ld, n_samples, hop, n_frames, window, detrend, DS_TF_H1,
                                  amp_sqrt, norm_scale, factor, halve_edges, (float2*)csd, nullptr, 2);
         if (W == 16384 && welch16k::buf_fits(n_samples, n_frames, hop))
@@ -1665,10 +1621,10 @@ static int csm_dev(ds_ctx* c, const float* x, int n_ch, int64_t ld, int64_t n_sa
     // up to 64 channels: one workgroup per bin shares the operand loads between the three tile
     // pairs (the spectra of an even-length real transform are purely real at both edge bins,
     // which the kernel relies on)
-    static const bool no64 = getenv("DSPTOOLBOX_AMD_CSM_GENERIC") != nullptr;
+    const bool no64 = c->cfg.csm_generic;
     // the same product from bf16 triples on the 16 x faster bf16 matrix pipe
     // (kernels_csm_b3.hpp; DSPTOOLBOX_AMD_CSM_F32=1 keeps the fp32 matrix instructions)
-    static const bool f32_only = getenv("DSPTOOLBOX_AMD_CSM_F32") != nullptr;
+    const bool f32_only = c->cfg.csm_f32;
     const bool one_wg_per_bin = all_bins && n_ch <= 64 && n_frames >= 8 && nb >= 3 && !no64;
     if (one_wg_per_bin && !f32_only && csmb3::fits(n_ch, n_frames))
         CHK(launch(c, "csm_gemm", csmb3::k_csm_gemm64_b3, dim3(nb - 1), 256, 0, a));
@@ -1956,15 +1912,6 @@ static int64_t blue_len(int64_t L) {
     return m;
 }
 
-static size_t blue_cache_cap() {
-    static size_t cap = 0;
-    if (!cap) {
-        cap = (size_t)256 << 20;  // two of the largest tables, or dozens of audio-length ones
-        if (const char* e = getenv("DSPTOOLBOX_AMD_BLUESTEIN_CACHE_MB")) cap = (size_t)std::max(1, atoi(e)) << 20;
-    }
-    return cap;
-}
-
 static int blue_filter(ds_ctx* c, int64_t L, int64_t M, const float2** out) {
     auto key = std::make_pair(L, M);
     auto it = c->blue.find(key);
@@ -1976,7 +1923,7 @@ static int blue_filter(ds_ctx* c, int64_t L, int64_t M, const float2** out) {
     const size_t bytes = sizeof(float2) * (size_t)M;
     // make room: drop the least recently used tables (hipFree waits for the device, so a table
     // still referenced by queued kernels of an earlier call is never pulled from under them)
-    while (!c->blue.empty() && c->blue_bytes + bytes > blue_cache_cap()) {
+    while (!c->blue.empty() && c->blue_bytes + bytes > c->cfg.bluestein_cache_bytes) {
         auto lru = c->blue.begin();
         for (auto jt = c->blue.begin(); jt != c->blue.end(); ++jt)
             if (jt->second.stamp < lru->second.stamp) lru = jt;
@@ -2123,7 +2070,7 @@ extern "C" int ds_deconv_dev(ds_ctx* c, const float* y, int n_items, int n_ch, i
                           n_out, ld_out, ir);
     }
     CHK(check_fft_len(c, n_fft, "ds_deconv n_fft"));
-    static const bool no8k = getenv("DSPTOOLBOX_AMD_DECONV_GENERIC") != nullptr;
+    const bool no8k = c->cfg.deconv_generic;
     if (n_fft == deconv8k::N && !r_per_channel && !no8k) {
         // 8192 points, one inverse spectrum for all channels: two register-resident 4096-point
         // transforms per channel pair, the packed spectrum multiplied directly (kernels_deconv8k.hpp)
@@ -2141,10 +2088,10 @@ extern "C" int ds_deconv_dev(ds_ctx* c, const float* y, int n_items, int n_ch, i
                           (const float2*)r, ir};
         // one 256-thread group per channel pair, its two sub-spectra one after the other: three independent
         // workgroups per CU (k_deconv3); DSPTOOLBOX_AMD_DECONV_2PERCU=1 keeps the 512-thread kernel (A/B)
-        static const bool two = getenv("DSPTOOLBOX_AMD_DECONV_2PERCU") != nullptr;
+        const bool two = c->cfg.deconv_2percu;
         // four workgroups per CU (k_deconv3q: all 1024 pairs of the benchmark resident at once) unless
         // DSPTOOLBOX_AMD_DECONV_4PERCU=0 (k_deconv3: three, 168 registers)
-        static const bool four = !(getenv("DSPTOOLBOX_AMD_DECONV_4PERCU") && atoi(getenv("DSPTOOLBOX_AMD_DECONV_4PERCU")) == 0);
+        const bool four = c->cfg.deconv_4percu;
         if (!two && four && (int64_t)((n_ch + 1) / 2) * n_items < ((int64_t)1 << 31))
             return launch(c, "deconv", deconv8k::k_deconv3q, dim3((unsigned)(((n_ch + 1) / 2) * n_items)), 256,
                           deconv8k::LDS_BYTES_3, a8);
@@ -2172,17 +2119,14 @@ static int upload_table_fwd(ds_ctx* c, float2** slot, const std::vector<float2>&
     return DS_OK;
 }
 
-static int fir_block_len(int n_taps) {
+static int fir_block_len(int n_taps, int v = 0) {  // v: forced block length (DSPTOOLBOX_AMD_FIR_BLOCK), 0 = none
     int n = 1024;
     while (n < 4 * n_taps && n < kMaxFft) n <<= 1;
     // 1025 .. 2048 taps would take generic 8192-point blocks (75 % of every block new samples): the
     // register kernel for 16384-point blocks with its whole-group stores is faster (1025 taps:
     // 2.06 -> 1.57 ms on the 32-band x 8 x 2^22 shape) when the discarded length is a multiple of 4
     if (n == 8192 && ((n_taps - 1) & 3) == 0) n = 16384;
-    if (const char* e = getenv("DSPTOOLBOX_AMD_FIR_BLOCK")) {
-        int v = atoi(e);
-        if (v >= 1024 && v <= kMaxFft && is_pow2(v) && n_taps - 1 <= v / 2) n = v;
-    }
+    if (v >= 1024 && v <= kMaxFft && is_pow2(v) && n_taps - 1 <= v / 2) n = v;  // DSPTOOLBOX_AMD_FIR_BLOCK
     return n;
 }
 
@@ -2244,14 +2188,6 @@ static int fir_long(ds_ctx* c, const float* x, int n_ch, int64_t ldx, int64_t n_
 // Up to 4097 taps: uniformly partitioned overlap-save on the 4096-point register transform, three (one
 // partition) or two (two partitions) independent workgroups per CU (kernels_fir4k.hpp).
 // DSPTOOLBOX_AMD_FIR_4K=0 keeps the block kernels below (A/B); =1 also sends the short filters here.
-static int fir4k_min_taps() {
-    if (const char* e = getenv("DSPTOOLBOX_AMD_FIR_4K")) {
-        if (e[0] == '0') return 1 << 30;
-        if (e[0] == '1') return 1;
-        if (atoi(e) > 1) return atoi(e);
-    }
-    return 1025;  // below: the generic kernels with 1024 ... 4096-point blocks (see DESIGN, tap-count sweep)
-}
 static int fir4k_run(ds_ctx* c, const float* x, int n_ch, int64_t ldx, int64_t n_samples, const float* taps,
                      int n_filt, int n_taps, float* y, int64_t ld_y) {
     namespace f4 = fir4k;
@@ -2273,7 +2209,7 @@ static int fir4k_run(ds_ctx* c, const float* x, int n_ch, int64_t ldx, int64_t n
     // every workgroup resident at once (3 or 2 per CU): a run of blocks each, one extra forward
     // transform per run with two partitions
     int chunks = std::max(1, (P == 1 ? 768 : 512) / pairs);
-    if (const char* e = getenv("DSPTOOLBOX_AMD_FIR_CHUNKS")) chunks = std::max(1, atoi(e));
+    if (c->cfg.fir_chunks > 0) chunks = c->cfg.fir_chunks;
     chunks = std::min(chunks, n_blocks);
     f4::Args a{x, n_samples, ldx, ld_y, n_ch, n_filt, n_blocks, chunks, c->w4_tables, hp, y};
     if (P == 1) return launch(c, "fir", f4::k_fir<1>, dim3((unsigned)(pairs * chunks)), f4::NT, f4::LDS_BYTES, a);
@@ -2282,13 +2218,13 @@ static int fir4k_run(ds_ctx* c, const float* x, int n_ch, int64_t ldx, int64_t n
 
 static int fir_once(ds_ctx* c, const float* x, int n_ch, int64_t ldx, int64_t n_samples,
                     const float* taps, int n_filt, int n_taps, float* y, int64_t ld_y) {
-    if (n_taps >= fir4k_min_taps() && fir4k::partitions(n_taps) <= 2 && fir4k::fits(n_samples) && n_filt <= 16384)
+    if (n_taps >= c->cfg.fir4k_min_taps && fir4k::partitions(n_taps) <= 2 && fir4k::fits(n_samples) && n_filt <= 16384)
         return fir4k_run(c, x, n_ch, ldx, n_samples, taps, n_filt, n_taps, y, ld_y);
-    const int N = fir_block_len(n_taps);
+    const int N = fir_block_len(n_taps, c->cfg.fir_block);
     if (n_taps - 1 > N / 2) return fir_long(c, x, n_ch, ldx, n_samples, taps, n_filt, n_taps, y, ld_y);
     const float2* tw;
     CHK(get_twiddles(c, N, &tw));
-    static const bool no16k = getenv("DSPTOOLBOX_AMD_FIR_GENERIC") != nullptr;
+    const bool no16k = c->cfg.fir_generic;
     const bool use16k = N == fir16k::NBIG && !no16k;
     CHK(reserve(c, &c->ws, &c->ws_bytes, (use16k ? 2 : 1) * Carver::pad(sizeof(float2) * (size_t)n_filt * N)));
     Carver cvw(c->ws);
@@ -2351,7 +2287,7 @@ static int fir_once(ds_ctx* c, const float* x, int n_ch, int64_t ldx, int64_t n_
                         split = s;
                     }
                 }
-                if (const char* e = getenv("DSPTOOLBOX_AMD_FIR_SPLIT")) split = std::max(1, std::min(atoi(e), n_filt));
+                if (c->cfg.fir_split > 0) split = std::min(c->cfg.fir_split, n_filt);
             }
             CHK(launch(c, "fir", fir16k::k_fir<true>, dim3((unsigned)n_plain, (n_ch + 1) / 2, split), fir16k::NTB,
                        fir16k::LDS_BYTES, a));

@@ -18,7 +18,12 @@ inline int host_threads(int threads, int64_t work_items) {
     if (threads <= 0) {
         unsigned hc = std::thread::hardware_concurrency();
         threads = (int)std::min<unsigned>(16u, hc ? hc : 1u);
-        if (const char* e = getenv("DSPTOOLBOX_AMD_HOST_THREADS")) threads = std::max(1, atoi(e));
+        // (host-side casts have no context: read once per process)
+        static const int forced = [] {
+            const char* e = getenv("DSPTOOLBOX_AMD_HOST_THREADS");
+            return e ? std::max(1, atoi(e)) : 0;
+        }();
+        if (forced) threads = forced;
     }
     // below ~1 M elements a thread start costs more than it saves
     const int64_t by_work = std::max<int64_t>(1, work_items / (1 << 20));

@@ -359,7 +359,7 @@ struct Plan {
     size_t bytes;
 };
 template <int NN>
-inline Plan plan(int n_frames, int n_cy, int n_cx = 1) {
+inline Plan plan(int n_frames, int n_cy, int n_cx = 1, int want_chunks = 0) {  // want_chunks: ds_config::welch1k_chunks
     using W = WG<NN>;
     Plan pl;
     pl.n_pairs = (n_frames + 1) / 2;
@@ -370,9 +370,7 @@ inline Plan plan(int n_frames, int n_cy, int n_cx = 1) {
     want = (want + 7) & ~7;
     const int by_len = (pl.n_pairs + 63) / 64;
     if (want < by_len) want = (by_len + 7) & ~7;
-    if (const char* e = getenv("DSPTOOLBOX_AMD_WELCH1K_CHUNKS")) {
-        if (atoi(e) > 0) want = atoi(e);
-    }
+    if (want_chunks > 0) want = want_chunks;
     want = std::max(1, std::min(want, pl.n_pairs));
     if (want >= 8) want &= ~7;  // whole chunks per XCD: the input spectra a chunk re-reads stay in one L2
     pl.n_chunks = want;         // chunk q = pairs [q n_pairs / n_chunks, (q+1) n_pairs / n_chunks)

@@ -255,7 +255,7 @@ struct Args {
     // k_x3 / k_y3 only: number of input channels (0 or 1: one input for every output channel; else
     // one per output channel: xs[cx][pair][...], px[cx][pair][NB], psx[chunk][cx][NB])
     int n_cx;
-    const float* xsig;  // k_h1f only (kernels_welch4096f.hpp): the input channel (sig = the output channels)
+    const float* xsig;  // tools/exp/kernels_welch4096f.hpp only: the input channel (sig = the output channels)
 };
 
 // twt: fp64-computed tables, [15][256] W4096^(t k1) (k1 = 1..15) then [16][16] W256^(n3 k2)
@@ -537,18 +537,8 @@ __global__ __launch_bounds__(NT, 2) void k_y(Args p) {
 }
 
 // ---- host side -----------------------------------------------------------------
-inline bool enabled() {
-    static int on = -1;
-    if (on < 0) {
-        const char* e = getenv("DSPTOOLBOX_AMD_NO_WELCH4096");
-        on = (e && e[0] == '1') ? 0 : 1;
-    }
-    return on == 1;
-}
-
-inline int chunks_for(int n_pairs, int n_ch) {
-    const char* e = getenv("DSPTOOLBOX_AMD_WELCH_CHUNKS");
-    int want = e ? atoi(e) : 0;
+// `want`: the caller's chunk count (ds_config::welch_chunks), 0 = choose here
+inline int chunks_for(int n_pairs, int n_ch, int want = 0) {
     if (want <= 0) {
         // exactly two workgroups per CU (512 on the 256 CUs) when there is enough work: all of
         // them are resident at once, no tail; fp32 accumulation chains stay <= 64 pairs
@@ -567,10 +557,10 @@ struct Plan {
     int n_pairs, n_chunks, ppc;
     size_t bytes;
 };
-inline Plan plan(int n_frames, int n_cy) {
+inline Plan plan(int n_frames, int n_cy, int want_chunks = 0) {
     Plan pl;
     pl.n_pairs = (n_frames + 1) / 2;
-    pl.n_chunks = chunks_for(pl.n_pairs, n_cy);  // chunk q = pairs [q n_pairs / n_chunks, (q+1) n_pairs / n_chunks)
+    pl.n_chunks = chunks_for(pl.n_pairs, n_cy, want_chunks);  // chunk q = pairs [q n_pairs / n_chunks, (q+1) n_pairs / n_chunks)
     pl.ppc = (pl.n_pairs + pl.n_chunks - 1) / pl.n_chunks;
     auto pad = [](size_t b) { return (b + 255) & ~size_t(255); };
     pl.bytes = pad(sizeof(float2) * (size_t)pl.n_pairs * N) + pad(sizeof(float) * (size_t)pl.n_pairs * NB) +

@@ -66,6 +66,10 @@ __device__ __forceinline__ void wave_sync() {
 #ifndef W4_NO_READ2
 #define W4_NO_READ2 1
 #endif
+#ifndef W4_WIN_GLOBAL
+#define W4_WIN_GLOBAL 0  // experiment (tools/exp): window values by buffer loads (L1-resident 16 KB) instead of the LDS copy
+#endif
+constexpr int LDS3G_BYTES = 16 * L1S * 8 + 256 * 8;  // ... which leaves exchange + W256 = 36864 bytes: four workgroups per CU
 
 struct Tw6 {
 #if W4_TW6
@@ -450,7 +454,10 @@ __global__ __launch_bounds__(NT, W4_OCC) void k_y3(Args p) {
     Tw6 tw;
     load_tw6(tw, p.twt, tid);
     tw2[tid] = p.twt[15 * 256 + tid];
-#if W4_OCC == 3
+#if W4_WIN_GLOBAL
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.window), 0, N * 4, 0x00020000);
+    (void)winl;
+#elif W4_OCC == 3
 #pragma unroll
     for (int n1 = 0; n1 < 16; ++n1) winl[tid + 256 * n1] = p.window[tid + 256 * n1];
 #else
@@ -514,7 +521,11 @@ __global__ __launch_bounds__(NT, W4_OCC) void k_y3(Args p) {
 #if W4_TIMING
     const unsigned long long life_r1 = __builtin_amdgcn_s_memrealtime();
 #endif
-#if W4_OCC == 3 && W4_WIN_ROT
+#if W4_WIN_GLOBAL
+    float winr[16];
+#pragma unroll
+    for (int n1 = 0; n1 < 16; ++n1) winr[n1] = ld_sample(wrs, 4 * (tid + 256 * n1));
+#elif W4_OCC == 3 && W4_WIN_ROT
     // the window values of an iteration are requested from LDS at the end of the previous one (into
     // registers the accumulation has just freed) instead of in front of their first use
     float winr[16];
@@ -528,7 +539,7 @@ __global__ __launch_bounds__(NT, W4_OCC) void k_y3(Args p) {
         set_prio(level16, (pr * 5) & 3);
 #pragma unroll
         for (int n1 = 0; n1 < 16; ++n1) {
-#if W4_OCC == 3 && !W4_WIN_ROT
+#if W4_OCC == 3 && !W4_WIN_ROT && !W4_WIN_GLOBAL
             const float w = winl[tid + 256 * n1];
 #else
             const float w = winr[n1];
@@ -556,6 +567,11 @@ __global__ __launch_bounds__(NT, W4_OCC) void k_y3(Args p) {
                 }
             },
             [&](int g) {  // input spectrum of this pair, two 16-byte loads per call-out
+#if W4_WIN_GLOBAL
+                // the next pair's window values (their registers are free since the windowing above)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) winr[4 * g + j] = ld_sample(wrs, 4 * (tid + 256 * (4 * g + j)));
+#endif
                 if (!AUTO) {
 #pragma unroll
                     for (int j = 0; j < 2; ++j) {
@@ -581,7 +597,7 @@ __global__ __launch_bounds__(NT, W4_OCC) void k_y3(Args p) {
             }
             P[k3] = fmaf(z.x, z.x, fmaf(z.y, z.y, P[k3]));
         }
-#if W4_OCC == 3 && W4_WIN_ROT
+#if W4_OCC == 3 && W4_WIN_ROT && !W4_WIN_GLOBAL
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int n1 = 0; n1 < 16; ++n1) winr[n1] = winl[tid + 256 * n1];
@@ -634,9 +650,7 @@ __global__ __launch_bounds__(NT, W4_OCC) void k_y3(Args p) {
 // three workgroups per CU, all resident at once: 768 (chunk, channel) units when there is enough
 // work; fp32 accumulation chains stay <= 64 pairs; grid a multiple of 8 where possible so the
 // XCD-aware decode of k_y3 applies
-inline int chunks_for3(int n_pairs, int n_ch) {
-    const char* e = getenv("DSPTOOLBOX_AMD_WELCH_CHUNKS");
-    int want = e ? atoi(e) : 0;
+inline int chunks_for3(int n_pairs, int n_ch, int want = 0) {  // want: the caller's chunk count, 0 = choose here
     if (want <= 0) {
         want = (768 + n_ch - 1) / n_ch;
         const int by_len = (n_pairs + 63) / 64;
@@ -652,10 +666,10 @@ inline int chunks_for3(int n_pairs, int n_ch) {
     if (want < 1) want = 1;
     return want;
 }
-inline Plan plan3(int n_frames, int n_cy) {
+inline Plan plan3(int n_frames, int n_cy, int want_chunks = 0) {
     Plan pl;
     pl.n_pairs = (n_frames + 1) / 2;
-    pl.n_chunks = chunks_for3(pl.n_pairs, n_cy);
+    pl.n_chunks = chunks_for3(pl.n_pairs, n_cy, want_chunks);
     pl.ppc = (pl.n_pairs + pl.n_chunks - 1) / pl.n_chunks;
     auto pad = [](size_t b) { return (b + 255) & ~size_t(255); };
     pl.bytes = pad(sizeof(float2) * (size_t)pl.n_pairs * N) + pad(sizeof(float) * (size_t)pl.n_pairs * NB) +
@@ -709,14 +723,6 @@ inline void place_remainder(Args& a, int n_ch) {
 // the raw-buffer loads carry byte offsets in 32 bits
 inline bool fits3(int64_t n_samples, int n_frames) {
     return n_samples < ((int64_t)1 << 30) - 8192 && (int64_t)(n_frames + 2) * 2048 < ((int64_t)1 << 30) - 8192;
-}
-inline bool enabled3() {
-    static int on = -1;
-    if (on < 0) {
-        const char* e = getenv("DSPTOOLBOX_AMD_W4_TWO_PER_CU");  // A/B: the round-1 kernel
-        on = (e && e[0] == '1') ? 0 : 1;
-    }
-    return on == 1;
 }
 
 }  // namespace welch4096

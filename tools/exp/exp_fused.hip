@@ -11,7 +11,7 @@
 #include <random>
 #include <vector>
 
-#include "../../dsptoolbox_amd/csrc/kernels_welch4096f.hpp"
+#include "kernels_welch4096f.hpp"
 
 namespace w4 = welch4096;
 #define CK(e)                                                                      \

@@ -1,5 +1,5 @@
 // Welch H1 / H2 / H3, nfft 4096, 50 % overlap, ONE input channel: the whole estimate in ONE launch.
-// gfx950.  (compute_transfer_function, transfer_functions/transfer_functions.py:476-534: the
+// gfx950.  NOT part of the library: tools/exp only (see the note at the end).  (compute_transfer_function, transfer_functions/transfer_functions.py:476-534: the
 // per-channel _welch loop, _spectral_methods.py:10-173, and the H / coherence lines :525-534.)
 //
 // kernels_welch4096w.hpp runs the step as three launches: k_x3 (input spectra) -> k_y3 (output
@@ -39,7 +39,7 @@
 // The host launches this kernel only when the whole grid is resident at once (occupancy query x
 // CUs); otherwise, and for paired inputs / other hops, the three-launch path stays.
 #pragma once
-#include "kernels_welch4096w.hpp"
+#include "../../dsptoolbox_amd/csrc/kernels_welch4096w.hpp"
 
 namespace welch4096 {
 
@@ -436,19 +436,11 @@ __device__ __forceinline__ void tail(const FusedArgs& fa, float2* lds, float2 (&
     }
 }
 
-// the fused launch needs every workgroup resident at once
-// OPT-IN (DSPTOOLBOX_AMD_W4_ONE_LAUNCH=1, read per call).  Measured on MI355X, 64 x 2^20 samples
-// (tools/exp/exp_fused.hip, per-workgroup s_memrealtime stamps, gpurun_out/exp_fused*.log of round 3):
-// the one launch is correct (bit-identical to the three launches, also beside a competing kernel and
-// over repeated launches) but SLOWER, 165-190 us against 107-110 us: what a kernel boundary does for
-// free -- making one workgroup's stores visible to workgroups on other XCDs -- costs as much inside a
-// launch as the boundary itself.  Write-through stores drain in 0.5 us at the median but 15-25 us at
-// the 90th percentile while every CU streams reads (input spectra "ready" at 25 us instead of 6; chunk
-// partials "published" 5-20 us behind the end of the pair loop), and the grid-wide wait in front of the
-// finish is a barrier at the slowest workgroup either way.  The three-launch path stays the default.
-inline bool fused_enabled() {
-    const char* e = getenv("DSPTOOLBOX_AMD_W4_ONE_LAUNCH");
-    return e && e[0] == '1';
-}
+// EXPERIMENT ONLY since round 4 (it lived behind DSPTOOLBOX_AMD_W4_ONE_LAUNCH in the library in round 3).
+// Measured on MI355X, 64 x 2^20 samples (tools/exp/exp_fused.hip, per-workgroup s_memrealtime stamps,
+// profiles/r03_welch_one_launch_stamps.txt): the one launch is correct (bit-identical to the three
+// launches, also beside a competing kernel and over repeated launches) but SLOWER, 165-190 us against
+// 107-110 us, and a kernel whose workgroups wait for each other stalls behind any other stream that
+// holds CUs -- so it is not shipped.  The harness needs every workgroup resident at once.
 
 }  // namespace welch4096
