@@ -7,7 +7,11 @@ Default workload (BASELINE.json configs[1], the one the metric is quoted on):
 64-channel Welch H1 transfer-function estimation, one sweep input channel,
 2^20 samples per channel, nfft 4096, Hann, 50 % overlap.  One step = one
 ds_welch_tf_dev call over inputs that are already resident in HBM.
-N > 1: one process per GPU (torch.distributed.run).
+N > 1: one process per GPU, as the driver launches it (`python -m torch.distributed.run ... bench.py --gpus N`:
+torch is the process launcher and nothing else) or, with no launcher environment, started by this script
+itself.  The ranks meet over the package's own host exchange (dsptoolbox_amd/rendezvous.py: barrier, max over
+ranks, the 128-byte RCCL id) and the ONLY RCCL communicator of the job is the library's (ds_comm_init); the line
+reports how many ranks RCCL itself counts ("rccl_ranks", ncclCommCount through ds_comm_count).
   --scaling weak   (default) every rank owns an independent 64-channel batch, no data-path
                    collective; the shared sweep channel is broadcast once over RCCL/xGMI
                    before the timed region;
@@ -15,8 +19,9 @@ N > 1: one process per GPU (torch.distributed.run).
                    bands / items / bins by shard_range, the shared input by ds_bcast, and every
                    step ends with the RCCL all-gather of the result slices (ds_allgather).
 At N = 1, `--predict-ranks 8` also times the per-rank shard shape of an 8-GPU strong-scaling
-job and prints the implied speed-up T(full) / T(shard) ("shard_prediction"; results of this
-round: profiles/r02_shard_prediction.jsonl).
+job and prints the implied speed-up T(full) / T(shard) ("shard_prediction"; profiles/rNN_shard_prediction.jsonl).
+At N = 1 the default line also carries "workloads": the other BASELINE configs (welch_h1_1024, fir_bank, csm,
+deconv), each timed the same way over a shorter region with a bounded CPU leg (`--no-workloads` skips them).
 
 Prints ONE JSON line on rank 0.
 """
@@ -43,7 +48,7 @@ MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense, MI355X_MICROARCH.md
 FS = 48000
 
 # bench kernel name (ds_profile_*) -> how rocprofv3's kernel trace names the same kernel
-KERNEL_HINTS = {"welch4096_fused": ("welch4096::k_h1f",), "welch4096_main": ("welch4096::k_y3<", "welch4096::k_y<"),
+KERNEL_HINTS = {"welch4096_main": ("welch4096::k_y3<", "welch4096::k_y<"),
                 "welch1024_main": ("welch1k::k_y<",), "welch_yacc": ("k_yacc",),
                 "fir": ("fir4k::k_fir<", "fir16k::k_fir<true>", "fir16k::k_fir", "k_fir<"),
                 "csm_gemm": ("k_csm_fused", "k_csm_gemm"), "stft": ("k_stft_wave", "k_stft"),
@@ -66,24 +71,25 @@ def parse_args():
     ap.add_argument("--cpu-channels", type=int, default=64,
                     help="output channels of the bounded CPU-baseline sample")
     ap.add_argument("--detrend", type=int, default=1)
+    ap.add_argument("--no-workloads", action="store_true",
+                    help="default workload at N = 1: do not time the other BASELINE configs into \"workloads\"")
+    ap.add_argument("--workload-steps", type=int, default=40, help="timed steps of each entry of \"workloads\"")
     return ap.parse_args()
 
 
 # ---------------------------------------------------------------------------
 class Dist:
-    """torch.distributed only as plumbing: rendezvous, barrier, max over ranks."""
+    """Rendezvous, barrier, max over ranks: the package's own host exchange (a TCP star around rank 0 at
+    MASTER_ADDR : MASTER_PORT + 23 of the launcher's environment, dsptoolbox_amd/rendezvous.py).  No torch:
+    `torch.distributed.run` may have started the ranks, this process never imports it."""
 
     def __init__(self, n_gpus: int):
         self.rank = int(os.environ.get("RANK", "0"))
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-        self.torch = None
-        try:
-            import torch
-            self.torch = torch
-        except Exception:  # pragma: no cover
-            pass
-        self.backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")  # gloo: rehearsal on one GPU
+        # ranks that share ONE GPU (a rehearsal on a one-GPU box): RCCL refuses two ranks on a device
+        self.rehearsal = os.environ.get("BENCH_DIST_BACKEND", "") == "gloo" or os.environ.get("BENCH_BCAST", "rccl") != "rccl"
+        self.ex = None
         if self.world != n_gpus:
             # (main() starts the ranks itself when there is no launcher environment at all; a launcher
             # that made a different number of ranks than --gpus says is an error, never an N = 1 line)
@@ -91,54 +97,45 @@ class Dist:
                   "refusing to report a line for the wrong number of GPUs", file=sys.stderr, flush=True)
             sys.exit(2)
         if self.world > 1:
-            import torch.distributed as dist
-            if self.backend == "nccl":
-                self.torch.cuda.set_device(self.local_rank)
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            dist.init_process_group(backend=self.backend)
-            self.dist = dist
+            from dsptoolbox_amd import distributed as dd
+            try:
+                self.ex = dd.init()
+            except Exception as ex:  # noqa: BLE001 - e.g. the exchange's port is taken, a rank never arrived
+                print(f"[bench] rank {self.rank}/{self.world}: host exchange not available ({ex!r}); the ranks cannot "
+                      "be timed together. Exiting with status 3.", file=sys.stderr, flush=True)
+                sys.exit(3)
 
     def barrier_sync(self, ctx):
         ctx.sync()
-        if self.torch is not None and self.torch.cuda.is_available():
-            self.torch.cuda.synchronize()
-        if self.world > 1:
-            self.dist.barrier()
+        if self.ex is not None:
+            self.ex.barrier()
+
+    def _gather_f64(self, v: float):
+        import struct
+        return [struct.unpack("<d", b)[0] for b in self.ex.allgather_bytes(struct.pack("<d", float(v)))]
 
     def max_over_ranks(self, v: float) -> float:
-        if self.world == 1:
-            return v
-        t = self.torch.tensor([v], dtype=self.torch.float64,
-                              device="cuda" if self.backend == "nccl" else "cpu")
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
-        return float(t.item())
-
-    def bcast_bytes(self, b: bytes, n: int) -> bytes:
-        if self.world == 1:
-            return b
-        box = [b if self.rank == 0 else None]
-        self.dist.broadcast_object_list(box, src=0)
-        return box[0]
-
-    def finish(self):
-        if self.world > 1:
-            try:
-                self.dist.barrier()
-                self.dist.destroy_process_group()
-            except Exception:  # pragma: no cover - teardown only
-                pass
+        return v if self.ex is None else max(self._gather_f64(v))
 
     def all_ok(self, ok: bool) -> bool:
-        if self.world == 1:
-            return ok
-        t = self.torch.tensor([1.0 if ok else 0.0], dtype=self.torch.float64,
-                              device="cuda" if self.backend == "nccl" else "cpu")
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN)
-        return bool(t.item() > 0.5)
+        return ok if self.ex is None else min(self._gather_f64(1.0 if ok else 0.0)) > 0.5
+
+    def bcast_bytes(self, b: bytes, n: int) -> bytes:
+        return b if self.ex is None else self.ex.broadcast_bytes(b if self.rank == 0 else None, src=0)
+
+    def finish(self):
+        if self.ex is not None:
+            try:
+                self.ex.barrier()
+            except Exception:  # pragma: no cover - teardown only
+                pass
+            from dsptoolbox_amd import distributed as dd
+            dd.shutdown()
+            self.ex = None
 
 
 RCCL_ERROR = None  # set when a weak-scaling run went on without the library communicator
-HOST_EXCHANGE_ERROR = None  # set when a weak-scaling run went on without the package's host exchange
 
 
 def setup_rccl(ctx, dist: Dist, required: bool = True):
@@ -153,9 +150,7 @@ def setup_rccl(ctx, dist: Dist, required: bool = True):
     global RCCL_ERROR
     if dist.world == 1:
         return False
-    if dist.backend != "nccl":
-        return False
-    if os.environ.get("BENCH_BCAST", "rccl") != "rccl":
+    if dist.rehearsal:
         return False
     ident = C.create_string_buffer(128)
     ok = True
@@ -250,7 +245,7 @@ def welch_h1(args, ctx, dist, shard, rccl, W=4096):
         ctx.sync()
         bcast_ms = (time.perf_counter() - t0) * 1e3
     else:
-        if dist.world > 1 and HOST_EXCHANGE_ERROR is None:  # BENCH_BCAST=host / gloo rehearsal: host broadcast, upload
+        if dist.world > 1:  # BENCH_BCAST=host (ranks sharing one GPU, RCCL opted out or failed): host broadcast, upload
             from dsptoolbox_amd.distributed import broadcast_array
             xp = broadcast_array(xp if dist.rank == 0 else None, src=0)
         ctx.upload(d_x.ptr, xp)
@@ -286,6 +281,8 @@ def welch_h1(args, ctx, dist, shard, rccl, W=4096):
         from oracle import dsp_oracle as orc
         cc = min(args.cpu_channels, n_cy)
         reps = 2  # ~14 s of single-core work for the full 64 channels
+        if args.cpu_bounded:  # an entry of "workloads": a quarter of the channels, once
+            cc, reps = min(cc, 16), 1
         t0 = time.perf_counter()
         for _ in range(reps):
             rt, rc = orc.compute_transfer_function(y[:, :cc], x, FS, W, "H1", detrend=bool(args.detrend))
@@ -313,7 +310,7 @@ def welch_h1(args, ctx, dist, shard, rccl, W=4096):
                            f"scipy.fft workers=-1), all {n_cy} channels, {reps} passes of {dt:.1f} s")
 
     return step, samples_per_step, alg_bytes, "hbm", info, (cpu_reference_loop, cpu_batched), bcast_ms, \
-        ("welch4096_fused", "welch4096_main", "welch1024_main", "welch_yacc")
+        ("welch4096_main", "welch1024_main", "welch_yacc")
 
 
 def fir_bank(args, ctx, dist, shard, rccl):
@@ -344,8 +341,9 @@ def fir_bank(args, ctx, dist, shard, rccl):
     def cpu_baseline():
         from oracle import dsp_oracle as orc
         err = 0.0
+        bands = list(range(a, b, 4 if args.cpu_bounded else 1))  # an entry of "workloads": every 4th band
         t0 = time.perf_counter()
-        for k in range(a, b):  # the reference loop: one oaconvolve per band (~0.5 s each)
+        for k in bands:  # the reference loop: one oaconvolve per band (~0.5 s each)
             ref = orc.lfilter_fir(taps[k].astype(np.float64), x)
             if k % 8 == 0:  # parity on every 8th band (the download is outside what is measured)
                 t1 = time.perf_counter()
@@ -353,9 +351,10 @@ def fir_bank(args, ctx, dist, shard, rccl):
                 ctx.download(d_y.ptr + 4 * (k - a) * n_ch * n, got)
                 err = max(err, orc.rel_max(got.T, ref))
                 t0 += time.perf_counter() - t1
-        dt = time.perf_counter() - t0
+        dt = (time.perf_counter() - t0) * (b - a) / max(1, len(bands))  # scaled to the whole bank
         return dict(value=n_ch * n / dt / 1e6, unit="Msamples/s", cores=1, kind="port",
-                    sample=f"oracle.lfilter_fir (scipy oaconvolve), all {K} bands, {dt:.1f} s",
+                    sample=f"oracle.lfilter_fir (scipy oaconvolve), {len(bands)} of {K} bands timed "
+                           f"({dt * len(bands) / max(1, b - a):.1f} s), scaled to all {K}; parity on every 8th band",
                     parity_rel_max_vs_gpu=err)
 
     return step, n_ch * n, alg_bytes, "hbm", info, (cpu_baseline,), None, ("fir",)
@@ -399,14 +398,16 @@ def csm(args, ctx, dist, shard, rccl):
     # what SURVEY 8(d) counts for the fused ideal (samples in, matrices out).
     x_bytes = B * n_frames * n_ch * 8.0
     alg = {"stft": n_ch * n * 4.0 + x_bytes, "csm_gemm": x_bytes + B * n_ch * n_ch * 8.0,
-           "step": n_ch * n * 4.0 + B * n_ch * n_ch * 8.0, "gemm_flops": flops}
+           "step": n_ch * n * 4.0 + B * n_ch * n_ch * 8.0, "gemm_flops": flops,
+           # 64 000 framed rFFTs of 1024 points at 2.5 W log2 W
+           "fft_flops": n_ch * n_frames * 2.5 * W * np.log2(W)}
     info = dict(workload="csm: 64-mic Welch cross-spectral matrix, nfft 1024, 1000 frames",
                 channels=n_ch, samples_per_channel=n, nfft=W, frames=n_frames,
                 gemm_flops="513*64*64*1000*8 (full Hermitian count, fp32-equivalent)")
 
     def cpu_baseline():
         from oracle import dsp_oracle as orc
-        reps = 3
+        reps = 1 if args.cpu_bounded else 3
         t0 = time.perf_counter()
         for _ in range(reps):
             f, ref = orc.csm_welch_batched(x, FS, W, "hann", 50, True, "FFTBackward", workers=-1)
@@ -449,7 +450,7 @@ def deconv(args, ctx, dist, shard, rccl):
         # the reference's per-item path (_transfer_functions.py:19-42): rfft, multiply, irfft
         yy = y.astype(np.float64)
         rr = r.astype(np.complex128)
-        reps = 80  # ~0.1 s per pass
+        reps = 20 if args.cpu_bounded else 80  # ~0.1 s per pass
         t0 = time.perf_counter()
         for _ in range(reps):
             for i in range(items):
@@ -517,66 +518,57 @@ def timed_steps(ctx, dist, step, steps: int, events: bool, dominant):
 
 
 def launch_ranks(n_gpus: int) -> int:
-    """`python bench.py --gpus N` with no launcher environment: start the N ranks here, as children
-    of a process that has not touched the GPU (torch.distributed.run, one rank per GPU, loopback
-    rendezvous on a free port), pass their output through and return their exit status."""
+    """`python bench.py --gpus N` with no launcher environment: start the N ranks here, as children of a
+    process that has not touched the GPU -- one rank per GPU, the launcher's usual environment (RANK,
+    LOCAL_RANK, WORLD_SIZE, MASTER_ADDR = 127.0.0.1, a free MASTER_PORT) --, pass their output through
+    and return the first non-zero exit status (the other ranks are stopped then)."""
     import socket
     import subprocess
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}",
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    env = dict(os.environ)
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    print(f"[bench] no launcher environment: starting {n_gpus} ranks: {' '.join(cmd)}", file=sys.stderr, flush=True)
-    return subprocess.run(cmd, env=env).returncode
+    print(f"[bench] no launcher environment: starting {n_gpus} ranks of {os.path.basename(__file__)} "
+          f"(rendezvous 127.0.0.1:{port})", file=sys.stderr, flush=True)
+    procs = []
+    for r in range(n_gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_gpus), LOCAL_WORLD_SIZE=str(n_gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    live = list(procs)
+    while live:
+        time.sleep(0.05)
+        for p in list(live):
+            code = p.poll()
+            if code is None:
+                continue
+            live.remove(p)
+            if code != 0 and rc == 0:
+                rc = code
+                for q in live:  # a rank failed: the others would wait for it in the next barrier
+                    q.terminate()
+    return rc
 
 
-def main():
-    args = parse_args()
-    if args.gpus < 1:
-        print("[bench] --gpus must be >= 1", file=sys.stderr)
-        sys.exit(2)
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
-        sys.exit(launch_ranks(args.gpus))  # nothing has touched the GPU in this process
-    from dsptoolbox_amd._build import build_library
-    from dsptoolbox_amd._lib import Context
-
-    build_library()
-    dist = Dist(args.gpus)
-    ctx = Context(None)  # device = LOCAL_RANK (modulo the visible device count)
-    if dist.world > 1:
-        from dsptoolbox_amd import distributed as dd
-        ok, err = True, None
-        try:
-            dd.init()  # host exchange of the package (TCP star from the launcher's environment)
-        except Exception as ex:  # noqa: BLE001 - e.g. the exchange's port is taken
-            ok, err = False, repr(ex)[:200]
-        if not dist.all_ok(ok):
-            # strong scaling shards ONE job and needs the exchange; the batches of a weak-scaling run are
-            # independent (every rank builds the same shared sweep from its seed), so it goes on and says so
-            print(f"[bench] rank {dist.rank}: host exchange not available: {err}", file=sys.stderr, flush=True)
-            if args.scaling == "strong":
-                sys.exit(3)
-            global HOST_EXCHANGE_ERROR
-            HOST_EXCHANGE_ERROR = err or "failed on another rank"
-    rccl = setup_rccl(ctx, dist, required=(args.scaling == "strong"))
-    strong = args.scaling == "strong" and dist.world > 1
+def measure(args, ctx, dist, workload: str, steps: int, warmup: int, strong: bool, rccl: bool):
+    """Time one workload on this rank's GPU: warm-up (its last step bracketed kernel by kernel), then exactly
+    `steps` steps between two barrier + synchronize brackets with the dominant kernel's own dispatch
+    timestamps sampled inside.  -> (result dict on rank 0 | None, maker tuple, wall seconds)."""
     shard = (dist.rank, dist.world) if strong else None
     maker = dict(welch_h1=welch_h1, welch_h1_1024=lambda a, c, d, sh, r: welch_h1(a, c, d, sh, r, W=1024),
-                 fir_bank=fir_bank, csm=csm, deconv=deconv)[args.workload]
-    step, units, alg, bound, info, cpu_legs, bcast_ms, dominant = maker(args, ctx, dist, shard, rccl)
+                 fir_bank=fir_bank, csm=csm, deconv=deconv)[workload]
+    made = maker(args, ctx, dist, shard, rccl)
+    step, units, alg, bound, info, cpu_legs, bcast_ms, dominant = made
     info["parallelism"] = (f"strong: one job sharded x{dist.world}" if strong
                            else f"weak: independent batch x{dist.world}")
-
     # Warm-up; its last step is bracketed kernel by kernel (HIP events on the library's stream) to
     # find the dominant kernel and the per-kernel breakdown.  An event pair costs ~3 us of stream
     # time, so in the timed region only the dominant kernel is bracketed.
     events = not os.environ.get("BENCH_NO_KERNEL_EVENTS")
     prof_all = {}
-    for i in range(args.warmup):
-        if events and i == args.warmup - 1:
+    for i in range(warmup):
+        if events and i == warmup - 1:
             ctx.sync()
             ctx.profile_enable(True)
             ctx.profile_report()
@@ -588,76 +580,90 @@ def main():
     dom = max((k for k in dominant if k in prof_all), key=lambda k: prof_all[k][0], default=None)
     if dom is None and prof_all:
         dom = max(prof_all, key=lambda k: prof_all[k][0])
-    wall, ev_ms, prof = timed_steps(ctx, dist, step, args.steps, events, dom)
+    wall, ev_ms, prof = timed_steps(ctx, dist, step, steps, events, dom)
     wall = dist.max_over_ranks(wall)
-
     if dist.rank != 0:
-        dist.finish()
-        return
-    ms_per_step = wall * 1e3 / args.steps
+        return None, made, wall
+    ms_per_step = wall * 1e3 / steps
     # weak: every rank ran the whole job's units; strong: the ranks shared them
-    value = units * (1 if strong else dist.world) / (wall / args.steps) / 1e6
+    value = units * (1 if strong else dist.world) / (wall / steps) / 1e6
     if not prof:  # BENCH_NO_KERNEL_EVENTS=1: step time without the per-kernel event markers (dev)
-        print(json.dumps({"value": value, "ms_per_step": ms_per_step, "step_event_ms": ev_ms / args.steps,
-                          "note": "no per-kernel events: no roofline"}), flush=True)
-        dist.finish()
-        return
+        return {"value": value, "ms_per_step": ms_per_step, "step_event_ms": ev_ms / steps,
+                "note": "no per-kernel events: no roofline"}, made, wall
     if dom is None or dom not in prof:
         dom = next((k for k in dominant if k in prof), max(prof, key=lambda k: prof[k][0]))
     # roofline.frac / achieved / kernel_avg_ms: the dominant kernel's own begin / end timestamps (the two
     # events ride on its dispatch packet, hipExtLaunchKernel -- what rocprofv3's kernel trace reports),
     # averaged over the sampled launches of the timed region.  Nothing is subtracted.
     dom_ms = prof[dom][0] / prof[dom][1]
-    launches_per_step = max(1, round(prof[dom][1] * EVENT_STRIDE / args.steps))
+    launches_per_step = max(1, round(prof[dom][1] * EVENT_STRIDE / steps))
     # algorithmic work of ONE launch on THIS rank (strong scaling: its share of the job)
     alg_parts = alg if isinstance(alg, dict) else None  # per kernel (csm: two streaming kernels)
     if alg_parts:
         alg = alg_parts["step"]
-    alg_launch = (alg_parts[dom] if alg_parts else alg) / launches_per_step / (dist.world if strong else 1)
+    div = dist.world if strong else 1
+    alg_launch = (alg_parts[dom] if alg_parts else alg) / launches_per_step / div
     if alg_parts and dom == "stft":  # the bin shards of a strong-scaling run all transform every frame
         alg_launch = alg_parts[dom] / launches_per_step
-    if bound == "hbm":
-        achieved = alg_launch / (dom_ms * 1e-3) / 1e9
-        roof = dict(bound="hbm", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
-                    frac=achieved / HBM_PEAK_GBS, traffic=None)
-        # the second denominator SURVEY 8(d) asks for: what a plain copy reaches on THIS GPU
-        gbs = C.c_double(0.0)
-        if ctx.lib.ds_measure_copy(ctx.handle, 1 << 30, 10, C.byref(gbs)) == 0 and gbs.value > 0:
-            roof["measured_copy_gbs"] = gbs.value
-            roof["frac_of_measured_copy"] = achieved / gbs.value
+    step_ms = ev_ms / steps
+    achieved = alg_launch / (dom_ms * 1e-3) / 1e9
+    hbm = dict(bound="hbm", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS, traffic=None)
+    # the second denominator SURVEY 8(d) asks for: what a plain copy reaches on THIS GPU
+    gbs = C.c_double(0.0)
+    if ctx.lib.ds_measure_copy(ctx.handle, 1 << 30, 10, C.byref(gbs)) == 0 and gbs.value > 0:
+        hbm["measured_copy_gbs"] = gbs.value
+        hbm["frac_of_measured_copy"] = achieved / gbs.value
+    if alg_parts:
+        # config 4, SURVEY 8(d): algorithmic flops (framed rFFTs + the full Hermitian count of the Gram products) over
+        # the STEP against the fp32 matrix peak; the two kernels' HBM fractions follow under "kernels"
+        flops = (alg_parts["gemm_flops"] + alg_parts["fft_flops"]) / div
+        tf = flops / (step_ms * 1e-3) / 1e12
+        roof = dict(bound="mfma", achieved=tf, peak=MFMA_F32_PEAK_TFLOPS, unit="TFLOP/s", frac=tf / MFMA_F32_PEAK_TFLOPS,
+                    traffic=None, algorithmic_flops_per_step=flops, time_base="step (both kernels), HIP events",
+                    dominant_kernel_hbm=hbm)
     else:
-        achieved = alg_launch / (dom_ms * 1e-3) / 1e12
-        roof = dict(bound="mfma", achieved=achieved, peak=MFMA_F32_PEAK_TFLOPS, unit="TFLOP/s",
-                    frac=achieved / MFMA_F32_PEAK_TFLOPS, traffic=None)
+        roof = hbm
     hints = KERNEL_HINTS.get(dom, (dom,))
-    pmc, src = pmc_summary(args.workload, hints)
+    pmc, src = pmc_summary(workload, hints)
     if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
         # KiB, separate --pmc passes; on gfx950 FETCH_SIZE counts half of a coalesced streaming
         # read (MI355X_MICROARCH.md, HBM section), hence the factor 2
         roof["traffic"] = (2.0 * pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024.0
         roof["traffic_source"] = src + " (2*FETCH_SIZE + WRITE_SIZE) KiB"
+        if alg_parts:  # both kernels of the step against the step's algorithmic bytes
+            tot = 0.0
+            for h in (("k_stft",), ("k_csm_gemm",)):
+                kp, _ = pmc_summary(workload, h)
+                tot += (2.0 * kp.get("FETCH_SIZE", 0.0) + kp.get("WRITE_SIZE", 0.0)) * 1024.0
+            roof["traffic"] = tot
+            roof["traffic_source"] = src + " (2*FETCH_SIZE + WRITE_SIZE) KiB, transform + Gram kernel"
     if "SQ_INSTS_VALU" in pmc:
         # the ceiling the vector pipe puts on this kernel: wave-level VALU instructions of one
         # launch x 2 cycles (wave64 on a SIMD-32) over 1024 SIMDs; at the 2.4 GHz maximum clock --
-        # under load the chip holds 1.9-2.1 GHz (s_memtime / s_memrealtime in the kernel)
+        # under load the chip holds 1.8-2.0 GHz (s_memtime / s_memrealtime in the kernel)
         floor_ms = pmc["SQ_INSTS_VALU"] * 2.0 / 1024.0 / 2.4e9 * 1e3
         roof["valu_issue"] = dict(insts_per_launch=pmc["SQ_INSTS_VALU"], floor_ms_at_2p4_ghz=floor_ms,
                                   valu_issue_frac=floor_ms / dom_ms, source=src)
+    if workload == "welch_h1" and dom == "welch4096_main":
+        # the demonstrated ceiling of this instruction stream: the kernel with every load, LDS access and
+        # barrier removed (VALU only) on the same chip, profiles/r04_welch_ceiling.txt
+        roof["ceiling_ms"] = WELCH_CEILING_MS
+        roof["ceiling_source"] = "profiles/r04_welch_ceiling.txt (tools/exp/exp_w4.hip -DW4_AB=15, steady state)"
+        roof["ceiling_frac"] = alg_launch / (WELCH_CEILING_MS * 1e-3) / 1e9 / HBM_PEAK_GBS
     if alg_parts and prof_all:
         # every kernel of the step against the HBM roofline (warm-up step, every kernel bracketed), and
         # the Gram product's matrix-pipe numbers: fp32-equivalent flops by the full Hermitian count, and
         # the bf16 instructions really issued (v_mfma_f32_32x32x16_bf16 = 32768 flop; 60 per 16 frames
         # and workgroup: 10 of the 16 tile products, 6 piece products each)
-        div = dist.world if strong else 1
         roof["kernels"] = {}
         for k in ("stft", "csm_gemm"):
             if k in prof_all:
                 nbytes = alg_parts[k] / (1 if k == "stft" else div)
-                gbs = nbytes / (prof_all[k][0] * 1e-3) / 1e9
-                roof["kernels"][k] = dict(ms=prof_all[k][0], algorithmic_bytes=nbytes, gbs=gbs, frac=gbs / HBM_PEAK_GBS)
+                kg = nbytes / (prof_all[k][0] * 1e-3) / 1e9
+                roof["kernels"][k] = dict(ms=prof_all[k][0], algorithmic_bytes=nbytes, gbs=kg, frac=kg / HBM_PEAK_GBS)
         if "csm_gemm" in prof_all:
             g_ms = prof_all["csm_gemm"][0]
-            gpmc, gsrc = pmc_summary(args.workload, ("k_csm_gemm",))
+            gpmc, gsrc = pmc_summary(workload, ("k_csm_gemm",))
             gemm = dict(ms=g_ms, fp32_equivalent_tflops=alg_parts["gemm_flops"] / div / (g_ms * 1e-3) / 1e12,
                         fp32_mfma_peak_tflops=MFMA_F32_PEAK_TFLOPS,
                         note="fp32-exact product from three bf16 pieces per value on the bf16 matrix pipe; "
@@ -675,35 +681,105 @@ def main():
     roof["algorithmic_per_launch"] = alg_launch
     out = {
         "metric": "Msamples/s + GB/s vs HBM roofline, 64ch Welch H1 nfft=4096 @1/2/4/8 GPU"
-                  if args.workload == "welch_h1" else f"Msamples/s ({args.workload})",
-        "value": value, "unit": "Msamples/s", "n_gpus": dist.world, "steps": args.steps,
-        "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+                  if workload == "welch_h1" else f"Msamples/s ({workload})",
+        "value": value, "unit": "Msamples/s", "n_gpus": dist.world, "steps": steps,
+        "warmup": warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
         "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": info, "roofline": roof,
-        "step_event_ms": ev_ms / args.steps,
+        "step_event_ms": step_ms,
         "kernels_ms_per_step": ({k: v[0] for k, v in prof_all.items()} if prof_all
-                                else {k: v[0] / args.steps for k, v in prof.items()}),
+                                else {k: v[0] / steps for k, v in prof.items()}),
         "kernels_ms_per_step_source": ("last warm-up step, every kernel bracketed" if prof_all
                                        else "timed region"),
-        "whole_step_gbs": (alg / (dist.world if strong else 1) / (ev_ms / args.steps * 1e-3) / 1e9)
-        if bound == "hbm" else None,
+        "whole_step_gbs": alg / div / (step_ms * 1e-3) / 1e9,
+        "algorithmic_bytes_per_step": alg / div,
     }
-    if dist.world > 1:
-        out["bcast"] = "rccl" if rccl else "host"
-        if RCCL_ERROR:
-            out["rccl_error"] = RCCL_ERROR
-        if HOST_EXCHANGE_ERROR:
-            if not rccl:
-                out["bcast"] = "none (every rank built the shared input from its seed)"
-            out["host_exchange_error"] = HOST_EXCHANGE_ERROR
-        if strong:
-            out["result_gather"] = "rccl all-gather per step" if rccl else "none"
     if bcast_ms is not None:
         out["rccl_bcast_ms"] = bcast_ms
+    return out, made, wall
+
+
+WELCH_CEILING_MS = 0.0645  # VALU-only build of welch4096::k_y3, profiles/r04_welch_ceiling.txt
+
+
+def workload_entry(args, ctx, dist, name: str):
+    """One entry of the default line's "workloads": the same measurement over a shorter timed region, the
+    fraction by SURVEY 8(d)'s own definition for that config, and a BOUNDED CPU leg with its parity."""
+    import gc
+    args.cpu_bounded = True
+    out, made, _ = measure(args, ctx, dist, name, args.workload_steps, 8, False, False)
+    roof = out["roofline"]
+    alg = roof.get("algorithmic_flops_per_step") if roof["bound"] == "mfma" else roof["algorithmic_per_launch"]
+    ent = dict(workload=out["config"]["workload"], ms_per_step=out["ms_per_step"], step_event_ms=out["step_event_ms"],
+               value=out["value"], unit=out["unit"], steps=args.workload_steps,
+               kernel=roof["kernel"], kernel_avg_ms=roof["kernel_avg_ms"], kernels_ms_per_step=out["kernels_ms_per_step"],
+               bound=roof["bound"], frac=roof["frac"], achieved=roof["achieved"], peak=roof["peak"], roofline_unit=roof["unit"],
+               frac_definition=("algorithmic flops (framed rFFTs + full Hermitian Gram count) / step time / 157.3 TFLOP/s fp32 matrix peak"
+                                if roof["bound"] == "mfma" else
+                                "algorithmic bytes of one launch / dominant kernel's dispatch time / 8 TB/s"))
+    if roof.get("traffic"):
+        base = out["algorithmic_bytes_per_step"] if roof["bound"] == "mfma" else roof["algorithmic_per_launch"]
+        ent["traffic_ratio"] = roof["traffic"] / base
+        ent["traffic_source"] = roof.get("traffic_source")
+    else:
+        ent["traffic_ratio"] = None
+    if roof["bound"] == "mfma":
+        ent["kernels_hbm_frac"] = {k: v["frac"] for k, v in roof.get("kernels", {}).items()}
+        if "gemm" in roof and "frac_of_bf16_peak" in roof["gemm"]:
+            ent["executed_bf16_frac"] = roof["gemm"]["frac_of_bf16_peak"]
+            ent["executed_bf16_tflops"] = roof["gemm"]["executed_bf16_tflops"]
+    cpu = made[5][0]()
+    cpu["host_cpus"] = os.cpu_count()
+    ent["parity_rel_max_vs_oracle"] = cpu.pop("parity_rel_max_vs_gpu", None)
+    ent["cpu_baseline"] = cpu
+    args.cpu_bounded = False
+    del made, out
+    gc.collect()  # the workload's device buffers go with its closures
+    return ent
+
+
+def main():
+    args = parse_args()
+    args.cpu_bounded = False
+    if args.gpus < 1:
+        print("[bench] --gpus must be >= 1", file=sys.stderr)
+        sys.exit(2)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        sys.exit(launch_ranks(args.gpus))  # nothing has touched the GPU in this process
+    from dsptoolbox_amd._build import build_library
+    from dsptoolbox_amd._lib import Context
+
+    build_library()
+    dist = Dist(args.gpus)
+    ctx = Context(None)  # device = LOCAL_RANK (modulo the visible device count)
+    rccl = setup_rccl(ctx, dist, required=(args.scaling == "strong"))
+    strong = args.scaling == "strong" and dist.world > 1
+    out, made, wall = measure(args, ctx, dist, args.workload, args.steps, args.warmup, strong, rccl)
+    if dist.rank != 0:
+        dist.finish()
+        return
+    if "roofline" not in out:
+        print(json.dumps(out), flush=True)
+        dist.finish()
+        return
+    if dist.world > 1:
+        out["bcast"] = "rccl" if rccl else "host"
+        out["host_exchange"] = "dsptoolbox_amd.rendezvous.TcpExchange (no torch in this process: " + \
+                               ("true" if "torch" not in sys.modules else "false") + ")"
+        if rccl:
+            n = C.c_int(0)
+            ctx.check(ctx.lib.ds_comm_count(ctx.handle, C.byref(n)), "ds_comm_count")
+            out["rccl_ranks"] = int(n.value)  # what RCCL itself says (ncclCommCount of the library's communicator)
+        if RCCL_ERROR:
+            out["rccl_error"] = RCCL_ERROR
+        if strong:
+            out["result_gather"] = "rccl all-gather per step" if rccl else "none"
     if dist.world == 1 and args.predict_ranks > 1:
         # what one rank of an N-GPU strong-scaling job would run, timed on this GPU (no collective
         # here: the all-gather of 24 KB result slices and the one-off broadcast are extra)
         R = args.predict_ranks
+        maker = dict(welch_h1=welch_h1, welch_h1_1024=lambda a, c, d, sh, r: welch_h1(a, c, d, sh, r, W=1024),
+                     fir_bank=fir_bank, csm=csm, deconv=deconv)[args.workload]
         s_step = maker(args, ctx, dist, (0, R), False)[0]
         for _ in range(max(3, args.warmup // 2)):
             s_step()
@@ -713,13 +789,26 @@ def main():
                                                             "welch_h1_1024": "64 output channels (+ the sweep)",
                                                             "fir_bank": "32 bands", "csm": "513 bins",
                                                             "deconv": "1024 items"}[args.workload],
-            ms_full=ms_per_step, ms_shard=s_wall * 1e3 / args.steps, implied_speedup=wall / s_wall,
+            ms_full=out["ms_per_step"], ms_shard=s_wall * 1e3 / args.steps, implied_speedup=wall / s_wall,
             note="single-GPU timing of the per-rank shape; excludes the per-step all-gather")
+    cpu_legs = made[5]
     if cpu_legs and not args.no_cpu_baseline and dist.world == 1:
         out["cpu_baseline"] = cpu_legs[0]()
         out["cpu_baseline"]["host_cpus"] = os.cpu_count()
         if len(cpu_legs) > 1:
             out["cpu_baseline_batched"] = cpu_legs[1]()
+    if args.workload == "welch_h1" and dist.world == 1 and not args.no_workloads and not args.no_cpu_baseline:
+        # the other BASELINE configs, driver-timed inside the default line
+        import gc
+        del made, cpu_legs
+        gc.collect()
+        out["workloads"] = {}
+        t_all = time.perf_counter()
+        for name in ("welch_h1_1024", "fir_bank", "csm", "deconv"):
+            t0 = time.perf_counter()
+            out["workloads"][name] = workload_entry(args, ctx, dist, name)
+            out["workloads"][name]["wall_s_including_setup_and_cpu_leg"] = time.perf_counter() - t0
+        out["workloads_wall_s"] = time.perf_counter() - t_all
     print(json.dumps(out), flush=True)
     dist.finish()
 

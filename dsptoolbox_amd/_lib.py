@@ -37,6 +37,7 @@ SIGNATURES = {
     "ds_max_fft_len": (C.c_int, []),
     "ds_profile_enable": (C.c_int, [ctx_p, C.c_int]),
     "ds_profile_report": (C.c_char_p, [ctx_p]),
+    "ds_routes": (C.c_char_p, [ctx_p]),
     "ds_profile_only": (C.c_int, [ctx_p, C.c_char_p]),
     "ds_profile_stride": (C.c_int, [ctx_p, C.c_int]),
     "ds_profile_overhead": (C.c_int, [ctx_p, C.c_int, C.c_int, C.POINTER(C.c_double)]),
@@ -99,11 +100,16 @@ SIGNATURES = {
     "ds_welch_tf_x64": (C.c_int, [ctx_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, i64, C.c_int, C.c_int, C.c_int,
                                   C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int,
                                   C.c_void_p, C.c_void_p]),
+    "ds_welch_spec_x64": (C.c_int, [ctx_p, C.c_void_p, C.c_void_p, C.c_int, i64, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                    C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, C.c_void_p]),
+    "ds_csm_x64": (C.c_int, [ctx_p, C.c_void_p, C.c_int, i64, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int,
+                             C.c_double, C.c_double, C.c_int, C.c_void_p]),
     "ds_fir_part_step_dev": (C.c_int, [ctx_p, f32_p, f32_p, C.c_int, C.c_int, C.c_int, C.c_int, c32_p, C.c_int,
                                        C.c_int, c32_p, C.c_int, f32_p]),
     "ds_fir_ols_step_dev": (C.c_int, [ctx_p, f32_p, f32_p, C.c_int, i64, c32_p, f32_p]),
     "ds_comm_unique_id": (C.c_int, [C.c_char_p]),
     "ds_comm_init": (C.c_int, [ctx_p, C.c_int, C.c_int, C.c_char_p]),
+    "ds_comm_count": (C.c_int, [ctx_p, C.POINTER(C.c_int)]),
     "ds_bcast": (C.c_int, [ctx_p, C.c_void_p, C.c_size_t, C.c_int]),
     "ds_allgather": (C.c_int, [ctx_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "ds_comm_destroy": (C.c_int, [ctx_p]),
@@ -240,6 +246,10 @@ class Context:
             out[name] = (float(ms), int(cnt))
         return out
 
+    def routes(self) -> set:
+        """Launch names since the previous call: "group" or "group@variant" (which kernel family ran)."""
+        return set(self.lib.ds_routes(self.handle).decode().split())
+
     def close(self):
         if getattr(self, "handle", None):
             self.lib.ds_destroy(self.handle)
@@ -264,6 +274,18 @@ def get_context() -> Context:
     if ctx is None:
         ctx = _tls.ctx = Context()
     return ctx
+
+
+def reset_context() -> Context:
+    """Close the calling thread's default context and open a new one.  A context reads the
+    DSPTOOLBOX_AMD_* switches ONCE, in ds_init (csrc/config.hpp): this is how a process
+    changes them afterwards (tests, A/B timing tools).  Device buffers of the old context
+    must not be used after the call."""
+    ctx = getattr(_tls, "ctx", None)
+    if ctx is not None:
+        ctx.close()
+    _tls.ctx = Context()
+    return _tls.ctx
 
 
 class DeviceBuffer:

@@ -134,8 +134,20 @@ def _welch(x, y, fs_hz: int, window_type, window_length_samples: int, overlap_pe
     amp, norm_scale, factor, phys = _finish_params(scaling, W, fs_hz, window)
     avg = DS_AVG[average]
     ctx = get_context()
-    w32 = window.astype(np.float32)
     B = W // 2 + 1
+    n_chan = x.shape[1] if multi else 1
+    if _x64_short(SPEC_PRECISION, (1 if auto else 2) * n_chan, n_frames, W, average):
+        # short estimate: the reference's own float64 arithmetic on the device (ds_welch_spec_x64)
+        x64 = np.ascontiguousarray(x.reshape(x.shape[0], n_chan), dtype=np.float64)
+        y64 = None if auto else np.ascontiguousarray(y.reshape(x.shape[0], n_chan), dtype=np.float64)
+        w64 = np.ascontiguousarray(window, dtype=np.float64)
+        out = np.empty((B, n_chan), dtype=np.complex128)
+        ctx.check(ctx.lib.ds_welch_spec_x64(ctx.handle, _ptr(x64), None if auto else _ptr(y64), n_chan, x.shape[0], W, hop,
+                                            n_frames, _ptr(w64), int(bool(detrend)), avg, amp, norm_scale, factor, phys,
+                                            _ptr(out)), "ds_welch_spec_x64")
+        res = out if (not auto or avg) else np.ascontiguousarray(out.real)  # (median auto spectra are complex in the reference)
+        return res if multi else res[:, 0]
+    w32 = window.astype(np.float32)
     if auto and _fusable(x):
         n, n_ch = x.shape
         out = np.empty((B, n_ch), dtype=np.float32)
@@ -175,7 +187,26 @@ def _welch(x, y, fs_hz: int, window_type, window_length_samples: int, overlap_pe
 # DSPTOOLBOX_AMD_TF_PRECISION.  backend.welch_transfer_function itself defaults to "f32".
 TF_PRECISION = os.environ.get("DSPTOOLBOX_AMD_TF_PRECISION", "auto")
 _X64_AUTO_BYTES = 64 << 20
-_X64_SHORT_BYTES = 1 << 30
+_X64_SHORT_BYTES = 256 << 20  # (1 GB in round 3: 64 channels x 100 frames of 8192 samples took the slow route)
+
+
+# The same for the Welch spectra themselves (get_spectrum with the Welch method: ds_welch_psd / ds_welch_csd) and
+# the cross-spectral matrix (get_csm: ds_csm): "auto" sends SHORT estimates -- fewer than 128 frames, frame
+# spectra <= 256 MB, window <= 16384; the matrix: mean averaging and up to 64 channels -- through
+# ds_welch_spec_x64 / ds_csm_x64; "f32" keeps the fp32 kernels for every shape.  Environment:
+# DSPTOOLBOX_AMD_SPEC_PRECISION.  (tests/sweeps/edge_welch.py, round 4: fp32 cross spectra and matrices of
+# one to five frames reach 2-3e-6 of the largest element under the amplitude scalings.)
+SPEC_PRECISION = os.environ.get("DSPTOOLBOX_AMD_SPEC_PRECISION", "auto")
+
+
+def _x64_short(precision, n_spectra: int, n_frames: int, W: int, average: str) -> bool:
+    """Does a SHORT estimate of `n_spectra` channel spectra take the float64 route?"""
+    assert precision in ("auto", "f32"), "DSPTOOLBOX_AMD_SPEC_PRECISION: 'auto' or 'f32'"
+    if precision != "auto" or W > 16384 or n_frames >= 128:
+        return False
+    if average != "mean" and n_frames > 4096:
+        return False
+    return n_spectra * n_frames * (W // 2 + 1) * 16 <= _X64_SHORT_BYTES
 
 
 def _tf_x64_applies(precision, n_cx: int, n_cy: int, n_frames: int, W: int, average: str) -> bool:
@@ -423,6 +454,15 @@ def _csm_welch(time_data, sampling_rate_hz: int, window_length_samples: int, win
     hop, n_frames = _welch_framing(n, W, overlap_percent, window)
     amp, norm_scale, factor, phys = _finish_params(scaling, W, sampling_rate_hz, window)
     B = W // 2 + 1
+    if average == "mean" and n_ch <= 64 and _x64_short(SPEC_PRECISION, n_ch, n_frames, W, average):
+        # short estimate: float64 end to end on the device (ds_csm_x64)
+        x64 = np.ascontiguousarray(td.reshape(n, n_ch) if td.ndim == 2 else td[:, None], dtype=np.float64)
+        out64 = np.empty((B, n_ch, n_ch), dtype=np.complex128)
+        w64 = np.ascontiguousarray(window, dtype=np.float64)
+        ctx = get_context()
+        ctx.check(ctx.lib.ds_csm_x64(ctx.handle, _ptr(x64), n_ch, n, W, hop, n_frames, _ptr(w64), int(bool(detrend)), amp,
+                                     norm_scale, factor, phys, _ptr(out64)), "ds_csm_x64")
+        return np.fft.rfftfreq(W, 1 / sampling_rate_hz), out64
     out = np.empty((B, n_ch, n_ch), dtype=np.complex64)
     w32 = window.astype(np.float32)
     ctx = get_context()

@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <set>
 #include <string>
 #include <thread>
 #include <vector>
@@ -87,6 +88,9 @@ struct ds_ctx {
     std::string prof_only;  // non-empty: only launches of this kernel name are bracketed
     int prof_stride = 1;    // bracket every prof_stride-th matching launch (an event pair costs ~3 us of stream time)
     long prof_seen = 0;
+    std::set<const char*> routes;                     // launch names ("group@variant" literals) since the last ds_routes()
+    std::map<const char*, std::string> group_names;   // "group@variant" literal -> "group"
+    std::string routes_text;
 };
 
 static int fail(ds_ctx* c, int code, const std::string& msg) {
@@ -323,6 +327,21 @@ extern "C" const char* ds_profile_report(ds_ctx* c) {
     return c->prof_text.c_str();
 }
 
+// launch names since the last call, space separated, each "group" or "group@variant" (which kernel
+// family of a group ran: the tests of the kernel-selecting switches read it)
+extern "C" const char* ds_routes(ds_ctx* c) {
+    if (!c) return "";
+    std::set<std::string> names;
+    for (const char* n : c->routes) names.insert(n);
+    c->routes.clear();
+    c->routes_text.clear();
+    for (auto& n : names) {
+        if (!c->routes_text.empty()) c->routes_text += ' ';
+        c->routes_text += n;
+    }
+    return c->routes_text.c_str();
+}
+
 // ---- internal helpers ------------------------------------------------------
 static int get_twiddles(ds_ctx* c, int n, const float2** out);
 
@@ -367,6 +386,14 @@ static int launch(ds_ctx* c, const char* name, K kernel, dim3 grid, int threads,
                   const A& args) {
     if (lds > 64 * 1024)
         HIPCHK(c, hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    // "group@variant": the group is the name the profile reports (and ds_profile_only matches), the
+    // whole string goes into the set ds_routes() hands out -- which kernel family really ran
+    c->routes.insert(name);
+    if (const char* at = strchr(name, '@')) {
+        auto it = c->group_names.find(name);
+        if (it == c->group_names.end()) it = c->group_names.emplace(name, std::string(name, at)).first;
+        name = it->second.c_str();
+    }
     ds_ctx::ProfRec rec{name, nullptr, nullptr};
     bool prof = c->prof && (c->prof_only.empty() || c->prof_only == name);
     if (prof && c->prof_stride > 1 && (c->prof_seen++ % c->prof_stride) != 0) prof = false;
@@ -541,16 +568,16 @@ extern "C" int ds_stft_r2c_dev(ds_ctx* c, const float* x, int64_t n_samples, int
                    *tab, scale, edge_scale, (float2*)out, decim};
         dim3 grid((unsigned)((n_fp + fpw - 1) / fpw), (unsigned)n_ct);
         if (nfft == 2048)
-            return power ? launch(c, "stft", stft1k::k_stft_wave<2048, true>, grid, threads, lds, a)
-                         : launch(c, "stft", stft1k::k_stft_wave<2048, false>, grid, threads, lds, a);
+            return power ? launch(c, "stft@wave", stft1k::k_stft_wave<2048, true>, grid, threads, lds, a)
+                         : launch(c, "stft@wave", stft1k::k_stft_wave<2048, false>, grid, threads, lds, a);
         if (nfft == 1024)
-            return power ? launch(c, "stft", stft1k::k_stft_wave<1024, true>, grid, threads, lds, a)
-                         : launch(c, "stft", stft1k::k_stft_wave<1024, false>, grid, threads, lds, a);
+            return power ? launch(c, "stft@wave", stft1k::k_stft_wave<1024, true>, grid, threads, lds, a)
+                         : launch(c, "stft@wave", stft1k::k_stft_wave<1024, false>, grid, threads, lds, a);
         if (nfft == 512)
-            return power ? launch(c, "stft", stft1k::k_stft_wave<512, true>, grid, threads, lds, a)
-                         : launch(c, "stft", stft1k::k_stft_wave<512, false>, grid, threads, lds, a);
-        return power ? launch(c, "stft", stft1k::k_stft_wave<256, true>, grid, threads, lds, a)
-                     : launch(c, "stft", stft1k::k_stft_wave<256, false>, grid, threads, lds, a);
+            return power ? launch(c, "stft@wave", stft1k::k_stft_wave<512, true>, grid, threads, lds, a)
+                         : launch(c, "stft@wave", stft1k::k_stft_wave<512, false>, grid, threads, lds, a);
+        return power ? launch(c, "stft@wave", stft1k::k_stft_wave<256, true>, grid, threads, lds, a)
+                     : launch(c, "stft@wave", stft1k::k_stft_wave<256, false>, grid, threads, lds, a);
     }
     // 4096-point transforms: the register-resident transform of the Welch path, four teams of two neighbouring
     // channels per workgroup and frame (kernels_stft4096.hpp)
@@ -567,8 +594,8 @@ extern "C" int ds_stft_r2c_dev(ds_ctx* c, const float* x, int64_t n_samples, int
         stft4k::Args a{x, n_samples, ld, pad_front, n_ch, W, hop, n_frames, detrend, n_chunks, n_groups, window,
                        c->w4_tables, scale, edge_scale, (float2*)out, nullptr};
         const dim3 grid((unsigned)stft4k::grid_size(n_groups, n_chunks));
-        return power ? launch(c, "stft", stft4k::k_stft<true>, grid, stft4k::NT, stft4k::LDS_BYTES, a)
-                     : launch(c, "stft", stft4k::k_stft<false>, grid, stft4k::NT, stft4k::LDS_BYTES, a);
+        return power ? launch(c, "stft@4k", stft4k::k_stft<true>, grid, stft4k::NT, stft4k::LDS_BYTES, a)
+                     : launch(c, "stft@4k", stft4k::k_stft<false>, grid, stft4k::NT, stft4k::LDS_BYTES, a);
     }
     // 8192 / 16384 points: one radix-2 / radix-4 decimation-in-frequency stage on the windowed samples, then the
     // 4096-point kernel's structure per residue (kernels_stft4096.hpp, k_stft_dif)
@@ -594,10 +621,10 @@ extern "C" int ds_stft_r2c_dev(ds_ctx* c, const float* x, int64_t n_samples, int
                        c->w4_tables, scale, edge_scale, (float2*)out, *twn};
         const dim3 grid((unsigned)stft4k::grid_size(n_groups, n_chunks));
         if (nfft == 8192)
-            return power ? launch(c, "stft", stft4k::k_stft_dif<2, true>, grid, stft4k::NT, stft4k::Dif<2>::LDS_BYTES, a)
-                         : launch(c, "stft", stft4k::k_stft_dif<2, false>, grid, stft4k::NT, stft4k::Dif<2>::LDS_BYTES, a);
-        return power ? launch(c, "stft", stft4k::k_stft_dif<4, true>, grid, stft4k::NT, stft4k::Dif<4>::LDS_BYTES, a)
-                     : launch(c, "stft", stft4k::k_stft_dif<4, false>, grid, stft4k::NT, stft4k::Dif<4>::LDS_BYTES, a);
+            return power ? launch(c, "stft@dif", stft4k::k_stft_dif<2, true>, grid, stft4k::NT, stft4k::Dif<2>::LDS_BYTES, a)
+                         : launch(c, "stft@dif", stft4k::k_stft_dif<2, false>, grid, stft4k::NT, stft4k::Dif<2>::LDS_BYTES, a);
+        return power ? launch(c, "stft@dif", stft4k::k_stft_dif<4, true>, grid, stft4k::NT, stft4k::Dif<4>::LDS_BYTES, a)
+                     : launch(c, "stft@dif", stft4k::k_stft_dif<4, false>, grid, stft4k::NT, stft4k::Dif<4>::LDS_BYTES, a);
     }
     const float2* tw;
     CHK(get_twiddles(c, nfft, &tw));
@@ -624,7 +651,7 @@ extern "C" int ds_stft_r2c_dev(ds_ctx* c, const float* x, int64_t n_samples, int
     StftArgs a{x, n_samples, ld, pad_front, n_ch, W, hop, n_frames, detrend, power, ct, fpw, window, tw,
                scale, edge_scale, (float2*)out};
     dim3 grid((unsigned)((n_fp + fpw - 1) / fpw), (unsigned)n_ct);
-    DISPATCH_N(nfft, CHK(launch(c, "stft", k_stft<NN>, grid, threads, lds, a)));
+    DISPATCH_N(nfft, CHK(launch(c, "stft@generic", k_stft<NN>, grid, threads, lds, a)));
     return DS_OK;
 }
 
@@ -748,10 +775,10 @@ extern "C" int ds_istft_dev(ds_ctx* c, const ds_c32* stft, int n_bins, int n_fra
             IstftFusedArgs fa{IstftArgs{(const float2*)stft, n_bins, n_frames, n_ch, W, window, *tab, scale, nullptr, ct, fpw},
                               frame_offset, n_frames_total, total_length, ld_out, out};
             const dim3 grid((unsigned)((n_fp + fpw - 1) / fpw), (unsigned)n_ct);
-            if (nfft == 2048) return launch(c, "istft", stft1k::k_istft_wave<2048>, grid, threads, lds, fa);
-            if (nfft == 1024) return launch(c, "istft", stft1k::k_istft_wave<1024>, grid, threads, lds, fa);
-            if (nfft == 512) return launch(c, "istft", stft1k::k_istft_wave<512>, grid, threads, lds, fa);
-            return launch(c, "istft", stft1k::k_istft_wave<256>, grid, threads, lds, fa);
+            if (nfft == 2048) return launch(c, "istft@wave", stft1k::k_istft_wave<2048>, grid, threads, lds, fa);
+            if (nfft == 1024) return launch(c, "istft@wave", stft1k::k_istft_wave<1024>, grid, threads, lds, fa);
+            if (nfft == 512) return launch(c, "istft@wave", stft1k::k_istft_wave<512>, grid, threads, lds, fa);
+            return launch(c, "istft@wave", stft1k::k_istft_wave<256>, grid, threads, lds, fa);
         }
     }
     // ... and on the 4096-point register transform, two neighbouring channels per team (kernels_stft4096.hpp, k_istft)
@@ -768,7 +795,7 @@ extern "C" int ds_istft_dev(ds_ctx* c, const ds_c32* stft, int n_bins, int n_fra
         if (c->cfg.istft_fpw > 0) n_chunks = std::min(n_frames, c->cfg.istft_fpw);
         IstftFusedArgs fa{IstftArgs{(const float2*)stft, n_bins, n_frames, n_ch, W, window, c->w4_tables, scale, nullptr, 1, n_chunks},
                           frame_offset, n_frames_total, total_length, ld_out, out};
-        return launch(c, "istft", stft4k::k_istft, dim3((unsigned)stft4k::grid_size(n_groups, n_chunks)), stft4k::NT,
+        return launch(c, "istft@4k", stft4k::k_istft, dim3((unsigned)stft4k::grid_size(n_groups, n_chunks)), stft4k::NT,
                       stft4k::ISTFT_LDS_BYTES, fa);
     }
     if (W == nfft && 2 * step == nfft && n_ch > 1 && !no_fuse) {
@@ -792,7 +819,7 @@ extern "C" int ds_istft_dev(ds_ctx* c, const ds_c32* stft, int n_bins, int n_fra
                               frame_offset, n_frames_total, total_length, ld_out, out};
             DISPATCH_N(nfft, {
                 if constexpr (stft_max_teams<NN>() > 1 && NN % (2 * Cfg<NN>::NT) == 0)  // (ct > 1 never holds otherwise)
-                    CHK(launch(c, "istft", k_istft_fused<NN>, dim3((unsigned)((n_fp + fpw - 1) / fpw), (unsigned)n_ct),
+                    CHK(launch(c, "istft@fused", k_istft_fused<NN>, dim3((unsigned)((n_fp + fpw - 1) / fpw), (unsigned)n_ct),
                                threads, lds, fa));
             });
             return DS_OK;
@@ -819,11 +846,11 @@ extern "C" int ds_istft_dev(ds_ctx* c, const ds_c32* stft, int n_bins, int n_fra
         a.fpw = std::max(1, std::min(16, (int)(((int64_t)n_fp * n_ct + 511) / 512)));
         DISPATCH_N(nfft, {
             if constexpr (stft_max_teams<NN>() > 1)
-                CHK(launch(c, "istft", k_istft_ct<NN>, dim3((unsigned)((n_fp + a.fpw - 1) / a.fpw), (unsigned)n_ct), threads,
+                CHK(launch(c, "istft@ct", k_istft_ct<NN>, dim3((unsigned)((n_fp + a.fpw - 1) / a.fpw), (unsigned)n_ct), threads,
                            lds, a));
         });
     } else {
-        DISPATCH_N(nfft, CHK(launch(c, "istft", k_istft<NN>, dim3((n_frames + 1) / 2, n_ch), Cfg<NN>::NT,
+        DISPATCH_N(nfft, CHK(launch(c, "istft@generic", k_istft<NN>, dim3((n_frames + 1) / 2, n_ch), Cfg<NN>::NT,
                                     Cfg<NN>::LDS_BYTES, a)));
     }
     IstftOlaArgs o{frames, n_frames, n_ch, W, step, frame_offset, n_frames_total, window, total_length, ld_out, out};
@@ -1064,13 +1091,13 @@ static int welch4096_run(ds_ctx* c, const float* x, int n_cx, int64_t ldx, const
     if (three) {
         CHK(launch(c, "welch4096_x", w4::k_x3, dim3(pl.n_pairs * n_cx), w4::NT, w4::LDS3_BYTES, ax));
         if (n_cx > 1) CHK(launch(c, "welch4096_pxsum", w4::k_px_sum, dim3(pl.n_chunks, n_cx), 256, 0, ay));
-        CHK(launch(c, "welch4096_main", w4::k_y3<false>, dim3(pl.n_chunks * n_cy), w4::NT, w4::LDS3_BYTES, ay));
+        CHK(launch(c, "welch4096_main@3", w4::k_y3<false>, dim3(pl.n_chunks * n_cy), w4::NT, w4::LDS3_BYTES, ay));
     } else {
         auto kx = half ? w4::k_x<true> : w4::k_x<false>;
         auto ky = half ? w4::k_y<true> : w4::k_y<false>;
         CHK(launch(c, "welch4096_x", kx, dim3(pl.n_pairs, n_cx), w4::NT, w4::LDS_BYTES, ax));
         if (n_cx > 1) CHK(launch(c, "welch4096_pxsum", w4::k_px_sum, dim3(pl.n_chunks, n_cx), 256, 0, ay));
-        CHK(launch(c, "welch4096_main", ky, dim3(pl.n_chunks * n_cy), w4::NT, w4::LDS_BYTES_2, ay));
+        CHK(launch(c, "welch4096_main@2", ky, dim3(pl.n_chunks * n_cy), w4::NT, w4::LDS_BYTES_2, ay));
     }
     WelchFinArgs f{psx, pxy, pyy, pl.n_chunks, pl.n_chunks, n_cx, n_cy, kind, mode,
                    FinishPar{norm_scale / (double)n_frames, factor, halve_edges, amp_sqrt, w4::NB},
@@ -1276,10 +1303,10 @@ static int welch4096_psd_run(ds_ctx* c, const float* x, int n_cx, int64_t ldx, i
                c->w4_tables, nullptr, nullptr, nullptr, pyy, nullptr};
     if (three) {
         w4::place_remainder(a, n_cx);
-        CHK(launch(c, "welch4096_main", w4::k_y3<true>, dim3(pl.n_chunks * n_cx), w4::NT, w4::LDS3_BYTES, a));
+        CHK(launch(c, "welch4096_main@3", w4::k_y3<true>, dim3(pl.n_chunks * n_cx), w4::NT, w4::LDS3_BYTES, a));
     } else {
         auto ky = hop == 2048 ? w4::k_y<true, true> : w4::k_y<false, true>;
-        CHK(launch(c, "welch4096_main", ky, dim3(pl.n_chunks * n_cx), w4::NT, w4::LDS_BYTES_2, a));
+        CHK(launch(c, "welch4096_main@2", ky, dim3(pl.n_chunks * n_cx), w4::NT, w4::LDS_BYTES_2, a));
     }
     WelchFinArgs f{pyy, nullptr, nullptr, pl.n_chunks, pl.n_chunks, n_cx, 0, 1, 0,
                    FinishPar{norm_scale / (double)n_frames, factor, halve_edges, amp_sqrt, w4::NB},
@@ -1496,6 +1523,114 @@ extern "C" int ds_welch_tf_x64(ds_ctx* c, const double* x, int n_cx, const doubl
     return DS_OK;
 }
 
+// float64 frame spectra of a host (samples, channels) float64 array: upload, window / twiddle tables, k_frames.
+// The caller has reserved c->io and carves `dsig` (n_samples * n_ch doubles) and `spec` out of it.
+struct X64Tables {
+    double* dw = nullptr;
+    double2* tw = nullptr;
+};
+static int x64_tables(ds_ctx* c, Carver& cv, const double* window, int W, X64Tables* t) {
+    t->dw = cv.take<double>(W);
+    t->tw = cv.take<double2>(W / 2);
+    HIPCHK(c, hipMemcpyAsync(t->dw, window, (size_t)W * 8, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(w64::k_twiddles, dim3((W / 2 + 255) / 256), dim3(256), 0, c->stream, t->tw, W / 2);
+    HIPCHK(c, hipGetLastError());
+    return DS_OK;
+}
+static int x64_frames(ds_ctx* c, const X64Tables& t, const double* sig, double* dsig, int n_ch, int64_t n_samples, int W,
+                      int hop, int n_frames, int detrend, double2* spec) {
+    HIPCHK(c, hipMemcpyAsync(dsig, sig, (size_t)n_samples * n_ch * 8, hipMemcpyHostToDevice, c->stream));
+    int lg = 0;
+    while ((1 << lg) < W) ++lg;
+    const bool packed = W > 8192;  // the real frame as a W/2-point complex sequence: 128 KB of LDS either way
+    const size_t lds = (size_t)(packed ? W / 2 : W) * 16 + 256 * 8;
+    auto frames = packed ? w64::k_frames<true> : w64::k_frames<false>;
+    w64::FrameArgs fa{dsig, n_samples, n_ch, W, lg, hop, n_frames, detrend, t.dw, t.tw, spec};
+    return launch(c, "welch_f64_frames", frames, dim3(n_frames, n_ch), 256, lds, fa);
+}
+static int x64_shape_ok(ds_ctx* c, const char* who, int n_ch, int64_t n_samples, int W, int hop, int n_frames, int average) {
+    if (average != DS_AVG_MEAN && average != DS_AVG_MEDIAN)
+        return fail(c, DS_ERR_ARG, "welch: average must be mean (0) or median (1)");
+    if (average == DS_AVG_MEDIAN && n_frames > 4096)
+        return fail(c, DS_ERR_UNSUP, std::string(who) + ": median averaging over more than 4096 frames (use the fp32 entry point)");
+    if (n_ch <= 0 || n_samples <= 0 || hop <= 0 || hop > W || n_frames <= 0) return fail(c, DS_ERR_ARG, std::string(who) + ": bad shape");
+    if (!is_pow2(W) || W < 8 || W > 16384)
+        return fail(c, DS_ERR_UNSUP, std::string(who) + ": window length must be a power of two in [8, 16384]");
+    return DS_OK;
+}
+
+// _welch in float64 end to end (auto spectra: y = NULL; cross spectra conj(X_i) Y_i otherwise): the route
+// backend._welch takes for SHORT estimates.  out: [nb][n_ch] complex128 (auto spectra: imaginary part 0).
+extern "C" int ds_welch_spec_x64(ds_ctx* c, const double* x, const double* y, int n_ch, int64_t n_samples, int W,
+                                 int hop, int n_frames, const double* window, int detrend, int average, int amp_sqrt,
+                                 double norm_scale, double factor, int halve_edges, double* out) {
+    if (!c || !x || !window || !out) return fail(c, DS_ERR_ARG, "ds_welch_spec_x64: null argument");
+    CHK(x64_shape_ok(c, "ds_welch_spec_x64", n_ch, n_samples, W, hop, n_frames, average));
+    const int nb = W / 2 + 1, n_in = y ? 2 : 1;
+    const size_t spec = (size_t)n_ch * n_frames * nb;
+    if (spec * n_in * sizeof(double2) > ((size_t)2 << 30))
+        return fail(c, DS_ERR_UNSUP, "ds_welch_spec_x64: problem too large for the float64 route (use ds_welch_psd / ds_welch_csd)");
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t bsig = (size_t)n_samples * n_ch * 8, bout = (size_t)nb * n_ch;
+    CHK(reserve(c, &c->io, &c->io_bytes, n_in * (Carver::pad(bsig) + Carver::pad(spec * 16)) + 2 * Carver::pad((size_t)W * 8) +
+                                             Carver::pad(bout * 16)));
+    Carver cv(c->io);
+    X64Tables t;
+    CHK(x64_tables(c, cv, window, W, &t));
+    double* dx = cv.take<double>((size_t)n_samples * n_ch);
+    double2* xs = cv.take<double2>(spec);
+    CHK(x64_frames(c, t, x, dx, n_ch, n_samples, W, hop, n_frames, detrend, xs));
+    double2* ys = nullptr;
+    if (y) {
+        double* dy = cv.take<double>((size_t)n_samples * n_ch);
+        ys = cv.take<double2>(spec);
+        CHK(x64_frames(c, t, y, dy, n_ch, n_samples, W, hop, n_frames, detrend, ys));
+    }
+    double2* dout = cv.take<double2>(bout);
+    if (average == DS_AVG_MEDIAN) {
+        const int nbias = (n_frames & 1) ? n_frames : n_frames - 1;
+        w64::SpecArgs sa{xs, ys, n_ch, n_frames, FinishPar{norm_scale * (double)std::max(1, nbias), factor, halve_edges, amp_sqrt, nb}, dout};
+        CHK(launch(c, "welch_f64_spec_median", w64::k_spec_median, dim3(nb, n_ch), 256, sizeof(double) * (2 * (size_t)n_frames + 4), sa));
+    } else {
+        w64::SpecArgs sa{xs, ys, n_ch, n_frames, FinishPar{norm_scale / (double)n_frames, factor, halve_edges, amp_sqrt, nb}, dout};
+        CHK(launch(c, "welch_f64_spec", w64::k_spec, dim3((nb + 255) / 256, n_ch), 256, 0, sa));
+    }
+    HIPCHK(c, hipMemcpyAsync(out, dout, bout * 16, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return DS_OK;
+}
+
+// _csm_welch in float64 end to end (mean averaging, up to 64 channels): csm [nb][n_ch][n_ch] complex128
+extern "C" int ds_csm_x64(ds_ctx* c, const double* x, int n_ch, int64_t n_samples, int W, int hop, int n_frames,
+                          const double* window, int detrend, int amp_sqrt, double norm_scale, double factor,
+                          int halve_edges, double* csm) {
+    if (!c || !x || !window || !csm) return fail(c, DS_ERR_ARG, "ds_csm_x64: null argument");
+    CHK(x64_shape_ok(c, "ds_csm_x64", n_ch, n_samples, W, hop, n_frames, DS_AVG_MEAN));
+    if (n_ch > w64::CSM_MAX_CH) return fail(c, DS_ERR_UNSUP, "ds_csm_x64: more than 64 channels (use ds_csm)");
+    const int nb = W / 2 + 1;
+    const size_t spec = (size_t)n_ch * n_frames * nb, bout = (size_t)nb * n_ch * n_ch;
+    if (spec * sizeof(double2) > ((size_t)2 << 30))
+        return fail(c, DS_ERR_UNSUP, "ds_csm_x64: problem too large for the float64 route (use ds_csm)");
+    HIPCHK(c, hipSetDevice(c->device));
+    CHK(reserve(c, &c->io, &c->io_bytes, Carver::pad((size_t)n_samples * n_ch * 8) + Carver::pad(spec * 16) +
+                                             2 * Carver::pad((size_t)W * 8) + Carver::pad(bout * 16)));
+    Carver cv(c->io);
+    X64Tables t;
+    CHK(x64_tables(c, cv, window, W, &t));
+    double* dx = cv.take<double>((size_t)n_samples * n_ch);
+    double2* xs = cv.take<double2>(spec);
+    CHK(x64_frames(c, t, x, dx, n_ch, n_samples, W, hop, n_frames, detrend, xs));
+    double2* dcsm = cv.take<double2>(bout);
+    const int tile = std::max(1, std::min(n_frames, 4096 / n_ch));  // <= 64 KB of frame values per workgroup
+    w64::CsmArgs ca{xs, n_ch, n_frames, FinishPar{norm_scale / (double)n_frames, factor, halve_edges, amp_sqrt, nb}, dcsm};
+    hipLaunchKernelGGL(w64::k_csm, dim3(nb), dim3(256), (size_t)n_ch * tile * 16, c->stream, ca, tile);
+    HIPCHK(c, hipGetLastError());
+    c->routes.insert("csm_f64");
+    HIPCHK(c, hipMemcpyAsync(csm, dcsm, bout * 16, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return DS_OK;
+}
+
 extern "C" int ds_welch_psd_dev(ds_ctx* c, const float* x, int n_cx, int64_t ldx, int64_t n_samples,
                                 int W, int hop, int n_frames, const float* window, int detrend,
                                 int average, int amp_sqrt, double norm_scale, double factor,
@@ -1627,22 +1762,22 @@ static int csm_dev(ds_ctx* c, const float* x, int n_ch, int64_t ld, int64_t n_sa
     const bool f32_only = c->cfg.csm_f32;
     const bool one_wg_per_bin = all_bins && n_ch <= 64 && n_frames >= 8 && nb >= 3 && !no64;
     if (one_wg_per_bin && !f32_only && csmb3::fits(n_ch, n_frames))
-        CHK(launch(c, "csm_gemm", csmb3::k_csm_gemm64_b3, dim3(nb - 1), 256, 0, a));
+        CHK(launch(c, "csm_gemm@b3", csmb3::k_csm_gemm64_b3, dim3(nb - 1), 256, 0, a));
     else if (one_wg_per_bin)
-        CHK(launch(c, "csm_gemm", k_csm_gemm64, dim3(nb - 1), 256, 0, a));
+        CHK(launch(c, "csm_gemm@f32", k_csm_gemm64, dim3(nb - 1), 256, 0, a));
     else if (!all_bins && n_ch <= 64 && n_frames >= 8 && !no64 && !f32_only && csmb3::fits(n_ch, n_frames))
-        CHK(launch(c, "csm_gemm", csmb3::k_csm_gemm64_b3_range, dim3(bin_count), 256, 0, a));
+        CHK(launch(c, "csm_gemm@b3_range", csmb3::k_csm_gemm64_b3_range, dim3(bin_count), 256, 0, a));
     else if (n_ch > 64 && n_frames >= 8 && !no64 && !f32_only && csmb3::fits_groups(n_ch, n_frames)) {
         // groups of 64 channels: the diagonal blocks, then the blocks below the diagonal (two workgroups each)
         const int ng = (n_ch + 63) / 64;
         a.n_groups = ng;
         a.n_groups_bins = bin_count;
-        CHK(launch(c, "csm_gemm", csmb3::k_csm_group_b3, dim3(bin_count, ng), 256, 0, a));
+        CHK(launch(c, "csm_gemm@group_b3", csmb3::k_csm_group_b3, dim3(bin_count, ng), 256, 0, a));
         CHK(launch(c, "csm_gemm_offdiag", csmb3::k_csm_offdiag_b3, dim3(16 * ((bin_count + 7) / 8), ng * (ng - 1) / 2),
                    256, 0, a));
     }
     else
-        CHK(launch(c, "csm_gemm", k_csm_gemm, dim3(bin_count, nt * (nt + 1) / 2), 256, 0, a));
+        CHK(launch(c, "csm_gemm@generic", k_csm_gemm, dim3(bin_count, nt * (nt + 1) / 2), 256, 0, a));
     return DS_OK;
 }
 
@@ -1672,7 +1807,7 @@ extern "C" int ds_csm_spec_dev(ds_ctx* c, const ds_c32* X, int n_bins, int n_fra
     CsmArgs a{(const float2*)X, n_ch, n_frames,
               FinishPar{norm_scale / (double)n_frames, factor, halve_edges, amp_sqrt, n_bins},
               (float2*)csm, 0};
-    CHK(launch(c, "csm_gemm", k_csm_gemm, dim3(n_bins, nt * (nt + 1) / 2), 256, 0, a));
+    CHK(launch(c, "csm_gemm@generic", k_csm_gemm, dim3(n_bins, nt * (nt + 1) / 2), 256, 0, a));
     return DS_OK;
 }
 
@@ -2093,12 +2228,12 @@ extern "C" int ds_deconv_dev(ds_ctx* c, const float* y, int n_items, int n_ch, i
         // DSPTOOLBOX_AMD_DECONV_4PERCU=0 (k_deconv3: three, 168 registers)
         const bool four = c->cfg.deconv_4percu;
         if (!two && four && (int64_t)((n_ch + 1) / 2) * n_items < ((int64_t)1 << 31))
-            return launch(c, "deconv", deconv8k::k_deconv3q, dim3((unsigned)(((n_ch + 1) / 2) * n_items)), 256,
+            return launch(c, "deconv@8k_4percu", deconv8k::k_deconv3q, dim3((unsigned)(((n_ch + 1) / 2) * n_items)), 256,
                           deconv8k::LDS_BYTES_3, a8);
         if (!two && (int64_t)((n_ch + 1) / 2) * n_items < ((int64_t)1 << 31))
-            return launch(c, "deconv", deconv8k::k_deconv3, dim3((unsigned)(((n_ch + 1) / 2) * n_items)), 256,
+            return launch(c, "deconv@8k_3percu", deconv8k::k_deconv3, dim3((unsigned)(((n_ch + 1) / 2) * n_items)), 256,
                           deconv8k::LDS_BYTES_3, a8);
-        CHK(launch(c, "deconv", deconv8k::k_deconv, dim3((n_ch + 1) / 2, n_items), deconv8k::NTB,
+        CHK(launch(c, "deconv@8k_512", deconv8k::k_deconv, dim3((n_ch + 1) / 2, n_items), deconv8k::NTB,
                    deconv8k::LDS_BYTES, a8));
         return DS_OK;
     }
@@ -2106,7 +2241,7 @@ extern "C" int ds_deconv_dev(ds_ctx* c, const float* y, int n_items, int n_ch, i
     CHK(get_twiddles(c, n_fft, &tw));
     DeconvArgs a{y, n_samples, ld, n_out, ld_out, n_ch, r_per_channel, tw, (const float2*)r, ir};
     dim3 grid((n_ch + 1) / 2, n_items);
-    DISPATCH_N(n_fft, CHK(launch(c, "deconv", k_deconv<NN>, grid, Cfg<NN>::NT, Cfg<NN>::LDS_BYTES, a)));
+    DISPATCH_N(n_fft, CHK(launch(c, "deconv@generic", k_deconv<NN>, grid, Cfg<NN>::NT, Cfg<NN>::LDS_BYTES, a)));
     return DS_OK;
 }
 
@@ -2212,8 +2347,8 @@ static int fir4k_run(ds_ctx* c, const float* x, int n_ch, int64_t ldx, int64_t n
     if (c->cfg.fir_chunks > 0) chunks = c->cfg.fir_chunks;
     chunks = std::min(chunks, n_blocks);
     f4::Args a{x, n_samples, ldx, ld_y, n_ch, n_filt, n_blocks, chunks, c->w4_tables, hp, y};
-    if (P == 1) return launch(c, "fir", f4::k_fir<1>, dim3((unsigned)(pairs * chunks)), f4::NT, f4::LDS_BYTES, a);
-    return launch(c, "fir", f4::k_fir<2>, dim3((unsigned)(pairs * chunks)), f4::NT, f4::LDS_BYTES, a);
+    if (P == 1) return launch(c, "fir@4k_p1", f4::k_fir<1>, dim3((unsigned)(pairs * chunks)), f4::NT, f4::LDS_BYTES, a);
+    return launch(c, "fir@4k_p2", f4::k_fir<2>, dim3((unsigned)(pairs * chunks)), f4::NT, f4::LDS_BYTES, a);
 }
 
 static int fir_once(ds_ctx* c, const float* x, int n_ch, int64_t ldx, int64_t n_samples,
@@ -2289,20 +2424,20 @@ static int fir_once(ds_ctx* c, const float* x, int n_ch, int64_t ldx, int64_t n_
                 }
                 if (c->cfg.fir_split > 0) split = std::min(c->cfg.fir_split, n_filt);
             }
-            CHK(launch(c, "fir", fir16k::k_fir<true>, dim3((unsigned)n_plain, (n_ch + 1) / 2, split), fir16k::NTB,
+            CHK(launch(c, "fir@16k", fir16k::k_fir<true>, dim3((unsigned)n_plain, (n_ch + 1) / 2, split), fir16k::NTB,
                        fir16k::LDS_BYTES, a));
         }
         if (ragged && n_plain > 0) {
             HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
         } else if (ragged) {
-            CHK(launch(c, "fir", fir16k::k_fir<false>, dim3((unsigned)n_blocks, (n_ch + 1) / 2), fir16k::NTB,
+            CHK(launch(c, "fir@16k_ragged", fir16k::k_fir<false>, dim3((unsigned)n_blocks, (n_ch + 1) / 2), fir16k::NTB,
                        fir16k::LDS_BYTES, a));
         }
         return DS_OK;
     }
     FirArgs a{x, n_samples, ldx, ld_y, n_ch, n_filt, n_taps, tw, hs, y};
     dim3 grid((unsigned)n_blocks, (n_ch + 1) / 2);
-    DISPATCH_N(N, CHK(launch(c, "fir", k_fir<NN>, grid, Cfg<NN>::NT, Cfg<NN>::LDS_BYTES, a)));
+    DISPATCH_N(N, CHK(launch(c, "fir@generic", k_fir<NN>, grid, Cfg<NN>::NT, Cfg<NN>::LDS_BYTES, a)));
     return DS_OK;
 }
 
@@ -2879,6 +3014,17 @@ extern "C" int ds_comm_init(ds_ctx* c, int n_ranks, int rank, const char id[128]
         return fail(c, DS_ERR_COMM, std::string("ncclCommInitRank: ") + (es ? es(r) : "error"));
     }
     c->rccl = h;
+    return DS_OK;
+}
+
+// ranks of the library's communicator as RCCL itself counts them (ncclCommCount)
+extern "C" int ds_comm_count(ds_ctx* c, int* n_ranks) {
+    if (!c || !n_ranks) return fail(c, DS_ERR_ARG, "ds_comm_count: null argument");
+    if (!c->comm) return fail(c, DS_ERR_COMM, "ds_comm_count: communicator not initialised");
+    typedef int (*nccl_count_t)(void*, int*);
+    auto f = (nccl_count_t)dlsym(c->rccl, "ncclCommCount");
+    if (!f) return fail(c, DS_ERR_COMM, "ncclCommCount missing");
+    if (f(c->comm, n_ranks) != 0) return fail(c, DS_ERR_COMM, "ncclCommCount failed");
     return DS_OK;
 }
 

@@ -208,4 +208,133 @@ __global__ __launch_bounds__(256) void k_tf_median(TfArgs p) {
     p.coh[(size_t)b * p.n_cy + c] = axy2 / gxx / gyy;
 }
 
+// ---- auto / cross spectra and the cross-spectral matrix from the same float64 frame spectra ----------
+// (_welch itself, _spectral_methods.py:141-171, and _csm_welch, :351-369: short estimates -- a handful of
+// frames -- have no averaging to bring the fp32 transform rounding down, see backend._x64_short)
+struct SpecArgs {
+    const double2* xs;  // [n_ch][F][nb]
+    const double2* ys;  // [n_ch][F][nb] or nullptr: auto spectra of xs
+    int n_ch, n_frames;
+    dsk::FinishPar fin;
+    double2* out;  // [nb][n_ch]: auto spectra in .x (imaginary part 0), cross spectra conj(X) Y
+};
+
+// grid = (ceil(nb / 256), n_ch)
+__global__ __launch_bounds__(256) void k_spec(SpecArgs p) {
+    const int b = blockIdx.x * 256 + threadIdx.x, c = blockIdx.y, nb = p.fin.nb;
+    if (b >= nb) return;
+    const double2* X = p.xs + (size_t)c * p.n_frames * nb + b;
+    if (!p.ys) {
+        double s = 0.0;
+        for (int f = 0; f < p.n_frames; ++f) {
+            const double2 x = X[(size_t)f * nb];
+            s += x.x * x.x + x.y * x.y;
+        }
+        p.out[(size_t)b * p.n_ch + c] = make_double2(dsk::finish_real(s, b, p.fin), 0.0);
+        return;
+    }
+    const double2* Y = p.ys + (size_t)c * p.n_frames * nb + b;
+    cd s{0.0, 0.0};
+    for (int f = 0; f < p.n_frames; ++f) {
+        const double2 x = X[(size_t)f * nb], y = Y[(size_t)f * nb];
+        s.x += x.x * y.x + x.y * y.y;  // conj(x) y
+        s.y += x.x * y.y - x.y * y.x;
+    }
+    s.y += 0.0;  // a sum of -0 terms becomes +0 like the reference's mean
+    const cd g = dsk::finish_cplx(s, b, p.fin);
+    p.out[(size_t)b * p.n_ch + c] = make_double2(g.x, g.y);
+}
+
+// average = "median": grid = (nb, n_ch), LDS = (2 F + 4) doubles; the host folds the bias into fin.inv
+__global__ __launch_bounds__(256) void k_spec_median(SpecArgs p) {
+    extern __shared__ __align__(16) double ser[];
+    const int b = blockIdx.x, c = blockIdx.y, nb = p.fin.nb, F = p.n_frames, tid = threadIdx.x;
+    double* res = ser + 2 * (size_t)F;
+    const double2* X = p.xs + (size_t)c * F * nb + b;
+    const double2* Y = p.ys ? p.ys + (size_t)c * F * nb + b : nullptr;
+    for (int f = tid; f < F; f += 256) {
+        const double2 x = X[(size_t)f * nb];
+        if (Y) {
+            const double2 y = Y[(size_t)f * nb];
+            ser[f] = x.x * y.x + x.y * y.y;
+            ser[F + f] = x.x * y.y - x.y * y.x;
+        } else {
+            ser[f] = x.x * x.x + x.y * x.y;
+        }
+    }
+    __syncthreads();
+    median_rank(ser, F, tid, res);
+    if (Y) median_rank(ser + F, F, tid, res + 2);
+    __syncthreads();
+    if (tid != 0) return;
+    // the reference forms `median(real) + 1j * median(imag)` and finishes that complex number, auto spectra included
+    const cd s{0.5 * (res[0] + res[1]), Y ? 0.5 * (res[2] + res[3]) + 0.0 : 0.0};
+    const cd g = dsk::finish_cplx(s, b, p.fin);
+    p.out[(size_t)b * p.n_ch + c] = make_double2(g.x, g.y);
+}
+
+struct CsmArgs {
+    const double2* xs;  // [n_ch][F][nb]
+    int n_ch, n_frames;
+    dsk::FinishPar fin;
+    double2* csm;  // [nb][n_ch][n_ch]
+};
+constexpr int CSM_MAX_CH = 64, CSM_PAIRS_PER_THREAD = 9;  // 64 * 65 / 2 = 2080 <= 9 * 256
+
+// One workgroup per bin: the bin's frame values X[c][f] go through LDS in tiles of frames, every thread sums up to nine
+// (i2 >= i1) pairs conj(X_i1) X_i2 over the frames (fp64), finishes them and stores the element and its conjugate
+// mirror (the reference's lower triangle + swapaxes, :351-369).  grid = nb, dynamic LDS = n_ch * tile * 16 bytes.
+__global__ __launch_bounds__(256) void k_csm(CsmArgs p, int tile) {
+    extern __shared__ __align__(16) double2 xt[];  // [tile][n_ch]
+    const int b = blockIdx.x, nb = p.fin.nb, C = p.n_ch, F = p.n_frames, tid = threadIdx.x;
+    const int pairs = C * (C + 1) / 2;
+    int i1s[CSM_PAIRS_PER_THREAD], i2s[CSM_PAIRS_PER_THREAD];
+    cd acc[CSM_PAIRS_PER_THREAD];
+#pragma unroll
+    for (int s = 0; s < CSM_PAIRS_PER_THREAD; ++s) {
+        const int q = tid + 256 * s;
+        // pair q -> (i2, i1), i2 >= i1, rows of the lower triangle one after the other
+        int i2 = (int)((sqrt(8.0 * (double)q + 1.0) - 1.0) * 0.5);
+        while ((i2 + 1) * (i2 + 2) / 2 <= q) ++i2;
+        while (i2 * (i2 + 1) / 2 > q) --i2;
+        i2s[s] = i2;
+        i1s[s] = q - i2 * (i2 + 1) / 2;
+        acc[s] = cd{0.0, 0.0};
+    }
+    for (int f0 = 0; f0 < F; f0 += tile) {
+        const int nf = min(tile, F - f0);
+        __syncthreads();
+        for (int i = tid; i < nf * C; i += 256) {
+            const int c = i / nf, f = i - c * nf;  // frames fastest: neighbouring threads read neighbouring frames
+            xt[f * C + c] = p.xs[((size_t)c * F + f0 + f) * nb + b];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < CSM_PAIRS_PER_THREAD; ++s) {
+            if (tid + 256 * s >= pairs) continue;
+            const int i1 = i1s[s], i2 = i2s[s];
+            cd a = acc[s];
+            for (int f = 0; f < nf; ++f) {
+                const double2 u = xt[f * C + i1], v = xt[f * C + i2];
+                a.x += u.x * v.x + u.y * v.y;  // conj(u) v
+                a.y += u.x * v.y - u.y * v.x;
+            }
+            acc[s] = a;
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < CSM_PAIRS_PER_THREAD; ++s) {
+        if (tid + 256 * s >= pairs) continue;
+        const int i1 = i1s[s], i2 = i2s[s];
+        double2* m = p.csm + (size_t)b * C * C;
+        if (i1 == i2) {
+            m[(size_t)i1 * C + i1] = make_double2(dsk::finish_real(acc[s].x, b, p.fin), 0.0);
+        } else {
+            const cd g = dsk::finish_cplx(cd{acc[s].x, acc[s].y + 0.0}, b, p.fin);
+            m[(size_t)i2 * C + i1] = make_double2(g.x, g.y);
+            m[(size_t)i1 * C + i2] = make_double2(g.x, 0.0 - g.y);
+        }
+    }
+}
+
 }  // namespace w64

@@ -89,11 +89,19 @@ class TcpExchange(Exchange):
         self._sock = None
         if world == 1:
             return
-        token = job_token() if token is None else token
+        if token is None:
+            # the default token is a digest of the launcher's environment: good against cross-talk between jobs on one
+            # node, guessable by anyone who knows that environment -- so an outside interface needs an explicit secret
+            if not _is_loopback(addr) and not os.environ.get("DSPTOOLBOX_AMD_RDZV_TOKEN"):
+                raise RuntimeError(f"rendezvous on a non-loopback address ({addr}) needs DSPTOOLBOX_AMD_RDZV_TOKEN "
+                                   "(a secret shared by the ranks of this job)")
+            token = job_token()
         if rank == 0:
-            # Handshake: the server sends a fresh 16-byte challenge, the peer answers with its rank
-            # and HMAC-SHA256(token, challenge || rank).  A connection that fails it, names a rank
-            # outside 1 .. world-1 or one that is already connected is dropped and the wait goes on.
+            # Handshake, both ways: the server sends a fresh 16-byte challenge, the peer answers with its
+            # rank, HMAC-SHA256(token, challenge || rank) and a nonce of its own; the server proves itself
+            # with HMAC-SHA256(token, "rank0" || nonce).  A connection that fails it, names a rank outside
+            # 1 .. world-1 or one that is already connected is dropped and the wait goes on.  (The channel
+            # is authenticated at connect time only; what follows is plain TCP.)
             srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
             srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
             # a single-node job (the launcher's MASTER_ADDR is a loopback name) never listens on
@@ -113,12 +121,12 @@ class TcpExchange(Exchange):
                         conn.settimeout(min(10.0, timeout_s))
                         challenge = os.urandom(16)
                         conn.sendall(challenge)
-                        raw = _recv_exact(conn, 4 + 32)
+                        raw = _recv_exact(conn, 4 + 32 + 16)
                         (r,) = struct.unpack_from("<I", raw, 0)
                         want = hmac.new(token, challenge + raw[:4], hashlib.sha256).digest()
-                        if not hmac.compare_digest(want, raw[4:]) or not (0 < r < world) or r in self._peers:
+                        if not hmac.compare_digest(want, raw[4:36]) or not (0 < r < world) or r in self._peers:
                             raise ConnectionError("rendezvous: handshake rejected")
-                        conn.sendall(b"\x01")
+                        conn.sendall(b"\x01" + hmac.new(token, b"rank0" + raw[36:], hashlib.sha256).digest())
                         conn.settimeout(timeout_s)
                         self._peers[r] = conn
                     except (OSError, ConnectionError, struct.error):
@@ -139,9 +147,12 @@ class TcpExchange(Exchange):
             s.settimeout(timeout_s)
             challenge = _recv_exact(s, 16)
             me = struct.pack("<I", rank)
-            s.sendall(me + hmac.new(token, challenge + me, hashlib.sha256).digest())
+            nonce = os.urandom(16)
+            s.sendall(me + hmac.new(token, challenge + me, hashlib.sha256).digest() + nonce)
             if _recv_exact(s, 1) != b"\x01":
                 raise ConnectionError("rendezvous: rank 0 refused the handshake")
+            if not hmac.compare_digest(_recv_exact(s, 32), hmac.new(token, b"rank0" + nonce, hashlib.sha256).digest()):
+                raise ConnectionError("rendezvous: the listener at rank 0's address does not know this job's token")
             self._sock = s
 
     # -- collectives -------------------------------------------------------------------
@@ -182,9 +193,11 @@ class TcpExchange(Exchange):
         self._peers, self._sock = {}, None
 
 
-def from_environment(timeout_s: float = 120.0) -> Exchange:
+def from_environment(timeout_s: float | None = None) -> Exchange:
     """The launcher's rendezvous (see the module docstring); a single process gets the trivial
-    exchange."""
+    exchange.  Time limit: DSPTOOLBOX_AMD_RDZV_TIMEOUT seconds (default 120)."""
+    if timeout_s is None:
+        timeout_s = float(os.environ.get("DSPTOOLBOX_AMD_RDZV_TIMEOUT", "120"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     if world <= 1:

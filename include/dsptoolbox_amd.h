@@ -85,6 +85,11 @@ int         ds_profile_stride(ds_ctx* ctx, int every);
  * way, average over reps, in ms.  b1 (one kernel) and b2 (two) give 2 b1 - b2, a lower bound of the
  * bracket's fixed cost (bench.py reports kernel times with and without it) */
 int         ds_profile_overhead(ds_ctx* ctx, int reps, int n_kernels, double* ms);
+/* which kernel family ran: the launch names since the previous call, space separated, each "group" or
+ * "group@variant" (e.g. "csm_gemm@b3", "fir@4k_p2"; string owned by the context).  The library reads its
+ * DSPTOOLBOX_AMD_* switches once, in ds_init (csrc/config.hpp); tests open a context under a switch and
+ * check here that the other family really computed the result.                                          */
+const char* ds_routes(ds_ctx* ctx);
 /* max FFT length one workgroup transforms inside LDS (complex points)       */
 int         ds_max_fft_len(void);
 
@@ -160,6 +165,18 @@ int ds_welch_tf_x64(ds_ctx* ctx, const double* x, int n_cx, const double* y, int
                     int64_t n_samples, int W, int hop, int n_frames, const double* window,
                     int detrend, int average, int mode, int amp_sqrt, double norm_scale,
                     double factor, int halve_edges, double* tf, double* coh);
+/* _welch itself in float64 end to end (_spectral_methods.py:10-173): auto spectra (y NULL) or the cross
+ * spectra conj(X_i) Y_i of channel pairs, mean or median averaging; x, y (n_samples, n_ch) float64 C order,
+ * out [nb][n_ch] complex128 (auto spectra: imaginary part 0).  What the host mirror takes for SHORT
+ * estimates (fewer than 128 frames: no averaging-down of the fp32 transform rounding).                     */
+int ds_welch_spec_x64(ds_ctx* ctx, const double* x, const double* y, int n_ch, int64_t n_samples, int W,
+                      int hop, int n_frames, const double* window, int detrend, int average, int amp_sqrt,
+                      double norm_scale, double factor, int halve_edges, double* out);
+/* _csm_welch in float64 end to end (_spectral_methods.py:285-371; mean averaging, up to 64 channels):
+ * csm [nb][n_ch][n_ch] complex128, same element order as ds_csm.                                          */
+int ds_csm_x64(ds_ctx* ctx, const double* x, int n_ch, int64_t n_samples, int W, int hop, int n_frames,
+               const double* window, int detrend, int amp_sqrt, double norm_scale, double factor,
+               int halve_edges, double* csm);
 int ds_welch_psd_dev(ds_ctx* ctx, const float* x_dev, int n_cx, int64_t ldx,
                      int64_t n_samples, int W, int hop, int n_frames,
                      const float* window_dev, int detrend, int average, int amp_sqrt,
@@ -332,6 +349,8 @@ int ds_host_widen_f64(const float* src, int64_t n, double* dst, int threads); /*
  * on every rank (ncclAllGather on the context's stream; send may alias its own slot).  */
 int ds_comm_unique_id(char id_out[128]);
 int ds_comm_init(ds_ctx* ctx, int n_ranks, int rank, const char id[128]);
+/* ranks of that communicator as RCCL counts them (ncclCommCount): what a multi-GPU bench line reports */
+int ds_comm_count(ds_ctx* ctx, int* n_ranks);
 int ds_bcast(ds_ctx* ctx, void* buf_dev, size_t bytes, int root);
 int ds_allgather(ds_ctx* ctx, const void* send_dev, void* recv_dev, size_t bytes_per_rank);
 int ds_comm_destroy(ds_ctx* ctx);

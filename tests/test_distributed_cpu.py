@@ -220,7 +220,7 @@ def test_tcp_rendezvous_rejects_strangers():
         s.settimeout(10.0)
         ch = s.recv(16)
         me = struct.pack("<I", rank)
-        s.sendall(me + hmac.new(token, ch + me, hashlib.sha256).digest())
+        s.sendall(me + hmac.new(token, ch + me, hashlib.sha256).digest() + os.urandom(16))
         try:
             ans = s.recv(1)
         except OSError:
@@ -239,11 +239,97 @@ def test_tcp_rendezvous_rejects_strangers():
     assert srv.exitcode == 0
 
 
+def test_tcp_rendezvous_is_mutual_and_needs_a_secret_off_loopback(monkeypatch):
+    """rank 0 proves itself to the peers too (a listener that does not know the job's token is
+    refused by the connecting rank), and an outside interface is only used with an explicit shared secret."""
+    import threading
+    from dsptoolbox_amd.rendezvous import TcpExchange
+    port = _free_port()
+    srv = socket.socket()
+    srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+    srv.bind(("127.0.0.1", port))
+    srv.listen(1)
+
+    def impostor():  # accepts anybody, answers "ok" with a made-up proof
+        conn, _ = srv.accept()
+        conn.sendall(os.urandom(16))
+        conn.recv(4 + 32 + 16)
+        conn.sendall(b"\x01" + os.urandom(32))
+        conn.close()
+
+    th = threading.Thread(target=impostor, daemon=True)
+    th.start()
+    with pytest.raises(ConnectionError, match="does not know this job's token"):
+        TcpExchange(1, 2, "127.0.0.1", port, timeout_s=10.0, token=b"k" * 32)
+    th.join(timeout=10)
+    srv.close()
+    monkeypatch.delenv("DSPTOOLBOX_AMD_RDZV_TOKEN", raising=False)
+    with pytest.raises(RuntimeError, match="DSPTOOLBOX_AMD_RDZV_TOKEN"):
+        TcpExchange(1, 2, "10.1.2.3", port, timeout_s=1.0)
+
+
+_BENCH_DIST_RANK = r"""
+import os, sys, json
+sys.path.insert(0, {root!r})
+import bench
+d = bench.Dist(2)
+class Ctx:
+    synced = 0
+    def sync(self):
+        Ctx.synced += 1
+ctx = Ctx()
+d.barrier_sync(ctx)
+m = d.max_over_ranks(1.5 + d.rank)
+some_ok = d.all_ok(d.rank == 0)      # one rank says no: every rank must hear no
+all_ok = d.all_ok(True)
+ident = d.bcast_bytes(bytes(range(128)) if d.rank == 0 else b"", 128)
+d.barrier_sync(ctx)
+print(json.dumps(dict(rank=d.rank, world=d.world, max=m, some_ok=some_ok, all_ok=all_ok, ident=ident == bytes(range(128)),
+                      synced=Ctx.synced, torch="torch" in sys.modules)), flush=True)
+d.finish()
+"""
+
+
+@pytest.mark.timeout(120)
+def test_bench_rank_plumbing_without_torch_world2():
+    """bench.py's rendezvous / barrier / max over ranks / ok-reduction / id broadcast ride on the
+    package's own host exchange; two ranks as the launcher's environment would make them, no GPU needed for this
+    part, and torch is never imported."""
+    import json
+    import subprocess
+    port = _free_port()
+    base = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    procs = []
+    for r in range(2):
+        env = dict(base, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, "-c", _BENCH_DIST_RANK.format(root=ROOT)], env=env, cwd=ROOT,
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=100) for p in procs]
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, se[-2000:]
+    got = sorted((json.loads(so.strip().splitlines()[-1]) for so, _ in outs), key=lambda d: d["rank"])
+    assert [g["rank"] for g in got] == [0, 1] and all(g["world"] == 2 for g in got)
+    for g in got:
+        assert g["max"] == 2.5 and g["some_ok"] is False and g["all_ok"] is True and g["ident"] and g["synced"] == 2
+        assert g["torch"] is False
+
+
+def test_bench_refuses_a_missing_exchange():
+    """A rank whose peers never arrive cannot be timed: exit status 3, never a JSON line."""
+    import subprocess
+    env = dict({k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")},
+               RANK="1", LOCAL_RANK="1", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()),
+               DSPTOOLBOX_AMD_RDZV_TIMEOUT="2")
+    code = ("import sys; sys.path.insert(0, %r); import bench; bench.Dist(2)" % ROOT)
+    r = subprocess.run([sys.executable, "-c", code], env=env, cwd=ROOT, capture_output=True, text=True, timeout=100)
+    assert r.returncode == 3 and "host exchange not available" in r.stderr and "{" not in r.stdout, (r.returncode, r.stderr[-500:])
+
+
 @pytest.mark.timeout(300)
 def test_bench_gpus_without_launcher_never_reports_one_gpu():
     """`python bench.py --gpus N` with no launcher environment starts N ranks itself
-    (torch.distributed.run children of a process that has not touched the GPU); a launcher environment of
-    another size is refused.  Here (no GPU) the children fail -- what matters: no JSON line with n_gpus 1 is
+    (children of a process that has not touched the GPU; since round 4 without torch.distributed.run); a launcher
+    environment of another size is refused.  Here (no GPU) the children fail -- what matters: no JSON line with n_gpus 1 is
     ever printed for --gpus 2, and the exit status is non-zero."""
     import subprocess
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
