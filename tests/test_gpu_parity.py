@@ -1962,6 +1962,31 @@ def test_short_estimates_through_the_api_hold_1e6(W, monkeypatch):
     assert max(worst.values()) < TOL, worst
 
 
+@pytest.mark.parametrize("n_frames", [117, 500])
+def test_csm_amplitude_scaling_of_coherent_channels(n_frames, monkeypatch):
+    """DESIGN section 2, limit (ix), as a test: 32 coherent channels (one source through responses of either sign, a
+    little noise), amplitude scaling -- the square root amplifies the fp32 error of elements that are small against the
+    largest one.  117 frames is the shape the round-2 sweep flagged at 1.2e-6 on BOTH fp32 matrix kernels: through the
+    API it is a short estimate and takes the float64 route (1e-6 holds); the fp32 kernels alone are held to the band
+    the limit documents (2.5e-6), and to 1e-6 again once a few hundred frames average the transform rounding down."""
+    worst = {"f32": 0.0, "auto": 0.0}
+    for seed in range(4):
+        rng = np.random.default_rng(900 + seed)
+        W, C = 512, 32
+        n = 256 * (n_frames - 1) + W - 100
+        src = rng.standard_normal(n) * 0.3 + 0.05
+        h = rng.standard_normal((32, C)) * np.exp(-np.arange(32) / 6.0)[:, None]
+        x = 3.0 * (np.stack([np.convolve(src, h[:, c])[:n] for c in range(C)], axis=1) + 0.05 * rng.standard_normal((n, C)))
+        _, ref = orc.csm_welch_batched(x, 48000, W, "hann", 50.0, True, "FFTBackward")
+        for mode in ("f32", "auto"):
+            monkeypatch.setattr(backend, "SPEC_PRECISION", mode)
+            _, m = backend._csm_welch(x, 48000, W, Window.Hann, 50.0, True, "mean", SpectrumScaling.FFTBackward)
+            worst[mode] = max(worst[mode], relmax(m[1:], ref[1:]))
+    print("coherent channels, amplitude scaling,", n_frames, "frames: worst", worst)
+    assert worst["f32"] < (2.5e-6 if n_frames < 128 else TOL), worst
+    assert worst["auto"] < TOL, worst
+
+
 # ---- every kernel-selecting switch is a tested route (VERDICT r3, next 5) ---------------------------------
 # A context reads the DSPTOOLBOX_AMD_* switches once, in ds_init (csrc/config.hpp); the test opens a
 # new default context under each switch, runs the golden subset of the rows the switch re-routes, and
