@@ -720,6 +720,34 @@ def _lfilter_fir(b, a, x, zi=None, axis: int = 0):
     return y[: x.shape[0], :], zf
 
 
+def fir_transfer_function(taps_list, frequency_vector_hz, sampling_rate_hz: int) -> np.ndarray:
+    """H_k(f) = sum_n b_k[n] exp(-2 pi i f n / fs) for every filter of the list at every frequency, float64 on
+    the device (ds_fir_freqz) -- scipy.signal.freqz(b, 1, worN=f, fs=fs)[1] of the reference's
+    Filter.get_transfer_function (classes/filter.py:893-900).  -> (frequencies, filters) complex128."""
+    f = np.ascontiguousarray(frequency_vector_hz, dtype=np.float64)
+    assert f.ndim == 1, "Frequency vector can only have one dimension"
+    n_taps = max(len(t) for t in taps_list)
+    taps = np.zeros((len(taps_list), n_taps), dtype=np.complex128)
+    for k, t in enumerate(taps_list):
+        taps[k, :len(t)] = t
+    out = np.empty((len(taps_list), len(f)), dtype=np.complex128)
+    ctx = get_context()
+    ctx.check(ctx.lib.ds_fir_freqz(ctx.handle, _ptr(taps), taps.shape[0], n_taps, _ptr(f), len(f),
+                                   float(sampling_rate_hz), _ptr(out)), "ds_fir_freqz")
+    return np.ascontiguousarray(out.T)
+
+
+def _pad_trim(vector: np.ndarray, desired_length: int) -> np.ndarray:
+    """Zero-pad or trim the END of axis 0 (helpers/other.py:216-259 with its defaults)."""
+    v = np.asarray(vector)
+    n = v.shape[0]
+    if n == desired_length:
+        return v.copy()
+    if n > desired_length:
+        return v[:desired_length].copy()
+    return np.concatenate([v, np.zeros((desired_length - n,) + v.shape[1:], dtype=v.dtype)], axis=0)
+
+
 def _lfilter_fir_complex(b, x, zi=None):
     """_lfilter_fir for complex taps b on a real x: the real and the imaginary part of b are two band
     filters of one parallel bank; state (complex) as in the real case."""

@@ -1,5 +1,6 @@
 """Filter: FIR part of dsptoolbox/classes/filter.py (fir_filter :189-235,
-from_ba :237-260, ba setter :485-529, is_fir :460-470, filter_signal :648-743).
+from_ba :237-260, ba setter :485-529, is_fir :460-470, filter_signal :648-743,
+get_ir :818-860, get_transfer_function :862-900).
 FIR filtering runs on the device as FFT block convolution
 (dsptoolbox_amd.backend.fir_filter_bank), including filter state (zi, initialize_zi
 :331-353) and zero-phase filtering (two device convolutions).  IIR / SOS / zpk
@@ -169,6 +170,35 @@ class Filter:
             # call sees len(zi) == T-1 and re-initialises unless T-1 equals the channel count
             self.zi = zi
         return signal.copy_with_new_time_data(new_time_data)
+
+    def get_ir(self, length_samples: int, zero_phase: bool = False):
+        """Impulse response of the filter with the given length (classes/filter.py:818-860): the padded /
+        trimmed taps themselves, or -- zero phase -- a unit impulse through the device's two-pass filtering."""
+        from .impulse_response import ImpulseResponse
+        if not self.is_fir:
+            raise NotImplementedError("IIR filtering is outside the FFT-batchable GPU hot path")
+        if not zero_phase:
+            b = self.ba[0].copy()
+            if length_samples < len(b):
+                warn(f"{length_samples} is not enough for filter with length {len(b)}. IR will have the latter length.")
+                length_samples = len(b)
+            return ImpulseResponse(None, backend._pad_trim(b, length_samples), self.sampling_rate_hz,
+                                   constrain_amplitude=False)
+        d = np.zeros(length_samples)
+        d[0] = 1.0
+        ir = ImpulseResponse(None, d, self.sampling_rate_hz, constrain_amplitude=False)
+        return self.filter_signal(ir, zero_phase=True)
+
+    def get_transfer_function(self, frequency_vector_hz) -> np.ndarray:
+        """Complex transfer function at the given frequencies (classes/filter.py:862-900; the reference calls
+        scipy.signal.freqz, here the same sum in float64 on the device)."""
+        frequency_vector_hz = np.asarray(frequency_vector_hz)
+        assert frequency_vector_hz.ndim == 1, "Frequency vector can only have one dimension"
+        assert frequency_vector_hz.max() <= self.sampling_rate_hz / 2, \
+            "Queried frequency vector has values larger than nyquist"
+        if not self.is_fir:
+            raise NotImplementedError("IIR filters are outside the FFT-batchable GPU hot path")
+        return backend.fir_transfer_function([self.ba[0]], frequency_vector_hz, self.sampling_rate_hz)[:, 0]
 
     def initialize_zi(self, number_of_channels: int = 1):
         """Steady-state initial filter state for every channel (scipy.signal.lfilter_zi)."""

@@ -1,9 +1,11 @@
 """FilterBank (API mirror of dsptoolbox/classes/filterbank.py: ctor :33-66,
-filter_signal :415-477, and the loop of filter_helpers.py:385-451).
+filter_signal :415-477 and the loop of filter_helpers.py:385-451, swap_filters :365-393,
+filter_multiband_signal :479-532, get_ir :534-613, get_transfer_function :615-655).
 A bank of equal-length FIR filters is applied in ONE device call: every input
 block is transformed once and all band filters are applied on chip."""
 
 from copy import deepcopy
+from warnings import warn
 
 import numpy as np
 
@@ -72,6 +74,17 @@ class FilterBank:
         self.filters = fl
         return f if return_filter else self
 
+    def swap_filters(self, new_order):
+        """Rearranges the filters in the new given order (filterbank.py:365-393)."""
+        new_order = np.array(new_order).squeeze()
+        assert new_order.ndim == 1, "Too many or too few dimensions are given in the new arrangement vector"
+        assert self.number_of_filters == len(new_order), "The number of filters does not match"
+        assert all(new_order < self.number_of_filters) and all(new_order >= 0), \
+            f"Indexes of new filters have to be in [0, {self.number_of_filters - 1}]"
+        assert len(np.unique(new_order)) == len(new_order), "There are repeated indexes in the new order vector"
+        self.filters = [self.filters[i] for i in new_order]
+        return self
+
     def copy(self):
         return deepcopy(self)
 
@@ -134,3 +147,67 @@ class FilterBank:
                      for k in range(len(taps))]
             return MultiBandSignal(bands, same_sampling_rate=self.same_sampling_rate)
         return signal.copy_with_new_time_data(y)
+
+    def filter_multiband_signal(self, mbsignal: MultiBandSignal, activate_zi: bool = False,
+                                zero_phase: bool = False) -> MultiBandSignal:
+        """Band n of the MultiBandSignal through filter n, every channel (filterbank.py:479-532)."""
+        assert np.all(mbsignal.sampling_rate_hz == self.sampling_rate_hz), "Sampling rates do not match"
+        if zero_phase:
+            assert not activate_zi, "Zero-phase filtering and zi cannot be used at the same time"
+        if activate_zi:
+            if not hasattr(self.filters[0], "zi"):
+                self.initialize_zi(mbsignal.number_of_channels)
+            if len(self.filters[0].zi) != mbsignal.number_of_channels:
+                self.initialize_zi(mbsignal.number_of_channels)
+        new_sig = mbsignal.copy()
+        bands = list(new_sig.bands)
+        for n in range(mbsignal.number_of_bands):
+            bands[n] = self.filters[n].filter_signal(mbsignal.bands[n], channels=None, activate_zi=activate_zi,
+                                                     zero_phase=zero_phase)
+        new_sig.bands = bands
+        return new_sig
+
+    def get_ir(self, length_samples: int, mode: FilterBankMode, zero_phase: bool = False):
+        """Impulse response of the bank: a unit impulse through filter_signal (filterbank.py:534-613).
+        Parallel -> MultiBandSignal, Sequential / Summed -> ImpulseResponse."""
+        from .impulse_response import ImpulseResponse
+
+        def dirac(n, fs):
+            d = np.zeros((n, 1))
+            d[0, 0] = 1.0
+            return ImpulseResponse(None, d, fs)
+
+        if not self.same_sampling_rate:
+            assert mode == FilterBankMode.Parallel, "Multirate filter bank can only deliver an IR in parallel mode"
+            mb = MultiBandSignal(same_sampling_rate=False)
+            for f, sr in zip(self.filters, self.sampling_rate_hz):
+                mb.add_band(f.filter_signal(dirac(length_samples, sr), zero_phase=zero_phase))
+            return mb
+        max_order = max([0] + [b.order for b in self.filters])
+        if max_order > length_samples:
+            warn(f"Filter order {max_order} is longer than {length_samples}.The length will be adapted to be "
+                 "100 samples longer than the longest filter")
+            length_samples = max_order + 100
+        return self.filter_signal(dirac(length_samples, self.sampling_rate_hz), mode, zero_phase=zero_phase)
+
+    def get_transfer_function(self, frequency_vector_hz, mode: FilterBankMode) -> np.ndarray:
+        """Complex transfer function of the bank (filterbank.py:615-655): Parallel -> (frequency, filter);
+        Sequential -> the product; Summed -> ONE PLUS the sum (the reference starts its sum from ones)."""
+        frequency_vector_hz = np.asarray(frequency_vector_hz)
+        assert frequency_vector_hz.ndim == 1, "Frequency vector can only have one dimension"
+        if mode not in (FilterBankMode.Parallel, FilterBankMode.Sequential, FilterBankMode.Summed):
+            raise ValueError("No valid mode")
+        for f in self.filters:
+            assert frequency_vector_hz.max() <= f.sampling_rate_hz / 2, \
+                "Queried frequency vector has values larger than nyquist"
+            if not f.is_fir:
+                raise NotImplementedError("IIR filters are outside the FFT-batchable GPU hot path")
+        if self.same_sampling_rate:  # every filter in one device call
+            h = backend.fir_transfer_function([f.ba[0] for f in self.filters], frequency_vector_hz, self.sampling_rate_hz)
+        else:
+            h = np.stack([f.get_transfer_function(frequency_vector_hz) for f in self.filters], axis=1)
+        if mode == FilterBankMode.Parallel:
+            return h
+        if mode == FilterBankMode.Sequential:
+            return np.prod(h, axis=1)
+        return 1.0 + np.sum(h, axis=1)

@@ -2,6 +2,7 @@
 (API mirror of dsptoolbox/classes/multibandsignal.py:12-599, single-rate part)."""
 
 from copy import deepcopy
+from warnings import warn
 
 import numpy as np
 
@@ -106,6 +107,29 @@ class MultiBandSignal:
         b = bands.pop(index)
         self.bands = bands
         return b if return_band else self
+
+    def swap_bands(self, new_order):
+        """Rearranges the bands in the new given order (multibandsignal.py:378-410)."""
+        new_order = np.array(new_order).squeeze()
+        assert new_order.ndim == 1, "Too many or too few dimensions are given in the new arrangement vector"
+        assert self.number_of_bands == len(new_order), "The number of bands does not match"
+        assert all(new_order < self.number_of_bands) and all(new_order >= 0), \
+            f"Indexes of new bands have to be in [0, {self.number_of_bands - 1}]"
+        assert len(np.unique(new_order)) == len(new_order), "There are repeated indexes in the new order vector"
+        self.bands = [self.bands[i] for i in new_order]
+        return self
+
+    def get_all_bands(self, channel: int = 0):
+        """ONE channel of every band as the channels of a Signal of the bands' own type (multibandsignal.py:463-518);
+        bands of different sampling rates: (list of time vectors, list of sampling rates)."""
+        complex_data = self.bands[0].time_data_imaginary is not None
+        cols = [(b.time_data[:, channel] + 1j * b.time_data_imaginary[:, channel]) if complex_data
+                else b.time_data[:, channel] for b in self.bands]
+        if not self.same_sampling_rate:
+            if complex_data:
+                warn("Output is complex since signal data had imaginary part")
+            return [c.copy() for c in cols], [b.sampling_rate_hz for b in self.bands]
+        return type(self.bands[0])(None, np.stack(cols, axis=1), self.sampling_rate_hz)
 
     def collapse(self) -> Signal:
         """Sum of all bands as one Signal."""

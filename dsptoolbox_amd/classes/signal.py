@@ -233,6 +233,35 @@ class Signal(MultichannelData):
             self.__spectrogram_state_update = True
         return self
 
+    def add_channel(self, path=None, new_time_data=None, sampling_rate_hz=None, allow_padding_trimming: bool = True):
+        """Appends new channels (classes/signal.py:776-852); data of another length is zero-padded or trimmed at
+        its end when `allow_padding_trimming`.  Reading from a file (path) is audio IO: out of scope here."""
+        if path is not None:
+            assert new_time_data is None, "Only path or new time data is accepted, not both."
+            raise NotImplementedError("audio file IO is outside the GPU hot path: pass new_time_data")
+        assert sampling_rate_hz == self.sampling_rate_hz, \
+            f"{sampling_rate_hz} does not match {self.sampling_rate_hz} as the sampling rate"
+        new_time_data = np.array(new_time_data)
+        if new_time_data.ndim > 2:
+            new_time_data = new_time_data.squeeze()
+        assert new_time_data.ndim <= 2, (f"{new_time_data.ndim} are too many dimensions for time data. "
+                                         "Dimensions should be (time samples, channels)")
+        if new_time_data.ndim < 2:
+            new_time_data = new_time_data[..., None]
+        if new_time_data.shape[1] > new_time_data.shape[0]:
+            new_time_data = new_time_data.T
+        diff = new_time_data.shape[0] - self.time_data.shape[0]
+        if diff != 0:
+            if not allow_padding_trimming:
+                raise AttributeError(f"{new_time_data.shape[0]} does not match {self.time_data.shape[0]}. "
+                                     "Activate allow_padding_trimming for allowing this channel to be added")
+            new_time_data = backend._pad_trim(new_time_data, self.time_data.shape[0])
+            warn(("Padding" if diff < 0 else "Trimming") + " has been performed on the end of the new signal to "
+                 "match original one.")
+        self.time_data = np.concatenate([self.time_data, new_time_data], axis=1)
+        self.__update_state()
+        return self
+
     def clear_time_window(self):
         if hasattr(self, "window"):
             del self.window

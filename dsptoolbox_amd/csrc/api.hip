@@ -34,6 +34,7 @@
 #include "kernels_welch_f64.hpp"
 #include "kernels_stft_any.hpp"
 #include "kernels_fir_stream.hpp"
+#include "kernels_freqz.hpp"
 
 using namespace dsk;
 
@@ -2965,6 +2966,27 @@ extern "C" int ds_fir_ols_step_dev(ds_ctx* c, float* row, const float* block, in
                        (const float*)row, roll, L, bs);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(row, roll, sizeof(float) * (size_t)L, hipMemcpyDeviceToDevice, c->stream));
+    return DS_OK;
+}
+
+// FIR transfer functions at arbitrary frequencies (host pointers; complex128 taps and result)
+extern "C" int ds_fir_freqz(ds_ctx* c, const double* taps, int n_filt, int n_taps, const double* freqs_hz, int n_freq,
+                            double fs_hz, double* out) {
+    if (!c || !taps || !freqs_hz || !out) return fail(c, DS_ERR_ARG, "ds_fir_freqz: null argument");
+    if (n_filt <= 0 || n_taps <= 0 || n_freq <= 0 || !(fs_hz > 0.0)) return fail(c, DS_ERR_ARG, "ds_fir_freqz: bad shape");
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t bt = (size_t)n_filt * n_taps * 16, bf = (size_t)n_freq * 8, bo = (size_t)n_filt * n_freq * 16;
+    CHK(reserve(c, &c->io, &c->io_bytes, Carver::pad(bt) + Carver::pad(bf) + Carver::pad(bo)));
+    Carver cv(c->io);
+    double2* dt = cv.take<double2>((size_t)n_filt * n_taps);
+    double* df = cv.take<double>(n_freq);
+    double2* dout = cv.take<double2>((size_t)n_filt * n_freq);
+    HIPCHK(c, hipMemcpyAsync(dt, taps, bt, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(df, freqs_hz, bf, hipMemcpyHostToDevice, c->stream));
+    freqz::Args a{dt, n_filt, n_taps, df, n_freq, fs_hz, dout};
+    CHK(launch(c, "fir_freqz", freqz::k_freqz, dim3((n_freq + 255) / 256, n_filt), 256, 0, a));
+    HIPCHK(c, hipMemcpyAsync(out, dout, bo, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
     return DS_OK;
 }
 

@@ -340,6 +340,13 @@ int ds_host_interleave_f64(const float* src, int64_t n_samples, int n_ch, int64_
                            int threads); /* dst[n*n_ch + c] = (double)src[c*ld + n] */
 int ds_host_widen_f64(const float* src, int64_t n, double* dst, int threads); /* dst[i] = (double)src[i] */
 
+/* ---- FIR transfer functions: replaces scipy.signal.freqz(b, 1, worN=f, fs) in Filter.get_transfer_function
+ * (classes/filter.py:862-900) and its per-filter loop in FilterBank.get_transfer_function
+ * (classes/filterbank.py:615-655): out[k][i] = sum_n taps[k][n] exp(-2 pi i freqs_hz[i] n / fs_hz), float64.
+ * taps [n_filt][n_taps] and out [n_filt][n_freq] are complex128 (interleaved doubles), host pointers.   */
+int ds_fir_freqz(ds_ctx* ctx, const double* taps, int n_filt, int n_taps, const double* freqs_hz,
+                 int n_freq, double fs_hz, double* out);
+
 /* ---- multi-GPU: RCCL over xGMI, one process per GPU -----------------------
  * The hot path has no exchange step: the only collectives are the
  * broadcast of a shared input (sweep / taps / inverse spectrum) and the gather of sharded

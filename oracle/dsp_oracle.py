@@ -608,6 +608,83 @@ def filterbank_fir(taps_list, td, mode: str):
     raise ValueError("Invalid filter bank apply mode")
 
 
+def fir_transfer_function(b, frequency_vector_hz, fs_hz: int):
+    """Filter.get_transfer_function for a FIR filter (classes/filter.py:893-900):
+    scipy.signal.freqz(b, 1, worN=f, fs=fs)[1] = polyval of the taps in z^-1 = exp(-2 pi i f / fs)."""
+    from scipy.signal import freqz
+    return freqz(np.asarray(b), [1.0], np.asarray(frequency_vector_hz, dtype=np.float64), fs=fs_hz)[1]
+
+
+def filter_get_ir(b, length_samples: int, zero_phase: bool = False):
+    """Filter.get_ir (classes/filter.py:818-860) for a FIR filter: the padded taps (a length below the tap count is
+    raised to it), or a unit impulse through the zero-phase filtering.  -> (L, 1)"""
+    b = np.asarray(b, dtype=np.float64)
+    if not zero_phase:
+        return pad_trim(b[:, None], max(length_samples, len(b)))
+    d = np.zeros((length_samples, 1))
+    d[0] = 1.0
+    return filtfilt_fir(b, d)
+
+
+def _constrained(td):
+    """What the time_data setter of a Signal with constrain_amplitude=True keeps (classes/signal.py:273-292): data above
+    0 dBFS is divided by its peak."""
+    peak = np.max(np.abs(td))
+    return td / peak if peak > 1.0 else td
+
+
+def filterbank_get_ir(taps_list, length_samples: int, mode: str, zero_phase: bool = False):
+    """FilterBank.get_ir (classes/filterbank.py:534-613): a one-channel unit impulse through the bank; a length below the
+    highest order becomes that order + 100.  The impulse is an ImpulseResponse with constrain_amplitude=True
+    (generators.dirac, generators.py:310-313), and so is every Signal made from it on the way
+    (copy_with_new_time_data): an output above 0 dBFS comes back divided by its peak -- per band, and after every
+    stage of the sequential mode.  Parallel -> (L, 1, K), else (L, 1)."""
+    max_order = max(len(b) - 1 for b in taps_list)
+    if max_order > length_samples:
+        length_samples = max_order + 100
+    d = np.zeros((length_samples, 1))
+    d[0] = 1.0
+    f = (lambda b, x: filtfilt_fir(b, x)) if zero_phase else (lambda b, x: lfilter_fir(b, x))
+    if mode == "Parallel":
+        return np.stack([_constrained(f(b, d)) for b in taps_list], axis=-1)
+    if mode == "Sequential":
+        out = d
+        for b in taps_list:
+            out = _constrained(f(b, out))
+        return out
+    return _constrained(np.sum(np.stack([_constrained(f(b, d)) for b in taps_list], axis=-1), axis=-1))
+
+
+def filterbank_transfer_function(taps_list, frequency_vector_hz, fs_hz: int, mode: str):
+    """FilterBank.get_transfer_function (classes/filterbank.py:615-655): Parallel (frequency, filter); Sequential the
+    product; Summed ONE plus the sum (the reference initialises its sum with ones, :649)."""
+    h = np.stack([fir_transfer_function(b, frequency_vector_hz, fs_hz) for b in taps_list], axis=1)
+    if mode == "Parallel":
+        return h
+    if mode == "Sequential":
+        return np.prod(h, axis=1)
+    if mode == "Summed":
+        return 1.0 + np.sum(h, axis=1)
+    raise ValueError("No valid mode")
+
+
+def filter_multiband(taps_list, bands, zero_phase: bool = False):
+    """FilterBank.filter_multiband_signal (classes/filterbank.py:479-532): band n through filter n.  -> (N, K, C)"""
+    f = filtfilt_fir if zero_phase else lfilter_fir
+    return np.stack([f(b, np.asarray(td, dtype=np.float64)) for b, td in zip(taps_list, bands)], axis=1)
+
+
+def add_channel(td, new_td):
+    """Signal.add_channel (classes/signal.py:812-852): the new data as (samples, channels) -- transposed when it has more
+    columns than rows --, zero-padded or trimmed at its end to the signal's length, appended as new channels."""
+    new_td = np.array(new_td, dtype=np.float64)
+    if new_td.ndim < 2:
+        new_td = new_td[:, None]
+    if new_td.shape[1] > new_td.shape[0]:
+        new_td = new_td.T
+    return np.concatenate([np.asarray(td, dtype=np.float64), pad_trim(new_td, td.shape[0])], axis=1)
+
+
 def mel_filterbank(f_hz, range_hz=None, n_bands=40, normalize=True):
     """transforms/transforms.py:206-277"""
     f_hz = np.squeeze(f_hz)

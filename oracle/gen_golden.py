@@ -4,7 +4,7 @@ Runs only in the build container, where /root/reference exists.  The reference
 never travels: only the seeded inputs and the outputs it produced are written,
 as small .npz fixtures under tests/golden/.  Re-run with
 
-    python oracle/gen_golden.py
+    python oracle/gen_golden.py            (all fixtures; --only <name> ...: some; --out DIR: elsewhere)
 
 Recorded skew: the reference pins numpy~=2.4 / scipy~=1.17 and python>=3.11;
 this container has python 3.10, numpy 2.2.6, scipy 1.15.3.  The import recipe
@@ -640,76 +640,83 @@ def gen_csm_coherent(dsp):
     save("csm_coherent", dict(cases=cases, fs=fs), arrs)
 
 
-def main():
-    dsp = import_reference()
-    if "--only-stft-long" in sys.argv:
-        import warnings
-        warnings.simplefilter("ignore")
-        return gen_stft_long(dsp)
-    if "--only-stft-manych" in sys.argv:
-        import warnings
-        warnings.simplefilter("ignore")
-        return gen_stft_manych(dsp)
-    if "--only-csm-coherent" in sys.argv:
-        import warnings
-        warnings.simplefilter("ignore")
-        return gen_csm_coherent(dsp)
-    if "--only-deconv-scaled" in sys.argv:
-        import warnings
-        warnings.simplefilter("ignore")
-        return gen_deconv_scaled(dsp)
-    if "--only-fir-complex" in sys.argv:
-        return gen_fir_complex(dsp)
-    if "--only-istft-anylen" in sys.argv:
-        import warnings
-        warnings.simplefilter("ignore")
-        return gen_istft_anylen(dsp)
-    if "--only-das-signal" in sys.argv:
-        import warnings
-        warnings.simplefilter("ignore")
-        return gen_das_signal(dsp)
-    if "--only-welch4096" in sys.argv:
-        return gen_welch4096(dsp)
-    if "--only-welch-long" in sys.argv:
-        import warnings
-        warnings.simplefilter("ignore")
-        return gen_welch_long(dsp)
-    if "--only-deconv-nonfast" in sys.argv:
-        import warnings
-        warnings.simplefilter("ignore")
-        return gen_deconv_nonfast(dsp)
-    if "--only-chroma" in sys.argv:
-        import warnings
-        warnings.simplefilter("ignore")
-        return gen_chroma(dsp)
-    if "--only-fir-stream" in sys.argv:
-        import warnings
-        warnings.simplefilter("ignore")
-        return gen_fir_stream(dsp)
-    if "--only-mel" in sys.argv:
-        import warnings
-        warnings.simplefilter("ignore")
-        return gen_mel(dsp)
-    if "--only-das" in sys.argv:
-        import warnings
-        warnings.simplefilter("ignore")
-        return gen_das(dsp)
-    if "--only-rir" in sys.argv:
-        import warnings
-        warnings.simplefilter("ignore")
-        return gen_rir(dsp)
-    if "--only-stft-anylen" in sys.argv:
-        import warnings
-        warnings.simplefilter("ignore")
-        return gen_stft_anylen(dsp)
-    if "--only-istft" in sys.argv:
-        import warnings
-        warnings.simplefilter("ignore")
-        return gen_istft(dsp)
-    if "--only-fir-state" in sys.argv:
-        import warnings
-        warnings.simplefilter("ignore")
-        return gen_fir_state(dsp)
+def gen_api_rest(dsp):
+    """The FIR-side API around the hot path: Filter.get_ir / get_transfer_function
+    (classes/filter.py:818-900), FilterBank.get_ir / get_transfer_function / filter_multiband_signal /
+    swap_filters (classes/filterbank.py:479-655), Signal.add_channel (classes/signal.py:776-852),
+    MultiBandSignal.get_all_bands / swap_bands (classes/multibandsignal.py:378-410, 463-518)."""
+    import warnings
+    from dsptoolbox.standard.enums import FilterBankMode, FilterPassType
+    warnings.simplefilter("ignore")
+    fs = 48000
+    rng = np.random.default_rng(77)
+    cases, arrs = [], {}
+    f1 = dsp.Filter.fir_filter(300, [200.0, 5000.0], FilterPassType.Bandpass, fs)
+    f2 = dsp.Filter.fir_filter(150, 3000.0, FilterPassType.Lowpass, fs)
+    f3 = dsp.Filter.fir_filter(64, 1000.0, FilterPassType.Highpass, fs)
+    arrs["b1"], arrs["b2"], arrs["b3"] = f1.ba[0], f2.ba[0], f3.ba[0]
+    # -- Filter.get_ir: longer than the taps, shorter (warning, adapted), zero phase
+    for i, (L, zp) in enumerate([(1024, False), (100, False), (2048, True)]):
+        ir = f1.get_ir(L, zero_phase=zp)
+        assert type(ir).__name__ == "ImpulseResponse"
+        arrs[f"ir_{i}"] = ir.time_data
+        cases.append(dict(kind="filter_get_ir", length=L, zero_phase=zp, key=f"ir_{i}"))
+    # -- Filter.get_transfer_function: a uniform rfft grid and an arbitrary (log-spaced) vector
+    fv_u = np.fft.rfftfreq(4096, 1 / fs)
+    fv_l = np.logspace(np.log10(20.0), np.log10(23999.0), 500)
+    arrs["fv_uniform"], arrs["fv_log"] = fv_u, fv_l
+    arrs["h_uniform"] = f1.get_transfer_function(fv_u)
+    arrs["h_log"] = f1.get_transfer_function(fv_l)
+    cases.append(dict(kind="filter_get_tf", keys=["h_uniform", "h_log"]))
+    # -- FilterBank
+    fb = dsp.FilterBank([f1, f2, f3])
+    for mode in FilterBankMode:
+        o = fb.get_ir(1000, mode)
+        if mode == FilterBankMode.Parallel:
+            assert type(o).__name__ == "MultiBandSignal"
+            arrs[f"bank_ir_{mode.name}"] = np.asarray(o.get_all_time_data()[0])
+        else:
+            arrs[f"bank_ir_{mode.name}"] = o.time_data
+        arrs[f"bank_h_{mode.name}"] = fb.get_transfer_function(fv_l, mode)
+        cases.append(dict(kind="bank_get_ir_tf", mode=mode.name, length=1000, out_type=type(o).__name__))
+    o = fb.get_ir(100, FilterBankMode.Summed)  # shorter than the longest filter: order + 100
+    arrs["bank_ir_short"] = o.time_data
+    o = fb.get_ir(2000, FilterBankMode.Parallel, zero_phase=True)
+    arrs["bank_ir_zero_phase"] = np.asarray(o.get_all_time_data()[0])
+    cases.append(dict(kind="bank_get_ir_edge", keys=["bank_ir_short", "bank_ir_zero_phase"]))
+    # -- filter_multiband_signal: a 3-band, 2-channel multiband signal through the bank (band n by filter n)
+    bands = [rng.standard_normal((3000, 2)) * 0.2 for _ in range(3)]
+    for n, bnd in enumerate(bands):
+        arrs[f"mb_in_{n}"] = bnd
+    mb = dsp.MultiBandSignal([dsp.Signal(None, bnd.copy(), fs) for bnd in bands])
+    out = fb.filter_multiband_signal(mb)
+    arrs["mb_out"] = np.asarray(out.get_all_time_data()[0])
+    out_zp = fb.filter_multiband_signal(mb, zero_phase=True)
+    arrs["mb_out_zero_phase"] = np.asarray(out_zp.get_all_time_data()[0])
+    cases.append(dict(kind="filter_multiband_signal", shape=list(arrs["mb_out"].shape)))
+    # -- MultiBandSignal.get_all_bands / swap_bands, FilterBank.swap_filters
+    arrs["all_bands_ch1"] = out.get_all_bands(channel=1).time_data
+    out.swap_bands([2, 0, 1])
+    arrs["swapped_all_bands_ch0"] = out.get_all_bands(channel=0).time_data
+    fb2 = dsp.FilterBank([f1, f2, f3])
+    fb2.swap_filters([1, 2, 0])
+    arrs["swapped_first_taps"] = fb2.filters[0].ba[0]
+    cases.append(dict(kind="bands_and_filters_reordered", new_band_order=[2, 0, 1], new_filter_order=[1, 2, 0]))
+    # -- Signal.add_channel: same length, shorter (padded), longer (trimmed), flat vector
+    base = rng.standard_normal((1000, 2)) * 0.3
+    arrs["sig_base"] = base
+    for i, extra in enumerate([rng.standard_normal((1000, 1)) * 0.3, rng.standard_normal((700, 2)) * 0.3,
+                               rng.standard_normal((1300, 1)) * 0.3, rng.standard_normal(1000) * 0.3]):
+        sgl = dsp.Signal(None, base.copy(), fs)
+        sgl.add_channel(None, extra.copy(), fs)
+        arrs[f"add_in_{i}"] = extra
+        arrs[f"add_out_{i}"] = sgl.time_data
+        cases.append(dict(kind="add_channel", key=f"add_out_{i}", channels=int(sgl.number_of_channels)))
+    save("api_rest", dict(cases=cases, fs=fs), arrs)
+
+
+def gen_core(dsp):
+    """framing, welch, transfer_function, stft, csm, spectrum_fft, deconvolve, fir and chirp_pair."""
     from dsptoolbox.standard._spectral_methods import _welch
     from dsptoolbox.standard._framed_signal_representation import _get_framed_signal
     from dsptoolbox.helpers.other import _compute_number_frames
@@ -978,21 +985,62 @@ def main():
          dict(x_int16=xi, y_int16=yi, tf=np.asarray(sp.spectral_data), coh=np.asarray(sp.coherence),
               ir_head=ir.time_data[:48000], ir_tail=ir.time_data[-4096:],
               ir_peak=np.array([np.max(np.abs(ir.time_data))])))
-    gen_welch_long(dsp)
-    gen_welch4096(dsp)
-    gen_deconv_scaled(dsp)
-    gen_fir_complex(dsp)
-    gen_das_signal(dsp)
-    gen_csm_coherent(dsp)
-    gen_stft_manych(dsp)
-    gen_stft_long(dsp)
-    gen_fir_state(dsp)
-    gen_istft(dsp)
-    gen_istft_anylen(dsp)
-    gen_stft_anylen(dsp)
-    gen_rir(dsp)
-    gen_das(dsp)
-    gen_mel(dsp)
+
+
+# name -> (generator, fixtures it writes).  `python oracle/gen_golden.py` runs all of them;
+# `--only <name> [<name> ...]` some.  tests/test_oracle_golden.py checks that the union of the
+# fixture lists is exactly tests/golden/*.npz.
+GENERATORS = {
+    "core": (gen_core, ["framing", "welch", "transfer_function", "stft", "csm", "spectrum_fft", "deconvolve", "fir",
+                        "chirp_pair"]),
+    "welch_long": (gen_welch_long, ["welch_long"]),
+    "welch4096": (gen_welch4096, ["welch4096"]),
+    "deconv_scaled": (gen_deconv_scaled, ["deconv_scaled"]),
+    "deconv_nonfast": (gen_deconv_nonfast, ["deconv_nonfast"]),
+    "fir_complex": (gen_fir_complex, ["fir_complex"]),
+    "fir_state": (gen_fir_state, ["fir_state"]),
+    "fir_stream": (gen_fir_stream, ["fir_stream"]),
+    "das": (gen_das, ["das"]),
+    "das_signal": (gen_das_signal, ["das_signal"]),
+    "csm_coherent": (gen_csm_coherent, ["csm_coherent"]),
+    "stft_manych": (gen_stft_manych, ["stft_manych"]),
+    "stft_long": (gen_stft_long, ["stft_long"]),
+    "stft_anylen": (gen_stft_anylen, ["stft_anylen"]),
+    "istft": (gen_istft, ["istft"]),
+    "istft_anylen": (gen_istft_anylen, ["istft_anylen"]),
+    "rir": (gen_rir, ["rir"]),
+    "mel": (gen_mel, ["mel"]),
+    "chroma": (gen_chroma, ["chroma"]),
+    "api_rest": (gen_api_rest, ["api_rest"]),
+}
+
+
+def fixtures_written():
+    return sorted(n for _, names in GENERATORS.values() for n in names)
+
+
+def main(argv=None):
+    """All fixtures, or `--only name ...` (also the older `--only-some-name` flags); `--out DIR` writes
+    somewhere else than tests/golden (to compare a fresh run with the committed files)."""
+    global OUT
+    import warnings
+    argv = list(sys.argv[1:] if argv is None else argv)
+    if "--out" in argv:
+        i = argv.index("--out")
+        OUT = argv[i + 1]
+        del argv[i:i + 2]
+    want = []
+    if "--only" in argv:
+        want = [a for a in argv[argv.index("--only") + 1:] if not a.startswith("--")]
+    want += [a[len("--only-"):].replace("-", "_") for a in argv if a.startswith("--only-")]
+    unknown = [w for w in want if w not in GENERATORS]
+    if unknown:
+        raise SystemExit(f"unknown generator(s) {unknown}; known: {sorted(GENERATORS)}")
+    dsp = import_reference()
+    warnings.simplefilter("ignore")
+    for name, (fn, _) in GENERATORS.items():
+        if not want or name in want:
+            fn(dsp)
 
 
 if __name__ == "__main__":

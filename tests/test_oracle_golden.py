@@ -403,6 +403,57 @@ def test_welch4096_headline_shape_golden():
             close(coh[bins], z["coh_" + key], skip_dc=c["detrend"])
 
 
+def test_api_rest_fir_side():
+    """The FIR-side API around the hot path (tests/golden/api_rest.npz from the reference): Filter.get_ir /
+    get_transfer_function, FilterBank.get_ir / get_transfer_function / filter_multiband_signal, Signal.add_channel,
+    MultiBandSignal.get_all_bands / swap_bands."""
+    meta, z = load_golden("api_rest")
+    fs = meta["fs"]
+    taps = [z["b1"], z["b2"], z["b3"]]
+    for c in meta["cases"]:
+        if c["kind"] == "filter_get_ir":
+            close(orc.filter_get_ir(z["b1"], c["length"], c["zero_phase"]), z[c["key"]], 1e-12)
+        elif c["kind"] == "filter_get_tf":
+            close(orc.fir_transfer_function(z["b1"], z["fv_uniform"], fs), z["h_uniform"])
+            close(orc.fir_transfer_function(z["b1"], z["fv_log"], fs), z["h_log"])
+        elif c["kind"] == "bank_get_ir_tf":
+            ir = orc.filterbank_get_ir(taps, c["length"], c["mode"])
+            ref = z[f"bank_ir_{c['mode']}"]
+            close(np.transpose(ir, (0, 2, 1)) if c["mode"] == "Parallel" else ir, ref, 1e-12)
+            close(orc.filterbank_transfer_function(taps, z["fv_log"], fs, c["mode"]), z[f"bank_h_{c['mode']}"])
+        elif c["kind"] == "bank_get_ir_edge":
+            short = orc.filterbank_get_ir(taps, 100, "Summed")
+            assert short.shape == z["bank_ir_short"].shape == (400, 1)
+            close(short, z["bank_ir_short"], 1e-12)
+            zp = orc.filterbank_get_ir(taps, 2000, "Parallel", zero_phase=True)
+            close(np.transpose(zp, (0, 2, 1)), z["bank_ir_zero_phase"], 1e-11)
+        elif c["kind"] == "filter_multiband_signal":
+            bands = [z[f"mb_in_{n}"] for n in range(3)]
+            close(orc.filter_multiband(taps, bands), z["mb_out"], 1e-12)
+            close(orc.filter_multiband(taps, bands, zero_phase=True), z["mb_out_zero_phase"], 1e-11)
+        elif c["kind"] == "bands_and_filters_reordered":
+            out = z["mb_out"]  # (N, band, channel)
+            assert np.array_equal(out[:, :, 1], z["all_bands_ch1"])
+            assert np.array_equal(out[:, c["new_band_order"], 0], z["swapped_all_bands_ch0"])
+            assert np.array_equal(taps[c["new_filter_order"][0]], z["swapped_first_taps"])
+        elif c["kind"] == "add_channel":
+            i = int(c["key"].rsplit("_", 1)[1])
+            got = orc.add_channel(z["sig_base"], z[f"add_in_{i}"])
+            assert got.shape[1] == c["channels"] and np.array_equal(got, z[c["key"]])
+        else:
+            raise AssertionError(c["kind"])
+
+
+def test_gen_golden_writes_every_fixture():
+    """`python oracle/gen_golden.py` (no flags) must regenerate ALL of tests/golden: the generator table names every
+    fixture file exactly once."""
+    import os
+    from oracle import gen_golden
+    here = sorted(f[:-4] for f in os.listdir(os.path.join(os.path.dirname(__file__), "golden")) if f.endswith(".npz"))
+    assert gen_golden.fixtures_written() == here
+    assert len(set(gen_golden.fixtures_written())) == len(gen_golden.fixtures_written())
+
+
 @pytest.mark.parametrize("mode", ["H1", "H2", "H3"])
 def test_property_linearity_of_h1(mode):
     """Scaling the output by g scales H by g and leaves coherence unchanged."""
