@@ -107,6 +107,10 @@ SIGNATURES = {
     "ds_fir_part_step_dev": (C.c_int, [ctx_p, f32_p, f32_p, C.c_int, C.c_int, C.c_int, C.c_int, c32_p, C.c_int,
                                        C.c_int, c32_p, C.c_int, f32_p]),
     "ds_fir_ols_step_dev": (C.c_int, [ctx_p, f32_p, f32_p, C.c_int, i64, c32_p, f32_p]),
+    "ds_rfft_f64": (C.c_int, [ctx_p, C.c_void_p, C.c_int, i64, C.c_int, C.c_float, C.c_void_p]),
+    "ds_deconv_f64": (C.c_int, [ctx_p, C.c_void_p, C.c_int, i64, C.c_int, c32_p, C.c_int, i64, C.c_void_p]),
+    "ds_istft_f64": (C.c_int, [ctx_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                               f32_p, C.c_float, i64, C.c_void_p]),
     "ds_fir_freqz": (C.c_int, [ctx_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_double, C.c_void_p]),
     "ds_comm_unique_id": (C.c_int, [C.c_char_p]),
     "ds_comm_init": (C.c_int, [ctx_p, C.c_int, C.c_int, C.c_char_p]),

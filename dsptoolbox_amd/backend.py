@@ -424,12 +424,20 @@ def _istft(stft, nfft: int, W: int, step: int, window, scale: float, frame_offse
         raise ValueError("fft_length_samples must be at least 2")
     if np.isrealobj(stft):
         stft = stft.astype(np.complex128)
-    sp = np.ascontiguousarray(stft, dtype=np.complex64)
-    n_bins, n_frames, n_ch = sp.shape
+    n_bins, n_frames, n_ch = stft.shape
     if W > nfft:  # the reference's `td_framed *= window[:, None, None]` cannot broadcast either
         raise ValueError(f"operands could not be broadcast together with shapes ({nfft},{n_frames},{n_ch}) ({W},1,1)")
     # length of the reference's reconstruction buffer (same float expression, :112-115)
     total_length = int(step * n_frames_total + W * (1 - step / W))
+    if stft.dtype == np.complex128 and stft.flags.c_contiguous and stft.size >= (1 << 19):
+        # a large complex128 spectrogram: narrowed in host threads into pinned upload chunks, float64 (N, C) back
+        res = np.empty((total_length, n_ch), dtype=np.float64)
+        w32 = np.ascontiguousarray(window, dtype=np.float32)
+        ctx = get_context()
+        ctx.check(ctx.lib.ds_istft_f64(ctx.handle, _ptr(stft), n_bins, n_frames, n_ch, nfft, W, step, frame_offset,
+                                       n_frames_total, _ptr(w32), float(scale), total_length, _ptr(res)), "ds_istft_f64")
+        return res
+    sp = np.ascontiguousarray(stft, dtype=np.complex64)
     out = np.empty((n_ch, total_length), dtype=np.float32)
     w32 = np.ascontiguousarray(window, dtype=np.float32)
     ctx = get_context()
@@ -599,6 +607,12 @@ def _csm_fft(spectrum, scaling: SpectrumScaling, window, sampling_rate_hz: int):
 
 def rfft_spectrum(time_data, n_fft: int, scale: float = 1.0):
     """rfft(time_data, n=n_fft, axis=0) * scale -> (n_fft/2+1, C) complex128."""
+    if _fusable(time_data):  # float64 in, complex128 out through the pinned chunk pipelines
+        n, n_ch = time_data.shape
+        out = np.empty((n_fft // 2 + 1, n_ch), dtype=np.complex128)
+        ctx = get_context()
+        ctx.check(ctx.lib.ds_rfft_f64(ctx.handle, _ptr(time_data), n_ch, n, int(n_fft), float(scale), _ptr(out)), "ds_rfft_f64")
+        return out
     xp = _planar_f32(time_data)
     n_ch, n = xp.shape
     out = np.empty((n_fft // 2 + 1, n_ch), dtype=np.complex64)
@@ -614,6 +628,17 @@ def spectral_division(num_td, n_fft: int, inverse_spectrum, n_out: int):
     shared or (B, C) per channel.  -> same leading shape, float64."""
     num_td = np.asarray(num_td)
     batched = num_td.ndim == 3
+    if not batched and _fusable(num_td):  # one large item: float64 on both sides through the pinned chunk pipelines
+        n, n_ch = num_td.shape
+        r = np.asarray(inverse_spectrum)
+        per_channel = r.ndim == 2
+        rp = np.ascontiguousarray(r.T if per_channel else r, dtype=np.complex64)
+        assert rp.shape[-1] == n_fft // 2 + 1, "Frequency vector does not match"
+        res = np.empty((int(n_out), n_ch), dtype=np.float64)
+        ctx = get_context()
+        ctx.check(ctx.lib.ds_deconv_f64(ctx.handle, _ptr(num_td), n_ch, n, int(n_fft), _ptr(rp), int(per_channel), int(n_out),
+                                        _ptr(res)), "ds_deconv_f64")
+        return res
     items = num_td if batched else num_td[None]
     m, n, n_ch = items.shape
     yp = np.empty((m, n_ch, n), dtype=np.float32)  # (M, C, N)

@@ -2619,6 +2619,9 @@ struct HipTransport {
     bool d2h(float* dst, const float* src, size_t bytes, int b) {
         return ok(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream)) && mark(b);
     }
+    bool h2d(float* dst, const float* src, size_t bytes, int b) {
+        return ok(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream)) && mark(b);
+    }
 };
 static int pin_ready(ds_ctx* c, bool drain) {
     for (int i = 0; i < 2; ++i) {
@@ -2644,6 +2647,12 @@ static int upload_planar_f64(ds_ctx* c, const double* src, int64_t n_samples, in
     HipTransport tr{c};
     float* pin[2] = {(float*)c->pin[0], (float*)c->pin[1]};
     return pipe_result(c, dshost::upload_planar(tr, pin, kPinBytes, src, n_samples, n_ch, dst_dev, ld), tr, "upload_planar_f64");
+}
+static int upload_narrow_f64(ds_ctx* c, const double* src, int64_t n, float* dst_dev) {
+    CHK(pin_ready(c, false));
+    HipTransport tr{c};
+    float* pin[2] = {(float*)c->pin[0], (float*)c->pin[1]};
+    return pipe_result(c, dshost::upload_narrow(tr, pin, kPinBytes, src, n, dst_dev), tr, "upload_narrow_f64");
 }
 static int download_widen(ds_ctx* c, const float* src_dev, int64_t n, double* dst) {
     CHK(pin_ready(c, true));
@@ -2679,6 +2688,60 @@ extern "C" int ds_stft_r2c_f64(ds_ctx* c, const double* x, int64_t n_samples, in
     CHK(ds_stft_r2c_dev(c, dx, n_samples, n_ch, n_samples, W, hop, nfft, pad_front, n_frames, dw, detrend,
                         scale, edge_scale, power, (ds_c32*)dout));
     return download_widen(c, (const float*)dout, (int64_t)no * 2, out_c128);
+}
+
+// ds_rfft with the reference's layouts on both sides: x (n_samples, n_ch) float64 C-order in, (bins, channels)
+// complex128 out (Signal.get_spectrum with SpectrumMethod.FFT, classes/signal.py:899-911).
+extern "C" int ds_rfft_f64(ds_ctx* c, const double* x, int n_ch, int64_t n_samples, int n_fft, float scale,
+                           double* spec_c128) {
+    if (!c || !x || !spec_c128) return fail(c, DS_ERR_ARG, "ds_rfft_f64: null argument");
+    if (n_ch <= 0 || n_samples <= 0 || n_fft < 2) return fail(c, DS_ERR_ARG, "ds_rfft_f64: bad shape");
+    const size_t nx = (size_t)n_ch * n_samples, no = (size_t)(n_fft / 2 + 1) * n_ch;
+    CHK(stage_reserve(c, Carver::pad(nx * 4) + Carver::pad(no * 8)));
+    Carver cv(c->io);
+    float* dx = cv.take<float>(nx);
+    float2* ds = cv.take<float2>(no);
+    CHK(upload_planar_f64(c, x, n_samples, n_ch, dx, n_samples));
+    CHK(ds_rfft_dev(c, dx, n_ch, n_samples, n_samples, n_fft, scale, (ds_c32*)ds));
+    return download_widen(c, (const float*)ds, (int64_t)no * 2, spec_c128);
+}
+
+// ds_deconv for ONE item in the reference's layouts: y (n_samples, n_ch) float64 in, the impulse responses
+// (n_out, n_ch) float64 out (_spectral_deconvolve, transfer_functions/_transfer_functions.py:19-42).
+extern "C" int ds_deconv_f64(ds_ctx* c, const double* y, int n_ch, int64_t n_samples, int n_fft, const ds_c32* r,
+                             int r_per_channel, int64_t n_out, double* ir) {
+    if (!c || !y || !r || !ir) return fail(c, DS_ERR_ARG, "ds_deconv_f64: null argument");
+    if (n_ch <= 0 || n_samples <= 0 || n_fft < 2 || n_out <= 0 || n_out > n_fft) return fail(c, DS_ERR_ARG, "ds_deconv_f64: bad shape");
+    const size_t ny = (size_t)n_ch * n_samples, nr = (size_t)(r_per_channel ? n_ch : 1) * (n_fft / 2 + 1), no = (size_t)n_ch * n_out;
+    CHK(stage_reserve(c, Carver::pad(ny * 4) + Carver::pad(nr * 8) + Carver::pad(no * 4)));
+    Carver cv(c->io);
+    float* dy = cv.take<float>(ny);
+    float2* dr = cv.take<float2>(nr);
+    float* dout = cv.take<float>(no);
+    CHK(upload_planar_f64(c, y, n_samples, n_ch, dy, n_samples));
+    CHK(ds_upload(c, dr, r, nr * 8));
+    CHK(ds_deconv_dev(c, dy, 1, n_ch, n_samples, n_samples, n_fft, (const ds_c32*)dr, r_per_channel, n_out, n_out, dout));
+    return download_interleave(c, dout, n_out, n_ch, n_out, ir);
+}
+
+// ds_istft with the reference's layouts on both sides: the spectrogram (bins, frames, channels) complex128 in,
+// the signal (total_length, n_ch) float64 out (transforms.istft, transforms/transforms.py:444-586).
+extern "C" int ds_istft_f64(ds_ctx* c, const double* stft_c128, int n_bins, int n_frames, int n_ch, int nfft, int W,
+                            int step, int frame_offset, int n_frames_total, const float* window, float scale,
+                            int64_t total_length, double* out) {
+    if (!c || !stft_c128 || !window || !out) return fail(c, DS_ERR_ARG, "ds_istft_f64: null argument");
+    if (n_bins <= 0 || n_frames <= 0 || n_ch <= 0 || W <= 0 || total_length <= 0) return fail(c, DS_ERR_ARG, "ds_istft_f64: bad shape");
+    const size_t ns = (size_t)n_bins * n_frames * n_ch, no = (size_t)n_ch * total_length;
+    CHK(stage_reserve(c, Carver::pad(ns * 8) + Carver::pad((size_t)W * 4) + Carver::pad(no * 4)));
+    Carver cv(c->io);
+    float2* dsp = cv.take<float2>(ns);
+    float* dw = cv.take<float>(W);
+    float* dout = cv.take<float>(no);
+    CHK(upload_narrow_f64(c, stft_c128, (int64_t)ns * 2, (float*)dsp));
+    CHK(ds_upload(c, dw, window, (size_t)W * 4));
+    CHK(ds_istft_dev(c, (const ds_c32*)dsp, n_bins, n_frames, n_ch, nfft, W, step, frame_offset, n_frames_total, dw, scale,
+                     total_length, dout, total_length));
+    return download_interleave(c, dout, total_length, n_ch, total_length, out);
 }
 
 // ds_fir_ola with the reference's layouts on both sides: x (n_samples, n_ch) float64 in,

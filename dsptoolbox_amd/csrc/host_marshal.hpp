@@ -66,6 +66,13 @@ inline void widen_f64(const float* src, int64_t n, double* dst, int threads) {
         for (int64_t i = b; i < e; ++i) d[i] = (double)s[i];
     });
 }
+inline void narrow_f32(const double* src, int64_t n, float* dst, int threads) {
+    host_parallel(threads, n, [=](int64_t b, int64_t e) {
+        const double* __restrict__ s = src;
+        float* __restrict__ d = dst;
+        for (int64_t i = b; i < e; ++i) d[i] = (float)s[i];
+    });
+}
 // src[c * ld + n] float32  ->  dst (n_samples, n_ch) float64, C order
 inline void interleave_f64(const float* src, int64_t n_samples, int n_ch, int64_t ld, double* dst, int threads) {
     host_parallel(threads, n_samples, [=](int64_t b, int64_t e) {
@@ -131,6 +138,22 @@ inline bool download_interleave(T& tr, float* const pin[2], size_t pin_bytes, co
         if (!tr.wait((int)(k & 1))) return false;
         const int64_t s0 = k * cs, cn = std::min(cs, n_samples - s0);
         interleave_f64(pin[k & 1], cn, n_ch, cn, dst + s0 * n_ch, host_threads(0, cn * n_ch));
+    }
+    return true;
+}
+// contiguous float64 on the host -> float32 on the device (complex128 -> complex64 element by element): chunk k is
+// cast into staging chunk k & 1 while the copy of chunk k - 1 is in flight.
+//   T also needs:  bool h2d(float* dst, const float* src, size_t bytes, int b)
+template <typename T>
+inline bool upload_narrow(T& tr, float* const pin[2], size_t pin_bytes, const double* src, int64_t n, float* dst_dev) {
+    const int64_t cs = (int64_t)(pin_bytes / sizeof(float));
+    int k = 0;
+    for (int64_t s0 = 0; s0 < n; s0 += cs, ++k) {
+        const int b = k & 1;
+        const int64_t cn = std::min(cs, n - s0);
+        if (!tr.wait(b)) return false;
+        narrow_f32(src + s0, cn, pin[b], host_threads(0, cn));
+        if (!tr.h2d(dst_dev + s0, pin[b], (size_t)cn * sizeof(float), b)) return false;
     }
     return true;
 }

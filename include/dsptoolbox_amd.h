@@ -142,6 +142,17 @@ int ds_welch_tf(ds_ctx* ctx, const float* x, int n_cx, const float* y, int n_cy,
 int ds_stft_r2c_f64(ds_ctx* ctx, const double* x, int64_t n_samples, int n_ch, int W, int hop,
                     int nfft, int64_t pad_front, int n_frames, const float* window, int detrend,
                     float scale, float edge_scale, int power, double* out_c128);
+/* the same for whole-signal spectra, one-item spectral division and the inverse STFT (round 4): float64 /
+ * complex128 arrays in the reference's own layouts on both sides, cast in host threads through pinned chunks
+ * while the previous chunk's copy is in flight.  spec (bins, channels) complex128; ir (n_out, channels) float64;
+ * stft (bins, frames, channels) complex128 in, out (total_length, channels) float64.                          */
+int ds_rfft_f64(ds_ctx* ctx, const double* x, int n_ch, int64_t n_samples, int n_fft, float scale,
+                double* spec_c128);
+int ds_deconv_f64(ds_ctx* ctx, const double* y, int n_ch, int64_t n_samples, int n_fft, const ds_c32* r,
+                  int r_per_channel, int64_t n_out, double* ir);
+int ds_istft_f64(ds_ctx* ctx, const double* stft_c128, int n_bins, int n_frames, int n_ch, int nfft, int W,
+                 int step, int frame_offset, int n_frames_total, const float* window, float scale,
+                 int64_t total_length, double* out);
 int ds_fir_ola_f64(ds_ctx* ctx, const double* x, int n_ch, int64_t n_samples, const float* taps,
                    int n_filt, int n_taps, int mode, double* y);
 int ds_welch_psd_f64(ds_ctx* ctx, const double* x, int n_cx, int64_t n_samples, int W, int hop,

@@ -39,6 +39,7 @@ struct MemTransport {
     bool h2d_2d(float* d, size_t dp, const float* s, size_t sp, size_t w, size_t r, int b) { return copy2d(d, dp, s, sp, w, r, b); }
     bool d2h_2d(float* d, size_t dp, const float* s, size_t sp, size_t w, size_t r, int b) { return copy2d(d, dp, s, sp, w, r, b); }
     bool d2h(float* d, const float* s, size_t bytes, int b) { return copy2d(d, bytes, s, bytes, bytes, 1, b); }
+    bool h2d(float* d, const float* s, size_t bytes, int b) { return copy2d(d, bytes, s, bytes, bytes, 1, b); }
 };
 
 int main() {
@@ -103,6 +104,13 @@ int main() {
             ok = true;
             for (size_t i = 0; i < flat.size(); ++i) ok = ok && flat[i] == (double)dev[i];
             EXPECT(ok && dw.waits_on_idle == 0);
+            // contiguous float64 -> float32 (complex128 -> complex64) through the same chunks
+            std::vector<float> narrow(src.size() + 1, -2.f);
+            MemTransport un;
+            EXPECT(dshost::upload_narrow(un, pin, pin_bytes, src.data(), (int64_t)src.size(), narrow.data()));
+            ok = narrow.back() == -2.f;
+            for (size_t i = 0; i < src.size(); ++i) ok = ok && narrow[i] == (float)src[i];
+            EXPECT(ok && un.transfers == (int)((src.size() * 4 + pin_bytes - 1) / pin_bytes));
         }
     }
     {   // more channels than a chunk holds 256 samples of: refused, nothing written

@@ -43,3 +43,28 @@ for it in range(3):
     out = backend.fir_filter_bank(sig, taps, backend.DS_FB_PARALLEL)
     t1 = time.perf_counter()
     print(f"fir_filter_bank 4 x 4097 taps, 8 ch x 2^22 (-> {out.nbytes / 1e6:.0f} MB float64): {(t1 - t0) * 1e3:8.1f} ms")
+
+# round 4: whole-signal spectra, one-item deconvolution and the inverse STFT through the pinned pipelines
+# (ds_rfft_f64 / ds_deconv_f64 / ds_istft_f64) against the host-cast path (a Fortran-ordered view is not "fusable")
+big = rng.standard_normal((2**21, 8)) * 0.1
+for name, arr in (("pinned pipeline", big), ("host cast", np.asfortranarray(big))):
+    for it in range(2):
+        t0 = time.perf_counter()
+        sp = backend.rfft_spectrum(arr, 2**21)
+        t1 = time.perf_counter()
+    print(f"rfft_spectrum 8 ch x 2^21 (-> {sp.nbytes / 1e6:.0f} MB complex128), {name}: {(t1 - t0) * 1e3:8.1f} ms")
+inv = (rng.standard_normal(2**20 + 1) + 1j * rng.standard_normal(2**20 + 1)).astype(np.complex64)
+for name, arr in (("pinned pipeline", big), ("host cast", np.asfortranarray(big))):
+    for it in range(2):
+        t0 = time.perf_counter()
+        ir = backend.spectral_division(arr, 2**21, inv, 2**21)
+        t1 = time.perf_counter()
+    print(f"spectral_division 8 ch x 2^21 (-> {ir.nbytes / 1e6:.0f} MB float64), {name}: {(t1 - t0) * 1e3:8.1f} ms")
+S = dsp.Signal(None, mic, 48000)
+t, f, st = S.get_spectrogram()
+for name, arr in (("pinned pipeline", st), ("host cast", np.asfortranarray(st))):
+    for it in range(2):
+        t0 = time.perf_counter()
+        back = dsp.transforms.istft(arr, original_signal=S)
+        t1 = time.perf_counter()
+    print(f"istft of the {st.nbytes / 1e6:.0f} MB spectrogram (-> {back.time_data.nbytes / 1e6:.0f} MB float64), {name}: {(t1 - t0) * 1e3:8.1f} ms")
