@@ -522,6 +522,9 @@ def _csm_welch_device(time_data, sampling_rate_hz: int, window_length_samples: i
                                      C.c_void_p(d_w.ptr), int(bool(detrend)), DS_AVG[average], amp, norm_scale, factor,
                                      phys, C.c_void_p(d_c.ptr)), "ds_csm_dev")
         ctx.sync()
+    except BaseException:
+        d_c.free()  # (the matrix only leaves this function inside a DeviceCSM)
+        raise
     finally:
         d_x.free()
         d_w.free()

@@ -70,6 +70,8 @@ struct ds_ctx {
     void* io = nullptr;  // staging for the host-pointer entry points
     size_t io_bytes = 0;
     void* aux = nullptr;  // small persistent scratch (combined FIR taps, cascade ping-pong buffer)
+    void* frames = nullptr;  // time-domain frames of the inverse STFT with a non-power-of-two length
+    size_t frames_bytes = 0;
     void* pin[2] = {nullptr, nullptr};  // pinned host chunks of the fused float64 upload (double buffer)
     hipEvent_t pin_ev[2] = {nullptr, nullptr};
     bool pin_busy[2] = {false, false};
@@ -192,6 +194,7 @@ extern "C" void ds_destroy(ds_ctx* c) {
     if (c->ws) (void)hipFree(c->ws);
     if (c->io) (void)hipFree(c->io);
     if (c->aux) (void)hipFree(c->aux);
+    if (c->frames) (void)hipFree(c->frames);
     for (int i = 0; i < 2; ++i) {
         if (c->pin[i]) (void)hipHostFree(c->pin[i]);
         if (c->pin_ev[i]) (void)hipEventDestroy(c->pin_ev[i]);
@@ -728,17 +731,13 @@ extern "C" int ds_istft_dev(ds_ctx* c, const ds_c32* stft, int n_bins, int n_fra
     if (W > nfft) return fail(c, DS_ERR_ARG, "ds_istft: window longer than the FFT length");
     if (!is_pow2(nfft) || nfft < kMinFft || nfft > kMaxFft) {
         // (ws, io and aux are all taken -- the division's scratch, the host entry point's staging, the
-        // per-group spectra -- so the frames get a buffer of their own; this route is correct, not tuned)
-        float* frames = nullptr;
-        HIPCHK(c, hipMalloc((void**)&frames, sizeof(float) * (size_t)n_ch * n_frames * W));
-        int rc = istft_any_frames(c, (const float2*)stft, n_bins, n_frames, n_ch, nfft, W, window, scale, frames);
-        if (rc == DS_OK) {
-            IstftOlaArgs o{frames, n_frames, n_ch, W, step, frame_offset, n_frames_total, window, total_length, ld_out, out};
-            rc = launch(c, "istft_ola", k_istft_ola, dim3((unsigned)((total_length + 255) / 256), n_ch), 256, 0, o);
-        }
-        (void)hipStreamSynchronize(c->stream);
-        (void)hipFree(frames);
-        return rc;
+        // per-group spectra -- so the frames live in a fourth context-owned reserve: grown on demand like
+        // the others, no allocation, synchronisation or free per call; this route is correct, not tuned)
+        CHK(reserve(c, &c->frames, &c->frames_bytes, sizeof(float) * (size_t)n_ch * n_frames * W));
+        float* frames = (float*)c->frames;
+        CHK(istft_any_frames(c, (const float2*)stft, n_bins, n_frames, n_ch, nfft, W, window, scale, frames));
+        IstftOlaArgs o{frames, n_frames, n_ch, W, step, frame_offset, n_frames_total, window, total_length, ld_out, out};
+        return launch(c, "istft_ola", k_istft_ola, dim3((unsigned)((total_length + 255) / 256), n_ch), 256, 0, o);
     }
     CHK(check_fft_len(c, nfft, "ds_istft nfft"));
     const float2* tw;

@@ -371,7 +371,11 @@ __global__ __launch_bounds__(NT, P == 1 ? 3 : 2) void k_fir(Args p) {
     }
 }
 
-// 32-bit byte offsets, OOB stores dropped by the range check
-inline bool fits(int64_t n_samples) { return n_samples > 0 && n_samples < ((int64_t)1 << 30) - 8192; }
+// Byte offsets are formed in 32-bit signed arithmetic (4 * sample index) and a NEGATIVE offset is how the zeros
+// in front of the signal are read (the range check sees a huge unsigned number): signals below 2^29 samples.
+// (A wrapped negative register offset whose IMMEDIATE part carries it back over zero inside a wave was seen to
+// return samples from in front of the row -- profiles/r04_fir_16s_blocks.txt; here hop and immediate offsets are
+// multiples of 1024 samples, so a load's total offset is negative exactly when its register part is.)
+inline bool fits(int64_t n_samples) { return n_samples > 0 && n_samples < ((int64_t)1 << 29) - 8192; }
 
 }  // namespace fir4k

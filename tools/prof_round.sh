@@ -4,7 +4,7 @@
 #   strong-scaling job, the window-length sweeps (Welch / STFT incl. the four-step lengths), the API end-to-end times.
 set -u
 TAG=${1:-r04}
-tools/prof_all.sh $TAG
+tools/prof_all.sh $TAG "${2:-welch_h1 welch_h1_1024 fir_bank csm deconv}"
 : > gpurun_out/${TAG}_shard_prediction.jsonl
 for W in welch_h1 welch_h1_1024 fir_bank csm deconv; do
   python3 bench.py --workload $W --steps 100 --warmup 10 --predict-ranks 8 --no-cpu-baseline 2>> gpurun_out/${TAG}_shard_prediction.err | grep '^{' >> gpurun_out/${TAG}_shard_prediction.jsonl
