@@ -1,5 +1,5 @@
 """Every roofline fraction the round reports must follow from the files under profiles/ (VERDICT r2, next 2):
-each profiles/r03_<workload>_rocprofv3_summary.txt holds the rocprofv3 kernel-trace statistics of
+each profiles/r0N_<workload>_rocprofv3_summary.txt (rounds 3 and 4) holds the rocprofv3 kernel-trace statistics of
 `bench.py --workload <workload>` AND the JSON line that very run printed.  Recomputed here: algorithmic
 bytes of one launch / rocprofv3's average duration of the dominant kernel / the peak.
 
@@ -24,7 +24,8 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
-FILES = sorted(glob.glob(os.path.join(ROOT, "profiles", "r03_*_rocprofv3_summary.txt")))
+FILES = sorted(glob.glob(os.path.join(ROOT, "profiles", "r03_*_rocprofv3_summary.txt")) +
+               glob.glob(os.path.join(ROOT, "profiles", "r04_*_rocprofv3_summary.txt")))
 
 
 def _parse(path):
@@ -36,9 +37,18 @@ def _parse(path):
     return (json.loads(line) if line else None), stats
 
 
-def test_round3_profiles_are_committed():
-    names = {os.path.basename(f).split("_rocprofv3")[0][4:] for f in FILES}
-    assert {"welch_h1", "fir_bank", "csm", "deconv"} <= names, names
+def test_profiles_of_rounds_3_and_4_are_committed():
+    for tag in ("r03", "r04"):
+        names = {os.path.basename(f).split("_rocprofv3")[0][4:] for f in FILES if os.path.basename(f).startswith(tag)}
+        assert {"welch_h1", "welch_h1_1024", "fir_bank", "csm", "deconv"} <= names, (tag, names)
+
+
+def _trace_avg_ns(stats, bench_kernel):
+    import bench
+    hints = bench.KERNEL_HINTS.get(bench_kernel, (bench_kernel,))
+    match = [v for k, v in stats.items() for h in hints if h in k]
+    assert match, (bench_kernel, list(stats))
+    return max(match)[1]  # the most-called matching kernel
 
 
 @pytest.mark.parametrize("path", FILES, ids=[os.path.basename(f) for f in FILES])
@@ -47,6 +57,20 @@ def test_roofline_fraction_follows_from_the_committed_trace(path):
     line, stats = _parse(path)
     assert line is not None, "the summary must end with the bench line of the traced run"
     roof = line["roofline"]
+    if roof["bound"] == "mfma":
+        # config 4 since round 4: algorithmic flops of the step / step time / fp32 matrix peak.  The step
+        # cannot be shorter than its two kernels in the trace, nor longer than them plus the brackets and the launch gaps.
+        k_ns = _trace_avg_ns(stats, "stft") + _trace_avg_ns(stats, "csm_gemm")
+        step_ns = line["step_event_ms"] * 1e6
+        assert k_ns * 0.985 <= step_ns <= k_ns + 15000.0, (step_ns, k_ns)
+        assert abs(roof["frac"] - roof["algorithmic_flops_per_step"] / (step_ns * 1e-9) / 1e12 / roof["peak"]) < 1e-9
+        assert roof["peak"] == 157.3 and abs(roof["algorithmic_flops_per_step"] - (513 * 64 * 64 * 1000 * 8 + 64 * 1000 * 25600)) < 1.0
+        hbm = roof["dominant_kernel_hbm"]
+        avg_ns = _trace_avg_ns(stats, roof["kernel"])
+        assert avg_ns * 0.985 <= roof["kernel_avg_ms"] * 1e6 <= avg_ns + 6500.0
+        assert abs(hbm["frac"] - roof["algorithmic_per_launch"] / (roof["kernel_avg_ms"] * 1e-3) / 1e9 / 8000.0) < 1e-9
+        assert 3.0 < roof["traffic"] / line["algorithmic_bytes_per_step"] < 6.0  # the spectrogram crosses HBM twice
+        return
     hints = bench.KERNEL_HINTS.get(roof["kernel"], (roof["kernel"],))
     match = [v for k, v in stats.items() for h in hints if h in k]
     assert match, (roof["kernel"], list(stats))
@@ -59,3 +83,41 @@ def test_roofline_fraction_follows_from_the_committed_trace(path):
     # and the line is self-consistent
     assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-9
     assert roof["kernel_avg_ms"] < line["ms_per_step"] + 0.0065  # (back-to-back steps overlap their launch latencies; a bracket does not)
+
+
+def test_default_line_carries_the_other_configs_and_the_ceiling():
+    """the line `python3 bench.py` prints (traced in profiles/r04_welch_h1_*) has the
+    headline fields, `roofline.ceiling_ms` beside `kernel_avg_ms` -- the VALU-only time of profiles/r04_welch_ceiling.txt --
+    and "workloads": configs 3, 4, 5 and the 1024-sample window, each with its step, dominant kernel, fraction by
+    SURVEY 8(d)'s definition, traffic ratio, parity against the oracle and a CPU leg; every kernel time agrees with the
+    trace of that very run."""
+    path = os.path.join(ROOT, "profiles", "r04_welch_h1_rocprofv3_summary.txt")
+    line, stats = _parse(path)
+    roof = line["roofline"]
+    assert line["config"]["workload"].startswith("welch_h1") and roof["kernel"] == "welch4096_main"
+    assert roof["ceiling_ms"] == 0.0645 and roof["ceiling_ms"] < roof["kernel_avg_ms"]
+    text = open(os.path.join(ROOT, "profiles", "r04_welch_ceiling.txt")).read()
+    assert "roofline.ceiling_ms = 0.0645" in text and "VALU only" in text
+    assert abs(roof["ceiling_frac"] - roof["algorithmic_per_launch"] / 0.0645e-3 / 1e9 / 8000.0) < 1e-9
+    wl = line["workloads"]
+    assert set(wl) == {"welch_h1_1024", "fir_bank", "csm", "deconv"}
+    alg = {"welch_h1_1024": (65 * 2**20 * 4 + 513 * 64 * 12, 1e9, 8000.0), "fir_bank": (4429709440, 1e9, 8000.0),
+           "deconv": (134250504, 1e9, 8000.0)}
+    for name, e in wl.items():
+        for key in ("ms_per_step", "kernel", "kernel_avg_ms", "frac", "frac_definition", "traffic_ratio",
+                    "parity_rel_max_vs_oracle", "cpu_baseline", "bound", "achieved", "peak"):
+            assert key in e, (name, key)
+        assert e["parity_rel_max_vs_oracle"] < 1e-6 and e["cpu_baseline"]["value"] > 0 and "sample" in e["cpu_baseline"]
+        assert e["kernel_avg_ms"] <= e["ms_per_step"] + 0.0065 and 1.0 <= e["traffic_ratio"] < 6.0
+        avg_ns = _trace_avg_ns(stats, e["kernel"])
+        # (the entry's events sample every 4th launch of 40 steps; the trace averages all launches of the run, warm-up included)
+        assert avg_ns * 0.95 <= e["kernel_avg_ms"] * 1e6 <= avg_ns * 1.05 + 6500.0, (name, e["kernel_avg_ms"], avg_ns)
+        if name == "csm":
+            assert e["bound"] == "mfma" and e["peak"] == 157.3 and 0.3 < e["frac"] < 1.0
+            assert abs(e["frac"] - 18448384000.0 / (e["step_event_ms"] * 1e-3) / 1e12 / 157.3) < 1e-9
+            assert 0.0 < e["executed_bf16_frac"] < 1.0 and set(e["kernels_hbm_frac"]) == {"stft", "csm_gemm"}
+        else:
+            nbytes, unit, peak = alg[name]
+            assert e["bound"] == "hbm" and e["peak"] == peak
+            assert abs(e["frac"] - nbytes / (e["kernel_avg_ms"] * 1e-3) / unit / peak) < 1e-9, name
+    assert line["workloads_wall_s"] < 120.0
