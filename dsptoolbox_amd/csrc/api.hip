@@ -31,6 +31,7 @@
 #include "kernels_welch1024.hpp"
 #include "kernels_welch8192.hpp"
 #include "kernels_welch16384.hpp"
+#include "kernels_welch_long.hpp"
 #include "kernels_welch_f64.hpp"
 #include "kernels_stft_any.hpp"
 #include "kernels_fir_stream.hpp"
@@ -62,6 +63,7 @@ struct ds_ctx {
     float2* w4_tables = nullptr;  // welch4096::host_tables()
     float2* stft_dif_tw[2] = {nullptr, nullptr};  // stft4k::host_twiddles(8192 / 16384)
     float2* fir16k_tables = nullptr;  // fir16k::host_tables()
+    float2* wl_tables[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // welchl::host_tables(R), R = 4, 8, 16, 32, 64
     float2* deconv8k_tables = nullptr;  // deconv8k::host_tables()
     float2* stft1k_tables = nullptr;  // stft1k::host_tables<1024>()
     float2* stft_wave_tables[3] = {nullptr, nullptr, nullptr};  // stft1k::host_tables<512>(), <256>(), <2048>()
@@ -181,6 +183,8 @@ extern "C" void ds_destroy(ds_ctx* c) {
     for (float2* t : c->stft_dif_tw)
         if (t) (void)hipFree(t);
     if (c->fir16k_tables) (void)hipFree(c->fir16k_tables);
+    for (auto t : c->wl_tables)
+        if (t) (void)hipFree(t);
     if (c->deconv8k_tables) (void)hipFree(c->deconv8k_tables);
     if (c->stft1k_tables) (void)hipFree(c->stft1k_tables);
     for (float2* t : c->stft_wave_tables)
@@ -1253,6 +1257,98 @@ static int welch16384_run(ds_ctx* c, const float* x, int n_cx, int64_t ldx, cons
     CHK(launch(c, "welch_finish", k_welch_finish, dim3((unsigned)((total + 63) / 64)), 256, 0, f));
     return DS_OK;
 }
+// Windows of 2^15 ... 2^18 samples: decimation in frequency into R = W / 4096 class sequences (k_dif), the headline
+// kernel's loop on them (k_xc / k_yc), fold across the classes, finish (kernels_welch_long.hpp).
+// y == nullptr: auto spectra of x only (ds_welch_psd), the result in `coh`.
+static bool welch_long_applies(const ds_ctx* c, int W, int n_ch_total, int64_t n_samples, int n_frames, int hop, int average) {
+    if (!c || c->cfg.welch_generic || average != DS_AVG_MEAN || !welchl::classes_of(W) || W < c->cfg.welch_long_min) return false;
+    if (hop <= 0 || hop > W || !welchl::buf_fits(n_samples, n_frames, hop, W)) return false;
+    // the class sequences: one complex value per sample of every frame pair (8 bytes per sample at 50 % overlap)
+    const int64_t pairs = ((int64_t)frames_to_visit(n_samples, hop, n_frames) + 1) / 2;
+    return (int64_t)n_ch_total * pairs * W * 8 <= ((int64_t)16 << 30);
+}
+static int welch_long_run(ds_ctx* c, const float* x, int n_cx, int64_t ldx, const float* y, int n_cy, int64_t ldy,
+                          int64_t n_samples, int W, int hop, int n_frames, const float* window, int detrend, int mode,
+                          int amp_sqrt, double norm_scale, double factor, int halve_edges, float2* tf, float* coh,
+                          int kind = 0) {  // kind 0: tf + coherence, 1: auto spectra of x (y null), 2: cross spectra in tf
+    namespace wl = welchl;
+    const bool auto_only = kind == 1;
+    if (!x || !window || (!auto_only && !y)) return fail(c, DS_ERR_ARG, "ds_welch: null argument");
+    if (!auto_only && n_cx != 1 && n_cx != n_cy) return fail(c, DS_ERR_ARG, "ds_welch_tf: one input channel, or one per output channel");
+    if (n_cx <= 0 || n_samples <= 0 || n_frames <= 0 || ldx < n_samples || (!auto_only && (n_cy <= 0 || ldy < n_samples)))
+        return fail(c, DS_ERR_ARG, "ds_welch: bad shape");
+    if (!auto_only && kind == 0 && (mode < DS_TF_H1 || mode > DS_TF_H3)) return fail(c, DS_ERR_ARG, "welch: unsupported transfer function type");
+    const int R = wl::classes_of(W);
+    int lgR = 0;
+    while ((1 << lgR) < R) ++lgR;
+    if (!c->w4_tables) {
+        std::vector<float2> h;
+        welch4096::host_tables(h);
+        CHK(upload_table_fwd(c, &c->w4_tables, h));
+    }
+    float2** slot = &c->wl_tables[lgR - 2];
+    if (!*slot) {
+        std::vector<float2> h;
+        wl::host_tables(R, h);
+        CHK(upload_table_fwd(c, slot, h));
+    }
+    const int nf = frames_to_visit(n_samples, hop, n_frames), nb = W / 2 + 1;
+    const int n_out = auto_only ? n_cx : n_cy;  // channels that are accumulated
+    wl::Plan pl = wl::plan(nf, n_out, R);
+    const size_t seq = (size_t)pl.n_pairs * W;  // complex values per channel
+    CHK(reserve(c, &c->ws, &c->ws_bytes,
+                Carver::pad(sizeof(float2) * seq * n_cx) + (auto_only ? 0 : Carver::pad(sizeof(float2) * seq * n_cy)) +
+                    (auto_only ? 0 : Carver::pad(sizeof(float2) * seq * n_cx) + Carver::pad(sizeof(float) * seq * n_cx) +
+                                         Carver::pad(sizeof(float) * (size_t)pl.n_chunks * n_cx * nb) +
+                                         Carver::pad(sizeof(float2) * (size_t)pl.n_chunks * n_cy * nb) +
+                                         Carver::pad(sizeof(float2) * (size_t)pl.n_chunks * n_cy * W)) +
+                    Carver::pad(sizeof(float) * (size_t)pl.n_chunks * n_out * nb) + Carver::pad(sizeof(float) * (size_t)pl.n_chunks * n_out * W)));
+    Carver cv(c->ws);
+    float2* bx = cv.take<float2>(seq * n_cx);
+    float2* by = auto_only ? nullptr : cv.take<float2>(seq * n_cy);
+    float2* xs = auto_only ? nullptr : cv.take<float2>(seq * n_cx);
+    float* pxu = auto_only ? nullptr : cv.take<float>(seq * n_cx);
+    float* psx = auto_only ? nullptr : cv.take<float>((size_t)pl.n_chunks * n_cx * nb);
+    float2* pxy = auto_only ? nullptr : cv.take<float2>((size_t)pl.n_chunks * n_cy * nb);
+    float2* tu = auto_only ? nullptr : cv.take<float2>((size_t)pl.n_chunks * n_cy * W);
+    float* pyy = cv.take<float>((size_t)pl.n_chunks * n_out * nb);
+    float* pu = cv.take<float>((size_t)pl.n_chunks * n_out * W);
+    wl::Args ax{x, n_samples, ldx, n_cx, hop, nf, pl.n_pairs, detrend, pl.n_chunks, R, lgR, window, c->w4_tables, *slot,
+                bx, (float4*)xs, pxu, pxy, pyy, psx, n_cx, tu, pu};
+    auto dif = [&](const wl::Args& a, int n_ch) {
+        const dim3 grid(wl::M / wl::NT, pl.n_pairs, n_ch);
+        switch (R) {
+            case 4: return launch(c, "welch_long_dif", wl::k_dif<4>, grid, wl::NT, 0, a);
+            case 8: return launch(c, "welch_long_dif", wl::k_dif<8>, grid, wl::NT, 0, a);
+            case 16: return launch(c, "welch_long_dif", wl::k_dif<16>, grid, wl::NT, 0, a);
+            case 32: return launch(c, "welch_long_dif", wl::k_dif<32>, grid, wl::NT, 0, a);
+            default: return launch(c, "welch_long_dif", wl::k_dif<64>, grid, wl::NT, 0, a);
+        }
+    };
+    CHK(dif(ax, n_cx));
+    const dim3 fold_grid((nb + 255) / 256, pl.n_chunks * n_out);
+    if (auto_only) {
+        CHK(launch(c, "welch_long_main", wl::k_yc<true>, dim3((unsigned)(pl.n_chunks * n_cx * R)), wl::NT, wl::LDS_BYTES, ax));
+        CHK(launch(c, "welch_long_fold", wl::k_fold<true>, fold_grid, 256, 0, ax));
+        WelchFinArgs f{pyy, nullptr, nullptr, pl.n_chunks, pl.n_chunks, n_cx, 0, 1, 0,
+                       FinishPar{norm_scale / (double)n_frames, factor, halve_edges, amp_sqrt, nb}, nullptr, coh};
+        return launch(c, "welch_finish", k_welch_finish, dim3((unsigned)(((int64_t)nb * n_cx + 63) / 64)), 256, 0, f);
+    }
+    CHK(launch(c, "welch_long_x", wl::k_xc, dim3((unsigned)(pl.n_pairs * R * n_cx)), wl::NT, wl::LDS_BYTES, ax));
+    CHK(launch(c, "welch_long_pxsum", wl::k_px_sum, dim3((nb + 255) / 256, pl.n_chunks, n_cx), 256, 0, ax));
+    wl::Args ay = ax;
+    ay.sig = y;
+    ay.ld = ldy;
+    ay.n_ch = n_cy;
+    ay.b = by;
+    CHK(dif(ay, n_cy));
+    CHK(launch(c, "welch_long_main", wl::k_yc<false>, dim3((unsigned)(pl.n_chunks * n_cy * R)), wl::NT, wl::LDS_BYTES, ay));
+    CHK(launch(c, "welch_long_fold", wl::k_fold<false>, fold_grid, 256, 0, ay));
+    WelchFinArgs f{psx, pxy, pyy, pl.n_chunks, pl.n_chunks, n_cx, n_cy, kind, mode,
+                   FinishPar{norm_scale / (double)n_frames, factor, halve_edges, amp_sqrt, nb}, tf, coh};
+    return launch(c, "welch_finish", k_welch_finish, dim3((unsigned)(((int64_t)nb * n_cy + 63) / 64)), 256, 0, f);
+}
+
 static int welch16384_psd_run(ds_ctx* c, const float* x, int n_cx, int64_t ldx, int64_t n_samples, int hop,
                               int n_frames, const float* window, int detrend, int amp_sqrt, double norm_scale,
                               double factor, int halve_edges, float* psd) {
@@ -1434,6 +1530,9 @@ extern "C" int ds_welch_tf_dev(ds_ctx* c, const float* x, int n_cx, int64_t ldx,
         return welch4096_run(c, x, n_cx, ldx, y, n_cy, ldy, n_samples, hop, n_frames, window, detrend, mode,
                              amp_sqrt, norm_scale, factor, halve_edges, (float2*)tf, coh);
     const bool no1k = c && c->cfg.welch_generic;
+    if ((n_cx == 1 || n_cx == n_cy) && welch_long_applies(c, W, n_cx + n_cy, n_samples, n_frames, hop, average))
+        return welch_long_run(c, x, n_cx, ldx, y, n_cy, ldy, n_samples, W, hop, n_frames, window, detrend, mode, amp_sqrt,
+                              norm_scale, factor, halve_edges, (float2*)tf, coh);
     if (c && W == 16384 && (n_cx == 1 || n_cx == n_cy) && average == DS_AVG_MEAN && !no1k &&
         welch16k::buf_fits(n_samples, n_frames, hop))
         return welch16384_run(c, x, n_cx, ldx, y, n_cy, ldy, n_samples, hop, n_frames, window, detrend, mode,
@@ -1637,6 +1736,9 @@ extern "C" int ds_welch_psd_dev(ds_ctx* c, const float* x, int n_cx, int64_t ldx
                                 int halve_edges, float* psd) {
     if (!psd) return fail(c, DS_ERR_ARG, "ds_welch_psd: null output");
     const bool no1k = c && c->cfg.welch_generic;
+    if (welch_long_applies(c, W, n_cx, n_samples, n_frames, hop, average))
+        return welch_long_run(c, x, n_cx, ldx, nullptr, 0, 0, n_samples, W, hop, n_frames, window, detrend, 0, amp_sqrt,
+                              norm_scale, factor, halve_edges, nullptr, psd, 1);
     if (c && W == 16384 && average == DS_AVG_MEAN && !no1k && welch16k::buf_fits(n_samples, n_frames, hop))
         return welch16384_psd_run(c, x, n_cx, ldx, n_samples, hop, n_frames, window, detrend, amp_sqrt,
                                   norm_scale, factor, halve_edges, psd);
@@ -1672,6 +1774,9 @@ static int welch_csd_dev(ds_ctx* c, const float* x, const float* y, int n_ch, in
         if (W == 4096 && !c->cfg.no_welch4096)
             return welch4096_run(c, x, n_ch, ld, y, n_ch, ld, n_samples, hop, n_frames, window, detrend, DS_TF_H1,
                                  amp_sqrt, norm_scale, factor, halve_edges, (float2*)csd, nullptr, 2);
+        if (welch_long_applies(c, W, 2 * n_ch, n_samples, n_frames, hop, average))
+            return welch_long_run(c, x, n_ch, ld, y, n_ch, ld, n_samples, W, hop, n_frames, window, detrend, DS_TF_H1, amp_sqrt,
+                                  norm_scale, factor, halve_edges, (float2*)csd, nullptr, 2);
         if (W == 16384 && welch16k::buf_fits(n_samples, n_frames, hop))
             return welch16384_run(c, x, n_ch, ld, y, n_ch, ld, n_samples, hop, n_frames, window, detrend, DS_TF_H1,
                                   amp_sqrt, norm_scale, factor, halve_edges, (float2*)csd, nullptr, 2);

@@ -28,6 +28,8 @@ struct ds_config {
     // ---- tuning overrides (0 = the built-in choice) ------------------------------------------------
     int stft_ct = 0, stft_fpw = 0, stft4k_chunks = 0, istft_fpw = 0;
     int welch_chunks = 0, welch1k_chunks = 0;
+    int welch_long_min = 16384;   // DSPTOOLBOX_AMD_WELCH_LONG_MIN: smallest window (16384 ... 262144) on kernels_welch_long.hpp
+                                  //   (32768: 16384-sample windows on kernels_welch16384.hpp, 0.45 against 0.36 ms on the headline shape)
     int fir_block = 0, fir_chunks = 0, fir_split = 0;
     size_t bluestein_cache_bytes = (size_t)256 << 20;  // DSPTOOLBOX_AMD_BLUESTEIN_CACHE_MB
 
@@ -69,6 +71,7 @@ struct ds_config {
         g.istft_fpw = num("DSPTOOLBOX_AMD_ISTFT_FPW");
         g.welch_chunks = num("DSPTOOLBOX_AMD_WELCH_CHUNKS");
         g.welch1k_chunks = num("DSPTOOLBOX_AMD_WELCH1K_CHUNKS");
+        if (num("DSPTOOLBOX_AMD_WELCH_LONG_MIN") >= 16384) g.welch_long_min = num("DSPTOOLBOX_AMD_WELCH_LONG_MIN");
         g.fir_block = num("DSPTOOLBOX_AMD_FIR_BLOCK");
         g.fir_chunks = num("DSPTOOLBOX_AMD_FIR_CHUNKS");
         g.fir_split = num("DSPTOOLBOX_AMD_FIR_SPLIT");
