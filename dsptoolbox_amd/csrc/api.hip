@@ -32,6 +32,7 @@
 #include "kernels_welch8192.hpp"
 #include "kernels_welch16384.hpp"
 #include "kernels_welch_long.hpp"
+#include "kernels_stft_long.hpp"
 #include "kernels_welch_f64.hpp"
 #include "kernels_stft_any.hpp"
 #include "kernels_fir_stream.hpp"
@@ -525,6 +526,48 @@ extern "C" int ds_stft_r2c_dev(ds_ctx* c, const float* x, int64_t n_samples, int
     if (!is_pow2(nfft) || nfft < kMinFft)  // numpy's rfft(n=...) takes any n: crop or pad
         return stft_any(c, x, n_samples, n_ch, ld, W, hop, nfft, pad_front, n_frames, window, detrend, scale,
                         edge_scale, power, (float2*)out);
+    // 2^15 ... 2^18 points: one decimation-in-frequency pass, then the 4096-point register transform per class
+    // (kernels_stft_long.hpp)
+    if (const int R = stftl::classes_of(nfft); R && W <= nfft && (W == nfft || !detrend) && !c->cfg.stft_generic) {
+        int lgR = 0;
+        while ((1 << lgR) < R) ++lgR;
+        if (!c->w4_tables) {
+            std::vector<float2> h;
+            welch4096::host_tables(h);
+            CHK(upload_table_fwd(c, &c->w4_tables, h));
+        }
+        float2** slot = &c->wl_tables[lgR - 2];
+        if (!*slot) {
+            std::vector<float2> h;
+            welchl::host_tables(R, h);
+            CHK(upload_table_fwd(c, slot, h));
+        }
+        const int n_pc = (n_ch + 1) / 2, n_groups = (n_ch + 15) / 16;
+        const int per = stftl::frames_per_group(n_ch, nfft, n_frames);
+        CHK(reserve(c, &c->ws, &c->ws_bytes, Carver::pad(sizeof(float2) * (size_t)n_pc * per * nfft)));
+        Carver cv(c->ws);
+        float2* b = cv.take<float2>((size_t)n_pc * per * nfft);
+        for (int f0 = 0; f0 < n_frames; f0 += per) {
+            const int nf = std::min(per, n_frames - f0);
+            // chunks of (frame, kind) units: two rounds of one workgroup (8 channels) per CU, as for 8192 / 16384 points
+            const int n_units = nf * (R - 1);
+            int n_chunks = std::max(1, std::min(n_units, 256 / std::max(1, std::min(256, n_groups))));
+            if (c->cfg.stft4k_chunks > 0) n_chunks = std::min(n_units, c->cfg.stft4k_chunks);
+            stftl::Args a{x, n_samples, ld, pad_front, n_ch, W, hop, n_frames, detrend, n_chunks, n_groups, R, lgR, f0, nf,
+                          window, c->w4_tables, *slot, scale, edge_scale, b, (float2*)out};
+            const dim3 gd(16, (unsigned)nf, (unsigned)n_pc);
+            switch (R) {
+                case 8: CHK(launch(c, "stft_long_dif", stftl::k_sdif<8>, gd, 256, 0, a)); break;
+                case 16: CHK(launch(c, "stft_long_dif", stftl::k_sdif<16>, gd, 256, 0, a)); break;
+                case 32: CHK(launch(c, "stft_long_dif", stftl::k_sdif<32>, gd, 256, 0, a)); break;
+                default: CHK(launch(c, "stft_long_dif", stftl::k_sdif<64>, gd, 256, 0, a)); break;
+            }
+            const dim3 grid((unsigned)stft4k::grid_size(n_groups, n_chunks));
+            CHK(power ? launch(c, "stft@long", stftl::k_stft_cls<true>, grid, stftl::NT, stftl::LDS_BYTES, a)
+                      : launch(c, "stft@long", stftl::k_stft_cls<false>, grid, stftl::NT, stftl::LDS_BYTES, a));
+        }
+        return DS_OK;
+    }
     if (nfft > kMaxFft && is_pow2(nfft)) {  // four-step transform per frame pair
         CHK(reserve(c, &c->ws, &c->ws_bytes, stft_big_ws(n_ch, n_frames, nfft)));
         Carver cv(c->ws);
@@ -2458,6 +2501,14 @@ static int fir4k_run(ds_ctx* c, const float* x, int n_ch, int64_t ldx, int64_t n
 
 static int fir_once(ds_ctx* c, const float* x, int n_ch, int64_t ldx, int64_t n_samples,
                     const float* taps, int n_filt, int n_taps, float* y, int64_t ld_y) {
+    // a signal shorter than the filter (or a tiny one): the direct sum in float64 -- no rounding floor set by the block's
+    // peak, which is what an FFT convolution leaves on an output far below (peak of the block) x (size of the taps)
+    // (kernels_freqz.hpp; DESIGN section 2, limit (x)).  At most 2^28 multiply-adds.
+    if ((n_samples < n_taps || n_samples <= 512) && n_samples * std::min<int64_t>(n_samples, n_taps) * n_ch * n_filt <= ((int64_t)1 << 28) &&
+        n_filt <= 65535 && n_ch <= 65535) {
+        freqz::DirectArgs a{x, taps, n_samples, ldx, ld_y, n_ch, n_taps, y};
+        return launch(c, "fir@direct_f64", freqz::k_fir_direct, dim3((unsigned)((n_samples + 255) / 256), n_ch, n_filt), 256, 0, a);
+    }
     if (n_taps >= c->cfg.fir4k_min_taps && fir4k::partitions(n_taps) <= 2 && fir4k::fits(n_samples) && n_filt <= 16384)
         return fir4k_run(c, x, n_ch, ldx, n_samples, taps, n_filt, n_taps, y, ld_y);
     const int N = fir_block_len(n_taps, c->cfg.fir_block);

@@ -720,6 +720,22 @@ def test_fir_one_and_two_tap_filters():
             assert y.shape == r.shape and relmax(y, r) < TOL, (T, name, relmax(y, r))
 
 
+def test_fir_signal_shorter_than_the_filter():
+    """DESIGN section 2, limit (x), closed for small problems: 4097 taps with near-zero leading taps on 100 ... 3000
+    samples.  The FFT routes leave 3-4e-5 of the (tiny) output there; such calls take the direct float64 sum."""
+    from dsptoolbox_amd._lib import get_context
+    ctx = get_context()
+    rng = np.random.default_rng(4097)
+    for n, n_ch in ((100, 2), (1000, 1), (3000, 3), (300, 1)):
+        x = rng.standard_normal((n, n_ch)) * 0.1
+        taps = [rng.standard_normal(4097) * np.hanning(4097) / 64.0 for _ in range(2)]
+        ctx.routes()
+        y = backend.fir_filter_bank(x, taps, backend.DS_FB_PARALLEL)
+        assert ctx.routes() == {"fir@direct_f64"}
+        for k in range(2):
+            assert relmax(y[k], orc.lfilter_fir(taps[k], x)) < TOL, (n, n_ch, k)
+
+
 def test_fir_long_filters_vs_oracle():
     """> 8193 taps: overlap-save on the four-step FFT, several blocks, bank modes."""
     rng = np.random.default_rng(91)
@@ -1508,6 +1524,48 @@ def test_stft_8192_and_16384_frame_kernels_vs_oracle():
     print("stft 8192 / 16384 frame kernels worst rel-max", worst)
 
 
+def test_stft_long_frames_on_the_register_transform():
+    """Frames of 2^15 ... 2^18 points (kernels_stft_long.hpp): one decimation-in-frequency pass per frame and channel
+    pair, then the 4096-point register transform per class, mirror classes r / R - r read out together.  Odd and even
+    channel counts (narrow / wide stores, idle teams, a last pair with one channel), one frame and several, padding,
+    detrend (bin 0), amplitude / power scalings, shorter windows zero-padded to the transform; the routes are asserted."""
+    from dsptoolbox_amd._lib import get_context
+    ctx = get_context()
+    rng = np.random.default_rng(32768)
+    worst = 0.0
+    for n_ch, n, W, ov, pad, det, sc in (
+            (1, 40000, 2**15, 50, True, False, SpectrumScaling.FFTBackward),
+            (3, 150011, 2**15, 50, True, True, SpectrumScaling.AmplitudeSpectrum),
+            (4, 200000, 2**16, 75, False, False, SpectrumScaling.PowerSpectralDensity),
+            (5, 300000, 2**16, 0, True, True, SpectrumScaling.PowerSpectrum),
+            (18, 140000, 2**15, 25, False, False, SpectrumScaling.FFTOrthogonal),
+            (20, 100000, 2**15, 50, True, False, SpectrumScaling.FFTBackward)):
+        x = rng.standard_normal((n, n_ch)) * 0.3 + 0.05
+        ctx.routes()
+        t, f, st = backend._stft(x, 48000, W, Window.Hann, ov, None, det, pad, sc)
+        assert {"stft_long_dif", "stft@long"} <= ctx.routes()
+        rt, rf, rs = orc.stft(x, 48000, W, "hann", ov, None, det, pad, sc.name)
+        assert st.shape == rs.shape and np.allclose(t, rt) and np.array_equal(f, rf)
+        if det:
+            assert np.max(np.abs(st[0])) <= 1e-6 * np.max(np.abs(rs))
+        e = relmax(st, rs)
+        worst = max(worst, e)
+        assert e < TOL, (W, n_ch, n, ov, pad, det, sc, e)
+    # (the reference's window stops at 2^16 samples, its transform length does not)
+    for W, nfft, det, route in ((8192, 2**15, False, True), (2**15, 2**16, False, True), (4096, 2**15, True, False),
+                                (2**16, 2**17, False, True), (2**16, 2**18, False, True)):
+        x = rng.standard_normal((150000 if nfft < 2**17 else 300000, 3)) * 0.3 + 0.05
+        ctx.routes()
+        t, f, st = backend._stft(x, 48000, W, Window.Hann, 50, nfft, det, True, SpectrumScaling.FFTBackward)
+        assert ("stft@long" in ctx.routes()) == route  # (detrend of a zero-padded frame: the four-step path)
+        rt, rf, rs = orc.stft(x, 48000, W, "hann", 50, nfft, det, True, "FFTBackward")
+        assert st.shape == rs.shape
+        e = relmax(st, rs)
+        worst = max(worst, e)
+        assert e < TOL, (W, nfft, det, e)
+    print("stft long frames worst rel-max", worst)
+
+
 def test_stft_and_csm_long_windows_vs_oracle():
     rng = np.random.default_rng(5)
     n = 200000
@@ -2162,8 +2220,10 @@ SWITCH_ROUTES = [
      [lambda: test_fir_golden(), lambda: test_fir_16k_blocks_vs_oracle(4097, 12288 * 3, 2)], {"fir@generic"},
      {"fir@4k_p1", "fir@4k_p2", "fir@16k", "fir@16k_ragged"}),
     ({"DSPTOOLBOX_AMD_FIR_4K": "0"}, [lambda: test_fir_golden(), lambda: test_fir_16k_blocks_vs_oracle(4097, 12288 * 3, 2),
-                                      lambda: test_fir_bank_4097_taps()], {"fir@16k_ragged"}, {"fir@4k_p1", "fir@4k_p2"}),
+                                      lambda: test_fir_16k_blocks_vs_oracle(4097, 5000, 5),
+                                      lambda: test_fir_bank_4097_taps()], {"fir@16k_ragged", "fir@direct_f64"}, {"fir@4k_p1", "fir@4k_p2"}),
     ({"DSPTOOLBOX_AMD_FIR_4K": "1"}, [lambda: test_fir_golden(), lambda: test_fir_one_and_two_tap_filters()], {"fir@4k_p1"}, set()),
+    ({"DSPTOOLBOX_AMD_STFT_GENERIC": "1"}, [lambda: test_stft_and_csm_long_windows_vs_oracle()], set(), {"stft@long", "stft_long_dif"}),
     ({"DSPTOOLBOX_AMD_ISTFT_FUSED": "0"}, [lambda: test_istft_golden_and_round_trip("istft")], {"istft_ola"},
      {"istft@wave", "istft@4k", "istft@fused"}),
     ({"DSPTOOLBOX_AMD_ISTFT_WAVE": "0"}, [lambda: test_istft_golden_and_round_trip("istft")], set(), {"istft@wave"}),

@@ -15,9 +15,10 @@ from dsptoolbox_amd.standard.enums import SpectrumScaling, Window  # noqa: E402
 ctx = get_context()
 n, n_ch = 512000, 64
 x = np.random.default_rng(0).standard_normal((n, n_ch))
-sizes = [int(a) for a in sys.argv[1:]] or [256, 512, 1024, 2048, 4096]
-for W in sizes:
-    pl = backend._stft_plan(x, 48000, W, Window.Hann, 50, None, True, SpectrumScaling.FFTBackward)
+sizes = sys.argv[1:] or ["256", "512", "1024", "2048", "4096"]  # "W" or "W:nfft"
+for arg in sizes:
+    W, nfft = (int(a) for a in arg.split(":")) if ":" in arg else (int(arg), None)
+    pl = backend._stft_plan(x, 48000, W, Window.Hann, 50, nfft, True, SpectrumScaling.FFTBackward)
     d_x = DeviceBuffer.from_array(ctx, pl["xp"])
     d_w = DeviceBuffer.from_array(ctx, pl["w32"])
     nbytes_out = pl["B"] * pl["n_frames"] * pl["n_ch"] * 8
@@ -38,6 +39,6 @@ for W in sizes:
     ctx.sync()
     ms = (time.perf_counter() - t0) / K * 1e3
     tot = pl["xp"].nbytes + nbytes_out
-    print(f"W {W:5d}: {ms:7.3f} ms  frames {pl['n_frames']:6d}  {tot / 1e6:7.1f} MB  {tot / ms / 1e9:5.2f} TB/s", flush=True)
+    print(f"W {arg:>13s}: {ms:7.3f} ms  frames {pl['n_frames']:6d}  {tot / 1e6:7.1f} MB  {tot / ms / 1e9:5.2f} TB/s", flush=True)
     for d in (d_x, d_w, d_s):
         d.free()
