@@ -178,7 +178,7 @@ def _welch(x, y, fs_hz: int, window_type, window_length_samples: int, overlap_pe
 # Arithmetic of the transfer-function estimate behind the reference-shaped API
 # (transfer_functions.compute_transfer_function): "auto" takes the float64 route
 # (ds_welch_tf_x64: float64 transforms, sums and finish, the reference's own precision) when the
-# problem is small -- frame spectra of all channels <= 64 MB, window <= 16384 (median averaging: at
+# problem is small -- frame spectra of all channels <= 64 MB, window <= 262144 (median averaging: at
 # most 4096 frames) -- or when it is SHORT: fewer than 128 frames (and <= 1 GB of frame spectra), where
 # an fp32 estimate has too few frames to average its transform rounding down (the two sweep cases of
 # round 2 that reached 1.1e-6 / 1.8e-6 in the coherence had 98 and 110 frames of 8192 samples: they are
@@ -187,12 +187,13 @@ def _welch(x, y, fs_hz: int, window_type, window_length_samples: int, overlap_pe
 # DSPTOOLBOX_AMD_TF_PRECISION.  backend.welch_transfer_function itself defaults to "f32".
 TF_PRECISION = os.environ.get("DSPTOOLBOX_AMD_TF_PRECISION", "auto")
 _X64_AUTO_BYTES = 64 << 20
+_X64_MAX_WINDOW = 262144  # (16384 until round 4: k_frames_cls / k_split of kernels_welch_f64.hpp carry it to the reference's limit)
 _X64_SHORT_BYTES = 256 << 20  # (1 GB in round 3: 64 channels x 100 frames of 8192 samples took the slow route)
 
 
 # The same for the Welch spectra themselves (get_spectrum with the Welch method: ds_welch_psd / ds_welch_csd) and
 # the cross-spectral matrix (get_csm: ds_csm): "auto" sends SHORT estimates -- fewer than 128 frames, frame
-# spectra <= 256 MB, window <= 16384; the matrix: mean averaging and up to 64 channels -- through
+# spectra <= 256 MB, window <= 262144; the matrix: mean averaging and up to 64 channels -- through
 # ds_welch_spec_x64 / ds_csm_x64; "f32" keeps the fp32 kernels for every shape.  Environment:
 # DSPTOOLBOX_AMD_SPEC_PRECISION.  (tests/sweeps/edge_welch.py, round 4: fp32 cross spectra and matrices of
 # one to five frames reach 2-3e-6 of the largest element under the amplitude scalings.)
@@ -202,7 +203,7 @@ SPEC_PRECISION = os.environ.get("DSPTOOLBOX_AMD_SPEC_PRECISION", "auto")
 def _x64_short(precision, n_spectra: int, n_frames: int, W: int, average: str) -> bool:
     """Does a SHORT estimate of `n_spectra` channel spectra take the float64 route?"""
     assert precision in ("auto", "f32"), "DSPTOOLBOX_AMD_SPEC_PRECISION: 'auto' or 'f32'"
-    if precision != "auto" or W > 16384 or n_frames >= 128:
+    if precision != "auto" or W > _X64_MAX_WINDOW or n_frames >= 128:
         return False
     if average != "mean" and n_frames > 4096:
         return False
@@ -210,10 +211,10 @@ def _x64_short(precision, n_spectra: int, n_frames: int, W: int, average: str) -
 
 
 def _tf_x64_applies(precision, n_cx: int, n_cy: int, n_frames: int, W: int, average: str) -> bool:
-    ok = W <= 16384 and (average == "mean" or n_frames <= 4096)
+    ok = W <= _X64_MAX_WINDOW and (average == "mean" or n_frames <= 4096)
     if precision == "f64":
         if not ok:
-            raise NotImplementedError("the float64 route covers windows up to 16384 (median: up to 4096 frames)")
+            raise NotImplementedError("the float64 route covers windows up to 262144 (median: up to 4096 frames)")
         return True
     if precision == "auto":
         nbytes = (n_cx + n_cy) * n_frames * (W // 2 + 1) * 16

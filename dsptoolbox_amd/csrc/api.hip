@@ -1600,6 +1600,32 @@ extern "C" int ds_welch_tf_dev(ds_ctx* c, const float* x, int n_cx, int64_t ldx,
     return welch_common(c, 0, x, n_cx, ldx, y, n_cy, ldy, n_samples, W, hop, n_frames, window, detrend,
                         average, mode, amp_sqrt, norm_scale, factor, halve_edges, (float2*)tf, coh);
 }
+// float64 frame spectra of a device-resident (samples, channels) float64 array: W <= 16384 one workgroup per
+// (frame, channel); 2^15 ... 2^18 one per (frame, class, channel) + the split (class spectra in the workspace)
+static const int kMaxX64Window = 262144;
+static int x64_launch_frames(ds_ctx* c, const double* dsig, int n_ch, int64_t n_samples, int W, int hop, int n_frames,
+                             int detrend, const double* dw, const double2* tw, double2* spec) {
+    int lg = 0;
+    while ((1 << lg) < W) ++lg;
+    w64::FrameArgs fa{dsig, n_samples, n_ch, W, lg, hop, n_frames, detrend, dw, tw, spec};
+    if (W <= 16384) {
+        const bool packed = W > 8192;  // the real frame as a W/2-point complex sequence: 128 KB of LDS either way
+        const size_t lds = (size_t)(packed ? W / 2 : W) * 16 + 256 * 8;
+        auto frames = packed ? w64::k_frames<true> : w64::k_frames<false>;
+        return launch(c, "welch_f64_frames", frames, dim3(n_frames, n_ch), 256, lds, fa);
+    }
+    const int rc = (W / 2) / w64::LONG_M;
+    int lg_rc = 0;
+    while ((1 << lg_rc) < rc) ++lg_rc;
+    if ((int64_t)n_frames * rc > 0x7fffffff || n_ch > 65535 || n_frames > 65535)
+        return fail(c, DS_ERR_UNSUP, "float64 Welch route: too many frames / channels for the long-window kernels");
+    CHK(reserve(c, &c->ws, &c->ws_bytes, Carver::pad(sizeof(double2) * (size_t)n_ch * n_frames * (W / 2))));
+    w64::LongArgs la{fa, rc, lg_rc, (double2*)c->ws};
+    CHK(launch(c, "welch_f64_frames@long", w64::k_frames_cls, dim3((unsigned)(n_frames * rc), n_ch), 256,
+               (size_t)w64::LONG_M * 16 + 256 * 8, la));
+    return launch(c, "welch_f64_split", w64::k_split, dim3((W / 2 + 1 + 255) / 256, n_frames, n_ch), 256, 0, la);
+}
+
 // float64 end to end (kernels_welch_f64.hpp): host arrays in the reference's own layout
 extern "C" int ds_welch_tf_x64(ds_ctx* c, const double* x, int n_cx, const double* y, int n_cy,
                                int64_t n_samples, int W, int hop, int n_frames, const double* window,
@@ -1612,8 +1638,8 @@ extern "C" int ds_welch_tf_x64(ds_ctx* c, const double* x, int n_cx, const doubl
         return fail(c, DS_ERR_UNSUP, "ds_welch_tf_x64: median averaging over more than 4096 frames (use ds_welch_tf)");
     if (n_cy <= 0 || (n_cx != 1 && n_cx != n_cy) || n_samples <= 0 || hop <= 0 || hop > W || n_frames <= 0)
         return fail(c, DS_ERR_ARG, "ds_welch_tf_x64: bad shape");
-    if (!is_pow2(W) || W < 8 || W > 16384)
-        return fail(c, DS_ERR_UNSUP, "ds_welch_tf_x64: window length must be a power of two in [8, 16384]");
+    if (!is_pow2(W) || W < 8 || W > kMaxX64Window)
+        return fail(c, DS_ERR_UNSUP, "ds_welch_tf_x64: window length must be a power of two in [8, 262144]");
     if (mode < DS_TF_H1 || mode > DS_TF_H3) return fail(c, DS_ERR_ARG, "welch: unsupported transfer function type");
     const int nb = W / 2 + 1;
     const size_t spec_x = (size_t)n_cx * n_frames * nb, spec_y = (size_t)n_cy * n_frames * nb;
@@ -1639,15 +1665,8 @@ extern "C" int ds_welch_tf_x64(ds_ctx* c, const double* x, int n_cx, const doubl
     HIPCHK(c, hipMemcpyAsync(dw, window, (size_t)W * 8, hipMemcpyHostToDevice, c->stream));
     hipLaunchKernelGGL(w64::k_twiddles, dim3((W / 2 + 255) / 256), dim3(256), 0, c->stream, tw, W / 2);
     HIPCHK(c, hipGetLastError());
-    int lg = 0;
-    while ((1 << lg) < W) ++lg;
-    const bool packed = W > 8192;  // the real frame as a W/2-point complex sequence: 128 KB of LDS either way
-    const size_t lds = (size_t)(packed ? W / 2 : W) * 16 + 256 * 8;
-    auto frames = packed ? w64::k_frames<true> : w64::k_frames<false>;
-    w64::FrameArgs fx{dx, n_samples, n_cx, W, lg, hop, n_frames, detrend, dw, tw, xs};
-    CHK(launch(c, "welch_f64_frames", frames, dim3(n_frames, n_cx), 256, lds, fx));
-    w64::FrameArgs fy{dy, n_samples, n_cy, W, lg, hop, n_frames, detrend, dw, tw, ys};
-    CHK(launch(c, "welch_f64_frames", frames, dim3(n_frames, n_cy), 256, lds, fy));
+    CHK(x64_launch_frames(c, dx, n_cx, n_samples, W, hop, n_frames, detrend, dw, tw, xs));
+    CHK(x64_launch_frames(c, dy, n_cy, n_samples, W, hop, n_frames, detrend, dw, tw, ys));
     if (average == DS_AVG_MEDIAN) {
         const int nbias = (n_frames & 1) ? n_frames : n_frames - 1;
         w64::TfArgs ta{xs, ys, n_cx, n_cy, n_frames, mode,
@@ -1682,13 +1701,7 @@ static int x64_tables(ds_ctx* c, Carver& cv, const double* window, int W, X64Tab
 static int x64_frames(ds_ctx* c, const X64Tables& t, const double* sig, double* dsig, int n_ch, int64_t n_samples, int W,
                       int hop, int n_frames, int detrend, double2* spec) {
     HIPCHK(c, hipMemcpyAsync(dsig, sig, (size_t)n_samples * n_ch * 8, hipMemcpyHostToDevice, c->stream));
-    int lg = 0;
-    while ((1 << lg) < W) ++lg;
-    const bool packed = W > 8192;  // the real frame as a W/2-point complex sequence: 128 KB of LDS either way
-    const size_t lds = (size_t)(packed ? W / 2 : W) * 16 + 256 * 8;
-    auto frames = packed ? w64::k_frames<true> : w64::k_frames<false>;
-    w64::FrameArgs fa{dsig, n_samples, n_ch, W, lg, hop, n_frames, detrend, t.dw, t.tw, spec};
-    return launch(c, "welch_f64_frames", frames, dim3(n_frames, n_ch), 256, lds, fa);
+    return x64_launch_frames(c, dsig, n_ch, n_samples, W, hop, n_frames, detrend, t.dw, t.tw, spec);
 }
 static int x64_shape_ok(ds_ctx* c, const char* who, int n_ch, int64_t n_samples, int W, int hop, int n_frames, int average) {
     if (average != DS_AVG_MEAN && average != DS_AVG_MEDIAN)
@@ -1696,8 +1709,8 @@ static int x64_shape_ok(ds_ctx* c, const char* who, int n_ch, int64_t n_samples,
     if (average == DS_AVG_MEDIAN && n_frames > 4096)
         return fail(c, DS_ERR_UNSUP, std::string(who) + ": median averaging over more than 4096 frames (use the fp32 entry point)");
     if (n_ch <= 0 || n_samples <= 0 || hop <= 0 || hop > W || n_frames <= 0) return fail(c, DS_ERR_ARG, std::string(who) + ": bad shape");
-    if (!is_pow2(W) || W < 8 || W > 16384)
-        return fail(c, DS_ERR_UNSUP, std::string(who) + ": window length must be a power of two in [8, 16384]");
+    if (!is_pow2(W) || W < 8 || W > kMaxX64Window)
+        return fail(c, DS_ERR_UNSUP, std::string(who) + ": window length must be a power of two in [8, 262144]");
     return DS_OK;
 }
 

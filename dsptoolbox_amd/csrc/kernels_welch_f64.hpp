@@ -8,7 +8,7 @@
 // has a 78 TFLOP/s fp64 vector pipe and such problems are a few hundred transforms: one
 // workgroup per (frame, channel) runs a plain radix-2 transform in LDS on double2 values
 // (W <= 8192: 128 KB; W = 16384 as the 8192-point complex transform of the even / odd samples plus the
-// real-input split), the frame spectra go to HBM as complex128, and a second kernel sums them
+// real-input split; W = 2^15 ... 2^18: one decimation-in-frequency stage in front of it, k_frames_cls), the frame spectra go to HBM as complex128, and a second kernel sums them
 // per (bin, channel) in fp64 and applies the same finish() as the fp32 path.
 //   inputs: float64 (samples, channels) C-order arrays exactly as the reference holds them
 //   (the stride between samples is n_ch), float64 window, mean averaging.
@@ -107,6 +107,115 @@ __global__ __launch_bounds__(256) void k_frames(FrameArgs p) {
         const double2 w = k < M ? p.tw[k] : make_double2(-1.0, 0.0);
         out[k] = make_double2(e.x + o.x * w.x - o.y * w.y, e.y + o.x * w.y + o.y * w.x);
     }
+}
+
+// ---- windows of 2^15 ... 2^18 samples --------------------------------------------------------------------------
+// The packed sequence z[n] = v[2n] + i v[2n+1] has Wh = W/2 = RC x 8192 points (RC = 2 ... 16): one radix-RC
+// decimation-in-frequency stage in front of the 8192-point LDS transform,
+//     b_r[m] = ( sum_{s < RC} z[m + 8192 s] W_RC^(r s) ) W_Wh^(r m) ,   Z[RC k' + r] = FFT8192(b_r)[k'] ,
+// one workgroup per (frame, class r, channel) -- every class reads the whole frame (L2; this is the route of SHORT
+// estimates) -- into zc[channel][frame][r][k'], then k_split forms X[k] = (Z[k] + conj Z[Wh-k]) / 2 + W^k (...) / (2i)
+// as k_frames<true> does.  Removing the mean of the windowed frame only changes class 0 (sum_s W_RC^(r s) = 0 otherwise):
+// b_0[m] -= RC mean (1 + i).
+constexpr int LONG_M = 8192, LONG_LG = 13;
+
+// exp(-2 pi i k / W) from the half table tw[0 .. W/2)
+__device__ __forceinline__ double2 tw_full(const double2* __restrict__ tw, unsigned k, int W) {
+    k &= (unsigned)(W - 1);
+    if (k < (unsigned)(W / 2)) return tw[k];
+    const double2 t = tw[k - (unsigned)(W / 2)];
+    return make_double2(-t.x, -t.y);
+}
+
+struct LongArgs {
+    FrameArgs f;
+    int rc, lg_rc;  // classes: W / 2 = rc * 8192
+    double2* zc;    // [n_ch][n_frames][rc][8192]
+};
+
+// grid = (n_frames * rc, n_ch); dynamic LDS = 8192 * 16 + 256 * 8 bytes
+__global__ __launch_bounds__(256) void k_frames_cls(LongArgs q) {
+    extern __shared__ __align__(16) double2 buf[];
+    const FrameArgs& p = q.f;
+    constexpr int M = LONG_M, lg = LONG_LG;
+    const int tid = threadIdx.x, f = (int)blockIdx.x >> q.lg_rc, r = (int)blockIdx.x & (q.rc - 1), c = blockIdx.y;
+    const int W = p.W, Wh = W / 2;
+    double* red = reinterpret_cast<double*>(buf + M);
+    const int64_t start = (int64_t)f * p.hop;
+    const unsigned step_rs = (unsigned)(W >> q.lg_rc);  // W_RC^1 = exp(-2 pi i (W / RC) / W)
+    double part = 0.0;
+    for (int m = tid; m < M; m += 256) {
+        double2 acc = make_double2(0.0, 0.0);
+        for (int s = 0; s < q.rc; ++s) {
+            const int n = m + M * s;
+            const int64_t i = start + 2 * n;
+            const double a = i < p.n_samples ? p.sig[i * p.n_ch + c] * p.window[2 * n] : 0.0;
+            const double b = i + 1 < p.n_samples ? p.sig[(i + 1) * p.n_ch + c] * p.window[2 * n + 1] : 0.0;
+            part += a + b;
+            const double2 w = tw_full(p.tw, (unsigned)(r * s) * step_rs, W);
+            acc.x += a * w.x - b * w.y;
+            acc.y += a * w.y + b * w.x;
+        }
+        buf[m] = acc;
+    }
+    if (p.detrend && r == 0) {  // (block-uniform branch)
+        red[tid] = part;
+        __syncthreads();
+        for (int s = 128; s > 0; s >>= 1) {
+            if (tid < s) red[tid] += red[tid + s];
+            __syncthreads();
+        }
+        const double sub = red[0] / (double)W * (double)q.rc;
+        for (int m = tid; m < M; m += 256) {  // (a thread's own slots)
+            buf[m].x -= sub;
+            buf[m].y -= sub;
+        }
+    }
+    __syncthreads();
+    // twiddle W_Wh^(r m) = exp(-2 pi i (2 r m) / W), then into bit-reversed order (through registers: 32 per thread)
+    double2 v[M / 256];
+#pragma unroll
+    for (int j = 0; j < M / 256; ++j) {
+        const int m = tid + 256 * j;
+        const double2 b = buf[m], w = tw_full(p.tw, 2u * (unsigned)r * (unsigned)m, W);
+        v[j] = make_double2(b.x * w.x - b.y * w.y, b.x * w.y + b.y * w.x);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < M / 256; ++j) buf[__brev((unsigned)(tid + 256 * j)) >> (32 - lg)] = v[j];
+    __syncthreads();
+    const int tstep = W >> lg;  // exp(-2 pi i k / 8192) = tw[k * W / 8192]
+    for (int s = 0; s < lg; ++s) {
+        const int half = 1 << s;
+        for (int i = tid; i < M / 2; i += 256) {
+            const int j = i & (half - 1), a = ((i >> s) << (s + 1)) + j, b = a + half;
+            const double2 w = p.tw[(size_t)(j << (lg - 1 - s)) * tstep];
+            const double2 u = buf[a], t0 = buf[b];
+            const double2 t = make_double2(t0.x * w.x - t0.y * w.y, t0.x * w.y + t0.y * w.x);
+            buf[a] = make_double2(u.x + t.x, u.y + t.y);
+            buf[b] = make_double2(u.x - t.x, u.y - t.y);
+        }
+        __syncthreads();
+    }
+    double2* out = q.zc + ((((size_t)c * p.n_frames + f) << q.lg_rc) + r) * M;
+    for (int k = tid; k < M; k += 256) out[k] = buf[k];
+}
+
+// grid = (ceil((W/2 + 1) / 256), n_frames, n_ch)
+__global__ __launch_bounds__(256) void k_split(LongArgs q) {
+    const FrameArgs& p = q.f;
+    const int Wh = p.W / 2, k = blockIdx.x * 256 + threadIdx.x, f = blockIdx.y, c = blockIdx.z;
+    if (k > Wh) return;
+    const double2* z = q.zc + (((size_t)c * p.n_frames + f) << q.lg_rc) * LONG_M;
+    auto Z = [&](int n) {
+        n &= Wh - 1;
+        return z[(size_t)(n & (q.rc - 1)) * LONG_M + (n >> q.lg_rc)];
+    };
+    const double2 zk = Z(k), zm = Z(Wh - k);
+    const double2 e = make_double2(0.5 * (zk.x + zm.x), 0.5 * (zk.y - zm.y));
+    const double2 o = make_double2(0.5 * (zk.y + zm.y), -0.5 * (zk.x - zm.x));
+    const double2 w = k < Wh ? p.tw[k] : make_double2(-1.0, 0.0);
+    p.spec[((size_t)c * p.n_frames + f) * (Wh + 1) + k] = make_double2(e.x + o.x * w.x - o.y * w.y, e.y + o.x * w.y + o.y * w.x);
 }
 
 struct TfArgs {

@@ -168,7 +168,8 @@ int ds_welch_tf_f64(ds_ctx* ctx, const double* x, int n_cx, const double* y, int
 /* The same estimate in float64 END TO END (transforms, sums, finish) for small or ill-conditioned
  * problems: x (n_samples, n_cx), y (n_samples, n_cy) float64 C-order exactly as the reference
  * holds them, float64 window, mean or median averaging (median: at most 4096 frames), W a power
- * of two <= 16384 (16384: as the 8192-point complex transform of the even / odd samples); tf[b][c] complex128
+ * of two <= 262144 (16384: as the 8192-point complex transform of the even / odd samples; 2^15 ... 2^18: one
+ * decimation-in-frequency stage in front of that transform); tf[b][c] complex128
  * (interleaved re, im), coh[b][c] float64.  With fp32 transforms every frame's rounding floor
  * (1e-7 of its peak) lands on all bins, so bins 80 dB down -- the top of a fast pink sweep,
  * BASELINE config 1 -- are only good to 1e-4; this route keeps the reference's 1e-12.        */

@@ -2153,6 +2153,49 @@ def test_short_estimates_through_the_api_hold_1e6(W, monkeypatch):
     assert max(worst.values()) < TOL, worst
 
 
+@pytest.mark.parametrize("W", [32768, 65536, 131072, 262144])
+def test_short_estimates_with_long_windows_hold_1e6(W, monkeypatch):
+    """The same for windows of 2^15 ... 2^18 samples -- where estimates are short almost by definition (a 2^20-sample
+    signal has 7 frames of 2^18): the float64 route's long-window kernels (k_frames_cls + k_split: one decimation stage
+    in front of the 8192-point LDS transform).  tests/sweeps/fuzz_long_windows.py: the fp32 long-window kernels alone
+    reach 6e-6 (tf) / 5e-5 (coherence) on such shapes.  Auto / cross spectra, matrices, H1 / H2 with coherence."""
+    from dsptoolbox_amd._lib import get_context
+    monkeypatch.setattr(backend, "SPEC_PRECISION", "auto")
+    rng = np.random.default_rng(W)
+    ctx = get_context()
+    worst = {"psd": 0.0, "csd": 0.0, "csm": 0.0, "tf": 0.0, "coh": 0.0}
+    for n, C in ((W + 1, 3), (3 * W - 1, 1), (2 * W + 5, 2)):
+        for det in (False, True):
+            x = rng.standard_normal((n, C)) * 0.3
+            y = np.stack([np.convolve(x[:, i], rng.standard_normal(5))[:n] for i in range(C)], axis=1)
+            y += 0.01 * rng.standard_normal((n, C))
+            lo = 1 if det else 0
+            for sc, avg in ((SpectrumScaling.FFTBackward, "mean"), (SpectrumScaling.PowerSpectralDensity, "median")):
+                ctx.routes()
+                a = backend._welch(y, None, 48000, Window.Hann, W, 50, det, avg, sc)
+                k = backend._welch(x, y, 48000, Window.Hann, W, 50, det, avg, sc)
+                seen = ctx.routes()
+                assert {"welch_f64_frames@long", "welch_f64_split"} <= seen and all(r.startswith("welch_f64") for r in seen), seen
+                ra = orc.welch(y, None, 48000, "hann", W, 50, det, avg, sc.name)
+                rk = orc.welch(x, y, 48000, "hann", W, 50, det, avg, sc.name)
+                assert a.dtype == ra.dtype and a.shape == ra.shape and k.shape == rk.shape
+                worst["psd"] = max(worst["psd"], relmax(np.atleast_2d(a.T).T[lo:], np.atleast_2d(ra.T).T[lo:]))
+                worst["csd"] = max(worst["csd"], relmax(np.atleast_2d(k.T).T[lo:], np.atleast_2d(rk.T).T[lo:]))
+            if C > 1:
+                ctx.routes()
+                _, m = backend._csm_welch(y, 48000, W, Window.Hann, 50, det, "mean", SpectrumScaling.AmplitudeSpectrum)
+                assert ctx.routes() == {"welch_f64_frames@long", "welch_f64_split", "csm_f64"}
+                _, rm = orc.csm_welch(y, 48000, W, "hann", 50, det, "mean", "AmplitudeSpectrum")
+                worst["csm"] = max(worst["csm"], relmax(m[lo:], rm[lo:]))
+            for mode in ("H1", "H2"):
+                tf, coh = backend.welch_transfer_function(y, x, 48000, W, mode, detrend=det, precision="auto")
+                rt, rc = orc.compute_transfer_function(y, x, 48000, W, mode, detrend=det)
+                worst["tf"] = max(worst["tf"], relmax(tf[lo:], rt[lo:]))
+                worst["coh"] = max(worst["coh"], relmax(coh[lo:], rc[lo:]))
+    print("short estimates with long windows through the API, worst rel-max", W, worst)
+    assert max(worst.values()) < TOL, worst
+
+
 @pytest.mark.parametrize("n_frames", [117, 500])
 def test_csm_amplitude_scaling_of_coherent_channels(n_frames, monkeypatch):
     """DESIGN section 2, limit (ix), as a test: 32 coherent channels (one source through responses of either sign, a
