@@ -33,6 +33,7 @@
 #include "kernels_welch16384.hpp"
 #include "kernels_welch_long.hpp"
 #include "kernels_stft_long.hpp"
+#include "kernels_istft_long.hpp"
 #include "kernels_welch_f64.hpp"
 #include "kernels_stft_any.hpp"
 #include "kernels_fir_stream.hpp"
@@ -64,7 +65,7 @@ struct ds_ctx {
     float2* w4_tables = nullptr;  // welch4096::host_tables()
     float2* stft_dif_tw[2] = {nullptr, nullptr};  // stft4k::host_twiddles(8192 / 16384)
     float2* fir16k_tables = nullptr;  // fir16k::host_tables()
-    float2* wl_tables[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // welchl::host_tables(R), R = 4, 8, 16, 32, 64
+    float2* wl_tables[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // welchl::host_tables(R), R = 2, 4, ..., 64
     float2* deconv8k_tables = nullptr;  // deconv8k::host_tables()
     float2* stft1k_tables = nullptr;  // stft1k::host_tables<1024>()
     float2* stft_wave_tables[3] = {nullptr, nullptr, nullptr};  // stft1k::host_tables<512>(), <256>(), <2048>()
@@ -536,7 +537,7 @@ extern "C" int ds_stft_r2c_dev(ds_ctx* c, const float* x, int64_t n_samples, int
             welch4096::host_tables(h);
             CHK(upload_table_fwd(c, &c->w4_tables, h));
         }
-        float2** slot = &c->wl_tables[lgR - 2];
+        float2** slot = &c->wl_tables[lgR - 1];
         if (!*slot) {
             std::vector<float2> h;
             welchl::host_tables(R, h);
@@ -776,6 +777,73 @@ extern "C" int ds_istft_dev(ds_ctx* c, const ds_c32* stft, int n_bins, int n_fra
         n_frames_total < n_frames + frame_offset || total_length <= 0 || ld_out < total_length)
         return fail(c, DS_ERR_ARG, "ds_istft: bad shape");
     if (W > nfft) return fail(c, DS_ERR_ARG, "ds_istft: window longer than the FFT length");
+    // 8192 ... 262144 points: class transforms on the 4096-point register kernel, then the radix-R stage with the
+    // overlap-add fused where frames overlap by half (kernels_istft_long.hpp)
+    if (const int R = istftl::classes_of(nfft); R && c->cfg.istft_wave && c->cfg.istft_fused && n_frames <= 65535 &&
+                                                 (n_ch + 1) / 2 <= 65535 &&
+                                                 (int64_t)n_bins * n_frames * n_ch * 8 < ((int64_t)1 << 32) - 16) {
+        int lgR = 0;
+        while ((1 << lgR) < R) ++lgR;
+        if (!c->w4_tables) {
+            std::vector<float2> h;
+            welch4096::host_tables(h);
+            CHK(upload_table_fwd(c, &c->w4_tables, h));
+        }
+        float2** slot = &c->wl_tables[lgR - 1];
+        if (!*slot) {
+            std::vector<float2> h;
+            welchl::host_tables(R, h);
+            CHK(upload_table_fwd(c, slot, h));
+        }
+        const int n_pc = (n_ch + 1) / 2, n_groups = (n_ch + 15) / 16;
+        const bool fused = W == nfft && 2 * step == nfft && R <= 16;
+        const int per = fused ? n_frames : istftl::frames_per_group(n_ch, nfft, n_frames);
+        const size_t cq_bytes = Carver::pad(sizeof(float2) * (size_t)n_pc * per * nfft);
+        CHK(reserve(c, &c->ws, &c->ws_bytes, cq_bytes + (fused ? 0 : Carver::pad(sizeof(float) * (size_t)n_ch * n_frames * W))));
+        Carver cv(c->ws);
+        float2* cq = cv.take<float2>((size_t)n_pc * per * nfft);
+        float* frames = fused ? nullptr : cv.take<float>((size_t)n_ch * n_frames * W);
+        istftl::Args a{(const float2*)stft, n_bins, n_frames, n_ch, W, step, 1, n_groups, R, lgR, 0, n_frames, window,
+                       c->w4_tables, *slot, scale, cq, frames, frame_offset, n_frames_total, total_length, ld_out, out};
+        for (int f0 = 0; f0 < n_frames; f0 += per) {
+            a.f0 = f0;
+            a.nf = std::min(per, n_frames - f0);
+            const int n_units = a.nf * (R - 1);
+            a.n_chunks = std::max(1, std::min(n_units, 256 / std::max(1, std::min(256, n_groups))));
+            const dim3 gc((unsigned)stft4k::grid_size(n_groups, a.n_chunks));
+            CHK((n_ch & 1) ? launch(c, "istft_long_cls", istftl::k_icls<false>, gc, istftl::NT, istftl::LDS_BYTES, a)
+                           : launch(c, "istft_long_cls", istftl::k_icls<true>, gc, istftl::NT, istftl::LDS_BYTES, a));
+            if (fused) break;
+            const dim3 gd(16, (unsigned)a.nf, (unsigned)n_pc);
+            switch (R) {
+                case 2: CHK(launch(c, "istft@long", istftl::k_isdif_frames<2>, gd, 256, istftl::xch_bytes(2), a)); break;
+                case 4: CHK(launch(c, "istft@long", istftl::k_isdif_frames<4>, gd, 256, istftl::xch_bytes(4), a)); break;
+                case 8: CHK(launch(c, "istft@long", istftl::k_isdif_frames<8>, gd, 256, istftl::xch_bytes(8), a)); break;
+                case 16: CHK(launch(c, "istft@long", istftl::k_isdif_frames<16>, gd, 256, istftl::xch_bytes(16), a)); break;
+                case 32: CHK(launch(c, "istft@long", istftl::k_isdif_frames<32>, gd, 256, istftl::xch_bytes(32), a)); break;
+                default: CHK(launch(c, "istft@long", istftl::k_isdif_frames<64>, gd, 256, istftl::xch_bytes(64), a)); break;
+            }
+        }
+        if (fused) {
+            // chunks of frames (+ 1 frame each for the carry): 8192 workgroups of 256 threads where the frames allow
+            // (a thread has only R loads in flight), at least 4 frames per chunk
+            const int want = std::max(1, 8192 / std::max(1, 16 * n_pc));
+            a.n_chunks = std::max(1, std::min((n_frames + 3) / 4, want));
+            if (c->cfg.istft_fpw > 0) a.n_chunks = std::min(n_frames, c->cfg.istft_fpw);
+            const dim3 gd(16, (unsigned)a.n_chunks, (unsigned)n_pc);
+            switch (R) {
+                case 2: return launch(c, "istft@long_ola", istftl::k_isdif_ola<2>, gd, 256, istftl::xch_bytes(2), a);
+                case 4: return launch(c, "istft@long_ola", istftl::k_isdif_ola<4>, gd, 256, istftl::xch_bytes(4), a);
+                case 8: return launch(c, "istft@long_ola", istftl::k_isdif_ola<8>, gd, 256, istftl::xch_bytes(8), a);
+                default: return launch(c, "istft@long_ola", istftl::k_isdif_ola<16>, gd, 256, istftl::xch_bytes(16), a);
+            }
+        }
+        IstftOlaArgs o{frames, n_frames, n_ch, W, step, frame_offset, n_frames_total, window, total_length, ld_out, out};
+        if (W % 4 == 0 && step % 4 == 0 && total_length % 4 == 0 && ld_out % 4 == 0 && ((uintptr_t)out & 15) == 0 &&
+            ((uintptr_t)window & 15) == 0)
+            return launch(c, "istft_ola", k_istft_ola4, dim3((unsigned)((total_length / 4 + 255) / 256), n_ch), 256, 0, o);
+        return launch(c, "istft_ola", k_istft_ola, dim3((unsigned)((total_length + 255) / 256), n_ch), 256, 0, o);
+    }
     if (!is_pow2(nfft) || nfft < kMinFft || nfft > kMaxFft) {
         // (ws, io and aux are all taken -- the division's scratch, the host entry point's staging, the
         // per-group spectra -- so the frames live in a fourth context-owned reserve: grown on demand like
@@ -1329,7 +1397,7 @@ static int welch_long_run(ds_ctx* c, const float* x, int n_cx, int64_t ldx, cons
         welch4096::host_tables(h);
         CHK(upload_table_fwd(c, &c->w4_tables, h));
     }
-    float2** slot = &c->wl_tables[lgR - 2];
+    float2** slot = &c->wl_tables[lgR - 1];
     if (!*slot) {
         std::vector<float2> h;
         wl::host_tables(R, h);

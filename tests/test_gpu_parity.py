@@ -583,8 +583,13 @@ def test_transfer_function_float64_route_vs_oracle():
         sp = dsp.transfer_functions.compute_transfer_function(out, inp, W, TransferFunctionType.H1)
         rt, rc = orc.compute_transfer_function(out.time_data, inp.time_data, 48000, W, "H1", average=avg)
         assert relmax(sp.spectral_data, rt, True) < TOL and relmax(sp.coherence, rc, True) < TOL, (W, avg)
-    with pytest.raises(NotImplementedError):  # the float64 route ends at 16384-sample windows
-        backend.welch_transfer_function(y, x, 48000, 32768, "H1", precision="f64")
+    # since round 4 the float64 route reaches the reference's longest window (a 5000-sample signal: one zero-padded frame)
+    tf, coh = backend.welch_transfer_function(y, x, 48000, 32768, "H1", precision="f64")
+    rt, rc = orc.compute_transfer_function(y, x, 48000, 32768, "H1")
+    assert relmax(tf, rt) < 1e-9 and relmax(coh, rc) < 1e-9
+    with pytest.raises(NotImplementedError):  # median averaging: at most 4096 frames
+        backend.welch_transfer_function(np.zeros((40000, 1)), np.zeros((40000, 1)), 48000, 16, "H1", average="median",
+                                        precision="f64")
 
 
 def test_deconvolve_golden():
@@ -1488,6 +1493,41 @@ def test_istft_channel_tiles_and_fused_overlap_add_vs_oracle(n_ch):
     print("istft worst rel-max", worst)
 
 
+@pytest.mark.parametrize("n_ch", [1, 2, 5, 20])
+def test_istft_long_frames_on_the_register_transform(n_ch):
+    """Inverse STFT with frames of 8192 ... 262144 points (kernels_istft_long.hpp): class transforms on the 4096-point
+    register kernel + the radix-R stage, overlap-add fused for full-length frames at 50 % overlap (R <= 16), windowed
+    frames + k_istft_ola otherwise.  Random spectrograms (every frame half matters), odd / even frame counts, with and
+    without the reference's padding, odd channel counts (a last pair with one channel, narrow loads), idle teams, shorter
+    windows under a longer transform, other overlaps; routes asserted."""
+    from dsptoolbox_amd._lib import get_context
+    ctx = get_context()
+    rng = np.random.default_rng(8192 + n_ch)
+    worst = 0.0
+    for W, nfft, ov, pad, n_frames, fused in (
+            (8192, None, 50, True, 9, True), (8192, None, 50, False, 30, True), (16384, None, 50, False, 7, True),
+            (16384, None, 50, True, 12, True), (32768, None, 50, True, 5, True), (65536, None, 50, False, 4, True),
+            (8192, None, 75, True, 10, False), (16384, None, 25, False, 6, False), (4096, 8192, 50, False, 11, False),
+            (8192, 32768, 50, True, 6, False), (65536, 131072, 50, False, 3, False), (65536, 262144, 50, True, 2, False),
+            (32768, None, 0, False, 3, False), (8192, None, 50, False, 1, True)):
+        nb = (nfft or W) // 2 + 1
+        sp = rng.standard_normal((nb, n_frames, n_ch)) + 1j * rng.standard_normal((nb, n_frames, n_ch))
+        sp[0].imag = 0
+        sp[-1].imag = 0
+        ctx.routes()
+        got = dsp.transforms.istft(sp, sampling_rate_hz=48000, window_length_samples=W, window_type=Window.Hann,
+                                   overlap_percent=ov, fft_length_samples=nfft, padding=pad,
+                                   scaling=SpectrumScaling.FFTBackward)
+        seen = ctx.routes()
+        assert "istft_long_cls" in seen and (("istft@long_ola" in seen) == fused) and (("istft@long" in seen) != fused), (W, nfft, ov, seen)
+        ref = orc.istft(sp, 48000, W, "hann", ov, nfft, pad, "FFTBackward")
+        assert got.time_data.shape == ref.shape, (W, nfft, ov, pad, got.time_data.shape, ref.shape)
+        e = relmax(got.time_data, ref)
+        worst = max(worst, e)
+        assert e < TOL, (W, nfft, ov, pad, n_frames, e)
+    print("istft long frames worst rel-max", worst)
+
+
 def test_stft_8192_and_16384_frame_kernels_vs_oracle():
     """Frames of 8192 / 16384 points (kernels_stft4096.hpp, k_stft_long): two / four decimated 4096-point transforms per
     channel pair, combined at the read-out; two teams (4 channels) / one team (2 channels) per workgroup.  Odd and
@@ -2237,6 +2277,15 @@ def _csm_64_bench_shape_reduced():
     test_csm_64ch_vs_oracle(64)
 
 
+def _istft_16384_round_trip():
+    x = np.random.default_rng(3).standard_normal((70000, 3)) * 0.3
+    s = dsp.Signal(None, x, 48000)
+    s.set_spectrogram_parameters(window_length_samples=16384, overlap_percent=50, padding=True)
+    t, f, st = s.get_spectrogram()
+    back = dsp.transforms.istft(st, original_signal=s)
+    assert relmax(back.time_data, s.time_data) < 2e-6
+
+
 SWITCH_ROUTES = [
     # (environment, golden subset, launch names (ds_routes) that must / must not appear)
     ({}, [lambda: _welch_golden_body(), lambda: _welch4096_golden(), lambda: test_stft_golden(), lambda: _csm_golden_body(),
@@ -2269,7 +2318,8 @@ SWITCH_ROUTES = [
     ({"DSPTOOLBOX_AMD_STFT_GENERIC": "1"}, [lambda: test_stft_and_csm_long_windows_vs_oracle()], set(), {"stft@long", "stft_long_dif"}),
     ({"DSPTOOLBOX_AMD_ISTFT_FUSED": "0"}, [lambda: test_istft_golden_and_round_trip("istft")], {"istft_ola"},
      {"istft@wave", "istft@4k", "istft@fused"}),
-    ({"DSPTOOLBOX_AMD_ISTFT_WAVE": "0"}, [lambda: test_istft_golden_and_round_trip("istft")], set(), {"istft@wave"}),
+    ({"DSPTOOLBOX_AMD_ISTFT_WAVE": "0"}, [lambda: test_istft_golden_and_round_trip("istft"), _istft_16384_round_trip], set(),
+     {"istft@wave", "istft@long", "istft@long_ola", "istft_long_cls"}),
     ({"DSPTOOLBOX_AMD_ISTFT_CT": "1"}, [lambda: test_istft_golden_and_round_trip("istft")], set(), {"istft@ct"}),
 ]
 

@@ -39,6 +39,12 @@ for W in sizes:
     ctx.sync()
     ms = (time.perf_counter() - t0) / K * 1e3
     tot = sp.nbytes + n_ch * total * 4
+    ctx.profile_enable(True)
+    for _ in range(5):
+        stepf()
+    ctx.sync()
+    print("   kernels (ms over 5 calls):", ctx.profile_report())
+    ctx.profile_enable(False)
     print(f"W {W:5d}: {ms:7.3f} ms  frames {n_frames:6d}  {tot / 1e6:7.1f} MB  {tot / ms / 1e9:5.2f} TB/s", flush=True)
     for d in (d_s, d_w, d_o):
         d.free()
