@@ -20,6 +20,24 @@
 
 namespace deconv8k {
 
+// W32^n1 = exp(-2 pi i n1 / 32), n1 < 16, as compile-time constants (the float values of host_tables()'s second part).
+// kernels_welch8192.hpp uses them since round 4: read from the table in global memory they are wave-uniform, but hipcc
+// issues VECTOR loads for them, and a vector load in the middle of a loop's sample loads makes each a separate wait.
+// (The deconvolution kernels below keep the table reads: with the constants k_deconv3q's loads and stores flow freely
+// -- no s_waitcnt vmcnt(0) per group of four any more -- but it spills 33 ... 46 registers instead of 5 at its 128 and
+// measured 47-49 us against 46.5, profiles/r04_deconv_constants.txt.)
+__device__ __forceinline__ float2 w32(int n1) {
+    constexpr float C[16] = {1.0f, 0.9807852506637573f, 0.9238795042037964f, 0.8314695954322815f, 0.7071067690849304f,
+                             0.5555702447891235f, 0.3826834261417389f, 0.19509032368659973f, 6.123234262925839e-17f,
+                             -0.19509032368659973f, -0.3826834261417389f, -0.5555702447891235f, -0.7071067690849304f,
+                             -0.8314695954322815f, -0.9238795042037964f, -0.9807852506637573f};
+    constexpr float S[16] = {-0.0f, -0.19509032368659973f, -0.3826834261417389f, -0.5555702447891235f, -0.7071067690849304f,
+                             -0.8314695954322815f, -0.9238795042037964f, -0.9807852506637573f, -1.0f, -0.9807852506637573f,
+                             -0.9238795042037964f, -0.8314695954322815f, -0.7071067690849304f, -0.5555702447891235f,
+                             -0.3826834261417389f, -0.19509032368659973f};
+    return make_float2(C[n1], S[n1]);
+}
+
 namespace w4 = welch4096;
 using fir16k::cmul;
 using fir16k::cmulc;

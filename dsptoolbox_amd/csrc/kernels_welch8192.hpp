@@ -104,7 +104,7 @@ inline bool buf_fits(int64_t n_samples, int n_frames, int hop) {
 // v[n1] = (z[n'] + (-1)^q z[n' + 4096]) W8192^(n' q), n' = t + 256 n1
 template <bool HALF_HOP>
 __device__ __forceinline__ void front(float2 (&v)[16], const Raw<HALF_HOP>& r, const float* __restrict__ window,
-                                      int q, float2 wt, const float2* __restrict__ c32, bool drop, int t) {
+                                      int q, float2 wt, bool drop, int t) {
 #pragma unroll
     for (int n1 = 0; n1 < 16; ++n1) {
         const float w0 = window[t + 256 * n1], w1 = window[M + t + 256 * n1];
@@ -119,7 +119,7 @@ __device__ __forceinline__ void front(float2 (&v)[16], const Raw<HALF_HOP>& r, c
         if (q == 0)
             v[n1] = make_float2(lo.x + hi.x, lo.y + hi.y);
         else
-            v[n1] = cmul(make_float2(lo.x - hi.x, lo.y - hi.y), cmul(wt, c32[n1]));
+            v[n1] = cmul(make_float2(lo.x - hi.x, lo.y - hi.y), cmul(wt, deconv8k::w32(n1)));
     }
 }
 
@@ -151,7 +151,7 @@ __global__ __launch_bounds__(NTB) void k_x(Args p) {
     const float2 wt = p.twn[t];
     __syncthreads();
     float2 v[16];
-    front<HALF_HOP>(v, raw, p.window, q, wt, p.twn + 256, needs_drop(p, pr), t);
+    front<HALF_HOP>(v, raw, p.window, q, wt, needs_drop(p, pr), t);
     w4::fft4096_plain<true>(v, tw, buf, tw2, t);
     if (p.detrend && tid == 0) v[pos16(0)] = make_float2(0.f, 0.f);  // bin 0 = class 0, k' = 0
     float4* xo = p.xs + (((int64_t)cx * p.n_pairs + pr) * 2 + q) * (M / 2) + t;
@@ -207,7 +207,6 @@ __global__ __launch_bounds__(NTB, 1) void k_y(Args p) {
     for (int k1 = 1; k1 < 16; ++k1) tw.w[k1 - 1] = p.twt[(k1 - 1) * 256 + t];
     if (tid < 256) tw2[tid] = p.twt[15 * 256 + tid];
     const float2 wt = p.twn[t];
-    const float2* c32 = p.twn + 256;
     const float* ch = p.sig + (int64_t)c * p.ld;
     const int p0 = (int)((int64_t)cq * p.n_pairs / p.n_chunks), p1 = (int)((int64_t)(cq + 1) * p.n_pairs / p.n_chunks);
     if (!AUTO && p.n_cx <= 1) {
@@ -235,7 +234,7 @@ __global__ __launch_bounds__(NTB, 1) void k_y(Args p) {
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): keep the pre-loop loads out of the loop's wait counts
     for (int pr = p0; pr < p1; ++pr) {
         float2 v[16];
-        front<HALF_HOP>(v, raw, wsrc, q, wt, c32, needs_drop(p, pr), t);
+        front<HALF_HOP>(v, raw, wsrc, q, wt, needs_drop(p, pr), t);
         float2 xw[16];
         auto issue_loads = [&]() {
             __builtin_amdgcn_sched_barrier(0);
