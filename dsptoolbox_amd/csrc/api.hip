@@ -862,7 +862,8 @@ extern "C" int ds_istft_dev(ds_ctx* c, const ds_c32* stft, int n_bins, int n_fra
     // ... on the wave-level transform for 256 ... 2048 points (kernels_stft1024.hpp, k_istft_wave)
     const bool no_wave = !c->cfg.istft_wave;
     if (W == nfft && 2 * step == nfft && n_ch > 1 && !no_fuse && !no_wave &&
-        (nfft == 2048 || nfft == 1024 || nfft == 512 || nfft == 256)) {
+        (nfft == 2048 || nfft == 1024 || nfft == 512 || nfft == 256) &&
+        (int64_t)n_bins * n_frames * n_ch * 8 < ((int64_t)1 << 32) - 16) {
         // (2048 points: 45 registers over the 128 of a 1024-thread workgroup: four teams = 512 threads there)
         const int slot = nfft == 1024 ? 0 : (nfft == 512 ? 1 : (nfft == 256 ? 2 : 3));
         float2** tab = slot == 0 ? &c->stft1k_tables : &c->stft_wave_tables[slot - 1];
@@ -898,7 +899,7 @@ extern "C" int ds_istft_dev(ds_ctx* c, const ds_c32* stft, int n_bins, int n_fra
     }
     // ... and on the 4096-point register transform, two neighbouring channels per team (kernels_stft4096.hpp, k_istft)
     if (W == nfft && nfft == 4096 && 2 * step == nfft && n_ch > 1 && !no_fuse && !no_wave &&
-        total_length < ((int64_t)1 << 31)) {
+        total_length < ((int64_t)1 << 31) && (int64_t)n_bins * n_frames * n_ch * 8 < ((int64_t)1 << 32) - 16) {
         if (!c->w4_tables) {
             std::vector<float2> h;
             welch4096::host_tables(h);
@@ -910,8 +911,9 @@ extern "C" int ds_istft_dev(ds_ctx* c, const ds_c32* stft, int n_bins, int n_fra
         if (c->cfg.istft_fpw > 0) n_chunks = std::min(n_frames, c->cfg.istft_fpw);
         IstftFusedArgs fa{IstftArgs{(const float2*)stft, n_bins, n_frames, n_ch, W, window, c->w4_tables, scale, nullptr, 1, n_chunks},
                           frame_offset, n_frames_total, total_length, ld_out, out};
-        return launch(c, "istft@4k", stft4k::k_istft, dim3((unsigned)stft4k::grid_size(n_groups, n_chunks)), stft4k::NT,
-                      stft4k::ISTFT_LDS_BYTES, fa);
+        const dim3 g4((unsigned)stft4k::grid_size(n_groups, n_chunks));
+        return (n_ch & 1) ? launch(c, "istft@4k", stft4k::k_istft<false>, g4, stft4k::NT, stft4k::ISTFT_LDS_BYTES, fa)
+                          : launch(c, "istft@4k", stft4k::k_istft<true>, g4, stft4k::NT, stft4k::ISTFT_LDS_BYTES, fa);
     }
     if (W == nfft && 2 * step == nfft && n_ch > 1 && !no_fuse) {
         int ct = 1;

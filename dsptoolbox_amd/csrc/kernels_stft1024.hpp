@@ -424,6 +424,8 @@ __global__ __launch_bounds__(NN == 2048 ? 512 : (NN >= 1024 ? 1024 : NN)) void k
     const int c = c0 + team;
     const bool live = c < p.n_ch;
     const int64_t F = p.n_frames, Cn = p.n_ch;
+    const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(  // (smaller than 4 GB: the host checks)
+        const_cast<float2*>(p.stft), 0, (int)(uint32_t)((int64_t)p.n_bins * F * Cn * 8), 0x00020000);
     const int lct = __ffs(p.ct) - 1;
     const int cl = threadIdx.x & (p.ct - 1);
     float2* img = lds + cl * CHS;
@@ -456,18 +458,33 @@ __global__ __launch_bounds__(NN == 2048 ? 512 : (NN >= 1024 ? 1024 : NN)) void k
         const bool v1 = f0 + 1 < p.n_frames;
         const bool owned = fp >= fp0;  // the pair in front of the range only yields the carry
         __syncthreads();  // tables written / the previous pair's images have been consumed
-        for (int k = threadIdx.x >> lct; k <= NN / 2; k += blockDim.x >> lct) {
-            float2 A = make_float2(0.f, 0.f), B = make_float2(0.f, 0.f);
-            if (cl < ctv && k < p.n_bins) {
-                const float2* s = p.stft + ((int64_t)k * F + f0) * Cn + c0 + cl;
-                A = s[0];
-                if (v1) B = s[Cn];
+        {
+            // Bins k0 + (NN / 16) j of channel cl, frames f0 and f0 + 1: all eighteen loads are requested before the first
+            // value is placed, as raw-buffer loads whose offset lies behind the end where there is nothing to read.
+            // (Until round 4: a rolled loop of plain loads inside `if (channel and bin exist)`, each followed by a full
+            // wait -- nine memory round trips per frame pair with every wave of the workgroup in step.)
+            constexpr int KS = NN / 16;  // = blockDim.x >> lct
+            const int k0 = (int)threadIdx.x >> lct;
+            float2 ga[9], gb[9];
+#pragma unroll
+            for (int j = 0; j < 9; ++j) {
+                const int k = k0 + KS * j;
+                const bool ok = cl < ctv && k <= NN / 2 && k < p.n_bins;
+                const uint32_t off = ok ? (uint32_t)((((int64_t)k * F + f0) * Cn + c0 + cl) * 8) : 0xfffffff0u;
+                const uint32_t off2 = (ok && v1) ? off + (uint32_t)(Cn * 8) : 0xfffffff0u;
+                ga[j] = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(srs, (int)off, 0, 0));
+                gb[j] = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(srs, (int)off2, 0, 0));
             }
-            if (k == 0 || k == NN / 2) {
-                img[k] = make_float2(A.x, -B.x);  // conj(A.x + i B.x)
-            } else {
-                img[k] = make_float2(A.x - B.y, -A.y - B.x);      // conj(A + i B)
-                img[NN - k] = make_float2(A.x + B.y, A.y - B.x);  // conj(conj A + i conj B)
+#pragma unroll
+            for (int j = 0; j < 9; ++j) {
+                const int k = k0 + KS * j;
+                const float2 A = ga[j], B = gb[j];
+                if (k == 0 || k == NN / 2) {
+                    img[k] = make_float2(A.x, -B.x);  // conj(A.x + i B.x)
+                } else if (k < NN / 2) {
+                    img[k] = make_float2(A.x - B.y, -A.y - B.x);      // conj(A + i B)
+                    img[NN - k] = make_float2(A.x + B.y, A.y - B.x);  // conj(conj A + i conj B)
+                }
             }
         }
         __syncthreads();

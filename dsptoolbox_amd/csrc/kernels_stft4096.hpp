@@ -398,7 +398,9 @@ __global__ __launch_bounds__(NT) void k_stft_dif(Args p) {
 // frames, after the frame in front of it (for the carry).
 constexpr int ISTFT_LDS_BYTES = TEAMS * IMG * 8 + 256 * 8 + (N / 2) * 4;  // images, W256, 1 / envelope
 
-// (q.a.tw = welch4096::host_tables(), q.a.fpw = the number of frame chunks)
+// (q.a.tw = welch4096::host_tables(), q.a.fpw = the number of frame chunks; WIDE: an even channel count, one 16-byte load
+// per bin and channel pair; the spectrogram is smaller than 4 GB, the host checks)
+template <bool WIDE>
 __global__ __launch_bounds__(NT) void k_istft(dsk::IstftFusedArgs q) {
     using namespace welch4096;
     constexpr int STEP = N / 2;
@@ -429,7 +431,8 @@ __global__ __launch_bounds__(NT) void k_istft(dsk::IstftFusedArgs q) {
     }
     const int bt = bin_thread(tid);
     const int64_t F = p.n_frames, C = p.n_ch;
-    const bool wide = !(p.n_ch & 1);
+    const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float2*>(p.stft), 0, (int)(uint32_t)((int64_t)p.n_bins * F * C * 8), 0x00020000);
     float ca[8], cbv[8];  // second half of the frame before, channels c0 and c0 + 1
 #pragma unroll
     for (int j = 0; j < 8; ++j) ca[j] = cbv[j] = 0.f;
@@ -465,34 +468,50 @@ __global__ __launch_bounds__(NT) void k_istft(dsk::IstftFusedArgs q) {
         int tx = (int)threadIdx.x;
         asm volatile("" : "+v"(tx));
         __syncthreads();  // tables / the previous frame's read-out
-        {   // load: thread -> (pair rp, bin row rk); conj(Z) and its mirror half into image rp, padded natural order
+        {   // load: thread -> (pair rp, bin row rk); conj(Z) and its mirror half into image rp, padded natural order.
+            // All nine loads are requested before the first value is placed, as raw-buffer loads whose offset lies
+            // behind the end where there is nothing to read (zero): until round 4 each was a plain load inside
+            // `if (channel and bin exist)`, which hipcc follows with a full wait -- nine memory round trips per frame
+            // with the sixteen waves of the CU in step.
             const int rp = tx & 3, rk = tx >> 2;
             float2* im = lds + rp * IMG;
             const int rc = cb + 2 * rp;
             const bool r_one = rc < p.n_ch, r_two = rc + 1 < p.n_ch;
-            auto bin = [&](int k) {
-                float2 A = make_float2(0.f, 0.f), B = make_float2(0.f, 0.f);
-                if (r_one && k < p.n_bins) {
-                    const float2* sp = p.stft + ((int64_t)k * F + f) * C + rc;
-                    if (wide) {
-                        const float4 v4 = *reinterpret_cast<const float4*>(sp);
-                        A = make_float2(v4.x, v4.y);
-                        B = make_float2(v4.z, v4.w);
-                    } else {
-                        A = sp[0];
-                        if (r_two) B = sp[1];
-                    }
+            auto fetch = [&](int k) {
+                const bool ok = r_one && k < p.n_bins;
+                const uint32_t off = ok ? (uint32_t)((((int64_t)k * F + f) * C + rc) * 8) : 0xfffffff0u;
+                if constexpr (WIDE) {
+                    return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(srs, (int)off, 0, 0));
+                } else {
+                    const float2 A = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(srs, (int)off, 0, 0));
+                    const uint32_t off2 = (ok && r_two) ? off + 8u : 0xfffffff0u;
+                    const float2 B = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(srs, (int)off2, 0, 0));
+                    return make_float4(A.x, A.y, B.x, B.y);
                 }
-                if (k == 0 || k == N / 2) {
-                    im[fold_pos(k)] = make_float2(A.x, -B.x);  // conj(A.x + i B.x): numpy's irfft drops the imaginary parts
+            };
+            float4 gq[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) gq[j] = fetch(rk + 256 * j);
+            float2 ge;  // real parts of bin N / 2 (the threads with rk == 0; everybody else reads behind the end)
+            {
+                const bool ok = rk == 0 && r_one && N / 2 < p.n_bins;
+                const uint32_t off = ok ? (uint32_t)((((int64_t)(N / 2) * F + f) * C + rc) * 8) : 0xfffffff0u;
+                const uint32_t off2 = (ok && r_two) ? off + 8u : 0xfffffff0u;
+                ge.x = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srs, (int)off, 0, 0));
+                ge.y = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srs, (int)off2, 0, 0));
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int k = rk + 256 * j;
+                const float2 A = make_float2(gq[j].x, gq[j].y), B = make_float2(gq[j].z, gq[j].w);
+                if (k == 0) {
+                    im[fold_pos(0)] = make_float2(A.x, -B.x);  // conj(A.x + i B.x): numpy's irfft drops the imaginary parts
                 } else {
                     im[fold_pos(k)] = make_float2(A.x - B.y, -A.y - B.x);      // conj(A + i B)
                     im[fold_pos(N - k)] = make_float2(A.x + B.y, A.y - B.x);  // conj(conj A + i conj B)
                 }
-            };
-#pragma unroll
-            for (int j = 0; j < 8; ++j) bin(rk + 256 * j);
-            if (rk == 0) bin(N / 2);
+            }
+            if (rk == 0) im[fold_pos(N / 2)] = make_float2(ge.x, -ge.y);
         }
         __syncthreads();
         const int tl = tx & 255, bt_l = bin_thread(tl);
