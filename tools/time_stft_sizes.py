@@ -39,6 +39,12 @@ for arg in sizes:
     ctx.sync()
     ms = (time.perf_counter() - t0) / K * 1e3
     tot = pl["xp"].nbytes + nbytes_out
+    ctx.profile_enable(True)
+    for _ in range(5):
+        step()
+    ctx.sync()
+    print("   kernels (ms over 5 calls):", ctx.profile_report())
+    ctx.profile_enable(False)
     print(f"W {arg:>13s}: {ms:7.3f} ms  frames {pl['n_frames']:6d}  {tot / 1e6:7.1f} MB  {tot / ms / 1e9:5.2f} TB/s", flush=True)
     for d in (d_x, d_w, d_s):
         d.free()
