@@ -108,19 +108,40 @@ __global__ __launch_bounds__(256) void k_welch_finish(WelchFinArgs p) {
     const float* __restrict__ pyy = p.pyy;
     const int inb = p.in_nb > 0 ? p.in_nb : nb;  // bins per partial row
     const int64_t bi = (int64_t)b * p.in_step;    // this output bin within it
-    if (live) {
-        if (p.kind != 2) {
-            const int64_t sx = (int64_t)p.n_cx * inb, ox = (int64_t)cx * inb + bi;
-            for (int q = sub; q < p.n_chunks_x; q += 4) sxx += (double)pxx[q * sx + ox];
-        }
-        if (p.kind != 1) {
-            const int64_t sy = (int64_t)p.n_cy * inb, oy = (int64_t)c * inb + bi;
-            const bool want_yy = p.kind == 0;
-            for (int q = sub; q < p.n_chunks; q += 4) {
-                const float2 t = pxy[q * sy + oy];
-                sxy.x += (double)t.x;
-                sxy.y += (double)t.y;
-                if (want_yy) syy += (double)pyy[q * sy + oy];
+    // A wave's chunks q = sub, sub + 4, ... in batches of four, every load of a batch requested before the first sum
+    // (raw-buffer loads: a chunk past the last one, or a dead lane, is an offset behind the end and reads as zero).
+    // As a rolled loop of plain loads this was one memory round trip per chunk -- three in a row for the headline's
+    // twelve chunks, most of the kernel's 8 us.
+    {
+        constexpr int U = 4;
+        const int64_t sx = (int64_t)p.n_cx * inb, ox = (int64_t)cx * inb + bi;
+        const int64_t sy = (int64_t)p.n_cy * inb, oy = (int64_t)c * inb + bi;
+        const bool want_yy = p.kind == 0;
+        const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(pxx), 0, p.kind != 2 ? (int)(uint32_t)(sx * p.n_chunks_x * 4) : 0, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rxy = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float2*>(pxy), 0, p.kind != 1 ? (int)(uint32_t)(sy * p.n_chunks * 8) : 0, 0x00020000);
+        const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(pyy), 0, want_yy ? (int)(uint32_t)(sy * p.n_chunks * 4) : 0, 0x00020000);
+        const int n_max = p.n_chunks_x > p.n_chunks ? p.n_chunks_x : p.n_chunks;
+        for (int q0 = sub; q0 < n_max; q0 += 4 * U) {
+            float vx[U], vy[U];
+            float2 vxy[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int q = q0 + 4 * u;
+                const uint32_t offx = (live && q < p.n_chunks_x) ? (uint32_t)((q * sx + ox) * 4) : 0xfffffff0u;
+                const uint32_t offy = (live && q < p.n_chunks) ? (uint32_t)(q * sy + oy) : 0x1ffffffeu;
+                vx[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, (int)offx, 0, 0));
+                vxy[u] = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(rxy, (int)(offy * 8u), 0, 0));
+                vy[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ry, (int)(offy * 4u), 0, 0));
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                sxx += (double)vx[u];
+                sxy.x += (double)vxy[u].x;
+                sxy.y += (double)vxy[u].y;
+                syy += (double)vy[u];
             }
         }
     }
