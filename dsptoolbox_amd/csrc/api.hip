@@ -796,7 +796,9 @@ extern "C" int ds_istft_dev(ds_ctx* c, const ds_c32* stft, int n_bins, int n_fra
             CHK(upload_table_fwd(c, slot, h));
         }
         const int n_pc = (n_ch + 1) / 2, n_groups = (n_ch + 15) / 16;
-        const bool fused = W == nfft && 2 * step == nfft && R <= 16;
+        // (fused: the class sequences of ALL frames at once, addressed through a raw-buffer descriptor: below 4 GB)
+        const bool fused = W == nfft && 2 * step == nfft && R <= 16 &&
+                           (int64_t)n_pc * n_frames * nfft * 8 < ((int64_t)1 << 32) - 16;
         const int per = fused ? n_frames : istftl::frames_per_group(n_ch, nfft, n_frames);
         const size_t cq_bytes = Carver::pad(sizeof(float2) * (size_t)n_pc * per * nfft);
         CHK(reserve(c, &c->ws, &c->ws_bytes, cq_bytes + (fused ? 0 : Carver::pad(sizeof(float) * (size_t)n_ch * n_frames * W))));

@@ -117,24 +117,27 @@ __global__ __launch_bounds__(256) void k_welch_finish(WelchFinArgs p) {
         const int64_t sx = (int64_t)p.n_cx * inb, ox = (int64_t)cx * inb + bi;
         const int64_t sy = (int64_t)p.n_cy * inb, oy = (int64_t)c * inb + bi;
         const bool want_yy = p.kind == 0;
-        const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<float*>(pxx), 0, p.kind != 2 ? (int)(uint32_t)(sx * p.n_chunks_x * 4) : 0, 0x00020000);
-        const __amdgpu_buffer_rsrc_t rxy = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<float2*>(pxy), 0, p.kind != 1 ? (int)(uint32_t)(sy * p.n_chunks * 8) : 0, 0x00020000);
-        const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<float*>(pyy), 0, want_yy ? (int)(uint32_t)(sy * p.n_chunks * 4) : 0, 0x00020000);
+        // one descriptor per chunk slab (the chunk index is wave-uniform): 32-bit offsets stay inside ONE slab of
+        // channels x bins, whatever the number of chunks
+        const int subu = __builtin_amdgcn_readfirstlane(sub);
+        const uint32_t ex = live ? (uint32_t)ox : 0x3ffffffcu, ey = live ? (uint32_t)oy : 0x1ffffffeu;
         const int n_max = p.n_chunks_x > p.n_chunks ? p.n_chunks_x : p.n_chunks;
-        for (int q0 = sub; q0 < n_max; q0 += 4 * U) {
+        for (int q0 = subu; q0 < n_max; q0 += 4 * U) {
             float vx[U], vy[U];
             float2 vxy[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int q = q0 + 4 * u;
-                const uint32_t offx = (live && q < p.n_chunks_x) ? (uint32_t)((q * sx + ox) * 4) : 0xfffffff0u;
-                const uint32_t offy = (live && q < p.n_chunks) ? (uint32_t)(q * sy + oy) : 0x1ffffffeu;
-                vx[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, (int)offx, 0, 0));
-                vxy[u] = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(rxy, (int)(offy * 8u), 0, 0));
-                vy[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ry, (int)(offy * 4u), 0, 0));
+                const bool hx = p.kind != 2 && q < p.n_chunks_x, hy = p.kind != 1 && q < p.n_chunks;
+                const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+                    const_cast<float*>(pxx) + (hx ? q * sx : 0), 0, hx ? (int)(uint32_t)(sx * 4) : 0, 0x00020000);
+                const __amdgpu_buffer_rsrc_t rxy = __builtin_amdgcn_make_buffer_rsrc(
+                    const_cast<float2*>(pxy) + (hy ? q * sy : 0), 0, hy ? (int)(uint32_t)(sy * 8) : 0, 0x00020000);
+                const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(
+                    const_cast<float*>(pyy) + ((hy && want_yy) ? q * sy : 0), 0, (hy && want_yy) ? (int)(uint32_t)(sy * 4) : 0, 0x00020000);
+                vx[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, (int)(ex * 4u), 0, 0));
+                vxy[u] = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(rxy, (int)(ey * 8u), 0, 0));
+                vy[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ry, (int)(ey * 4u), 0, 0));
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
