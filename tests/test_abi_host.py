@@ -176,6 +176,24 @@ def test_compute_transfer_function_validation():
         dsp.transfer_functions.spectral_deconvolve(a, c)
 
 
+def test_precision_routing_rules():
+    """Which estimates the host mirror sends through the float64 kernels: short ones (fewer than 128
+    frames, frame spectra up to 256 MB) for every window the reference allows -- 2^18 samples since round 4 --, small
+    transfer-function problems, nothing under "f32"; median averaging up to 4096 frames; "f64" raises where the route ends."""
+    assert backend._x64_short("auto", 2, 5, 262144, "mean") and backend._x64_short("auto", 3, 1, 32768, "median")
+    assert not backend._x64_short("auto", 2, 5, 524288, "mean")       # beyond the reference's longest window
+    assert not backend._x64_short("auto", 64, 127, 262144, "mean")    # 17 GB of frame spectra
+    assert not backend._x64_short("auto", 2, 128, 1024, "mean") and not backend._x64_short("f32", 2, 5, 1024, "mean")
+    assert backend._tf_x64_applies("auto", 1, 3, 7, 131072, "mean") and backend._tf_x64_applies("auto", 1, 2, 2000, 256, "mean")
+    assert not backend._tf_x64_applies("auto", 1, 64, 511, 4096, "mean")  # the headline shape stays on the fp32 kernels
+    assert not backend._tf_x64_applies("f32", 1, 3, 7, 1024, "mean") and not backend._tf_x64_applies(None, 1, 3, 7, 1024, "mean")
+    assert backend._tf_x64_applies("f64", 1, 64, 511, 4096, "mean")
+    with pytest.raises(NotImplementedError):
+        backend._tf_x64_applies("f64", 1, 1, 5000, 16, "median")
+    with pytest.raises(NotImplementedError):
+        backend._tf_x64_applies("f64", 1, 1, 3, 524288, "mean")
+
+
 def test_no_gpu_means_loud_failure():
     lib = load_library()
     if lib.ds_device_count() > 0:
