@@ -200,6 +200,14 @@ _X64_SHORT_BYTES = 256 << 20  # (1 GB in round 3: 64 channels x 100 frames of 81
 SPEC_PRECISION = os.environ.get("DSPTOOLBOX_AMD_SPEC_PRECISION", "auto")
 
 
+def _short_bytes(W: int) -> int:
+    """Byte cap of a short estimate's frame spectra on the float64 route: 256 MB, four times that for windows beyond 16384
+    samples -- their frames are few by nature, the float64 long-window kernels cost about what the fp32 ones do, and the
+    fp32 rounding of a 2^15 ... 2^18-point transform is the largest (tests/sweeps/fuzz_long_windows.py: 37 frames of
+    65536 samples, 16 channels, 310 MB: coherence 1.2e-6 on fp32)."""
+    return _X64_SHORT_BYTES if W <= 16384 else 4 * _X64_SHORT_BYTES
+
+
 def _x64_short(precision, n_spectra: int, n_frames: int, W: int, average: str) -> bool:
     """Does a SHORT estimate of `n_spectra` channel spectra take the float64 route?"""
     assert precision in ("auto", "f32"), "DSPTOOLBOX_AMD_SPEC_PRECISION: 'auto' or 'f32'"
@@ -207,7 +215,7 @@ def _x64_short(precision, n_spectra: int, n_frames: int, W: int, average: str) -
         return False
     if average != "mean" and n_frames > 4096:
         return False
-    return n_spectra * n_frames * (W // 2 + 1) * 16 <= _X64_SHORT_BYTES
+    return n_spectra * n_frames * (W // 2 + 1) * 16 <= _short_bytes(W)
 
 
 def _tf_x64_applies(precision, n_cx: int, n_cy: int, n_frames: int, W: int, average: str) -> bool:
@@ -218,7 +226,7 @@ def _tf_x64_applies(precision, n_cx: int, n_cy: int, n_frames: int, W: int, aver
         return True
     if precision == "auto":
         nbytes = (n_cx + n_cy) * n_frames * (W // 2 + 1) * 16
-        return ok and (nbytes <= _X64_AUTO_BYTES or (n_frames < 128 and nbytes <= _X64_SHORT_BYTES))
+        return ok and (nbytes <= _X64_AUTO_BYTES or (n_frames < 128 and nbytes <= _short_bytes(W)))
     assert precision in (None, "f32"), "precision: 'f32', 'f64' or 'auto'"
     return False
 

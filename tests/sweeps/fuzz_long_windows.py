@@ -3,7 +3,8 @@
     auto spectra, 3 ... 40 frames: the fp32 kernels forced AND the API's default arithmetic ("auto": such estimates are
     short and take the float64 route, k_frames_cls / k_split of kernels_welch_f64.hpp), the latter held to 1e-6;
   * STFT with frames of 32768 / 65536 samples and transform lengths up to 262144 (kernels_stft_long.hpp);
-  * FIR banks whose signal is shorter than the filter (direct float64 sum).
+  * FIR banks whose signal is shorter than the filter (direct float64 sum);
+  * inverse STFT with frames of 8192 ... 65536 samples, transform lengths up to 131072, every overlap (kernels_istft_long.hpp).
 usage: python tests/sweeps/fuzz_long_windows.py [n_cases] [seed]
 Limits: auto spectra, STFT, FIR 1e-6; cross spectra / transfer functions / coherence of these few-frame fp32 estimates are
 REPORTED per kind (worst value) and flagged above 2e-5 -- a defect in the class bookkeeping shows as 1e-2 ... 1, rounding as 1e-6."""
@@ -35,7 +36,7 @@ def main():
     ctx = get_context()
     worst, fails, routes = {}, [], {}
     for it in range(n_cases):
-        kind = str(rng.choice(["tf", "tf_paired", "csd", "psd", "stft", "stft", "fir", "fir"]))
+        kind = str(rng.choice(["tf", "tf_paired", "csd", "psd", "stft", "stft", "fir", "fir", "istft", "istft"]))
         det = bool(rng.integers(0, 2))
         sc = scalings[int(rng.integers(0, len(scalings)))]
         ov = float(rng.choice([0, 25, 50, 50, 75]))
@@ -72,8 +73,23 @@ def main():
                     r = orc.welch(xs, ys, 48000, "hann", W, ov, det, "mean", sc.name)
                     e, limit = relmax(a, r, det), 2e-5
                     backend.SPEC_PRECISION = "auto"
-                    auto("csd", backend._welch(xs, ys, 48000, Window.Hann, W, ov, det, "mean", sc), r)
+                    a64 = backend._welch(xs, ys, 48000, Window.Hann, W, ov, det, "mean", sc)
+                    auto("csd", a64, r)
                     backend.SPEC_PRECISION = "f32"
+                    if os.environ.get("FUZZ_DEBUG") and e > 1e-3:
+                        lo = 1 if det else 0
+                        d = np.abs(np.asarray(a) - r)[lo:]
+                        b_, c_ = np.unravel_index(np.argmax(d), d.shape)
+                        print("   DEBUG worst bin", b_ + lo, "ch", c_, "got", a[b_ + lo, c_], "ref", r[b_ + lo, c_], "max|ref|", np.max(np.abs(r[lo:])),
+                              "per-channel err", [float(np.max(d[:, k]) / np.max(np.abs(r[lo:]))) for k in range(n_ch)],
+                              "bins > 1e-3:", int(np.sum(d > 1e-3 * np.max(np.abs(r[lo:])))), "of", d.size)
+                        big = backend._X64_SHORT_BYTES
+                        backend._X64_SHORT_BYTES = 1 << 40
+                        backend.SPEC_PRECISION = "auto"
+                        a64b = backend._welch(xs, ys, 48000, Window.Hann, W, ov, det, "mean", sc)
+                        backend.SPEC_PRECISION = "f32"
+                        backend._X64_SHORT_BYTES = big
+                        print("   DEBUG float64 route vs oracle", relmax(a64b, r, det), "fp32 vs float64 route", relmax(a, a64b, det))
                 else:
                     mode = str(rng.choice(["H1", "H2", "H3"]))
                     desc += (mode,)
@@ -112,6 +128,26 @@ def main():
                 rt_, rf_, rs = orc.stft(x, 48000, W, "hann", ov, nfft, det, pad, sc.name)
                 assert st.shape == rs.shape
                 e = relmax(st, rs)
+            elif kind == "istft":  # random spectrograms (not the transform of a signal: every frame half matters)
+                import dsptoolbox_amd as dsp
+                W = int(rng.choice([8192, 16384, 32768, 65536]))
+                nfft = [None, None, None, 2 * W][int(rng.integers(0, 4))]
+                n_frames = int(rng.integers(1, 14))
+                n_ch = int(rng.choice([1, 2, 3, 4, 5, 8, 9, 17]))
+                pad = bool(rng.integers(0, 2))
+                if pad and n_frames < 2 and ov > 0:
+                    n_frames = 2
+                nb = (nfft or W) // 2 + 1
+                desc = (kind, W, nfft, n_frames, n_ch, ov, pad)
+                sp = rng.standard_normal((nb, n_frames, n_ch)) + 1j * rng.standard_normal((nb, n_frames, n_ch))
+                sp[0].imag = 0
+                sp[-1].imag = 0
+                got = dsp.transforms.istft(sp, sampling_rate_hz=48000, window_length_samples=W, window_type=Window.Hann,
+                                           overlap_percent=ov, fft_length_samples=nfft, padding=pad,
+                                           scaling=SpectrumScaling.FFTBackward)
+                ref = orc.istft(sp, 48000, W, "hann", ov, nfft, pad, "FFTBackward")
+                assert got.time_data.shape == ref.shape, (got.time_data.shape, ref.shape)
+                e = relmax(got.time_data, ref)
             else:
                 n_taps = int(rng.integers(2, 9000))
                 n = int(rng.integers(1, n_taps))
