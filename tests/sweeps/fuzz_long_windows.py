@@ -137,6 +137,8 @@ def main():
                 pad = bool(rng.integers(0, 2))
                 if pad and n_frames < 2 and ov > 0:
                     n_frames = 2
+                if pad and ov == 0:  # the reference's td[overlap:-overlap] is EMPTY for overlap 0 (and a Signal of it (C, 0))
+                    pad = False
                 nb = (nfft or W) // 2 + 1
                 desc = (kind, W, nfft, n_frames, n_ch, ov, pad)
                 sp = rng.standard_normal((nb, n_frames, n_ch)) + 1j * rng.standard_normal((nb, n_frames, n_ch))
