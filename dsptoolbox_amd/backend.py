@@ -201,11 +201,12 @@ SPEC_PRECISION = os.environ.get("DSPTOOLBOX_AMD_SPEC_PRECISION", "auto")
 
 
 def _short_bytes(W: int) -> int:
-    """Byte cap of a short estimate's frame spectra on the float64 route: 256 MB, four times that for windows beyond 16384
-    samples -- their frames are few by nature, the float64 long-window kernels cost about what the fp32 ones do, and the
-    fp32 rounding of a 2^15 ... 2^18-point transform is the largest (tests/sweeps/fuzz_long_windows.py: 37 frames of
-    65536 samples, 16 channels, 310 MB: coherence 1.2e-6 on fp32)."""
-    return _X64_SHORT_BYTES if W <= 16384 else 4 * _X64_SHORT_BYTES
+    """Byte cap of a short estimate's frame spectra on the float64 route: 256 MB, five times that for windows beyond 16384
+    samples -- their frames are few by nature and the fp32 rounding of a 2^15 ... 2^18-point transform is the largest
+    (tests/sweeps/fuzz_long_windows.py: 37 frames of 65536 samples, 16 channels, 310 MB: coherence 1.2e-6 on fp32).  At 50 %
+    overlap the frame spectra of a signal are 16 bytes per sample whatever the window, so 1.25 GB is 64 + 1 channels x 2^20
+    samples: 4 ... 19 ms of float64 kernels there (tools/dbg/x64_long_time.py) beside ~15 ms of host conversion and PCIe."""
+    return _X64_SHORT_BYTES if W <= 16384 else 5 * _X64_SHORT_BYTES
 
 
 def _x64_short(precision, n_spectra: int, n_frames: int, W: int, average: str) -> bool:

@@ -183,7 +183,8 @@ def test_precision_routing_rules():
     assert backend._x64_short("auto", 2, 5, 262144, "mean") and backend._x64_short("auto", 3, 1, 32768, "median")
     assert not backend._x64_short("auto", 2, 5, 524288, "mean")       # beyond the reference's longest window
     assert not backend._x64_short("auto", 64, 127, 262144, "mean")    # 17 GB of frame spectra
-    assert backend._x64_short("auto", 10, 13, 262144, "mean")         # 272 MB: long windows have a 1 GB cap ...
+    assert backend._x64_short("auto", 10, 13, 262144, "mean")         # 272 MB: long windows have a 1.25 GB cap ...
+    assert backend._tf_x64_applies("auto", 1, 64, 8, 262144, "mean")     # ... = 64 + 1 channels x 2^20 samples
     assert not backend._x64_short("auto", 64, 100, 8192, "mean")      # ... 420 MB of 8192-sample frames stay on fp32 (256 MB)
     assert not backend._x64_short("auto", 2, 128, 1024, "mean") and not backend._x64_short("f32", 2, 5, 1024, "mean")
     assert backend._tf_x64_applies("auto", 1, 3, 7, 131072, "mean") and backend._tf_x64_applies("auto", 1, 2, 2000, 256, "mean")
