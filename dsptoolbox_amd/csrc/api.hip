@@ -1691,8 +1691,16 @@ static int x64_launch_frames(ds_ctx* c, const double* dsig, int n_ch, int64_t n_
     while ((1 << lg_rc) < rc) ++lg_rc;
     if ((int64_t)n_frames * rc > 0x7fffffff || n_ch > 65535 || n_frames > 65535)
         return fail(c, DS_ERR_UNSUP, "float64 Welch route: too many frames / channels for the long-window kernels");
-    CHK(reserve(c, &c->ws, &c->ws_bytes, Carver::pad(sizeof(double2) * (size_t)n_ch * n_frames * (W / 2))));
-    w64::LongArgs la{fa, rc, lg_rc, (double2*)c->ws};
+    CHK(reserve(c, &c->ws, &c->ws_bytes, Carver::pad(sizeof(double2) * (size_t)n_ch * n_frames * (W / 2)) +
+                                             Carver::pad(sizeof(double) * (size_t)n_ch * n_samples)));
+    Carver cvl(c->ws);
+    double2* zc = cvl.take<double2>((size_t)n_ch * n_frames * (W / 2));
+    double* planar = cvl.take<double>((size_t)n_ch * n_samples);
+    if ((n_samples + 31) / 32 > 0x7fffffff) return fail(c, DS_ERR_UNSUP, "float64 Welch route: signal too long for the long-window kernels");
+    hipLaunchKernelGGL(w64::k_planar, dim3((unsigned)((n_samples + 31) / 32), (unsigned)((n_ch + 31) / 32)), dim3(256), 0, c->stream,
+                       dsig, n_samples, n_ch, planar);
+    HIPCHK(c, hipGetLastError());
+    w64::LongArgs la{fa, rc, lg_rc, zc, planar};
     CHK(launch(c, "welch_f64_frames@long", w64::k_frames_cls, dim3((unsigned)(n_frames * rc), n_ch), 256,
                (size_t)w64::LONG_M * 16 + 256 * 8, la));
     return launch(c, "welch_f64_split", w64::k_split, dim3((W / 2 + 1 + 255) / 256, n_frames, n_ch), 256, 0, la);

@@ -131,7 +131,33 @@ struct LongArgs {
     FrameArgs f;
     int rc, lg_rc;  // classes: W / 2 = rc * 8192
     double2* zc;    // [n_ch][n_frames][rc][8192]
+    const double* planar;  // [n_ch][n_samples]: the signal channel by channel (k_planar)
 };
+
+// (samples, channels) -> [channel][samples] through a 32 x 32 tile: every class workgroup of a long window reads its
+// channel's frame rc times, and from the reference's channel-fastest layout each of those reads is one 8-byte value per
+// 128-byte line (64 + 1 channels x 2^20 samples: k_frames_cls 3.7 / 6.1 / 19.4 ms at 2^15 / 2^16 / 2^18-sample windows from the
+// host layout, 2.7 / 3.8 / 9.5 ms from the planar copy).
+// grid = (ceil(n_samples / 32), ceil(n_ch / 32)), 256 threads
+__global__ __launch_bounds__(256) void k_planar(const double* __restrict__ sig, int64_t n_samples, int n_ch, double* __restrict__ out) {
+    __shared__ double tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    const int64_t s0 = (int64_t)blockIdx.x * 32;
+    const int c0 = blockIdx.y * 32;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int64_t sI = s0 + ty + 8 * j;
+        const int c = c0 + tx;
+        tile[ty + 8 * j][tx] = (sI < n_samples && c < n_ch) ? sig[sI * n_ch + c] : 0.0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int c = c0 + ty + 8 * j;
+        const int64_t sI = s0 + tx;
+        if (c < n_ch && sI < n_samples) out[(int64_t)c * n_samples + sI] = tile[tx][ty + 8 * j];
+    }
+}
 
 // grid = (n_frames * rc, n_ch); dynamic LDS = 8192 * 16 + 256 * 8 bytes
 __global__ __launch_bounds__(256) void k_frames_cls(LongArgs q) {
@@ -143,14 +169,15 @@ __global__ __launch_bounds__(256) void k_frames_cls(LongArgs q) {
     double* red = reinterpret_cast<double*>(buf + M);
     const int64_t start = (int64_t)f * p.hop;
     const unsigned step_rs = (unsigned)(W >> q.lg_rc);  // W_RC^1 = exp(-2 pi i (W / RC) / W)
+    const double* __restrict__ chan = q.planar + (int64_t)c * p.n_samples;
     double part = 0.0;
     for (int m = tid; m < M; m += 256) {
         double2 acc = make_double2(0.0, 0.0);
         for (int s = 0; s < q.rc; ++s) {
             const int n = m + M * s;
             const int64_t i = start + 2 * n;
-            const double a = i < p.n_samples ? p.sig[i * p.n_ch + c] * p.window[2 * n] : 0.0;
-            const double b = i + 1 < p.n_samples ? p.sig[(i + 1) * p.n_ch + c] * p.window[2 * n + 1] : 0.0;
+            const double a = i < p.n_samples ? chan[i] * p.window[2 * n] : 0.0;
+            const double b = i + 1 < p.n_samples ? chan[i + 1] * p.window[2 * n + 1] : 0.0;
             part += a + b;
             const double2 w = tw_full(p.tw, (unsigned)(r * s) * step_rs, W);
             acc.x += a * w.x - b * w.y;
