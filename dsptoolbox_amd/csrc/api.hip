@@ -1679,8 +1679,19 @@ static int x64_launch_frames(ds_ctx* c, const double* dsig, int n_ch, int64_t n_
                              int detrend, const double* dw, const double2* tw, double2* spec) {
     int lg = 0;
     while ((1 << lg) < W) ++lg;
-    w64::FrameArgs fa{dsig, n_samples, n_ch, W, lg, hop, n_frames, detrend, dw, tw, spec};
+    w64::FrameArgs fa{dsig, n_samples, n_ch, W, lg, hop, n_frames, detrend, dw, tw, spec, n_ch, 1};
     if (W <= 16384) {
+        // four channels or more: read a planar copy (one 8-byte value per 32-byte sector otherwise)
+        if (n_ch >= 4 && (n_samples + 31) / 32 <= 0x7fffffff) {
+            CHK(reserve(c, &c->ws, &c->ws_bytes, Carver::pad(sizeof(double) * (size_t)n_ch * n_samples)));
+            double* planar = (double*)c->ws;
+            hipLaunchKernelGGL(w64::k_planar, dim3((unsigned)((n_samples + 31) / 32), (unsigned)((n_ch + 31) / 32)), dim3(256), 0,
+                               c->stream, dsig, n_samples, n_ch, planar);
+            HIPCHK(c, hipGetLastError());
+            fa.sig = planar;
+            fa.s_stride = 1;
+            fa.c_stride = n_samples;
+        }
         const bool packed = W > 8192;  // the real frame as a W/2-point complex sequence: 128 KB of LDS either way
         const size_t lds = (size_t)(packed ? W / 2 : W) * 16 + 256 * 8;
         auto frames = packed ? w64::k_frames<true> : w64::k_frames<false>;

@@ -29,6 +29,9 @@ struct FrameArgs {
     const double* window;  // [W]
     const double2* tw;     // [W / 2]: exp(-2 pi i k / W)
     double2* spec;         // [n_ch][n_frames][W / 2 + 1]
+    // sample s of channel c at sig[s * s_stride + c * c_stride]: (n_ch, 1) for the reference's layout, (1, n_samples) for
+    // the planar copy k_planar makes when there are enough channels for the strided reads to hurt
+    int64_t s_stride = 0, c_stride = 1;
 };
 
 __global__ __launch_bounds__(256) void k_twiddles(double2* tw, int half) {
@@ -51,17 +54,18 @@ __global__ __launch_bounds__(256) void k_frames(FrameArgs p) {
     const int M = PACKED ? W / 2 : W, lg = PACKED ? p.lgW - 1 : p.lgW;  // the transform that runs in LDS
     double* red = reinterpret_cast<double*>(buf + M);
     const int64_t start = (int64_t)f * p.hop;
+    const double* __restrict__ chan = p.sig + (int64_t)c * p.c_stride;
     // windowed frame, zero past the end of the signal (helpers/other.py:207-209)
     double part = 0.0;
     for (int n = tid; n < M; n += 256) {
         double2 z;
         if (PACKED) {
             const int64_t s = start + 2 * n;
-            z.x = s < p.n_samples ? p.sig[s * p.n_ch + c] * p.window[2 * n] : 0.0;
-            z.y = s + 1 < p.n_samples ? p.sig[(s + 1) * p.n_ch + c] * p.window[2 * n + 1] : 0.0;
+            z.x = s < p.n_samples ? chan[s * p.s_stride] * p.window[2 * n] : 0.0;
+            z.y = s + 1 < p.n_samples ? chan[(s + 1) * p.s_stride] * p.window[2 * n + 1] : 0.0;
         } else {
             const int64_t s = start + n;
-            z = make_double2(s < p.n_samples ? p.sig[s * p.n_ch + c] * p.window[n] : 0.0, 0.0);
+            z = make_double2(s < p.n_samples ? chan[s * p.s_stride] * p.window[n] : 0.0, 0.0);
         }
         part += z.x + z.y;
         buf[__brev((unsigned)n) >> (32 - lg)] = z;  // bit-reversed order in
