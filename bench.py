@@ -73,7 +73,8 @@ def parse_args():
     ap.add_argument("--detrend", type=int, default=1)
     ap.add_argument("--no-workloads", action="store_true",
                     help="default workload at N = 1: do not time the other BASELINE configs into \"workloads\"")
-    ap.add_argument("--workload-steps", type=int, default=40, help="timed steps of each entry of \"workloads\"")
+    ap.add_argument("--workload-steps", type=int, default=200,
+                    help="timed steps of each entry of \"workloads\" (40 until round 4: 5 ms of timed region sits inside the clock ramp of an idle chip -- the 1024-sample Welch step read 0.130 ms there and 0.103 ms over 60 000 steps)")
     return ap.parse_args()
 
 
@@ -707,7 +708,7 @@ def workload_entry(args, ctx, dist, name: str):
     fraction by SURVEY 8(d)'s own definition for that config, and a BOUNDED CPU leg with its parity."""
     import gc
     args.cpu_bounded = True
-    out, made, _ = measure(args, ctx, dist, name, args.workload_steps, 8, False, False)
+    out, made, _ = measure(args, ctx, dist, name, args.workload_steps, 20, False, False)
     roof = out["roofline"]
     alg = roof.get("algorithmic_flops_per_step") if roof["bound"] == "mfma" else roof["algorithmic_per_launch"]
     ent = dict(workload=out["config"]["workload"], ms_per_step=out["ms_per_step"], step_event_ms=out["step_event_ms"],

@@ -110,7 +110,7 @@ def test_default_line_carries_the_other_configs_and_the_ceiling():
         assert e["parity_rel_max_vs_oracle"] < 1e-6 and e["cpu_baseline"]["value"] > 0 and "sample" in e["cpu_baseline"]
         assert e["kernel_avg_ms"] <= e["ms_per_step"] + 0.0065 and 1.0 <= e["traffic_ratio"] < 6.0
         avg_ns = _trace_avg_ns(stats, e["kernel"])
-        # (the entry's events sample every 4th launch of 40 steps; the trace averages all launches of the run, warm-up included)
+        # (the entry's events sample every 4th launch of its 200 steps; the trace averages all launches of the run, warm-up included)
         assert avg_ns * 0.95 <= e["kernel_avg_ms"] * 1e6 <= avg_ns * 1.05 + 6500.0, (name, e["kernel_avg_ms"], avg_ns)
         if name == "csm":
             assert e["bound"] == "mfma" and e["peak"] == 157.3 and 0.3 < e["frac"] < 1.0
