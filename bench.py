@@ -73,6 +73,10 @@ def parse_args():
     ap.add_argument("--detrend", type=int, default=1)
     ap.add_argument("--no-workloads", action="store_true",
                     help="default workload at N = 1: do not time the other BASELINE configs into \"workloads\"")
+    ap.add_argument("--preheat-ms", type=float, default=40.0,
+                    help="untimed steps run for this long before the warm-up (clock ramp of an idle chip; 0 = none)")
+    ap.add_argument("--steady-steps", type=int, default=2000,
+                    help="steps of the second timed region behind the K steps of the command line -> \"steady_state\" (0 = none)")
     ap.add_argument("--workload-steps", type=int, default=200,
                     help="timed steps of each entry of \"workloads\" (40 until round 4: 5 ms of timed region sits inside the clock ramp of an idle chip -- the 1024-sample Welch step read 0.130 ms there and 0.103 ms over 60 000 steps)")
     return ap.parse_args()
@@ -196,6 +200,29 @@ def setup_rccl(ctx, dist: Dist, required: bool = True):
     return True
 
 
+def shared_upload(ctx, dist: Dist, rccl: bool, arr: np.ndarray):
+    """A device copy of `arr` on every rank, rank 0 owning the data: with the library's RCCL communicator rank 0
+    uploads and ds_bcast sends it over xGMI (-> milliseconds of that collective); without it (one rank, ranks sharing a
+    GPU, BENCH_BCAST=host) the host exchange carries the bytes and every rank uploads.  `arr` must have the same shape
+    and dtype on every rank; only rank 0's values are used.  -> (DeviceBuffer, bcast_ms | None)"""
+    from dsptoolbox_amd._lib import DeviceBuffer
+    arr = np.ascontiguousarray(arr)
+    buf = DeviceBuffer(ctx, max(arr.nbytes, 16))
+    if rccl:
+        if dist.rank == 0:
+            ctx.upload(buf.ptr, arr)
+        dist.barrier_sync(ctx)
+        t0 = time.perf_counter()
+        ctx.check(ctx.lib.ds_bcast(ctx.handle, C.c_void_p(buf.ptr), arr.nbytes, 0), "ds_bcast")
+        ctx.sync()
+        return buf, (time.perf_counter() - t0) * 1e3
+    if dist.world > 1:
+        from dsptoolbox_amd.distributed import broadcast_array
+        arr = broadcast_array(arr if dist.rank == 0 else None, src=0)
+    ctx.upload(buf.ptr, arr)
+    return buf, None
+
+
 def shard_of(n_units: int, shard):
     from dsptoolbox_amd.distributed import shard_range
     if shard is None:
@@ -234,22 +261,7 @@ def welch_h1(args, ctx, dist, shard, rccl, W=4096):
     amp, norm_scale, factor, phys = backend._finish_params(SpectrumScaling.FFTBackward, W, FS, window)
     d_y = DeviceBuffer.from_array(ctx, backend._planar_f32(y[:, a:b])) if n_loc else None
     d_w = DeviceBuffer.from_array(ctx, window.astype(np.float32))
-    xp = backend._planar_f32(x)
-    d_x = DeviceBuffer(ctx, xp.nbytes)
-    bcast_ms = None
-    if rccl:
-        if dist.rank == 0:
-            ctx.upload(d_x.ptr, xp)
-        dist.barrier_sync(ctx)
-        t0 = time.perf_counter()
-        ctx.check(ctx.lib.ds_bcast(ctx.handle, C.c_void_p(d_x.ptr), xp.nbytes, 0), "ds_bcast")
-        ctx.sync()
-        bcast_ms = (time.perf_counter() - t0) * 1e3
-    else:
-        if dist.world > 1:  # BENCH_BCAST=host (ranks sharing one GPU, RCCL opted out or failed): host broadcast, upload
-            from dsptoolbox_amd.distributed import broadcast_array
-            xp = broadcast_array(xp if dist.rank == 0 else None, src=0)
-        ctx.upload(d_x.ptr, xp)
+    d_x, bcast_ms = shared_upload(ctx, dist, rccl, backend._planar_f32(x))  # the shared sweep channel
     B = W // 2 + 1
     # result slice of this rank: tf (B, n_loc) complex64 then coh (B, n_loc) float32, one buffer
     slot = B * n_max * 12
@@ -326,13 +338,15 @@ def fir_bank(args, ctx, dist, shard, rccl):
     a, b = shard_of(K, shard)  # Parallel mode shards by bands
     k_loc = b - a
     d_x = DeviceBuffer.from_array(ctx, backend._planar_f32(x))
-    d_t = DeviceBuffer.from_array(ctx, np.ascontiguousarray(taps[a:b])) if k_loc else None
+    # the shared taps: rank 0 owns the bank, every rank receives all of it (RCCL broadcast over xGMI when the
+    # library's communicator is up) and filters with its own bands [a, b)
+    d_taps, bcast_ms = shared_upload(ctx, dist, rccl, taps)
     d_y = DeviceBuffer(ctx, max(k_loc, 1) * n_ch * n * 4)
 
     def step():  # the 4 GiB result stays sharded (band-major): no gather in the reference either
         if k_loc:
             ctx.check(ctx.lib.ds_fir_ola_dev(ctx.handle, C.c_void_p(d_x.ptr), n_ch, n, n,
-                                             C.c_void_p(d_t.ptr), k_loc, T, backend.DS_FB_PARALLEL,
+                                             C.c_void_p(d_taps.ptr + 4 * a * T), k_loc, T, backend.DS_FB_PARALLEL,
                                              C.c_void_p(d_y.ptr), n), "ds_fir_ola_dev")
 
     alg_bytes = n_ch * n * 4 + K * T * 4 + K * n_ch * n * 4
@@ -346,7 +360,7 @@ def fir_bank(args, ctx, dist, shard, rccl):
         t0 = time.perf_counter()
         for k in bands:  # the reference loop: one oaconvolve per band (~0.5 s each)
             ref = orc.lfilter_fir(taps[k].astype(np.float64), x)
-            if k % 8 == 0:  # parity on every 8th band (the download is outside what is measured)
+            if True:  # parity on every band the CPU leg computes (the download is outside what is measured)
                 t1 = time.perf_counter()
                 got = np.empty((n_ch, n), dtype=np.float32)
                 ctx.download(d_y.ptr + 4 * (k - a) * n_ch * n, got)
@@ -355,10 +369,10 @@ def fir_bank(args, ctx, dist, shard, rccl):
         dt = (time.perf_counter() - t0) * (b - a) / max(1, len(bands))  # scaled to the whole bank
         return dict(value=n_ch * n / dt / 1e6, unit="Msamples/s", cores=1, kind="port",
                     sample=f"oracle.lfilter_fir (scipy oaconvolve), {len(bands)} of {K} bands timed "
-                           f"({dt * len(bands) / max(1, b - a):.1f} s), scaled to all {K}; parity on every 8th band",
+                           f"({dt * len(bands) / max(1, b - a):.1f} s), scaled to all {K}; parity on each of them",
                     parity_rel_max_vs_gpu=err)
 
-    return step, n_ch * n, alg_bytes, "hbm", info, (cpu_baseline,), None, ("fir",)
+    return step, n_ch * n, alg_bytes, "hbm", info, (cpu_baseline,), bcast_ms, ("fir",)
 
 
 def csm(args, ctx, dist, shard, rccl):
@@ -424,17 +438,38 @@ def csm(args, ctx, dist, shard, rccl):
 
 
 def deconv(args, ctx, dist, shard, rccl):
+    from dsptoolbox_amd import backend
     from dsptoolbox_amd._lib import DeviceBuffer
+    from dsptoolbox_amd.generators import exponential_sweep
+    from dsptoolbox_amd.transfer_functions import (_inverse_hann_band, find_frequencies_above_threshold,
+                                                   find_nearest_points_index_in_vector)
 
     n, items_all, n_ch = 8192, 1024, 2
+    B = n // 2 + 1
+    # the shared reference sweep and 1024 stereo responses to it: y[i, c] = x (*) h_ic + noise, h a 256-tap decaying
+    # Gaussian-noise response (circular convolution: the reference divides whole-signal spectra)
+    x = exponential_sweep(n, FS)
     rng = np.random.default_rng(5000 + (dist.rank if shard is None else 0))
-    y = rng.standard_normal((items_all, n_ch, n)).astype(np.float32) * 0.1
-    r = (rng.standard_normal(n // 2 + 1) + 1j * rng.standard_normal(n // 2 + 1)).astype(np.complex64)
+    h = rng.standard_normal((items_all, n_ch, 256)) * np.exp(-np.arange(256) / 40.0)
+    y = np.fft.irfft(np.fft.rfft(x)[None, None, :] * np.fft.rfft(h, n, axis=-1), n, axis=-1)
+    y = (y + 1e-3 * rng.standard_normal(y.shape)).astype(np.float32)
+    del h
     a, b = shard_of(items_all, shard)  # independent items shard
     items = b - a
     y = y[a:b]
     d_y = DeviceBuffer.from_array(ctx, y) if items else None
-    d_r = DeviceBuffer.from_array(ctx, r)
+    # The regularised inverse of the sweep, conj(X) / (|X|^2 + eps) with the reference's band detection
+    # (transfer_functions.py:152-167, _transfer_functions.py:31-35), built ONCE by rank 0 through the package's own
+    # device path (ds_rfft -> ds_deconv_inverse) and handed to every rank: RCCL broadcast over xGMI (BASELINE config 5)
+    r = np.zeros(B, dtype=np.complex64)
+    if dist.rank == 0:
+        den = backend.rfft_spectrum(x[:, None], n)
+        freqs = np.fft.rfftfreq(n, 1 / FS)
+        lo_hi = find_frequencies_above_threshold(den[:, 0], freqs, -30.0)
+        band = np.array([lo_hi[0] / np.sqrt(2), lo_hi[0], lo_hi[1], np.min([lo_hi[1] * np.sqrt(2), FS / 2])])
+        eps = _inverse_hann_band(find_nearest_points_index_in_vector(band, freqs), B) * 10 ** (30 / 20)
+        r = np.ascontiguousarray(backend.regularized_inverse(den, eps)[:, 0].astype(np.complex64))
+    d_r, bcast_ms = shared_upload(ctx, dist, rccl, r)
     d_o = DeviceBuffer(ctx, max(y.nbytes, 16))
 
     def step():  # the impulse responses stay with the rank that owns the items
@@ -444,27 +479,32 @@ def deconv(args, ctx, dist, shard, rccl):
                       "ds_deconv_dev")
 
     alg_bytes = 2 * items_all * n_ch * n * 4 + r.nbytes
-    info = dict(workload="deconv: stereo spectral deconvolutions n=8192 against a shared inverse sweep",
+    info = dict(workload="deconv: stereo spectral deconvolutions n=8192 against a shared regularised inverse sweep",
                 items=items_all, channels=n_ch, samples_per_channel=n)
 
     def cpu_baseline():
-        # the reference's per-item path (_transfer_functions.py:19-42): rfft, multiply, irfft
-        yy = y.astype(np.float64)
-        rr = r.astype(np.complex128)
-        reps = 20 if args.cpu_bounded else 80  # ~0.1 s per pass
+        # the reference's own call, one per stereo item (transfer_functions.py:61-184: spectrum of the sweep, band
+        # detection, regularised division, irfft) on a bounded sample of items spread over the batch; every one of
+        # them is compared with the device result
+        from oracle import dsp_oracle as orc
+        count = min(items, 32 if args.cpu_bounded else 256)
+        pick = np.unique(np.linspace(0, items - 1, count).astype(int))
+        got_all = d_o.to_array((items, n_ch, n), np.float32)
+        xx = x[:, None]
+        err, refs = 0.0, []
         t0 = time.perf_counter()
-        for _ in range(reps):
-            for i in range(items):
-                ref = np.fft.irfft(np.fft.rfft(yy[i], n=n, axis=-1) * rr, n=n, axis=-1)
-        dt = (time.perf_counter() - t0) / reps
-        got = d_o.to_array((items, n_ch, n), np.float32)[-1]
-        den = float(np.max(np.abs(ref)))
-        return dict(value=items * n_ch * n / dt / 1e6, unit="Msamples/s", cores=1, kind="port",
-                    sample=f"numpy rfft * R -> irfft per item (reference loop), all {items} items, "
-                           f"{reps} passes of {dt:.1f} s",
-                    parity_rel_max_vs_gpu=float(np.max(np.abs(got - ref))) / den)
+        for i in pick:
+            refs.append(orc.spectral_deconvolve(y[i].T.astype(np.float64), xx, FS))
+        dt = time.perf_counter() - t0
+        for i, ref in zip(pick, refs):
+            err = max(err, orc.rel_max(got_all[i].T, ref))
+        return dict(value=len(pick) * n_ch * n / dt / 1e6, unit="Msamples/s", cores=1, kind="port",
+                    sample=f"oracle.spectral_deconvolve per stereo item (reference call structure: sweep spectrum, band "
+                           f"detection, regularised division, irfft), {len(pick)} of {items} items spread over the batch "
+                           f"in {dt:.2f} s; parity on every one of them",
+                    parity_rel_max_vs_gpu=err)
 
-    return step, items_all * n_ch * n, alg_bytes, "hbm", info, (cpu_baseline,), None, ("deconv",)
+    return step, items_all * n_ch * n, alg_bytes, "hbm", info, (cpu_baseline,), bcast_ms, ("deconv",)
 
 
 def pmc_summary(workload: str, kernel_hints):
@@ -518,6 +558,17 @@ def timed_steps(ctx, dist, step, steps: int, events: bool, dominant):
     return wall, ev_ms, prof
 
 
+def preheat_steps(ctx, step, ms: float):
+    """Run `step` back to back, untimed, for about `ms` milliseconds of wall time -> {"steps", "ms"}."""
+    n, t0 = 0, time.perf_counter()
+    while ms > 0 and (time.perf_counter() - t0) * 1e3 < ms:
+        for _ in range(20):
+            step()
+        ctx.sync()
+        n += 20
+    return dict(steps=n, ms=(time.perf_counter() - t0) * 1e3)
+
+
 def launch_ranks(n_gpus: int) -> int:
     """`python bench.py --gpus N` with no launcher environment: start the N ranks here, as children of a
     process that has not touched the GPU -- one rank per GPU, the launcher's usual environment (RANK,
@@ -568,6 +619,11 @@ def measure(args, ctx, dist, workload: str, steps: int, warmup: int, strong: boo
     # time, so in the timed region only the dominant kernel is bracketed.
     events = not os.environ.get("BENCH_NO_KERNEL_EVENTS")
     prof_all = {}
+    # Clock ramp: an MI355X that has been idle (the set-up above is host work) starts its first milliseconds of
+    # kernels at a low engine clock -- the same binary reads 105-107 us per launch in its first 8 ms and 91-93 us from
+    # then on (profiles/r05_clock_ramp.txt).  W = 5 warm-up steps are 0.6 ms.  So the step runs untimed for
+    # --preheat-ms first (reported as "preheat"); the W warm-up steps and the K timed steps follow unchanged.
+    preheat = preheat_steps(ctx, step, args.preheat_ms)
     for i in range(warmup):
         if events and i == warmup - 1:
             ctx.sync()
@@ -583,6 +639,19 @@ def measure(args, ctx, dist, workload: str, steps: int, warmup: int, strong: boo
         dom = max(prof_all, key=lambda k: prof_all[k][0])
     wall, ev_ms, prof = timed_steps(ctx, dist, step, steps, events, dom)
     wall = dist.max_over_ranks(wall)
+    # a second, longer region right behind the one the command line asks for: K = 20 steps are
+    # 2.5 ms and 5 event brackets; this one is --steady-steps steps and a quarter as many brackets
+    steady = None
+    if args.steady_steps > 0 and getattr(args, "steady_now", True):
+        s_wall, s_ev, s_prof = timed_steps(ctx, dist, step, args.steady_steps, events, dom)
+        s_wall = dist.max_over_ranks(s_wall)
+        steady = dict(steps=args.steady_steps, ms_per_step=s_wall * 1e3 / args.steady_steps,
+                      step_event_ms=s_ev / args.steady_steps,
+                      value=units * (1 if strong else dist.world) / (s_wall / args.steady_steps) / 1e6, unit="Msamples/s")
+        if s_prof and dom in s_prof:
+            steady["kernel"] = dom
+            steady["kernel_avg_ms"] = s_prof[dom][0] / s_prof[dom][1]
+            steady["kernel_brackets"] = s_prof[dom][1]
     if dist.rank != 0:
         return None, made, wall
     ms_per_step = wall * 1e3 / steps
@@ -695,6 +764,13 @@ def measure(args, ctx, dist, workload: str, steps: int, warmup: int, strong: boo
         "whole_step_gbs": alg / div / (step_ms * 1e-3) / 1e9,
         "algorithmic_bytes_per_step": alg / div,
     }
+    out["preheat"] = dict(preheat, note="untimed steps in front of the W warm-up steps: the engine clock of an idle "
+                                        "chip ramps for ~10 ms (profiles/r05_clock_ramp.txt)")
+    if steady:
+        if "kernel_avg_ms" in steady:  # the same fraction over the longer region
+            steady["roofline_frac"] = (roof["dominant_kernel_hbm"]["frac"] * dom_ms / steady["kernel_avg_ms"]
+                                       if "dominant_kernel_hbm" in roof else roof["frac"] * dom_ms / steady["kernel_avg_ms"])
+        out["steady_state"] = steady
     if bcast_ms is not None:
         out["rccl_bcast_ms"] = bcast_ms
     return out, made, wall
@@ -708,7 +784,9 @@ def workload_entry(args, ctx, dist, name: str):
     fraction by SURVEY 8(d)'s own definition for that config, and a BOUNDED CPU leg with its parity."""
     import gc
     args.cpu_bounded = True
+    args.steady_now = False  # these entries already time --workload-steps (200) steps
     out, made, _ = measure(args, ctx, dist, name, args.workload_steps, 20, False, False)
+    args.steady_now = True
     roof = out["roofline"]
     alg = roof.get("algorithmic_flops_per_step") if roof["bound"] == "mfma" else roof["algorithmic_per_launch"]
     ent = dict(workload=out["config"]["workload"], ms_per_step=out["ms_per_step"], step_event_ms=out["step_event_ms"],
@@ -736,6 +814,35 @@ def workload_entry(args, ctx, dist, name: str):
     args.cpu_bounded = False
     del made, out
     gc.collect()  # the workload's device buffers go with its closures
+    return ent
+
+
+def short_estimate_entry():
+    """The precision route of a SHORT estimate as a number: the reference's default
+    window (1024 samples) on one second of 64-channel audio at 48 kHz is 94 frames -- fewer than 128 --, so the
+    reference-shaped API (backend.welch_transfer_function, host float64 arrays in and out) sends it through the float64
+    kernels (ds_welch_tf_x64); the same call forced onto the fp32 kernels beside it.  PCIe-inclusive wall time, median
+    of 7 calls each after 2 warm-up calls; both results against the oracle."""
+    from dsptoolbox_amd import backend
+    from dsptoolbox_amd.generators import sweep_and_responses
+    from oracle import dsp_oracle as orc
+    n, n_cy, W = 48000, 64, 1024
+    x, y = sweep_and_responses(n, n_cy, FS)
+    rt, rc = orc.compute_transfer_function(y, x, FS, W, "H1")
+    fr = np.fft.rfftfreq(W, 1 / FS)
+    band = (fr >= 30.0) & (fr <= 19000.0)
+    ent = dict(workload=f"welch_h1 through the API, {n_cy} + 1 channels x {n} samples, window {W}: "
+                        f"{backend._welch_framing(n, W, 50, backend._window_array(backend.Window.Hann, W))[1]} frames "
+                        "(a short estimate: fewer than 128 frames)", unit="ms per call, host arrays in and out")
+    for name, prec in (("f64_route_auto", "auto"), ("f32_kernels_forced", "f32")):
+        ts = []
+        for i in range(9):
+            t0 = time.perf_counter()
+            tf, coh = backend.welch_transfer_function(y, x, FS, W, "H1", precision=prec)
+            if i >= 2:
+                ts.append((time.perf_counter() - t0) * 1e3)
+        ent[name] = dict(ms_median=float(np.median(ts)), ms_min=float(np.min(ts)),
+                         parity_rel_max_vs_oracle=max(orc.rel_max(tf[band], rt[band]), orc.rel_max(coh[band], rc[band])))
     return ent
 
 
@@ -809,6 +916,7 @@ def main():
             t0 = time.perf_counter()
             out["workloads"][name] = workload_entry(args, ctx, dist, name)
             out["workloads"][name]["wall_s_including_setup_and_cpu_leg"] = time.perf_counter() - t0
+        out["workloads"]["short_estimate_api"] = short_estimate_entry()
         out["workloads_wall_s"] = time.perf_counter() - t_all
     print(json.dumps(out), flush=True)
     dist.finish()

@@ -26,6 +26,13 @@ class ImpulseResponse(Signal):
     def from_time_data(time_data, sampling_rate_hz: int, constrain_amplitude: bool = True):
         return ImpulseResponse(None, time_data, sampling_rate_hz, constrain_amplitude)
 
+    def set_window(self, window):
+        """Keep the window that was applied to the impulse response, one column per channel
+        (dsptoolbox/classes/impulse_response.py:139-152; the reference only plots it)."""
+        assert window.shape == self.time_data.shape, f"{window.shape} does not match shape {self.time_data.shape}"
+        self.window = window
+        return self
+
     def copy_with_new_time_data(self, new_time_data) -> "ImpulseResponse":
         """An impulse response stays one when it is filtered (classes/impulse_response.py:355-371)."""
         if isinstance(new_time_data, np.ndarray) and new_time_data.base is not None:

@@ -90,6 +90,13 @@ class MultiBandSignal:
     def length_samples(self) -> int:
         return self.bands[0].length_samples if self.bands else 0
 
+    @property
+    def is_complex_signal(self) -> bool:
+        """Do the bands carry imaginary time data?  False without bands (multibandsignal.py:262-274)."""
+        if not self.bands:
+            return False
+        return self.bands[0].is_complex_signal
+
     def __iter__(self):
         return iter(self.bands)
 

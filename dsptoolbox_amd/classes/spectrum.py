@@ -89,6 +89,14 @@ class Spectrum(MultichannelData):
         assert not np.iscomplexobj(coherence), "Coherence cannot be complex"
         self.coherence = coherence
 
+    def sum_channels(self, power_sum: bool = True) -> "Spectrum":
+        """One-channel spectrum of all channels: the root of the summed powers (default), or the plain sum of the
+        magnitude / complex data (dsptoolbox/classes/spectrum.py:435-459)."""
+        if power_sum:
+            return self._create_copy_with_new_data(
+                np.sum(np.abs(self.spectral_data) ** 2.0, axis=1, keepdims=True) ** 0.5)
+        return super().sum_channels()
+
     def copy(self) -> "Spectrum":
         return deepcopy(self)
 

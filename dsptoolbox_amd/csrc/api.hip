@@ -423,6 +423,16 @@ static int launch(ds_ctx* c, const char* name, K kernel, dim3 grid, int threads,
     return DS_OK;
 }
 
+// every Welch route ends here: chunk partials -> spectra / transfer functions (kernels_finish.hpp).  Partial slabs of
+// 4 GiB or more leave the kernel's 32-bit raw-buffer descriptors (size_guards.hpp); DSPTOOLBOX_AMD_FINISH_WIDE=1
+// sends every call down that 64-bit-load path (the GPU test of it: such slabs themselves do not fit a test).
+static int launch_finish(ds_ctx* c, dim3 grid, WelchFinArgs f) {
+    f.force_wide = c->cfg.finish_wide ? 1 : 0;
+    const bool wide = f.force_wide || welch_finish_wide_slab((int64_t)f.n_cx * (f.in_nb > 0 ? f.in_nb : f.fin.nb),
+                                                             (int64_t)f.n_cy * (f.in_nb > 0 ? f.in_nb : f.fin.nb));
+    return launch(c, wide ? "welch_finish@wide" : "welch_finish", k_welch_finish, grid, 256, 0, f);
+}
+
 #define DISPATCH_N(n, CALL)                                                        \
     switch (n) {                                                                   \
         case 8: { constexpr int NN = 8; CALL; } break;                             \
@@ -529,7 +539,8 @@ extern "C" int ds_stft_r2c_dev(ds_ctx* c, const float* x, int64_t n_samples, int
                         edge_scale, power, (float2*)out);
     // 2^15 ... 2^18 points: one decimation-in-frequency pass, then the 4096-point register transform per class
     // (kernels_stft_long.hpp)
-    if (const int R = stftl::classes_of(nfft); R && W <= nfft && (W == nfft || !detrend) && !c->cfg.stft_generic) {
+    // (k_sdif: frames of a group on grid.y, channel pairs on grid.z)
+    if (const int R = stftl::classes_of(nfft); R && W <= nfft && (W == nfft || !detrend) && !c->cfg.stft_generic && (n_ch + 1) / 2 <= 65535) {
         int lgR = 0;
         while ((1 << lgR) < R) ++lgR;
         if (!c->w4_tables) {
@@ -544,7 +555,7 @@ extern "C" int ds_stft_r2c_dev(ds_ctx* c, const float* x, int64_t n_samples, int
             CHK(upload_table_fwd(c, slot, h));
         }
         const int n_pc = (n_ch + 1) / 2, n_groups = (n_ch + 15) / 16;
-        const int per = stftl::frames_per_group(n_ch, nfft, n_frames);
+        const int per = std::min(65535, stftl::frames_per_group(n_ch, nfft, n_frames));
         CHK(reserve(c, &c->ws, &c->ws_bytes, Carver::pad(sizeof(float2) * (size_t)n_pc * per * nfft)));
         Carver cv(c->ws);
         float2* b = cv.take<float2>((size_t)n_pc * per * nfft);
@@ -1118,7 +1129,7 @@ static int welch_common(ds_ctx* c, int kind, const float* x, int n_cx, int64_t l
                        FinishPar{norm_scale * (double)std::max(1, nbias), factor, halve_edges, amp_sqrt, nb},
                        out_c, out_r};
         int64_t total = (int64_t)nb * (kind == 1 ? n_cx : n_cy);
-        CHK(launch(c, "welch_finish", k_welch_finish, dim3((unsigned)((total + 63) / 64)), 256, 0, f));
+        CHK(launch_finish(c, dim3((unsigned)((total + 63) / 64)), f));
         return DS_OK;
     }
     const bool need_xs = kind != 1;
@@ -1153,7 +1164,7 @@ static int welch_common(ds_ctx* c, int kind, const float* x, int n_cx, int64_t l
                    FinishPar{norm_scale / (double)n_frames, factor, halve_edges, amp_sqrt, nb},
                    out_c, out_r};
     int64_t total = (int64_t)nb * (kind == 1 ? n_cx : n_cy);
-    CHK(launch(c, "welch_finish", k_welch_finish, dim3((unsigned)((total + 63) / 64)), 256, 0, f));
+    CHK(launch_finish(c, dim3((unsigned)((total + 63) / 64)), f));
     return DS_OK;
 }
 
@@ -1222,7 +1233,7 @@ static int welch4096_run(ds_ctx* c, const float* x, int n_cx, int64_t ldx, const
                    FinishPar{norm_scale / (double)n_frames, factor, halve_edges, amp_sqrt, w4::NB},
                    tf, coh};
     int64_t total = (int64_t)w4::NB * n_cy;
-    CHK(launch(c, "welch_finish", k_welch_finish, dim3((unsigned)((total + 63) / 64)), 256, 0, f));
+    CHK(launch_finish(c, dim3((unsigned)((total + 63) / 64)), f));
     return DS_OK;
 }
 
@@ -1278,7 +1289,7 @@ static int welch8192_run(ds_ctx* c, const float* x, int n_cx, int64_t ldx, const
                    FinishPar{norm_scale / (double)n_frames, factor, halve_edges, amp_sqrt, w8::NB},
                    tf, coh};
     int64_t total = (int64_t)w8::NB * n_cy;
-    CHK(launch(c, "welch_finish", k_welch_finish, dim3((unsigned)((total + 63) / 64)), 256, 0, f));
+    CHK(launch_finish(c, dim3((unsigned)((total + 63) / 64)), f));
     return DS_OK;
 }
 
@@ -1313,7 +1324,7 @@ static int welch8192_psd_run(ds_ctx* c, const float* x, int n_cx, int64_t ldx, i
                    FinishPar{norm_scale / (double)n_frames, factor, halve_edges, amp_sqrt, w8::NB},
                    nullptr, psd};
     int64_t total = (int64_t)w8::NB * n_cx;
-    CHK(launch(c, "welch_finish", k_welch_finish, dim3((unsigned)((total + 63) / 64)), 256, 0, f));
+    CHK(launch_finish(c, dim3((unsigned)((total + 63) / 64)), f));
     return DS_OK;
 }
 
@@ -1369,7 +1380,7 @@ static int welch16384_run(ds_ctx* c, const float* x, int n_cx, int64_t ldx, cons
                    FinishPar{norm_scale / (double)n_frames, factor, halve_edges, amp_sqrt, w16::NB},
                    tf, coh};
     int64_t total = (int64_t)w16::NB * n_cy;
-    CHK(launch(c, "welch_finish", k_welch_finish, dim3((unsigned)((total + 63) / 64)), 256, 0, f));
+    CHK(launch_finish(c, dim3((unsigned)((total + 63) / 64)), f));
     return DS_OK;
 }
 // Windows of 2^15 ... 2^18 samples: decimation in frequency into R = W / 4096 class sequences (k_dif), the headline
@@ -1380,6 +1391,11 @@ static bool welch_long_applies(const ds_ctx* c, int W, int n_ch_total, int64_t n
     if (hop <= 0 || hop > W || !welchl::buf_fits(n_samples, n_frames, hop, W)) return false;
     // the class sequences: one complex value per sample of every frame pair (8 bytes per sample at 50 % overlap)
     const int64_t pairs = ((int64_t)frames_to_visit(n_samples, hop, n_frames) + 1) / 2;
+    // launch grids: k_dif puts the frame pairs on grid.y and the channels on grid.z, k_fold (chunk, channel) units on
+    // grid.y (chunks <= max(768 / R, pairs / 64), kernels_welch_long.hpp plan()); shapes beyond 65535 there (99 %
+    // overlap on 2^25 samples, ...) fall through to the routes behind this one
+    const int64_t chunks_max = std::max<int64_t>(768 / welchl::classes_of(W) + 1, (pairs + 63) / 64);
+    if (pairs > 65535 || n_ch_total > 65535 || chunks_max * n_ch_total > 65535) return false;
     return (int64_t)n_ch_total * pairs * W * 8 <= ((int64_t)16 << 30);
 }
 static int welch_long_run(ds_ctx* c, const float* x, int n_cx, int64_t ldx, const float* y, int n_cy, int64_t ldy,
@@ -1447,7 +1463,7 @@ static int welch_long_run(ds_ctx* c, const float* x, int n_cx, int64_t ldx, cons
         CHK(launch(c, "welch_long_fold", wl::k_fold<true>, fold_grid, 256, 0, ax));
         WelchFinArgs f{pyy, nullptr, nullptr, pl.n_chunks, pl.n_chunks, n_cx, 0, 1, 0,
                        FinishPar{norm_scale / (double)n_frames, factor, halve_edges, amp_sqrt, nb}, nullptr, coh};
-        return launch(c, "welch_finish", k_welch_finish, dim3((unsigned)(((int64_t)nb * n_cx + 63) / 64)), 256, 0, f);
+        return launch_finish(c, dim3((unsigned)(((int64_t)nb * n_cx + 63) / 64)), f);
     }
     CHK(launch(c, "welch_long_x", wl::k_xc, dim3((unsigned)(pl.n_pairs * R * n_cx)), wl::NT, wl::LDS_BYTES, ax));
     CHK(launch(c, "welch_long_pxsum", wl::k_px_sum, dim3((nb + 255) / 256, pl.n_chunks, n_cx), 256, 0, ax));
@@ -1461,7 +1477,7 @@ static int welch_long_run(ds_ctx* c, const float* x, int n_cx, int64_t ldx, cons
     CHK(launch(c, "welch_long_fold", wl::k_fold<false>, fold_grid, 256, 0, ay));
     WelchFinArgs f{psx, pxy, pyy, pl.n_chunks, pl.n_chunks, n_cx, n_cy, kind, mode,
                    FinishPar{norm_scale / (double)n_frames, factor, halve_edges, amp_sqrt, nb}, tf, coh};
-    return launch(c, "welch_finish", k_welch_finish, dim3((unsigned)(((int64_t)nb * n_cy + 63) / 64)), 256, 0, f);
+    return launch_finish(c, dim3((unsigned)(((int64_t)nb * n_cy + 63) / 64)), f);
 }
 
 static int welch16384_psd_run(ds_ctx* c, const float* x, int n_cx, int64_t ldx, int64_t n_samples, int hop,
@@ -1487,7 +1503,7 @@ static int welch16384_psd_run(ds_ctx* c, const float* x, int n_cx, int64_t ldx, 
                    FinishPar{norm_scale / (double)n_frames, factor, halve_edges, amp_sqrt, w16::NB},
                    nullptr, psd};
     int64_t total = (int64_t)w16::NB * n_cx;
-    CHK(launch(c, "welch_finish", k_welch_finish, dim3((unsigned)((total + 63) / 64)), 256, 0, f));
+    CHK(launch_finish(c, dim3((unsigned)((total + 63) / 64)), f));
     return DS_OK;
 }
 
@@ -1523,7 +1539,7 @@ static int welch4096_psd_run(ds_ctx* c, const float* x, int n_cx, int64_t ldx, i
                    FinishPar{norm_scale / (double)n_frames, factor, halve_edges, amp_sqrt, w4::NB},
                    nullptr, psd};
     int64_t total = (int64_t)w4::NB * n_cx;
-    CHK(launch(c, "welch_finish", k_welch_finish, dim3((unsigned)((total + 63) / 64)), 256, 0, f));
+    CHK(launch_finish(c, dim3((unsigned)((total + 63) / 64)), f));
     return DS_OK;
 }
 
@@ -1592,7 +1608,7 @@ static int welch_wave_run(ds_ctx* c, const float* x, int n_cx, int64_t ldx, cons
                    FinishPar{norm_scale / (double)n_frames, factor, halve_edges, amp_sqrt, nb_out},
                    tf, coh, W::NB, decim};
     int64_t total = (int64_t)nb_out * n_cy;
-    CHK(launch(c, "welch_finish", k_welch_finish, dim3((unsigned)((total + 63) / 64)), 256, 0, f));
+    CHK(launch_finish(c, dim3((unsigned)((total + 63) / 64)), f));
     return DS_OK;
 }
 
@@ -1630,7 +1646,7 @@ static int welch_wave_psd_run(ds_ctx* c, const float* x, int n_cx, int64_t ldx, 
                    FinishPar{norm_scale / (double)n_frames, factor, halve_edges, amp_sqrt, nb_out},
                    nullptr, psd, W::NB, decim};
     int64_t total = (int64_t)nb_out * n_cx;
-    CHK(launch(c, "welch_finish", k_welch_finish, dim3((unsigned)((total + 63) / 64)), 256, 0, f));
+    CHK(launch_finish(c, dim3((unsigned)((total + 63) / 64)), f));
     return DS_OK;
 }
 
@@ -1846,13 +1862,13 @@ extern "C" int ds_welch_spec_x64(ds_ctx* c, const double* x, const double* y, in
     return DS_OK;
 }
 
-// _csm_welch in float64 end to end (mean averaging, up to 64 channels): csm [nb][n_ch][n_ch] complex128
+// _csm_welch in float64 end to end (mean averaging, up to 1024 channels): csm [nb][n_ch][n_ch] complex128
 extern "C" int ds_csm_x64(ds_ctx* c, const double* x, int n_ch, int64_t n_samples, int W, int hop, int n_frames,
                           const double* window, int detrend, int amp_sqrt, double norm_scale, double factor,
                           int halve_edges, double* csm) {
     if (!c || !x || !window || !csm) return fail(c, DS_ERR_ARG, "ds_csm_x64: null argument");
     CHK(x64_shape_ok(c, "ds_csm_x64", n_ch, n_samples, W, hop, n_frames, DS_AVG_MEAN));
-    if (n_ch > w64::CSM_MAX_CH) return fail(c, DS_ERR_UNSUP, "ds_csm_x64: more than 64 channels (use ds_csm)");
+    if (n_ch > w64::CSM_MAX_CH) return fail(c, DS_ERR_UNSUP, "ds_csm_x64: more than 1024 channels (use ds_csm)");
     const int nb = W / 2 + 1;
     const size_t spec = (size_t)n_ch * n_frames * nb, bout = (size_t)nb * n_ch * n_ch;
     if (spec * sizeof(double2) > ((size_t)2 << 30))
@@ -1869,7 +1885,7 @@ extern "C" int ds_csm_x64(ds_ctx* c, const double* x, int n_ch, int64_t n_sample
     double2* dcsm = cv.take<double2>(bout);
     const int tile = std::max(1, std::min(n_frames, 4096 / n_ch));  // <= 64 KB of frame values per workgroup
     w64::CsmArgs ca{xs, n_ch, n_frames, FinishPar{norm_scale / (double)n_frames, factor, halve_edges, amp_sqrt, nb}, dcsm};
-    hipLaunchKernelGGL(w64::k_csm, dim3(nb), dim3(256), (size_t)n_ch * tile * 16, c->stream, ca, tile);
+    hipLaunchKernelGGL(w64::k_csm, dim3(nb, w64::csm_pair_groups(n_ch)), dim3(256), (size_t)n_ch * tile * 16, c->stream, ca, tile);
     HIPCHK(c, hipGetLastError());
     c->routes.insert("csm_f64");
     HIPCHK(c, hipMemcpyAsync(csm, dcsm, bout * 16, hipMemcpyDeviceToHost, c->stream));
@@ -2288,7 +2304,7 @@ static int welch_big(ds_ctx* c, int kind, const float* x, int n_cx, int64_t ldx,
     WelchFinArgs f{pxx, pxy, pyy, 1, 1, n_cx, n_cy, kind, mode,
                    FinishPar{norm_scale / count, factor, halve_edges, amp_sqrt, nb}, out_c, out_r};
     int64_t total = (int64_t)nb * (kind == 1 ? n_cx : n_cy);
-    CHK(launch(c, "welch_finish", k_welch_finish, dim3((unsigned)((total + 63) / 64)), 256, 0, f));
+    CHK(launch_finish(c, dim3((unsigned)((total + 63) / 64)), f));
     return DS_OK;
 }
 
@@ -2608,8 +2624,11 @@ static int fir_once(ds_ctx* c, const float* x, int n_ch, int64_t ldx, int64_t n_
     // a signal shorter than the filter (or a tiny one): the direct sum in float64 -- no rounding floor set by the block's
     // peak, which is what an FFT convolution leaves on an output far below (peak of the block) x (size of the taps)
     // (kernels_freqz.hpp; DESIGN section 2, limit (x)).  At most 2^28 multiply-adds.
-    if ((n_samples < n_taps || n_samples <= 512) && n_samples * std::min<int64_t>(n_samples, n_taps) * n_ch * n_filt <= ((int64_t)1 << 28) &&
-        n_filt <= 65535 && n_ch <= 65535) {
+    // Every output sample is one thread's sum over min(n_samples, n_taps) products: at most 16384 of them (a 2^20-tap
+    // filter on 256 samples would be 256 threads of a million dependent steps each).  DSPTOOLBOX_AMD_FIR_DIRECT=0 turns
+    // the route off (A/B against the FFT routes on the same shape).
+    if (c->cfg.fir_direct && (n_samples < n_taps || n_samples <= 512) && std::min<int64_t>(n_samples, n_taps) <= 16384 &&
+        n_samples * std::min<int64_t>(n_samples, n_taps) * n_ch * n_filt <= ((int64_t)1 << 28) && n_filt <= 65535 && n_ch <= 65535) {
         freqz::DirectArgs a{x, taps, n_samples, ldx, ld_y, n_ch, n_taps, y};
         return launch(c, "fir@direct_f64", freqz::k_fir_direct, dim3((unsigned)((n_samples + 255) / 256), n_ch, n_filt), 256, 0, a);
     }

@@ -25,6 +25,8 @@ struct ds_config {
     bool deconv_4percu = true;    // DSPTOOLBOX_AMD_DECONV_4PERCU=0: k_deconv3 (three per CU) instead of k_deconv3q
     bool fir_generic = false;     // DSPTOOLBOX_AMD_FIR_GENERIC: k_fir<16384> instead of fir16k
     int fir4k_min_taps = 1025;    // DSPTOOLBOX_AMD_FIR_4K: 0 never fir4k, 1 always, n > 1 from n taps on
+    bool fir_direct = true;       // DSPTOOLBOX_AMD_FIR_DIRECT=0: no direct float64 sum for a signal shorter than the filter
+    bool finish_wide = false;     // DSPTOOLBOX_AMD_FINISH_WIDE=1: k_welch_finish by 64-bit loads (the path of partial slabs >= 4 GiB)
     // ---- tuning overrides (0 = the built-in choice) ------------------------------------------------
     int stft_ct = 0, stft_fpw = 0, stft4k_chunks = 0, istft_fpw = 0;
     int welch_chunks = 0, welch1k_chunks = 0;
@@ -56,7 +58,9 @@ struct ds_config {
         g.deconv_generic = set("DSPTOOLBOX_AMD_DECONV_GENERIC");
         g.deconv_2percu = set("DSPTOOLBOX_AMD_DECONV_2PERCU");
         g.deconv_4percu = !(set("DSPTOOLBOX_AMD_DECONV_4PERCU") && num("DSPTOOLBOX_AMD_DECONV_4PERCU") == 0);
+        g.finish_wide = is("DSPTOOLBOX_AMD_FINISH_WIDE", '1');
         g.fir_generic = set("DSPTOOLBOX_AMD_FIR_GENERIC");
+        g.fir_direct = !(set("DSPTOOLBOX_AMD_FIR_DIRECT") && num("DSPTOOLBOX_AMD_FIR_DIRECT") == 0);
         if (const char* e = getenv("DSPTOOLBOX_AMD_FIR_4K")) {
             if (e[0] == '0')
                 g.fir4k_min_taps = 1 << 30;

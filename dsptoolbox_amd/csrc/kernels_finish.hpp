@@ -7,6 +7,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "size_guards.hpp"
+
 namespace dsk {
 
 struct cd {
@@ -83,6 +85,7 @@ struct WelchFinArgs {
     // windows shorter than the transform that ran (128 / 64 / 32 samples on the 256-point kernels): the partial rows hold
     // in_nb bins of which every in_step-th is one of the fin.nb output bins (0: rows of fin.nb bins, every one)
     int in_nb = 0, in_step = 1;
+    int force_wide = 0;  // 64-bit loads whatever the slab size (launch_finish, api.hip)
 };
 
 // block = 256 threads = 64 output values x 4 waves; wave s sums the chunks q = s (mod 4) in fp64,
@@ -122,6 +125,21 @@ __global__ __launch_bounds__(256) void k_welch_finish(WelchFinArgs p) {
         const int subu = __builtin_amdgcn_readfirstlane(sub);
         const uint32_t ex = live ? (uint32_t)ox : 0x3ffffffcu, ey = live ? (uint32_t)oy : 0x1ffffffeu;
         const int n_max = p.n_chunks_x > p.n_chunks ? p.n_chunks_x : p.n_chunks;
+        // The descriptors above hold a slab's byte size in 32 bits and the lanes' offsets are 32-bit byte offsets: a slab
+        // of 4 GiB or more (windows of 2^23 / 2^24 samples with 128 / 64 channels on the four-step path) would wrap and
+        // read zeros.  Those slabs take plain 64-bit loads, one chunk at a time (welch_finish_wide_slab in tests/host_san).
+        if (p.force_wide || welch_finish_wide_slab(sx, sy)) {
+            for (int q = subu; q < n_max; q += 4) {
+                if (!live) continue;
+                if (p.kind != 2 && q < p.n_chunks_x) sxx += (double)pxx[(int64_t)q * sx + ox];
+                if (p.kind != 1 && q < p.n_chunks) {
+                    const float2 v = pxy[(int64_t)q * sy + oy];
+                    sxy.x += (double)v.x;
+                    sxy.y += (double)v.y;
+                    if (want_yy) syy += (double)pyy[(int64_t)q * sy + oy];
+                }
+            }
+        } else
         for (int q0 = subu; q0 < n_max; q0 += 4 * U) {
             float vx[U], vy[U];
             float2 vxy[U];

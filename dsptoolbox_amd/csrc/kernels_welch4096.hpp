@@ -44,6 +44,10 @@ namespace welch4096 {
 #define W4_ABLATE 0  // timing-only diagnostics (wrong results): 1 no xs loads, 2 no sample loads, 4 no LDS
 #endif
 
+#ifndef W4_AB
+#define W4_AB 0  // timing-only ablations (wrong results), see kernels_welch4096w.hpp; 16: no internal W16 twiddles in dft16_h
+#endif
+
 #ifndef W4_TIMING
 #define W4_TIMING 0  // dev only: per-phase s_memtime stamps of wave 0 / workgroup 0 -> w4_timing[]
 #endif
@@ -124,21 +128,27 @@ __device__ __forceinline__ void dft16_h(float2 (&v)[16], PA pre_a, HA after_a, H
     after_a(0);
     pre_a(std::integral_constant<int, 1>{});
     r4(v[1], v[5], v[9], v[13]);
+    if (!(W4_AB & 16)) {
     v[5] = mulw(v[5], C8, S8);                                                  // W16^1
     v[9] = make_float2((v[9].x + v[9].y) * R2, (v[9].y - v[9].x) * R2);         // W16^2
     v[13] = mulw(v[13], S8, C8);                                                // W16^3
+    }
     after_a(1);
     pre_a(std::integral_constant<int, 2>{});
     r4(v[2], v[6], v[10], v[14]);
+    if (!(W4_AB & 16)) {
     v[6] = make_float2((v[6].x + v[6].y) * R2, (v[6].y - v[6].x) * R2);         // W16^2
     v[10] = make_float2(v[10].y, -v[10].x);                                     // W16^4 = -i
     v[14] = make_float2((v[14].y - v[14].x) * R2, -(v[14].x + v[14].y) * R2);   // W16^6
+    }
     after_a(2);
     pre_a(std::integral_constant<int, 3>{});
     r4(v[3], v[7], v[11], v[15]);
+    if (!(W4_AB & 16)) {
     v[7] = mulw(v[7], S8, C8);                                                  // W16^3
     v[11] = make_float2((v[11].y - v[11].x) * R2, -(v[11].x + v[11].y) * R2);   // W16^6
     v[15] = mulw(v[15], -C8, -S8);                                              // W16^9
+    }
     after_a(3);
 #pragma unroll
     for (int g = 0; g < 4; ++g) {

@@ -201,7 +201,8 @@ __device__ __forceinline__ void fft4096_w(float2 (&v)[16], const Tw6& tw, float2
 #define W4_XS_EARLY 0
 #endif
 #ifndef W4_AB
-#define W4_AB 0  // timing-only ablations (wrong results): 1 no xs loads, 2 no sample loads, 4 no LDS traffic, 8 no barriers
+#define W4_AB 0  // timing-only ablations (wrong results): 1 no xs loads, 2 no sample loads, 4 no LDS traffic, 8 no barriers,
+                 // 16 no internal W16 twiddles, 32 no window (no LDS window reads), 64 single twiddle products (no rebuild)
 #endif
 #define W4_SYNC()                          \
     do {                                   \
@@ -253,7 +254,7 @@ __device__ __forceinline__ void fft4096_wi(float2 (&v)[16], const Tw6& tw, float
             float2 z = v[4 * g + j];
 #if W4_TW6
             if (g) z = cmul(z, tw.a[g - 1]);
-            if (j) z = cmul(z, tw.b[j - 1]);
+            if (j && !((W4_AB & 64) && g)) z = cmul(z, tw.b[j - 1]);
 #else
             if (g + 4 * j) z = cmul(z, tw.w[g + 4 * j - 1]);
 #endif
@@ -545,7 +546,7 @@ __global__ __launch_bounds__(NT, W4_OCC) void k_y3(Args p) {
             const float w = winr[n1];
 #endif
             const float a = n1 < 8 ? carry[n1] : nx[n1 - 8];
-            v[n1] = make_float2(a * w, nx[n1] * w);
+            v[n1] = (W4_AB & 32) ? make_float2(a, nx[n1]) : make_float2(a * w, nx[n1] * w);
         }
 #pragma unroll
         for (int j = 0; j < 8; ++j) carry[j] = nx[8 + j];
@@ -600,7 +601,8 @@ __global__ __launch_bounds__(NT, W4_OCC) void k_y3(Args p) {
 #if W4_OCC == 3 && W4_WIN_ROT && !W4_WIN_GLOBAL
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int n1 = 0; n1 < 16; ++n1) winr[n1] = winl[tid + 256 * n1];
+        for (int n1 = 0; n1 < 16; ++n1)
+            if (!(W4_AB & 32)) winr[n1] = winl[tid + 256 * n1];
         __builtin_amdgcn_sched_barrier(0);
 #endif
         ts(11);

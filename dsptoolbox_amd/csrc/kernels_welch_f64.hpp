@@ -419,20 +419,24 @@ struct CsmArgs {
     dsk::FinishPar fin;
     double2* csm;  // [nb][n_ch][n_ch]
 };
-constexpr int CSM_MAX_CH = 64, CSM_PAIRS_PER_THREAD = 9;  // 64 * 65 / 2 = 2080 <= 9 * 256
+// a workgroup takes 9 * 256 = 2304 channel pairs (64 * 65 / 2 = 2080: one workgroup per bin up to 64 channels); more
+// channels: further workgroups of the same bin (grid.y) take the next 2304 pairs each and stage the same frame values
+constexpr int CSM_MAX_CH = 1024, CSM_PAIRS_PER_THREAD = 9, CSM_PAIRS_PER_WG = CSM_PAIRS_PER_THREAD * 256;
+inline int csm_pair_groups(int n_ch) { return (n_ch * (n_ch + 1) / 2 + CSM_PAIRS_PER_WG - 1) / CSM_PAIRS_PER_WG; }
 
 // One workgroup per bin: the bin's frame values X[c][f] go through LDS in tiles of frames, every thread sums up to nine
 // (i2 >= i1) pairs conj(X_i1) X_i2 over the frames (fp64), finishes them and stores the element and its conjugate
-// mirror (the reference's lower triangle + swapaxes, :351-369).  grid = nb, dynamic LDS = n_ch * tile * 16 bytes.
+// mirror (the reference's lower triangle + swapaxes, :351-369).  grid = (nb, csm_pair_groups(n_ch)), dynamic LDS =
+// n_ch * tile * 16 bytes.
 __global__ __launch_bounds__(256) void k_csm(CsmArgs p, int tile) {
     extern __shared__ __align__(16) double2 xt[];  // [tile][n_ch]
     const int b = blockIdx.x, nb = p.fin.nb, C = p.n_ch, F = p.n_frames, tid = threadIdx.x;
-    const int pairs = C * (C + 1) / 2;
+    const int pairs = C * (C + 1) / 2, q0 = (int)blockIdx.y * CSM_PAIRS_PER_WG;
     int i1s[CSM_PAIRS_PER_THREAD], i2s[CSM_PAIRS_PER_THREAD];
     cd acc[CSM_PAIRS_PER_THREAD];
 #pragma unroll
     for (int s = 0; s < CSM_PAIRS_PER_THREAD; ++s) {
-        const int q = tid + 256 * s;
+        const int q = q0 + tid + 256 * s;
         // pair q -> (i2, i1), i2 >= i1, rows of the lower triangle one after the other
         int i2 = (int)((sqrt(8.0 * (double)q + 1.0) - 1.0) * 0.5);
         while ((i2 + 1) * (i2 + 2) / 2 <= q) ++i2;
@@ -451,7 +455,7 @@ __global__ __launch_bounds__(256) void k_csm(CsmArgs p, int tile) {
         __syncthreads();
 #pragma unroll
         for (int s = 0; s < CSM_PAIRS_PER_THREAD; ++s) {
-            if (tid + 256 * s >= pairs) continue;
+            if (q0 + tid + 256 * s >= pairs) continue;
             const int i1 = i1s[s], i2 = i2s[s];
             cd a = acc[s];
             for (int f = 0; f < nf; ++f) {
@@ -464,7 +468,7 @@ __global__ __launch_bounds__(256) void k_csm(CsmArgs p, int tile) {
     }
 #pragma unroll
     for (int s = 0; s < CSM_PAIRS_PER_THREAD; ++s) {
-        if (tid + 256 * s >= pairs) continue;
+        if (q0 + tid + 256 * s >= pairs) continue;
         const int i1 = i1s[s], i2 = i2s[s];
         double2* m = p.csm + (size_t)b * C * C;
         if (i1 == i2) {

@@ -715,6 +715,64 @@ def gen_api_rest(dsp):
     save("api_rest", dict(cases=cases, fs=fs), arrs)
 
 
+def gen_api_holes(dsp):
+    """Round 5 (missing 4 and 5): Spectrum.sum_channels(power_sum) (classes/spectrum.py:435-459),
+    MultiBandSignal.is_complex_signal (classes/multibandsignal.py:262-274), ImpulseResponse.set_window
+    (classes/impulse_response.py:139-152), and a SHORT cross-spectral matrix of more than 64 channels
+    (_spectral_methods.py:285-371 through Signal.get_csm: 70 channels, 22 frames)."""
+    import warnings
+    from dsptoolbox.standard.enums import SpectrumScaling, SpectrumMethod
+    warnings.simplefilter("ignore")
+    fs = 48000
+    rng = np.random.default_rng(505)
+    cases, arrs = [], {}
+    f = np.fft.rfftfreq(256, 1 / fs)
+    cplx = rng.standard_normal((129, 3)) + 1j * rng.standard_normal((129, 3))
+    mag = np.abs(rng.standard_normal((129, 4)))
+    arrs["freqs"], arrs["spec_complex"], arrs["spec_magnitude"] = f, cplx, mag
+    for name, data in (("complex", cplx), ("magnitude", mag)):
+        sp = dsp.Spectrum(f, data.copy())
+        for ps in (True, False):
+            out = sp.sum_channels(power_sum=ps)
+            assert type(out).__name__ == "Spectrum" and out.number_of_channels == 1
+            arrs[f"sum_{name}_{int(ps)}"] = out.spectral_data
+            cases.append(dict(kind="spectrum_sum_channels", data=name, power_sum=ps, key=f"sum_{name}_{int(ps)}"))
+        arrs[f"sum_{name}_default"] = sp.sum_channels().spectral_data  # the default is the power sum
+    # MultiBandSignal.is_complex_signal
+    real_bands = [dsp.Signal(None, rng.standard_normal((400, 2)) * 0.1, fs) for _ in range(2)]
+    cb = [rng.standard_normal((400, 2)) * 0.1 + 1j * rng.standard_normal((400, 2)) * 0.1 for _ in range(2)]
+    cplx_bands = [dsp.Signal(None, b, fs) for b in cb]
+    flags = dict(empty=bool(dsp.MultiBandSignal().is_complex_signal),
+                 real=bool(dsp.MultiBandSignal(real_bands).is_complex_signal),
+                 complex=bool(dsp.MultiBandSignal(cplx_bands).is_complex_signal))
+    arrs["complex_band_0"] = cb[0]
+    cases.append(dict(kind="multiband_is_complex", flags=flags))
+    # ImpulseResponse.set_window: kept as given, returns the object, refuses another shape
+    td = rng.standard_normal((300, 2)) * 0.1
+    ir = dsp.ImpulseResponse(None, td.copy(), fs)
+    w = np.abs(rng.standard_normal((300, 2)))
+    back = ir.set_window(w)
+    refused = False
+    try:
+        ir.set_window(w[:100])
+    except AssertionError:
+        refused = True
+    arrs["ir_td"], arrs["ir_window"], arrs["ir_window_kept"] = td, w, ir.window
+    cases.append(dict(kind="ir_set_window", returns_self=bool(back is ir), refuses_other_shape=refused))
+    # a short cross-spectral matrix of 70 channels (float64 route of the product: <= 128 frames)
+    n_ch, n, W = 70, 1400, 128
+    x = 0.1 * rng.standard_normal((n, n_ch)) + 0.2 * rng.standard_normal(n)[:, None]
+    sig = dsp.Signal(None, x.copy(), fs)
+    for i, sc in enumerate((SpectrumScaling.FFTBackward, SpectrumScaling.AmplitudeSpectrum)):
+        sig.set_spectrum_parameters(method=SpectrumMethod.WelchPeriodogram, window_length_samples=W, scaling=sc)
+        fv, m = sig.get_csm()
+        arrs[f"csm70_{i}"] = m[::8]  # every 8th bin (9 of 65): 0.7 MB instead of 5
+        cases.append(dict(kind="csm_short_many_channels", channels=n_ch, W=W, scaling=sc.name, key=f"csm70_{i}",
+                          bin_step=8, frames=int(np.ceil(n / (W // 2)))))
+    arrs["csm70_x"] = x
+    save("api_holes", dict(cases=cases, fs=fs), arrs)
+
+
 def gen_core(dsp):
     """framing, welch, transfer_function, stft, csm, spectrum_fft, deconvolve, fir and chirp_pair."""
     from dsptoolbox.standard._spectral_methods import _welch
@@ -1012,6 +1070,7 @@ GENERATORS = {
     "mel": (gen_mel, ["mel"]),
     "chroma": (gen_chroma, ["chroma"]),
     "api_rest": (gen_api_rest, ["api_rest"]),
+    "api_holes": (gen_api_holes, ["api_holes"]),
 }
 
 

@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "../../dsptoolbox_amd/csrc/host_marshal.hpp"
+#include "../../dsptoolbox_amd/csrc/size_guards.hpp"
 
 static int failures = 0;
 #define EXPECT(cond)                                                    \
@@ -43,6 +44,20 @@ struct MemTransport {
 };
 
 int main() {
+    // ---- k_welch_finish: which partial slabs leave the 32-bit raw-buffer descriptors (W = 2^24 with 64
+    // output channels is sy * 8 = 4 294 967 808 bytes and used to wrap to 512)
+    {
+        const int64_t nb24 = ((int64_t)1 << 23) + 1, nb23 = ((int64_t)1 << 22) + 1, nb4096 = 2049;
+        EXPECT(!welch_finish_wide_slab(1 * nb4096, 64 * nb4096));    // the headline shape
+        EXPECT(!welch_finish_wide_slab(1 * nb24, 63 * nb24));        // 4 227 858 936 bytes: below 2^32 - 16
+        EXPECT(welch_finish_wide_slab(1 * nb24, 64 * nb24));         // 4 294 967 808: wraps
+        EXPECT(!welch_finish_wide_slab(1 * nb23, 127 * nb23));
+        EXPECT(welch_finish_wide_slab(1 * nb23, 128 * nb23));
+        EXPECT(welch_finish_wide_slab(128 * nb24, 0));               // auto spectra: sx * 4
+        EXPECT(!welch_finish_wide_slab(127 * nb24, 0));
+        EXPECT(welch_finish_wide_slab(0, ((int64_t)0xfffffff0 + 7) / 8));
+        EXPECT(!welch_finish_wide_slab(0, (int64_t)0xfffffff0 / 8 - 1));
+    }
     std::mt19937 rng(7);
     std::uniform_real_distribution<double> ud(-1.0, 1.0);
     // ---- the plain helpers, every thread count

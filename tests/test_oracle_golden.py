@@ -444,6 +444,40 @@ def test_api_rest_fir_side():
             raise AssertionError(c["kind"])
 
 
+def test_api_holes_host_side():
+    """tests/golden/api_holes.npz (from the reference): Spectrum.sum_channels(power_sum), MultiBandSignal.is_complex_signal,
+    ImpulseResponse.set_window through the product's containers (host logic: no kernel runs), and the oracle's matrix
+    of a 70-channel short estimate (the GPU side: test_gpu_parity.py::test_csm_short_estimate_of_70_channels)."""
+    import dsptoolbox_amd as dsp
+    meta, z = load_golden("api_holes")
+    fs = meta["fs"]
+    for c in meta["cases"]:
+        if c["kind"] == "spectrum_sum_channels":
+            sp = dsp.Spectrum(z["freqs"], z["spec_" + c["data"]].copy())
+            out = sp.sum_channels(power_sum=c["power_sum"])
+            assert isinstance(out, dsp.Spectrum) and out.number_of_channels == 1
+            assert out.spectral_data.dtype == z[c["key"]].dtype
+            close(out.spectral_data, z[c["key"]], 1e-14)
+            close(sp.sum_channels().spectral_data, z[f"sum_{c['data']}_default"], 1e-14)
+        elif c["kind"] == "multiband_is_complex":
+            real = [dsp.Signal(None, np.real(z["complex_band_0"]).copy(), fs) for _ in range(2)]
+            cplx = [dsp.Signal(None, z["complex_band_0"].copy(), fs) for _ in range(2)]
+            got = dict(empty=dsp.MultiBandSignal().is_complex_signal, real=dsp.MultiBandSignal(real).is_complex_signal,
+                       complex=dsp.MultiBandSignal(cplx).is_complex_signal)
+            assert got == c["flags"]
+        elif c["kind"] == "ir_set_window":
+            ir = dsp.ImpulseResponse(None, z["ir_td"].copy(), fs)
+            back = ir.set_window(z["ir_window"])
+            assert (back is ir) == c["returns_self"]
+            assert np.array_equal(ir.window, z["ir_window_kept"])
+            with pytest.raises(AssertionError):
+                ir.set_window(z["ir_window"][:100])
+            assert c["refuses_other_shape"]
+        elif c["kind"] == "csm_short_many_channels":
+            f, m = orc.csm_welch(z["csm70_x"], fs, c["W"], "hann", 50, True, "mean", c["scaling"])
+            close(m[::c["bin_step"]], z[c["key"]], 1e-12)
+
+
 def test_gen_golden_writes_every_fixture():
     """`python oracle/gen_golden.py` (no flags) must regenerate ALL of tests/golden: the generator table names every
     fixture file exactly once."""
