@@ -52,7 +52,7 @@ KERNEL_HINTS = {"welch4096_main": ("welch4096::k_y3<", "welch4096::k_y<"),
                 "welch1024_main": ("welch1k::k_y<",), "welch_yacc": ("k_yacc",),
                 "fir": ("fir4k::k_fir<", "fir16k::k_fir<true>", "fir16k::k_fir", "k_fir<"),
                 "csm_gemm": ("k_csm_fused", "k_csm_gemm"), "stft": ("k_stft_wave", "k_stft"),
-                "deconv": ("k_deconv3", "k_deconv")}
+                "deconv": ("k_deconv_p", "k_deconv3", "k_deconv")}
 
 
 def parse_args():

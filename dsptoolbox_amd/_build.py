@@ -22,7 +22,7 @@ RES_PATH = os.path.join(LIB_DIR, "kernel_resources.json")
 NO_SCRATCH = [
     "welch40964k_y3", "welch40964k_x3", "welch40963k_y", "welch40963k_x",
     "stft1k11k_stft_wave", "stft4k6k_stft", "stft4k7k_istft", "stft4k10k_stft_dif", "welch1k3k_y", "welch1k3k_x", "welch8k3k_y", "welch8k3k_x", "welch16k3k_y", "welch16k3k_x", "welchl4k_yc", "welchl4k_xc", "stftl10k_stft_cls",
-    "fir16k5k_firILb1E", "fir4k5k_firILi1E", "fir4k5k_firILi2E", "deconv8k8k_deconv", "k_csm_gemm64",
+    "fir16k5k_firILb1E", "fir4k5k_firILi1E", "fir4k5k_firILi2E", "deconv8k10k_deconv_p", "k_csm_gemm64",
 ]
 
 

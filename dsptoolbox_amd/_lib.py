@@ -25,6 +25,8 @@ SIGNATURES = {
     "ds_last_error": (C.c_char_p, [ctx_p]),
     "ds_malloc": (C.c_int, [ctx_p, C.POINTER(C.c_void_p), C.c_size_t]),
     "ds_free": (C.c_int, [ctx_p, C.c_void_p]),
+    "ds_host_alloc": (C.c_int, [ctx_p, C.POINTER(C.c_void_p), C.c_size_t]),
+    "ds_host_free": (C.c_int, [ctx_p, C.c_void_p]),
     "ds_host_planar_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int64, C.c_int]),
     "ds_host_interleave_f64": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int64, C.c_void_p, C.c_int]),
     "ds_host_widen_f64": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int]),
@@ -209,6 +211,56 @@ class Context:
         self.upload(d, arr)
         return d
 
+    def staging(self, nbytes: int) -> np.ndarray:
+        """A page-locked host byte buffer of at least `nbytes`, owned by the context and reused by every call
+        (grown when needed): results are downloaded into it at the link's rate and copied / widened out of it
+        before the next call.  One buffer per context = per thread."""
+        cur = getattr(self, "_staging", None)
+        if cur is None or cur[1] < nbytes:
+            if cur is not None:
+                self.check(self.lib.ds_host_free(self.handle, C.c_void_p(cur[0])), "ds_host_free")
+                self._staging = None
+            size = max(int(nbytes), 1 << 22)
+            p = C.c_void_p()
+            self.check(self.lib.ds_host_alloc(self.handle, C.byref(p), size), "ds_host_alloc")
+            arr = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(size,))
+            self._staging = cur = (p.value, size, arr)
+        return cur[2][:nbytes]
+
+    def download_result(self, dptr: int, shape, dtype) -> np.ndarray:
+        """Device -> a page-locked host block the CALLER owns: the array returned is backed by a block of this
+        context's result pool, which takes the block back when the last array referring to it is gone (its reference
+        count says so).  For the small results of device-resident calls: no staging copy, no page faults of a fresh
+        allocation, the link's full rate."""
+        import sys
+        n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        size = max(4096, 1 << (n - 1).bit_length())
+        pool = self.__dict__.setdefault("_result_pool", {})
+        lst = pool.setdefault(size, [])
+        blk = None
+        for cand in lst:
+            if sys.getrefcount(cand[1]) <= 2:  # the tuple in the list and getrefcount's argument
+                blk = cand[1]
+                break
+        if blk is None:
+            p = C.c_void_p()
+            self.check(self.lib.ds_host_alloc(self.handle, C.byref(p), size), "ds_host_alloc")
+            blk = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(size,))
+            if len(lst) < 16:
+                lst.append((p.value, blk))
+            else:  # (more live results than the pool keeps: this block is simply never reused; freed with the context)
+                self.__dict__.setdefault("_result_overflow", []).append(p.value)
+        self.check(self.lib.ds_download(self.handle, blk.ctypes.data, C.c_void_p(dptr), n), "ds_download")
+        return blk[:n].view(dtype).reshape(shape)
+
+    def download_staged(self, dptr: int, shape, dtype) -> np.ndarray:
+        """Device -> page-locked staging buffer; the returned array is a VIEW of that buffer (valid until the
+        next staged download of this context)."""
+        n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        view = self.staging(n)
+        self.check(self.lib.ds_download(self.handle, view.ctypes.data, C.c_void_p(dptr), n), "ds_download")
+        return view.view(dtype).reshape(shape)
+
     def sync(self):
         self.check(self.lib.ds_sync(self.handle), "ds_sync")
 
@@ -257,6 +309,15 @@ class Context:
 
     def close(self):
         if getattr(self, "handle", None):
+            import sys
+            cur = getattr(self, "_staging", None)
+            if cur is not None:
+                self.lib.ds_host_free(self.handle, C.c_void_p(cur[0]))
+                self._staging = None
+            for lst in self.__dict__.pop("_result_pool", {}).values():
+                for ptr, blk in lst:
+                    if sys.getrefcount(blk) <= 3:  # (a block somebody still reads stays mapped until the process ends)
+                        self.lib.ds_host_free(self.handle, C.c_void_p(ptr))
             self.lib.ds_destroy(self.handle)
             self.handle = None
 
@@ -291,6 +352,48 @@ def reset_context() -> Context:
         ctx.close()
     _tls.ctx = Context()
     return _tls.ctx
+
+
+class DevicePlanar:
+    """Planar float32 samples that live in HBM: channel c at `ptr + 4 * c * ld`, `n_samples` valid samples each
+    (the layout every `_dev` entry point of the C-ABI takes).  `owner` is the DeviceBuffer the bytes belong to --
+    several DevicePlanar objects may share one (the bands of a filter bank's output are slices of ONE buffer) and it
+    is freed when the last of them goes.  Treated as immutable: nothing writes into a buffer once it is handed out."""
+
+    def __init__(self, owner: "DeviceBuffer", n_ch: int, n_samples: int, ld: int | None = None, offset_bytes: int = 0):
+        self.owner = owner
+        self.n_ch, self.n_samples = int(n_ch), int(n_samples)
+        self.ld = int(n_samples if ld is None else ld)
+        self.offset_bytes = int(offset_bytes)
+        assert self.offset_bytes + 4 * ((self.n_ch - 1) * self.ld + self.n_samples) <= owner.nbytes
+
+    @property
+    def ctx(self):
+        return self.owner.ctx
+
+    @property
+    def ptr(self) -> int:
+        return self.owner.ptr + self.offset_bytes
+
+    @classmethod
+    def from_planar(cls, ctx: "Context", planar: np.ndarray) -> "DevicePlanar":
+        """Upload a (channels, samples) float32 array (one copy over the link, no cast)."""
+        planar = np.ascontiguousarray(planar, dtype=np.float32)
+        assert planar.ndim == 2, "planar samples are (channels, samples)"
+        return cls(DeviceBuffer.from_array(ctx, planar), planar.shape[0], planar.shape[1])
+
+    def to_planar(self) -> np.ndarray:
+        """(channels, samples) float32 on the host."""
+        out = np.empty((self.n_ch, self.n_samples), dtype=np.float32)
+        if self.ld == self.n_samples:
+            self.ctx.download(self.ptr, out)
+        else:
+            for c in range(self.n_ch):
+                self.ctx.download(self.ptr + 4 * c * self.ld, out[c])
+        return out
+
+    def __deepcopy__(self, memo):
+        return self  # immutable and reference counted: copies of a Signal share the device samples
 
 
 class DeviceBuffer:

@@ -27,7 +27,7 @@ import numpy as np
 from scipy.signal import check_COLA
 from scipy.signal.windows import get_window
 
-from ._lib import DeviceBuffer, get_context, load_library
+from ._lib import DeviceBuffer, DevicePlanar, get_context, load_library
 from .standard.enums import SpectrumScaling, Window
 
 DS_TF = {"H1": 1, "H2": 2, "H3": 3}
@@ -66,10 +66,12 @@ def _interleaved_f64(planar: np.ndarray, dst: np.ndarray | None = None) -> np.nd
 def _widen(a: np.ndarray) -> np.ndarray:
     """float32 -> float64 / complex64 -> complex128 of a C-contiguous array (threaded for large ones)."""
     wide = np.complex128 if a.dtype == np.complex64 else np.float64
-    if a.dtype in (np.float32, np.complex64) and a.flags.c_contiguous and a.size >= (1 << 20):
+    if a.dtype in (np.float32, np.complex64) and a.flags.c_contiguous and a.size >= (1 << 14):
         out = np.empty(a.shape, dtype=wide)
         n = a.size * (2 if a.dtype == np.complex64 else 1)
-        if load_library().ds_host_widen_f64(_ptr(a), n, _ptr(out), 0) == 0:
+        # (mid-size arrays -- the spectra of a device-resident estimate -- in the calling thread: numpy's astype
+        # takes 80 us for 2049 x 64 complex values, this loop 25)
+        if load_library().ds_host_widen_f64(_ptr(a), n, _ptr(out), 0 if a.size >= (1 << 20) else 1) == 0:
             return out
     return a.astype(wide)
 
@@ -85,9 +87,25 @@ def _ptr(a: np.ndarray):
     return a.ctypes.data_as(C.c_void_p)
 
 
+_WINDOWS: dict = {}
+
+
 def _window_array(window_type, length: int) -> np.ndarray:
+    """scipy.signal.get_window(spec, length, fftbins=True), computed once per (spec, length): the array is handed out
+    read-only (55 us for 4096 Hann samples is a quarter of a device-resident transfer-function call)."""
     spec = window_type.to_scipy_format() if isinstance(window_type, Window) else window_type
-    return get_window(spec, length, fftbins=True)
+    try:
+        key = (spec if not isinstance(spec, list) else tuple(spec), int(length))
+        hash(key)
+    except TypeError:
+        return get_window(spec, length, fftbins=True)
+    w = _WINDOWS.get(key)
+    if w is None:
+        if len(_WINDOWS) >= 64:
+            _WINDOWS.pop(next(iter(_WINDOWS)))
+        w = _WINDOWS[key] = np.array(get_window(spec, length, fftbins=True))  # (scipy hands out a view: own the data)
+        w.setflags(write=False)
+    return w
 
 
 def _finish_params(scaling: SpectrumScaling, W: int, fs_hz: int, window: np.ndarray):
@@ -107,10 +125,31 @@ def _welch_checks(window_length_samples, overlap_percent, average):
     assert average in ("mean", "median"), f"{average} is not valid. Use either mean or median"
 
 
+_COLA: dict = {}
+
+
+def _window_key(window: np.ndarray):
+    """Identity of one of _window_array's read-only arrays (they live as long as the cache), content hash otherwise."""
+    if not window.flags.writeable and window.base is None:
+        return ("id", id(window), window.size)
+    return ("bytes", window.size, hash(np.ascontiguousarray(window).tobytes()))
+
+
+def _cola_ok(window: np.ndarray, overlap: int) -> bool:
+    """scipy.signal.check_COLA, remembered per (window, overlap)."""
+    key = (int(overlap), _window_key(window))
+    ok = _COLA.get(key)
+    if ok is None:
+        if len(_COLA) >= 256:
+            _COLA.clear()
+        ok = _COLA[key] = bool(check_COLA(window, nperseg=len(window), noverlap=overlap))
+    return ok
+
+
 def _welch_framing(n_samples: int, W: int, overlap_percent: float, window: np.ndarray):
     overlap = int(overlap_percent / 100 * W)  # truncation, _spectral_methods.py:106
     hop = W - overlap
-    if not check_COLA(window, nperseg=len(window), noverlap=overlap):
+    if not _cola_ok(window, overlap):
         warn("Selected window type and overlap do not meet the constant "
              "overlap and add constraint! Results might be distorted")
     n_frames = int(np.ceil(n_samples / hop))  # helpers/other.py:206
@@ -297,6 +336,233 @@ def welch_transfer_function(output_td, input_td, fs_hz: int, window_length_sampl
     return tf.astype(np.complex128), coh.astype(np.float64)
 
 
+# ---- the same calls over samples that are ALREADY in HBM (Signal.to_device / from_planar_f32) -------------------------
+# No cast, no transpose, no upload of the signal; small results come down through the context's page-locked staging
+# buffer, results that are signals stay on the device (DevicePlanar).  Windows and taps are a few KB: uploaded per call.
+class _Borrowed:
+    """A context-owned device buffer lent to one call: free() is a no-op."""
+
+    def __init__(self, buf: DeviceBuffer):
+        self.ptr, self.nbytes, self.ctx = buf.ptr, buf.nbytes, buf.ctx
+
+    def free(self):
+        pass
+
+
+def _window_dev(ctx, window: np.ndarray):
+    """The float32 window on the device, kept per context (a handful of KB each, keyed by content): a resident call
+    neither allocates nor uploads one (hipMalloc + hipFree cost more than the 0.12 ms of kernels they surround)."""
+    cache = ctx.__dict__.setdefault("_window_cache", {})
+    key = _window_key(window)
+    hit = cache.get(key)
+    if hit is None:
+        if len(cache) >= 32:
+            cache.pop(next(iter(cache)))[0].free()
+        # (the window object rides along: an id is only a key while its object lives)
+        hit = cache[key] = (DeviceBuffer.from_array(ctx, np.ascontiguousarray(window, dtype=np.float32)), window)
+    return _Borrowed(hit[0])
+
+
+def _result_scratch(ctx, nbytes: int):
+    """Context-owned device buffer for SMALL results that are downloaded before the call returns (transfer functions,
+    spectra): reused by every call of the thread, grown when needed."""
+    cur = ctx.__dict__.get("_result_scratch")
+    if cur is None or cur.nbytes < nbytes:
+        if cur is not None:
+            cur.free()
+        cur = ctx.__dict__["_result_scratch"] = DeviceBuffer(ctx, max(int(nbytes), 1 << 22))
+    return _Borrowed(cur)
+
+
+def welch_transfer_function_device(y_dev: DevicePlanar, x_dev: DevicePlanar, fs_hz: int, window_length_samples: int,
+                                   mode: str, window_type=Window.Hann, overlap_percent: float = 50.0,
+                                   detrend: bool = True, average: str = "mean",
+                                   scaling: SpectrumScaling = SpectrumScaling.FFTBackward, narrow: bool = False):
+    """welch_transfer_function on device-resident planar float32 samples (fp32 kernels, ds_welch_tf_dev).
+    -> (tf complex128 (B, Cy), coherence float64 (B, Cy)); narrow=True: the complex64 / float32 arrays as they came
+    off the device (page-locked, owned by the caller) -- what Spectrum widens on first access."""
+    _welch_checks(window_length_samples, overlap_percent, average)
+    if mode not in DS_TF:
+        raise ValueError("Unsupported transfer function type")
+    W = int(window_length_samples)
+    window = _window_array(window_type, W)
+    n, n_cy, n_cx = y_dev.n_samples, y_dev.n_ch, x_dev.n_ch
+    assert x_dev.n_samples == n, "Signal lengths do not match"
+    hop, n_frames = _welch_framing(n, W, overlap_percent, window)
+    amp, norm_scale, factor, phys = _finish_params(scaling, W, fs_hz, window)
+    B = W // 2 + 1
+    ctx = y_dev.ctx
+    d_w = _window_dev(ctx, window)
+    d_res = _result_scratch(ctx, B * n_cy * 12)
+    try:
+        ctx.check(ctx.lib.ds_welch_tf_dev(ctx.handle, C.c_void_p(x_dev.ptr), n_cx, x_dev.ld, C.c_void_p(y_dev.ptr), n_cy,
+                                          y_dev.ld, n, W, hop, n_frames, C.c_void_p(d_w.ptr), int(bool(detrend)),
+                                          DS_AVG[average], DS_TF[mode], amp, norm_scale, factor, phys,
+                                          C.c_void_p(d_res.ptr), C.c_void_p(d_res.ptr + B * n_cy * 8)), "ds_welch_tf_dev")
+        raw = ctx.download_result(d_res.ptr, (B * n_cy * 12,), np.uint8)
+        tf = raw[:B * n_cy * 8].view(np.complex64).reshape(B, n_cy)
+        coh = raw[B * n_cy * 8:].view(np.float32).reshape(B, n_cy)
+    finally:
+        d_w.free()
+        d_res.free()
+    return (tf, coh) if narrow else (_widen(tf), _widen(coh))
+
+
+def _welch_psd_device(x_dev: DevicePlanar, fs_hz: int, window_type, window_length_samples: int, overlap_percent: float,
+                      detrend: bool, average: str, scaling: SpectrumScaling):
+    """Welch auto spectra of every channel of a device-resident signal (ds_welch_psd_dev) -> (B, C) as _welch."""
+    _welch_checks(window_length_samples, overlap_percent, average)
+    W = int(window_length_samples)
+    window = _window_array(window_type, W)
+    hop, n_frames = _welch_framing(x_dev.n_samples, W, overlap_percent, window)
+    amp, norm_scale, factor, phys = _finish_params(scaling, W, fs_hz, window)
+    B = W // 2 + 1
+    ctx = x_dev.ctx
+    d_w = _window_dev(ctx, window)
+    d_o = _result_scratch(ctx, B * x_dev.n_ch * 4)
+    try:
+        ctx.check(ctx.lib.ds_welch_psd_dev(ctx.handle, C.c_void_p(x_dev.ptr), x_dev.n_ch, x_dev.ld, x_dev.n_samples, W, hop,
+                                           n_frames, C.c_void_p(d_w.ptr), int(bool(detrend)), DS_AVG[average], amp, norm_scale,
+                                           factor, phys, C.c_void_p(d_o.ptr)), "ds_welch_psd_dev")
+        out = ctx.download_staged(d_o.ptr, (B, x_dev.n_ch), np.float32)
+        return out.astype(np.complex128 if DS_AVG[average] else np.float64)
+    finally:
+        d_w.free()
+        d_o.free()
+
+
+class DeviceSTFT:
+    """A spectrogram that stays in HBM: (bins, frames, channels) complex64 in `buf` -- the layout ds_stft_r2c writes,
+    ds_istft and ds_band_power read.  What `Signal.get_spectrogram(on_device=True)` returns in place of the array;
+    `to_host()` gives the reference's complex128 array."""
+
+    def __init__(self, buf: DeviceBuffer, shape, power: bool):
+        self.buf, self.shape, self.power = buf, tuple(int(v) for v in shape), bool(power)
+
+    def to_host(self) -> np.ndarray:
+        out = self.buf.to_array(self.shape, np.complex64)
+        return out.real.astype(np.float64) if self.power else _widen(out)
+
+    def __deepcopy__(self, memo):
+        return self
+
+
+def _stft_device(x_dev: DevicePlanar, fs_hz: int, window_length_samples: int, window_type, overlap_percent: float,
+                 fft_length_samples, detrend: bool, padding: bool, scaling: SpectrumScaling, keep_on_device: bool):
+    """_stft of a device-resident signal -> (time_s, freqs_hz, stft): stft the (B', F, C) complex128 array, or a
+    DeviceSTFT when keep_on_device."""
+    pl = _stft_plan(_ShapeOnly(x_dev.n_samples, x_dev.n_ch), fs_hz, window_length_samples, window_type, overlap_percent,
+                    fft_length_samples, padding, scaling, planar=False)
+    ctx = x_dev.ctx
+    d_w = _window_dev(ctx, pl["w32"])
+    shape = (pl["B"], pl["n_frames"], pl["n_ch"])
+    d_s = DeviceBuffer(ctx, int(np.prod(shape)) * 8)
+    try:
+        ctx.check(ctx.lib.ds_stft_r2c_dev(ctx.handle, C.c_void_p(x_dev.ptr), pl["n"], pl["n_ch"], x_dev.ld, pl["W"], pl["hop"],
+                                          pl["nfft"], pl["pad_front"], pl["n_frames"], C.c_void_p(d_w.ptr), int(bool(detrend)),
+                                          pl["scale"], pl["edge"], pl["power"], C.c_void_p(d_s.ptr)), "ds_stft_r2c_dev")
+        dev = DeviceSTFT(d_s, shape, pl["power"])
+        if keep_on_device:
+            ctx.sync()  # (the window buffer is freed below)
+            return pl["time_s"], pl["freqs_hz"], dev
+        out = dev.to_host()
+        d_s.free()
+        return pl["time_s"], pl["freqs_hz"], out
+    finally:
+        d_w.free()
+
+
+class _ShapeOnly:
+    """(N, C) shape carrier for _stft_plan(planar=False) when the samples are on the device."""
+
+    def __init__(self, n: int, n_ch: int):
+        self.shape = (int(n), int(n_ch))
+
+
+def fir_filter_bank_device(x_dev: DevicePlanar, taps_list, mode: int):
+    """fir_filter_bank over device-resident samples (ds_fir_ola_dev): Parallel -> a list of K DevicePlanar (slices of ONE
+    output buffer, band-major as the kernel writes it), Sequential / Summed -> one DevicePlanar.  Nothing comes down."""
+    taps = np.ascontiguousarray(np.stack([np.asarray(t, dtype=np.float64) for t in taps_list]), dtype=np.float32)
+    k, t = taps.shape
+    ctx = x_dev.ctx
+    n, n_ch = x_dev.n_samples, x_dev.n_ch
+    n_out = k if mode == DS_FB_PARALLEL else 1
+    d_t = DeviceBuffer.from_array(ctx, taps)
+    d_y = DeviceBuffer(ctx, n_out * n_ch * n * 4)
+    try:
+        ctx.check(ctx.lib.ds_fir_ola_dev(ctx.handle, C.c_void_p(x_dev.ptr), n_ch, x_dev.ld, n, C.c_void_p(d_t.ptr), k, t,
+                                         int(mode), C.c_void_p(d_y.ptr), n), "ds_fir_ola_dev")
+        ctx.sync()  # (the taps buffer is freed below)
+    except BaseException:
+        d_y.free()
+        raise
+    finally:
+        d_t.free()
+    outs = [DevicePlanar(d_y, n_ch, n, n, 4 * i * n_ch * n) for i in range(n_out)]
+    return outs if mode == DS_FB_PARALLEL else outs[0]
+
+
+def _istft_device(stft: DeviceSTFT, nfft: int, W: int, step: int, window, scale: float, frame_offset: int,
+                  n_frames_total: int) -> DevicePlanar:
+    """_istft of a device-resident spectrogram -> device-resident planar samples (ds_istft_dev)."""
+    if nfft < 2:
+        raise ValueError("fft_length_samples must be at least 2")
+    assert not stft.power, "a power spectrogram has no phase to invert"
+    n_bins, n_frames, n_ch = stft.shape
+    if W > nfft:
+        raise ValueError(f"operands could not be broadcast together with shapes ({nfft},{n_frames},{n_ch}) ({W},1,1)")
+    total_length = int(step * n_frames_total + W * (1 - step / W))
+    ctx = stft.buf.ctx
+    d_w = _window_dev(ctx, window)
+    d_o = DeviceBuffer(ctx, n_ch * total_length * 4)
+    try:
+        ctx.check(ctx.lib.ds_istft_dev(ctx.handle, C.c_void_p(stft.buf.ptr), n_bins, n_frames, n_ch, nfft, W, step,
+                                       frame_offset, n_frames_total, C.c_void_p(d_w.ptr), float(scale), total_length,
+                                       C.c_void_p(d_o.ptr), total_length), "ds_istft_dev")
+        ctx.sync()
+    except BaseException:
+        d_o.free()
+        raise
+    finally:
+        d_w.free()
+    return DevicePlanar(d_o, n_ch, total_length)
+
+
+def spectral_division_device(y_dev: DevicePlanar, x_dev: DevicePlanar, n_fft: int, n_out: int, eps_from_spectrum=None):
+    """irfft(rfft(y, n_fft) * R, n_fft)[:n_out] with R = conj(X) / (|X|^2 + eps) (or 1 / X) built from the spectrum of the
+    device-resident x (one channel for every channel of y, or one per channel), all on the device: ds_rfft_dev ->
+    ds_deconv_inverse_dev -> ds_deconv_dev.  eps_from_spectrum(denum_fft (B, Cx) complex128) -> eps (B,) is the host's
+    band detection (the reference's find_frequencies_above_threshold on channel 0); None: plain division.
+    -> DevicePlanar (Cy, n_out)."""
+    ctx = y_dev.ctx
+    n, n_cy, n_cx = y_dev.n_samples, y_dev.n_ch, x_dev.n_ch
+    assert x_dev.n_samples == n and n <= n_fft and n_out <= n_fft
+    B = n_fft // 2 + 1
+    d_xs = DeviceBuffer(ctx, B * n_cx * 8)
+    d_r = DeviceBuffer(ctx, B * n_cx * 8)
+    d_o = DeviceBuffer(ctx, n_cy * int(n_out) * 4)
+    d_e = None
+    try:
+        ctx.check(ctx.lib.ds_rfft_dev(ctx.handle, C.c_void_p(x_dev.ptr), n_cx, x_dev.ld, n, int(n_fft), 1.0,
+                                      C.c_void_p(d_xs.ptr)), "ds_rfft_dev")
+        if eps_from_spectrum is not None:
+            den = ctx.download_staged(d_xs.ptr, (B, n_cx), np.complex64).astype(np.complex128)
+            d_e = DeviceBuffer.from_array(ctx, np.ascontiguousarray(eps_from_spectrum(den), dtype=np.float32))
+        ctx.check(ctx.lib.ds_deconv_inverse_dev(ctx.handle, C.c_void_p(d_xs.ptr), n_cx, B, C.c_void_p(d_e.ptr) if d_e else None,
+                                                C.c_void_p(d_r.ptr)), "ds_deconv_inverse")
+        ctx.check(ctx.lib.ds_deconv_dev(ctx.handle, C.c_void_p(y_dev.ptr), 1, n_cy, y_dev.ld, n, int(n_fft), C.c_void_p(d_r.ptr),
+                                        int(n_cx > 1), int(n_out), int(n_out), C.c_void_p(d_o.ptr)), "ds_deconv_dev")
+        ctx.sync()
+    except BaseException:
+        d_o.free()
+        raise
+    finally:
+        for d in (d_xs, d_r, d_e):
+            if d is not None:
+                d.free()
+    return DevicePlanar(d_o, n_cy, int(n_out))
+
+
 def _stft_plan(x, fs_hz: int, window_length_samples: int, window_type, overlap_percent: float,
                fft_length_samples, padding: bool, scaling: SpectrumScaling, planar: bool = True):
     """Argument checks and launch parameters of the STFT (shared by _stft and the fused
@@ -314,7 +580,7 @@ def _stft_plan(x, fs_hz: int, window_length_samples: int, window_type, overlap_p
     window = _window_array(window_type, W)
     overlap = int(overlap_percent / 100 * W + 0.5)  # rounding, _spectral_methods.py:247
     hop = W - overlap
-    if not check_COLA(window, nperseg=len(window), noverlap=overlap):
+    if not _cola_ok(window, overlap):
         warn("Selected window type and overlap do not meet the constant "
              "overlap and add constraint! Results might be distorted")
     if planar:
@@ -515,21 +781,30 @@ class DeviceCSM:
 
 def _csm_welch_device(time_data, sampling_rate_hz: int, window_length_samples: int, window_type,
                       overlap_percent, detrend: bool, average: str, scaling: SpectrumScaling) -> DeviceCSM:
-    """_csm_welch whose result stays on the device (ds_csm_dev) -> DeviceCSM."""
+    """_csm_welch whose result stays on the device (ds_csm_dev) -> DeviceCSM.  time_data: the (N, C) array, or the
+    DevicePlanar of a device-resident signal (read in place)."""
     _welch_checks(window_length_samples, overlap_percent, average)
     W = int(window_length_samples)
     window = _window_array(window_type, W)
-    xp = _planar_f32(np.asarray(time_data))
-    n_ch, n = xp.shape
+    resident = isinstance(time_data, DevicePlanar)
+    if resident:
+        ctx, n_ch, n, ld = time_data.ctx, time_data.n_ch, time_data.n_samples, time_data.ld
+        d_x = None
+        x_ptr = time_data.ptr
+    else:
+        xp = _planar_f32(np.asarray(time_data))
+        n_ch, n = xp.shape
+        ld = n
+        ctx = get_context()
+        d_x = DeviceBuffer.from_array(ctx, xp)
+        x_ptr = d_x.ptr
     hop, n_frames = _welch_framing(n, W, overlap_percent, window)
     amp, norm_scale, factor, phys = _finish_params(scaling, W, sampling_rate_hz, window)
     B = W // 2 + 1
-    ctx = get_context()
-    d_x = DeviceBuffer.from_array(ctx, xp)
     d_w = DeviceBuffer.from_array(ctx, window.astype(np.float32))
     d_c = DeviceBuffer(ctx, B * n_ch * n_ch * 8)
     try:
-        ctx.check(ctx.lib.ds_csm_dev(ctx.handle, C.c_void_p(d_x.ptr), n_ch, n, n, W, hop, n_frames,
+        ctx.check(ctx.lib.ds_csm_dev(ctx.handle, C.c_void_p(x_ptr), n_ch, ld, n, W, hop, n_frames,
                                      C.c_void_p(d_w.ptr), int(bool(detrend)), DS_AVG[average], amp, norm_scale, factor,
                                      phys, C.c_void_p(d_c.ptr)), "ds_csm_dev")
         ctx.sync()
@@ -537,7 +812,8 @@ def _csm_welch_device(time_data, sampling_rate_hz: int, window_length_samples: i
         d_c.free()  # (the matrix only leaves this function inside a DeviceCSM)
         raise
     finally:
-        d_x.free()
+        if d_x is not None:
+            d_x.free()
         d_w.free()
     return DeviceCSM(ctx, d_c, np.fft.rfftfreq(W, 1 / sampling_rate_hz), n_ch)
 

@@ -147,8 +147,13 @@ class Filter:
             zi = np.asarray(self.zi).T  # (T-1, C), filter_helpers.py:344-345
         else:
             zi = None
-        if self.order > signal.time_data.shape[0]:
+        if self.order > len(signal):
             warn("Filter is longer than signal, results might be meaningless!")
+        if (signal.on_device and zi is None and not zero_phase and len(channels) == signal.number_of_channels
+                and np.array_equal(channels, np.arange(signal.number_of_channels)) and not np.iscomplexobj(self.ba[0])):
+            # device-resident samples, every channel, plain causal filtering: read and written in HBM
+            y = backend.fir_filter_bank_device(signal.device_samples, [self.ba[0]], backend.DS_FB_PARALLEL)[0]
+            return signal._device_result(y)
         new_time_data = signal.time_data.copy()
         if zi is not None:
             y, zi[:, channels] = backend._lfilter_fir(self.ba[0], self.ba[1],

@@ -141,6 +141,13 @@ class FilterBank:
         ds_mode = {FilterBankMode.Parallel: backend.DS_FB_PARALLEL,
                    FilterBankMode.Sequential: backend.DS_FB_SEQUENTIAL,
                    FilterBankMode.Summed: backend.DS_FB_SUMMED}[mode]
+        if signal.on_device and not any(np.iscomplexobj(t) for t in taps):
+            # device-resident samples: the whole bank in one call, its output stays in HBM -- a Parallel bank's
+            # MultiBandSignal holds K device-resident bands (slices of ONE buffer), downloaded when asked for
+            y = backend.fir_filter_bank_device(signal.device_samples, taps, ds_mode)
+            if mode == FilterBankMode.Parallel:
+                return MultiBandSignal([signal._device_result(b) for b in y], same_sampling_rate=self.same_sampling_rate)
+            return signal._device_result(y)
         y = backend.fir_filter_bank(signal.time_data, taps, ds_mode)
         if mode == FilterBankMode.Parallel:
             bands = [signal.copy_with_new_time_data(np.ascontiguousarray(y[k]))

@@ -16,6 +16,10 @@ class ImpulseResponse(Signal):
                          constrain_amplitude=constrain_amplitude, activate_cache=activate_cache)
         self.spectrum_method = SpectrumMethod.FFT
 
+    def _after_init(self) -> None:
+        if self.spectrum_method != SpectrumMethod.FFT:
+            self.spectrum_method = SpectrumMethod.FFT
+
     @staticmethod
     def from_signal(signal: Signal):
         ir = ImpulseResponse(None, signal.time_data.copy(), signal.sampling_rate_hz,

@@ -58,7 +58,7 @@ class MultiBandSignal:
                     assert s.sampling_rate_hz == self.sampling_rate_hz, (
                         "Not all Signals have the same sampling rate. If you wish to create a "
                         "multirate system, set same_sampling_rate to False")
-                    assert s.time_data.shape[0] == n0, (
+                    assert s.length_samples == n0, (
                         "The length of the bands is not always the same. This behaviour is not "
                         "supported if there is a constant sampling rate")
             else:
@@ -138,6 +138,12 @@ class MultiBandSignal:
             return [c.copy() for c in cols], [b.sampling_rate_hz for b in self.bands]
         return type(self.bands[0])(None, np.stack(cols, axis=1), self.sampling_rate_hz)
 
+    @property
+    def on_device(self) -> bool:
+        """Do all bands hold their samples in HBM (the output of a filter bank over a device-resident signal)?
+        Nothing is downloaded until a band's `time_data` -- or `get_all_time_data()` -- is asked for."""
+        return bool(self.bands) and all(b.on_device for b in self.bands)
+
     def collapse(self) -> Signal:
         """Sum of all bands as one Signal."""
         assert self.same_sampling_rate, "Collapsing is only available for same sampling rate bands"
@@ -145,12 +151,18 @@ class MultiBandSignal:
         return self.bands[0].copy_with_new_time_data(np.sum(td, axis=1))
 
     def get_all_time_data(self):
-        """(time samples, band, channel) array and the sampling rate."""
+        """(time samples, band, channel) array and the sampling rate (multibandsignal.py:522-572).  Device-resident
+        bands are materialised here, one band at a time (each download is dropped again unless the band had a
+        host copy already: the whole bank's output exists once on the host, not twice)."""
         if not self.same_sampling_rate:
             return [(b.time_data, b.sampling_rate_hz) for b in self.bands]
         td = np.zeros((self.length_samples, self.number_of_bands, self.number_of_channels))
         for ind, b in enumerate(self.bands):
-            td[:, ind, :] = b.time_data
+            if b.on_device and not b._has_host_copy:
+                from .. import backend
+                backend._interleaved_f64(b.device_samples.to_planar(), td[:, ind, :])
+            else:
+                td[:, ind, :] = b.time_data
         return td, self.sampling_rate_hz
 
     def copy(self):

@@ -42,6 +42,73 @@ class Signal(MultichannelData):
     def from_time_data(time_data, sampling_rate_hz: int, constrain_amplitude: bool = True):
         return Signal(None, time_data, sampling_rate_hz, constrain_amplitude)
 
+    # ---- device residency (additive API: SURVEY section 7, hard parts 4 and 6) ----------------------------
+    # The reference keeps (samples, channels) float64 on the host; the kernels read planar float32 in HBM.  Through
+    # the plain API every hot-path call therefore casts, transposes and uploads its input and downloads and widens
+    # its output (13.5 ms around 0.12 ms of kernels for the headline estimate).  A Signal may instead HOLD its samples
+    # on the device: `from_planar_f32` / `to_device()` put them there once, compute_transfer_function,
+    # get_spectrogram, get_spectrum (Welch), get_csm, Filter / FilterBank.filter_signal, spectral_deconvolve and istft
+    # read them in place, and results that are signals (filter outputs, impulse responses, reconstructions) come back
+    # device-resident too.  `time_data` stays what it is in the reference -- (samples, channels) float64 -- and is
+    # materialised (one download + widen) the first time somebody asks for it; assigning to it drops the device copy.
+    @classmethod
+    def from_planar_f32(cls, planar, sampling_rate_hz: int):
+        """A signal whose samples are (channels, samples) float32 -- a host array (uploaded once, no cast, no
+        transpose) or a `DevicePlanar` that is already in HBM.  constrain_amplitude is False (the peak of samples
+        that never visit the host is not inspected)."""
+        from .._lib import DevicePlanar, get_context
+        dev = planar if isinstance(planar, DevicePlanar) else DevicePlanar.from_planar(get_context(), planar)
+        obj = cls.__new__(cls)
+        Signal._init_on_device(obj, dev, sampling_rate_hz)
+        return obj
+
+    def _init_on_device(self, dev, sampling_rate_hz: int):
+        self.__constrain_amplitude = False
+        self.calibrated_signal = False
+        self.activate_cache = False
+        self.__update_state()
+        assert sampling_rate_hz is not None, "A sampling rate should be passed!"
+        self.sampling_rate_hz = sampling_rate_hz
+        self.__adopt(dev)
+        self.set_spectrum_parameters()
+        self.set_spectrogram_parameters()
+        self._after_init()
+
+    def _after_init(self) -> None:  # (ImpulseResponse: the FFT spectrum method)
+        pass
+
+    def __adopt(self, dev):
+        self.__time_data = None
+        self.__time_data_imaginary = None
+        self.__device = dev
+        self.__shape = (dev.n_samples, dev.n_ch)
+        self.__amplitude_scale_factor = 1.0
+        self.__update_state()
+        self.clear_time_window()
+
+    @property
+    def on_device(self) -> bool:
+        """Are the samples held in HBM (planar float32)?"""
+        return getattr(self, "_Signal__device", None) is not None
+
+    def to_device(self):
+        """Put the samples in HBM (one cast + transpose + upload) and keep them there beside the host copy; the
+        hot-path calls then read them in place.  Real signals only.  Returns self."""
+        if not self.on_device:
+            assert not self.is_complex_signal, "signals with imaginary time data stay on the host"
+            from .._lib import DevicePlanar, get_context
+            self.__device = DevicePlanar.from_planar(get_context(), backend._planar_f32(self.__time_data))
+        return self
+
+    @property
+    def _has_host_copy(self) -> bool:
+        return self.__time_data is not None
+
+    @property
+    def device_samples(self):
+        """The `DevicePlanar` of a device-resident signal (None otherwise)."""
+        return getattr(self, "_Signal__device", None)
+
     def __update_state(self):
         self.__spectrum_state_update = True
         self.__csm_state_update = True
@@ -51,10 +118,13 @@ class Signal(MultichannelData):
     # ---- properties --------------------------------------------------------
     @property
     def time_data(self) -> np.ndarray:
+        if self.__time_data is None:  # device-born: one download + widen, kept from then on
+            self.__time_data = backend._interleaved_f64(self.__device.to_planar())
         return self.__time_data
 
     @time_data.setter
     def time_data(self, new_time_data):
+        self.__device = None  # new samples: the device copy (if any) no longer describes the signal
         new_time_data = np.atleast_2d(new_time_data).squeeze()
         assert new_time_data.ndim <= 2, (
             f"{new_time_data.ndim} are too many dimensions for time data. "
@@ -80,6 +150,7 @@ class Signal(MultichannelData):
                     new_imag = new_imag / peak
                 self.__amplitude_scale_factor = 1.0 / peak
         self.__time_data = new_time_data
+        self.__shape = new_time_data.shape
         self.time_data_imaginary = new_imag
         self.__update_state()
         self.clear_time_window()
@@ -110,8 +181,7 @@ class Signal(MultichannelData):
     def time_vector_s(self) -> np.ndarray:
         if self.__time_vector_update:
             self.__time_vector_update = False
-            self.__time_vector_s = np.linspace(0, len(self.time_data) / self.sampling_rate_hz,
-                                               len(self.time_data))
+            self.__time_vector_s = np.linspace(0, len(self) / self.sampling_rate_hz, len(self))
         return self.__time_vector_s
 
     @property
@@ -121,8 +191,9 @@ class Signal(MultichannelData):
     @time_data_imaginary.setter
     def time_data_imaginary(self, new_imag):
         if new_imag is not None:
-            assert new_imag.shape == self.__time_data.shape, \
+            assert new_imag.shape == self.__shape, \
                 "Shape of imaginary part time data does not match"
+            self.__device = None  # (a complex signal lives on the host)
         self.__time_data_imaginary = new_imag
 
     @property
@@ -160,7 +231,11 @@ class Signal(MultichannelData):
                     is_complex_signal=self.is_complex_signal)
 
     def __len__(self):
-        return self.time_data.shape[0]
+        return int(self.__shape[0])
+
+    @property
+    def number_of_channels(self) -> int:
+        return int(self.__shape[1])
 
     def __iter__(self):
         return iter([self.time_data[:, x] for x in range(self.number_of_channels)])
@@ -275,10 +350,15 @@ class Signal(MultichannelData):
             return self.spectrum[0].copy(), self.spectrum[1].copy()
         par = self._spectrum_parameters
         if self.spectrum_method == SpectrumMethod.WelchPeriodogram:
-            spectrum = backend._welch(self.time_data, None, self.sampling_rate_hz,
-                                      par["window_type"], par["window_length_samples"],
-                                      par["overlap_percent"], par["detrend"], par["average"],
-                                      par["scaling"])
+            if self.on_device and not self._short_estimate(par):
+                spectrum = backend._welch_psd_device(self.device_samples, self.sampling_rate_hz, par["window_type"],
+                                                     par["window_length_samples"], par["overlap_percent"],
+                                                     par["detrend"], par["average"], par["scaling"])
+            else:
+                spectrum = backend._welch(self.time_data, None, self.sampling_rate_hz,
+                                          par["window_type"], par["window_length_samples"],
+                                          par["overlap_percent"], par["detrend"], par["average"],
+                                          par["scaling"])
             if spectrum.ndim == 1:
                 spectrum = spectrum[:, None]
             fft_length = par["window_length_samples"]
@@ -309,6 +389,16 @@ class Signal(MultichannelData):
             self.__spectrum_state_update = False
         return freqs, spectrum
 
+    def _short_estimate(self, par) -> bool:
+        """Would backend._welch / _csm_welch send this signal's Welch estimate through the float64 kernels (fewer than
+        128 frames ...)?  Those take the host arrays."""
+        W = par["window_length_samples"]
+        if W not in [2**k for k in range(3, 19)] or not (0 <= par["overlap_percent"] < 100):
+            return True  # (let the host path raise the reference's assertion)
+        hop = W - int(par["overlap_percent"] / 100 * W)
+        n_frames = int(np.ceil(len(self) / hop))
+        return backend._x64_short(backend.SPEC_PRECISION, self.number_of_channels, n_frames, W, par["average"])
+
     def get_csm(self, force_computation=False, on_device: bool = False):
         """-> (freqs_hz, csm (bins, channels, channels)).  on_device=True (an extension; Welch method only):
         the matrix stays in HBM, csm is a backend.DeviceCSM handle for the device beamformer map."""
@@ -318,7 +408,8 @@ class Signal(MultichannelData):
             assert self.spectrum_method == SpectrumMethod.WelchPeriodogram, \
                 "a device-resident CSM is built for the Welch method"
             par = self._spectrum_parameters
-            dc = backend._csm_welch_device(self.time_data, self.sampling_rate_hz, par["window_length_samples"],
+            dc = backend._csm_welch_device(self.device_samples if self.on_device else self.time_data,
+                                           self.sampling_rate_hz, par["window_length_samples"],
                                            par["window_type"], par["overlap_percent"], par["detrend"],
                                            par["average"], par["scaling"])
             return dc.freqs_hz.copy(), dc
@@ -344,16 +435,27 @@ class Signal(MultichannelData):
             self.__csm_state_update = False
         return f, csm
 
-    def get_spectrogram(self, force_computation: bool = False):
-        """-> (time_s, freqs_hz, stft (bins, frames, channels))."""
+    def get_spectrogram(self, force_computation: bool = False, on_device: bool = False):
+        """-> (time_s, freqs_hz, stft (bins, frames, channels)).  on_device=True (an extension): the spectrogram
+        stays in HBM -- stft is a backend.DeviceSTFT for transforms.istft and the spectrogram features; its
+        `to_host()` is the array."""
+        par = self._spectrogram_parameters
+        if on_device:
+            return backend._stft_device(self.to_device().device_samples, self.sampling_rate_hz,
+                                        par["window_length_samples"], par["window_type"], par["overlap_percent"],
+                                        par["fft_length_samples"], par["detrend"], par["padding"], par["scaling"], True)
         if not (not hasattr(self, "spectrogram") or force_computation
                 or self.__spectrogram_state_update):
             return tuple(a.copy() for a in self.spectrogram)
-        par = self._spectrogram_parameters
-        out = backend._stft(self.time_data, self.sampling_rate_hz, par["window_length_samples"],
-                            par["window_type"], par["overlap_percent"],
-                            par["fft_length_samples"], par["detrend"], par["padding"],
-                            par["scaling"])
+        if self.on_device:
+            out = backend._stft_device(self.device_samples, self.sampling_rate_hz, par["window_length_samples"],
+                                       par["window_type"], par["overlap_percent"], par["fft_length_samples"],
+                                       par["detrend"], par["padding"], par["scaling"], False)
+        else:
+            out = backend._stft(self.time_data, self.sampling_rate_hz, par["window_length_samples"],
+                                par["window_type"], par["overlap_percent"],
+                                par["fft_length_samples"], par["detrend"], par["padding"],
+                                par["scaling"])
         self.__spectrogram_state_update = False
         if self.activate_cache:
             self.spectrogram = deepcopy(out)
@@ -374,6 +476,19 @@ class Signal(MultichannelData):
 
     def _update_state(self) -> None:
         self.__update_state()
+
+    def _device_result(self, dev):
+        """A signal of this object's type around device-resident result samples, with this signal's parameters --
+        or, for a type that constrains its amplitude, around their host copy (the peak has to be inspected)."""
+        if self.constrain_amplitude:
+            return self.copy_with_new_time_data(backend._interleaved_f64(dev.to_planar()))
+        new_signal = type(self).from_planar_f32(dev, self.sampling_rate_hz)
+        new_signal.calibrated_signal = self.calibrated_signal
+        new_signal.activate_cache = self.activate_cache
+        new_signal._spectrum_parameters = deepcopy(self._spectrum_parameters)
+        new_signal._spectrogram_parameters = deepcopy(self._spectrogram_parameters)
+        new_signal._after_init()
+        return new_signal
 
     def copy_with_new_time_data(self, new_time_data) -> "Signal":
         if isinstance(new_time_data, np.ndarray) and new_time_data.base is not None:

@@ -16,6 +16,34 @@ class Spectrum(MultichannelData):
         self.frequency_vector_hz = frequency_vector_hz
         self.spectral_data = spectral_data
 
+    @classmethod
+    def _from_device_result(cls, frequency_vector_hz, spectral_data, coherence=None) -> "Spectrum":
+        """The same object as Spectrum(f, data) + set_coherence for arrays the library has just produced: float64 /
+        complex128, (bins, channels), owned by nobody else -- no second copy, no re-validation (the checks and the
+        astype of the setters are half of a device-resident call's 0.2 ms)."""
+        obj = cls.__new__(cls)
+        obj._Spectrum__frequency_vector_hz = frequency_vector_hz
+        obj._Spectrum__spectral_data = None
+        obj._narrow = (spectral_data, coherence)  # complex64 / float32 as downloaded: widened on first access
+        return obj
+
+    def _widen_result(self):
+        """First look at a device-produced spectrum: complex64 -> complex128, float32 -> float64 (what the reference's
+        setters hold), once."""
+        narrow = self.__dict__.pop("_narrow", None)
+        if narrow is not None:
+            from .. import backend
+            self.__spectral_data = backend._widen(narrow[0])
+            if narrow[1] is not None:
+                self.__dict__["coherence"] = backend._widen(narrow[1])
+
+    def __getattr__(self, name):
+        # `coherence` is a plain attribute in the reference (set by set_coherence, looked for with hasattr)
+        if name == "coherence" and "_narrow" in self.__dict__ and self.__dict__["_narrow"][1] is not None:
+            self._widen_result()
+            return self.__dict__["coherence"]
+        raise AttributeError(name)
+
     @staticmethod
     def from_signal(sig, complex: bool = False) -> "Spectrum":
         if complex:
@@ -51,6 +79,8 @@ class Spectrum(MultichannelData):
 
     @property
     def spectral_data(self):
+        if self.__spectral_data is None:
+            self._widen_result()
         return self.__spectral_data
 
     @spectral_data.setter
@@ -69,7 +99,7 @@ class Spectrum(MultichannelData):
 
     @property
     def is_magnitude(self) -> bool:
-        return np.isrealobj(self.__spectral_data)
+        return np.isrealobj(self.spectral_data)
 
     @property
     def is_complex(self) -> bool:

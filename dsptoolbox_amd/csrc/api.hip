@@ -67,6 +67,8 @@ struct ds_ctx {
     float2* fir16k_tables = nullptr;  // fir16k::host_tables()
     float2* wl_tables[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // welchl::host_tables(R), R = 2, 4, ..., 64
     float2* deconv8k_tables = nullptr;  // deconv8k::host_tables()
+    float2* deconv_rperm = nullptr;     // deconv8k::k_rperm's output (64 KB), rewritten by every ds_deconv_dev call that uses it
+    int n_cu = 0;                       // compute units of the device (persistent grids)
     float2* stft1k_tables = nullptr;  // stft1k::host_tables<1024>()
     float2* stft_wave_tables[3] = {nullptr, nullptr, nullptr};  // stft1k::host_tables<512>(), <256>(), <2048>()
     void* ws = nullptr;         // kernel workspace (spectra, partials)
@@ -163,6 +165,7 @@ extern "C" int ds_init(int device, ds_ctx** out) {
     c->device = device;
     c->cfg = ds_config::from_env();
     HIPCHK(c, hipSetDevice(device));
+    HIPCHK(c, hipDeviceGetAttribute(&c->n_cu, hipDeviceAttributeMultiprocessorCount, device));
     HIPCHK(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     HIPCHK(c, hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
     HIPCHK(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
@@ -188,6 +191,7 @@ extern "C" void ds_destroy(ds_ctx* c) {
     for (auto t : c->wl_tables)
         if (t) (void)hipFree(t);
     if (c->deconv8k_tables) (void)hipFree(c->deconv8k_tables);
+    if (c->deconv_rperm) (void)hipFree(c->deconv_rperm);
     if (c->stft1k_tables) (void)hipFree(c->stft1k_tables);
     for (float2* t : c->stft_wave_tables)
         if (t) (void)hipFree(t);
@@ -227,6 +231,19 @@ extern "C" int ds_free(ds_ctx* c, void* dptr) {
     if (!c) return fail(c, DS_ERR_ARG, "ds_free: null ctx");
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipFree(dptr));
+    return DS_OK;
+}
+extern "C" int ds_host_alloc(ds_ctx* c, void** hptr, size_t bytes) {
+    if (!c || !hptr) return fail(c, DS_ERR_ARG, "ds_host_alloc: null argument");
+    HIPCHK(c, hipSetDevice(c->device));
+    hipError_t e = hipHostMalloc(hptr, bytes ? bytes : 1, hipHostMallocDefault);
+    if (e != hipSuccess) return fail(c, DS_ERR_NOMEM, std::string("hipHostMalloc: ") + hipGetErrorString(e));
+    return DS_OK;
+}
+extern "C" int ds_host_free(ds_ctx* c, void* hptr) {
+    if (!c) return fail(c, DS_ERR_ARG, "ds_host_free: null ctx");
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipHostFree(hptr));
     return DS_OK;
 }
 extern "C" int ds_upload(ds_ctx* c, void* dst, const void* src, size_t bytes) {
@@ -2491,6 +2508,17 @@ extern "C" int ds_deconv_dev(ds_ctx* c, const float* y, int n_items, int n_ch, i
                           (const float2*)r, ir};
         // one 256-thread group per channel pair, its two sub-spectra one after the other: three independent
         // workgroups per CU (k_deconv3); DSPTOOLBOX_AMD_DECONV_2PERCU=1 keeps the 512-thread kernel (A/B)
+        // default since round 5: two persistent workgroups per CU, the next unit's samples in flight during this unit's
+        // transforms, the inverse spectrum from a permuted copy (k_rperm + k_deconv_p); DSPTOOLBOX_AMD_DECONV_PERSIST=0
+        // keeps the one-unit-per-workgroup kernels below
+        const int64_t n_units = (int64_t)((n_ch + 1) / 2) * n_items;
+        if (c->cfg.deconv_persist && !c->cfg.deconv_2percu && n_units < ((int64_t)1 << 31) && c->n_cu > 0) {
+            if (!c->deconv_rperm) HIPCHK(c, hipMalloc((void**)&c->deconv_rperm, sizeof(float2) * deconv8k::RPERM_LEN));
+            CHK(launch(c, "deconv_rperm", deconv8k::k_rperm, dim3(32), 256, 0, deconv8k::RpArgs{(const float2*)r, c->deconv_rperm}));
+            deconv8k::PArgs pa{a8, c->deconv_rperm, (int)n_units};
+            const int grid = (int)std::min<int64_t>(n_units, 2 * (int64_t)c->n_cu);
+            return launch(c, "deconv@8k_persist", deconv8k::k_deconv_p, dim3((unsigned)grid), 256, deconv8k::LDS_BYTES_3, pa);
+        }
         const bool two = c->cfg.deconv_2percu;
         // four workgroups per CU (k_deconv3q: all 1024 pairs of the benchmark resident at once) unless
         // DSPTOOLBOX_AMD_DECONV_4PERCU=0 (k_deconv3: three, 168 registers)

@@ -22,6 +22,7 @@ struct ds_config {
     bool csm_f32 = false;         // DSPTOOLBOX_AMD_CSM_F32: fp32 matrix instructions instead of bf16 triples
     bool deconv_generic = false;  // DSPTOOLBOX_AMD_DECONV_GENERIC: k_deconv<8192> instead of deconv8k
     bool deconv_2percu = false;   // DSPTOOLBOX_AMD_DECONV_2PERCU: the 512-thread deconv8k kernel
+    bool deconv_persist = true;   // DSPTOOLBOX_AMD_DECONV_PERSIST=0: one unit per workgroup (k_deconv3q / k_deconv3) instead of k_deconv_p
     bool deconv_4percu = true;    // DSPTOOLBOX_AMD_DECONV_4PERCU=0: k_deconv3 (three per CU) instead of k_deconv3q
     bool fir_generic = false;     // DSPTOOLBOX_AMD_FIR_GENERIC: k_fir<16384> instead of fir16k
     int fir4k_min_taps = 1025;    // DSPTOOLBOX_AMD_FIR_4K: 0 never fir4k, 1 always, n > 1 from n taps on
@@ -57,6 +58,7 @@ struct ds_config {
         g.csm_f32 = set("DSPTOOLBOX_AMD_CSM_F32");
         g.deconv_generic = set("DSPTOOLBOX_AMD_DECONV_GENERIC");
         g.deconv_2percu = set("DSPTOOLBOX_AMD_DECONV_2PERCU");
+        g.deconv_persist = !(set("DSPTOOLBOX_AMD_DECONV_PERSIST") && num("DSPTOOLBOX_AMD_DECONV_PERSIST") == 0);
         g.deconv_4percu = !(set("DSPTOOLBOX_AMD_DECONV_4PERCU") && num("DSPTOOLBOX_AMD_DECONV_4PERCU") == 0);
         g.finish_wide = is("DSPTOOLBOX_AMD_FINISH_WIDE", '1');
         g.fir_generic = set("DSPTOOLBOX_AMD_FIR_GENERIC");

@@ -375,4 +375,143 @@ __global__ __launch_bounds__(256, 4) void k_deconv3q(Args p) {
     }
 }
 
+// ---- round 5: persistent, pipelined ---------------------------------------------------------------------------------
+// What the three kernels above have in common: ONE unit (channel pair of an item) per workgroup and every workgroup of the
+// grid resident at once, so the whole chip loads (67 MB), then the whole chip transforms, then the whole chip stores:
+// HBM idles while the vector pipe works and the other way round (VALU utilisation 0.23, 1.05 x the algorithmic traffic and
+// still 0.37 of the roofline).  And inside the 128 registers of four workgroups per CU the inverse spectrum's gather
+// (16 eight-byte loads per sub-problem, 64 different cache lines per wave instruction: neighbouring lanes sit 32 bins apart)
+// and the W32 table reads serialize into ~80 memory round trips per wave.
+// Here: TWO workgroups per CU (256 registers each) stay for the whole launch and take units u = block, block + grid, ...;
+//   * the 64 samples of the NEXT unit are requested (one burst, raw-buffer loads into 64 registers) as soon as the current
+//     unit's samples have been folded into its two sub-problems, and arrive during its four transforms;
+//   * the 64 results are stored in one burst that drains during the next unit's transforms;
+//   * the shared inverse spectrum is read from a PERMUTED copy (k_rperm: the transform's register layout, scale and the
+//     real-bin rule folded in; 64 KB, written once per call): 16 coalesced 8-byte loads per sub-problem through one
+//     descriptor, no index arithmetic, no 64-line gathers;
+//   * W32^n1 as compile-time constants.
+// No scratch.  A unit past the end is a descriptor of zero records (loads return 0, no branch around loads).
+constexpr int RPERM_LEN = 2 * 16 * 256;  // float2: [q][slot s][tid]
+
+// rperm[(q 16 + s) 256 + tid] = Rf[2 (bin_thread(tid) + 256 k3(s)) + q] / N, Rf the full Hermitian spectrum of the real
+// impulse response r describes (real at bins 0 and N / 2: numpy's irfft ignores the imaginary parts there).  grid = 32 x 256.
+struct RpArgs {
+    const float2* r;  // [N / 2 + 1]
+    float2* rperm;    // [RPERM_LEN]
+};
+__global__ __launch_bounds__(256) void k_rperm(RpArgs a) {
+    const float2* __restrict__ r = a.r;
+    float2* __restrict__ rperm = a.rperm;
+    const int tid = threadIdx.x, q = (int)blockIdx.x >> 4, s = (int)blockIdx.x & 15;
+    const int k3 = (s >> 2) + 4 * (s & 3);
+    const int k = 2 * (w4::bin_thread(tid) + 256 * k3) + q;
+    const float2 v = r[min(k, N - k)];
+    const float inv = 1.0f / (float)N;
+    const float sg = (k == 0 || k == N / 2) ? 0.f : (k < N / 2 ? inv : -inv);
+    rperm[(int)blockIdx.x * 256 + tid] = make_float2(v.x * inv, v.y * sg);
+}
+
+struct PArgs {
+    Args a;
+    const float2* rperm;
+    int n_units;  // ceil(n_ch / 2) * n_items
+};
+
+__global__ __launch_bounds__(256, 2) void k_deconv_p(PArgs pp) {
+    const Args& p = pp.a;
+    extern __shared__ __align__(16) float2 lds[];
+    float2* buf = lds;
+    float2* tw2 = lds + 16 * w4::L1S;
+    float2* tw2p = lds + 16 * w4::L1S + 256;
+    const int tid = threadIdx.x;
+    const int pairs = (p.n_ch + 1) / 2;
+    const uint32_t in_bytes = (uint32_t)(p.n_samples < (int64_t)N ? p.n_samples : (int64_t)N) * 4u;
+    const uint32_t out_bytes = (uint32_t)(p.n_out < (int64_t)N ? p.n_out : (int64_t)N) * 4u;
+    const int off0 = 4 * tid;
+    float za[32], zb[32];  // raw samples of a unit: [n1 + 16 j], half block j
+    // every sample of unit u (wave-uniform descriptors; past the last unit: zero records)
+    auto request = [&](int u) {
+        const bool live = u < pp.n_units;
+        const int uu = live ? u : 0;
+        const int64_t item = uu / pairs;
+        const int ca = 2 * (uu - (int)item * pairs);
+        const bool vb = ca + 1 < p.n_ch;
+        const float* ya = p.y + (item * p.n_ch + ca) * p.ld;
+        const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ya), 0, live ? (int)in_bytes : 0, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rb =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ya + (vb ? p.ld : 0)), 0, (live && vb) ? (int)in_bytes : 0, 0x00020000);
+#pragma unroll
+        for (int n1 = 0; n1 < 16; ++n1) {
+            za[n1] = w4::ld_sample(ra, off0 + 1024 * n1);
+            zb[n1] = w4::ld_sample(rb, off0 + 1024 * n1);
+            za[16 + n1] = w4::ld_sample(ra, off0 + 1024 * n1 + 4 * M);
+            zb[16 + n1] = w4::ld_sample(rb, off0 + 1024 * n1 + 4 * M);
+        }
+    };
+    int u = blockIdx.x;
+    request(u);
+    __builtin_amdgcn_sched_barrier(0);
+    w4::Tw6 tw;
+    w4::load_tw6(tw, p.twt, tid);
+    tw2[tid] = p.twt[15 * 256 + tid];
+    fir4k::fill_tw2p(tw2p, p.twt, tid);
+    const float2 wt = p.twn[tid];  // W8192^tid
+    const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float2*>(pp.rperm), 0, RPERM_LEN * 8, 0x00020000);
+    auto spectrum = [&](float2 (&rf)[16], int q) {
+#pragma unroll
+        for (int s = 0; s < 16; ++s)
+            rf[s] = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(rr, ((q * 16 + s) * 256) * 8 + 8 * tid, 0, 0));
+    };
+    w4::Stamp ts;
+    auto none = [](int) {};
+    __syncthreads();  // the tables
+    for (; u < pp.n_units; u += gridDim.x) {
+        // b_0 = z[n'] + z[n' + 4096] ,  b_1 = (z[n'] - z[n' + 4096]) W8192^n' ,  n' = tid + 256 n1
+        float2 v[16], b1[16];
+#pragma unroll
+        for (int n1 = 0; n1 < 16; ++n1) {
+            v[n1] = make_float2(za[n1] + za[16 + n1], zb[n1] + zb[16 + n1]);
+            b1[n1] = cmul(make_float2(za[n1] - za[16 + n1], zb[n1] - zb[16 + n1]), cmul(wt, w32(n1)));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        request(u + (int)gridDim.x);  // the next unit's samples: in flight during this unit's transforms
+        __builtin_amdgcn_sched_barrier(0);
+        float2 rf[16];
+        w4::fft4096_wi(v, tw, buf, tw2, tid, none, none, ts, 0);
+        spectrum(rf, 0);
+#pragma unroll
+        for (int s = 0; s < 16; ++s) v[s] = cmul(v[s], rf[s]);
+        fir4k::ifft4096_wi(v, tw, buf, tw2p, tid, none, none);
+        float2 g0[16];
+#pragma unroll
+        for (int n1 = 0; n1 < 16; ++n1) {
+            g0[n1] = v[n1];
+            v[n1] = b1[n1];
+        }
+        __syncthreads();  // the column reads of the transform back: the forward transform stores into the image at once
+        w4::fft4096_wi(v, tw, buf, tw2, tid, none, none, ts, 0);
+        spectrum(rf, 1);
+#pragma unroll
+        for (int s = 0; s < 16; ++s) v[s] = cmul(v[s], rf[s]);
+        fir4k::ifft4096_wi(v, tw, buf, tw2p, tid, none, none);
+        // y[n'] = g_0 + W8192^(-n') g_1 ,  y[n' + 4096] = g_0 - W8192^(-n') g_1
+        const int64_t item = u / pairs;
+        const int ca = 2 * (u - (int)item * pairs);
+        const bool vb = ca + 1 < p.n_ch;
+        float* oa = p.ir + (item * p.n_ch + ca) * p.ld_out;
+        const __amdgpu_buffer_rsrc_t sa = __builtin_amdgcn_make_buffer_rsrc(oa, 0, (int)out_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t sb = __builtin_amdgcn_make_buffer_rsrc(oa + (vb ? p.ld_out : 0), 0, vb ? (int)out_bytes : 0, 0x00020000);
+#pragma unroll
+        for (int n1 = 0; n1 < 16; ++n1) {
+            const float2 w = cmulc(v[n1], cmul(wt, w32(n1)));
+            const int off = 4 * (tid + 256 * n1);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, g0[n1].x + w.x), sa, off, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, g0[n1].y + w.y), sb, off, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, g0[n1].x - w.x), sa, off + 4 * M, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, g0[n1].y - w.y), sb, off + 4 * M, 0, 0);
+        }
+        __syncthreads();  // the last column reads of this unit's transform back, before the next unit's first image stores
+    }
+}
+
 }  // namespace deconv8k

@@ -21,7 +21,7 @@ def compute_transfer_function(output: Signal, input: Signal, window_length_sampl
     input is the input of every output channel.  Window, overlap, detrend,
     average and scaling are taken from the INPUT signal's spectrum parameters."""
     assert input.sampling_rate_hz == output.sampling_rate_hz, "Sampling rates do not match"
-    assert input.time_data.shape[0] == output.time_data.shape[0], "Signal lengths do not match"
+    assert len(input) == len(output), "Signal lengths do not match"
     if input.number_of_channels != 1:
         assert input.number_of_channels == output.number_of_channels, \
             "Channel number does not match between signals"
@@ -31,6 +31,19 @@ def compute_transfer_function(output: Signal, input: Signal, window_length_sampl
         par.pop(k)
     if not isinstance(mode, TransferFunctionType):
         raise ValueError("Unsupported transfer function type")
+    W = int(window_length_samples)
+    if output.on_device and not output.is_complex_signal and not input.is_complex_signal:
+        # device-resident samples (Signal.to_device / from_planar_f32): the fp32 kernels read them in place -- unless
+        # the precision rule sends this shape through the float64 kernels, which take the host arrays
+        window = backend._window_array(par["window_type"], W) if W in [2**k for k in range(3, 19)] else None
+        if window is not None:
+            _, n_frames = backend._welch_framing(output.length_samples, W, par["overlap_percent"], window)
+            if not backend._tf_x64_applies(backend.TF_PRECISION, input.number_of_channels, output.number_of_channels,
+                                           n_frames, W, par["average"]):
+                tf, coherence = backend.welch_transfer_function_device(
+                    output.device_samples, input.to_device().device_samples, input.sampling_rate_hz, W, mode.name,
+                    narrow=True, **par)
+                return Spectrum._from_device_result(np.fft.rfftfreq(W, 1 / input.sampling_rate_hz), tf, coherence)
     # small problems run in float64 end to end like the reference (backend.TF_PRECISION)
     tf, coherence = backend.welch_transfer_function(
         output.time_data, input.time_data, input.sampling_rate_hz, window_length_samples,
@@ -123,8 +136,7 @@ def spectral_deconvolve(output: Signal, input: Signal, apply_regularization: boo
                         start_stop_hz=None, threshold_db: float = -30.0, padding: bool = False,
                         keep_original_length: bool = False) -> ImpulseResponse:
     """Impulse response by (regularised) spectral division output / input."""
-    assert output.time_data.shape[0] == input.time_data.shape[0], \
-        "Lengths do not match for spectral deconvolution"
+    assert len(output) == len(input), "Lengths do not match for spectral deconvolution"
     multichannel = input.number_of_channels == 1
     if not multichannel:
         assert output.number_of_channels == input.number_of_channels, \
@@ -145,10 +157,28 @@ def spectral_deconvolve(output: Signal, input: Signal, apply_regularization: boo
         return _spectral_deconvolve_scaled(output, input, apply_regularization, start_stop_hz, threshold_db,
                                            padding, keep_original_length, multichannel)
     fs_hz = output.sampling_rate_hz
-    original_length = output.time_data.shape[0]
+    original_length = len(output)
     n_time = original_length * 2 if padding else original_length
     n_fft = (next_fast_len(n_time, True)
              if input._spectrum_parameters["pad_to_fast_length"] else n_time)
+    if output.on_device and n_fft == n_time and not output.is_complex_signal and not input.is_complex_signal:
+        # device-resident samples: spectrum of the input, regularised inverse, division and inverse transform on the
+        # device; only the input's spectrum comes down for the band detection (and a (bins,) eps goes up)
+        freqs_dev = np.fft.rfftfreq(n_fft, 1 / fs_hz)
+
+        def eps_of(den, band=start_stop_hz):
+            if band is None:  # band from the FIRST denominator channel only
+                band = find_frequencies_above_threshold(den[:, 0], freqs_dev, threshold_db)
+            if len(band) == 2:
+                band = np.array([band[0] / np.sqrt(2), band[0], band[1], np.min([band[1] * np.sqrt(2), fs_hz / 2])])
+            elif len(band) != 4:
+                raise ValueError("start_stop_hz vector should have 2 or 4 values")
+            return _inverse_hann_band(find_nearest_points_index_in_vector(band, freqs_dev), len(freqs_dev)) * 10 ** (30 / 20)
+
+        n_out = original_length if (padding and keep_original_length) else n_time
+        dev = backend.spectral_division_device(output.device_samples, input.to_device().device_samples, n_fft, n_out,
+                                               eps_of if apply_regularization else None)
+        return ImpulseResponse.from_planar_f32(dev, fs_hz)
     # rfft(n=n_fft) zero pads, so the optional x2 padding needs no copy
     denum_fft = backend.rfft_spectrum(input.time_data, n_fft)
     freqs_hz = np.fft.rfftfreq(n_fft, 1 / fs_hz)

@@ -29,8 +29,10 @@ def istft(stft, original_signal: Signal | None = None, parameters: dict | None =
           fft_length_samples: int | None = None, padding: bool | None = None,
           scaling=None) -> Signal:
     """Complex STFT (frequency, time frame, channel) -> time signal (Griffin & Lim)."""
-    stft = np.asarray(stft)
-    assert stft.ndim == 3, f"{stft.ndim} is not a valid number of dimensions. It must be 3"
+    resident = isinstance(stft, backend.DeviceSTFT)  # Signal.get_spectrogram(on_device=True): stays in HBM
+    if not resident:
+        stft = np.asarray(stft)
+    assert len(stft.shape) == 3, f"{len(stft.shape)} is not a valid number of dimensions. It must be 3"
     if original_signal is not None:
         assert parameters is None, "A signal was passed. No parameters dictionary should be passed"
         parameters = original_signal._spectrogram_parameters.copy()
@@ -57,15 +59,30 @@ def istft(stft, original_signal: Signal | None = None, parameters: dict | None =
     step = int((1 - parameters["overlap_percent"] / 100) * len(window))
     n_frames = stft.shape[1]
     pad = bool(parameters["padding"])
-    td = backend._istft(stft, nfft_eff, W, step, window, scale, frame_offset=0 if pad else 1,
-                        n_frames_total=n_frames if pad else n_frames + 2)
+    if resident:
+        from .._lib import DevicePlanar
+        dev = backend._istft_device(stft, nfft_eff, W, step, window, scale, frame_offset=0 if pad else 1,
+                                    n_frames_total=n_frames if pad else n_frames + 2)
+        cut = int(parameters["overlap_percent"] / 100 * len(window)) if pad else step
+        length = dev.n_samples - 2 * cut
+        want = len(original_signal) if original_signal is not None else length
+        if cut > 0 and 0 < want <= length:
+            # trimming both ends (and to the original length) is a view of the same device samples
+            view = DevicePlanar(dev.owner, dev.n_ch, want, dev.ld, 4 * cut)
+            if original_signal is not None:
+                return original_signal._device_result(view)
+            return Signal.from_planar_f32(view, sampling_rate_hz)
+        td = backend._interleaved_f64(dev.to_planar())  # (padding would need zeros behind the samples: host)
+    else:
+        td = backend._istft(stft, nfft_eff, W, step, window, scale, frame_offset=0 if pad else 1,
+                            n_frames_total=n_frames if pad else n_frames + 2)
     if pad:
         overlap = int(parameters["overlap_percent"] / 100 * len(window))
         td = td[overlap:-overlap, :]
     else:
         td = td[step:-step, :]
     if original_signal is not None:
-        td = _pad_trim(td, original_signal.time_data.shape[0])
+        td = _pad_trim(td, len(original_signal))
         return original_signal.copy_with_new_time_data(td)
     return Signal(None, time_data=td, sampling_rate_hz=sampling_rate_hz)
 

@@ -63,6 +63,10 @@ void        ds_destroy(ds_ctx* ctx);
 const char* ds_last_error(ds_ctx* ctx);            /* ctx may be NULL          */
 int         ds_malloc(ds_ctx* ctx, void** dptr, size_t bytes);
 int         ds_free(ds_ctx* ctx, void* dptr);
+/* Page-locked host memory for result staging (device-resident signals): a download into
+ * it runs at the link's rate and needs no driver-side bounce buffer.  Plumbing: nothing in the reference.     */
+int         ds_host_alloc(ds_ctx* ctx, void** hptr, size_t bytes);
+int         ds_host_free(ds_ctx* ctx, void* hptr);
 int         ds_upload(ds_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);
 int         ds_download(ds_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes);
 int         ds_memset(ds_ctx* ctx, void* dst_dev, int value, size_t bytes);

@@ -273,11 +273,25 @@ import os, sys, json
 sys.path.insert(0, {root!r})
 import bench
 d = bench.Dist(2)
+import numpy as np
 class Ctx:
     synced = 0
+    handle = 1
+    uploaded = None
     def sync(self):
         Ctx.synced += 1
+    def malloc(self, n):
+        return 4096
+    def free(self, p):
+        pass
+    def upload(self, ptr, arr):
+        Ctx.uploaded = np.array(arr, copy=True)
 ctx = Ctx()
+# the shared FIR taps / inverse sweep without RCCL (ranks sharing a GPU, BENCH_BCAST=host): rank 0 owns the values,
+# the host exchange carries them, every rank uploads what rank 0 holds
+taps = np.arange(12, dtype=np.float32).reshape(3, 4) * (1.0 if d.rank == 0 else -7.0)
+buf, bcast_ms = bench.shared_upload(ctx, d, False, taps)
+shared_ok = bcast_ms is None and np.array_equal(Ctx.uploaded, np.arange(12, dtype=np.float32).reshape(3, 4))
 d.barrier_sync(ctx)
 m = d.max_over_ranks(1.5 + d.rank)
 some_ok = d.all_ok(d.rank == 0)      # one rank says no: every rank must hear no
@@ -285,7 +299,7 @@ all_ok = d.all_ok(True)
 ident = d.bcast_bytes(bytes(range(128)) if d.rank == 0 else b"", 128)
 d.barrier_sync(ctx)
 print(json.dumps(dict(rank=d.rank, world=d.world, max=m, some_ok=some_ok, all_ok=all_ok, ident=ident == bytes(range(128)),
-                      synced=Ctx.synced, torch="torch" in sys.modules)), flush=True)
+                      synced=Ctx.synced, torch="torch" in sys.modules, shared_ok=bool(shared_ok))), flush=True)
 d.finish()
 """
 
@@ -312,6 +326,7 @@ def test_bench_rank_plumbing_without_torch_world2():
     for g in got:
         assert g["max"] == 2.5 and g["some_ok"] is False and g["all_ok"] is True and g["ident"] and g["synced"] == 2
         assert g["torch"] is False
+        assert g["shared_ok"] is True  # bench.shared_upload's host-exchange fallback (fir_bank taps, deconv inverse sweep)
 
 
 def test_bench_refuses_a_missing_exchange():

@@ -2331,7 +2331,7 @@ SWITCH_ROUTES = [
     # (environment, golden subset, launch names (ds_routes) that must / must not appear)
     ({}, [lambda: _welch_golden_body(), lambda: _welch4096_golden(), lambda: test_stft_golden(), lambda: _csm_golden_body(),
           lambda: test_deconvolve_batch_8192(), lambda: test_fir_bank_4097_taps(), lambda: test_istft_golden_and_round_trip("istft")],
-     {"welch1024_main", "welch4096_main@3", "stft@wave", "csm_gemm@b3", "deconv@8k_4percu", "fir@4k_p2", "istft@wave"}, set()),
+     {"welch1024_main", "welch4096_main@3", "stft@wave", "csm_gemm@b3", "deconv@8k_persist", "fir@4k_p2", "istft@wave"}, set()),
     ({}, [lambda: test_welch_long_windows_golden()], {"welch_long_main", "welch8192_main"}, {"welch16384_main"}),
     ({"DSPTOOLBOX_AMD_WELCH_GENERIC": "1"}, [lambda: _welch_golden_body(), lambda: test_welch_long_windows_golden()],
      {"welch_xspec"}, {"welch1024_main", "welch8192_main", "welch16384_main", "welch_long_main"}),
@@ -2346,9 +2346,11 @@ SWITCH_ROUTES = [
     ({"DSPTOOLBOX_AMD_CSM_F32": "1"}, [lambda: _csm_golden_body(), lambda: test_csm_coherent_channels_golden(),
                                        _csm_64_bench_shape_reduced], {"csm_gemm@f32"}, {"csm_gemm@b3"}),
     ({"DSPTOOLBOX_AMD_DECONV_GENERIC": "1"}, [lambda: test_deconvolve_golden(), lambda: test_deconvolve_batch_8192()],
-     {"deconv@generic"}, {"deconv@8k_4percu", "deconv@8k_3percu", "deconv@8k_512"}),
-    ({"DSPTOOLBOX_AMD_DECONV_2PERCU": "1"}, [lambda: test_deconvolve_batch_8192()], {"deconv@8k_512"}, {"deconv@8k_4percu"}),
-    ({"DSPTOOLBOX_AMD_DECONV_4PERCU": "0"}, [lambda: test_deconvolve_batch_8192()], {"deconv@8k_3percu"}, {"deconv@8k_4percu"}),
+     {"deconv@generic"}, {"deconv@8k_persist", "deconv@8k_4percu", "deconv@8k_3percu", "deconv@8k_512"}),
+    ({"DSPTOOLBOX_AMD_DECONV_2PERCU": "1"}, [lambda: test_deconvolve_batch_8192()], {"deconv@8k_512"}, {"deconv@8k_persist", "deconv@8k_4percu"}),
+    ({"DSPTOOLBOX_AMD_DECONV_PERSIST": "0"}, [lambda: test_deconvolve_batch_8192()], {"deconv@8k_4percu"}, {"deconv@8k_persist"}),
+    ({"DSPTOOLBOX_AMD_DECONV_PERSIST": "0", "DSPTOOLBOX_AMD_DECONV_4PERCU": "0"}, [lambda: test_deconvolve_batch_8192()], {"deconv@8k_3percu"},
+     {"deconv@8k_persist", "deconv@8k_4percu"}),
     ({"DSPTOOLBOX_AMD_FIR_GENERIC": "1", "DSPTOOLBOX_AMD_FIR_4K": "0"},
      [lambda: test_fir_golden(), lambda: test_fir_16k_blocks_vs_oracle(4097, 12288 * 3, 2)], {"fir@generic"},
      {"fir@4k_p1", "fir@4k_p2", "fir@16k", "fir@16k_ragged"}),
@@ -2387,3 +2389,141 @@ def test_kernel_selecting_switches(route, monkeypatch):
         for k in env:
             monkeypatch.delenv(k, raising=False)
         _lib.reset_context()
+
+
+# ---- device-resident signals (hard parts 4 and 6) ---------------------------------
+def _resident_pair(n=2**17 + 333, n_ch=6, seed=5):
+    rng = np.random.default_rng(seed)
+    x = rng.standard_normal((n, 1)) * 0.3
+    h = rng.standard_normal((n_ch, 24)) * np.exp(-np.arange(24) / 6.0)
+    y = np.stack([np.convolve(x[:, 0], h[c])[:n] for c in range(n_ch)], axis=1) + 0.01 * rng.standard_normal((n, n_ch))
+    return x, y
+
+
+def test_device_resident_transfer_function_spectrum_and_matrix(monkeypatch):
+    """compute_transfer_function, get_spectrum (Welch) and get_csm read a device-resident signal in place: same numbers
+    as the host path of the same fp32 kernels, 1e-6 against the oracle, and no host copy is ever made."""
+    monkeypatch.setattr(backend, "TF_PRECISION", "f32")
+    monkeypatch.setattr(backend, "SPEC_PRECISION", "f32")
+    x, y = _resident_pair()
+    fs = 48000
+    for W, mode, det in ((4096, TransferFunctionType.H1, True), (1024, TransferFunctionType.H2, False),
+                         (512, TransferFunctionType.H3, True)):
+        si_h, so_h = dsp.Signal(None, x.copy(), fs), dsp.Signal(None, y.copy(), fs)
+        si_d = dsp.Signal.from_planar_f32(backend._planar_f32(x), fs)
+        so_d = dsp.Signal(None, y.copy(), fs).to_device()
+        for s in (si_h, si_d):
+            s.set_spectrum_parameters(window_length_samples=W, detrend=det)
+        ref = dsp.transfer_functions.compute_transfer_function(so_h, si_h, W, mode)
+        got = dsp.transfer_functions.compute_transfer_function(so_d, si_d, W, mode)
+        assert si_d.on_device and not si_d._has_host_copy  # nothing came down but the small result
+        assert np.array_equal(got.spectral_data, ref.spectral_data) and np.array_equal(got.coherence, ref.coherence)
+        rt, rc = orc.compute_transfer_function(y, x, fs, W, mode.name, detrend=det)
+        lo = 1 if det else 0
+        assert relmax(got.spectral_data[lo:], rt[lo:]) < (TOL if mode != TransferFunctionType.H2 else 5e-6)
+        assert relmax(got.coherence[lo:], rc[lo:]) < TOL
+    # Welch auto spectra and the cross-spectral matrix
+    sh = dsp.Signal(None, y.copy(), fs)
+    sd = dsp.Signal.from_planar_f32(backend._planar_f32(y), fs)
+    for s in (sh, sd):
+        s.set_spectrum_parameters(window_length_samples=2048, scaling=SpectrumScaling.PowerSpectralDensity)
+    fh, ph = sh.get_spectrum()
+    fd, pd_ = sd.get_spectrum()
+    assert np.array_equal(fh, fd) and np.array_equal(ph, pd_) and not sd._has_host_copy
+    _, ch = sh.get_csm(on_device=True)
+    _, cd = sd.get_csm(on_device=True)
+    assert np.array_equal(ch.to_host(), cd.to_host()) and not sd._has_host_copy
+
+
+def test_device_resident_spectrogram_and_inverse():
+    """get_spectrogram of a device-resident signal (array result and on_device=True handle) and transforms.istft of the
+    handle: the reconstruction stays in HBM and equals the host path's."""
+    rng = np.random.default_rng(12)
+    x = rng.standard_normal((40000, 3)) * 0.3
+    fs = 48000
+    for W, pad in ((1024, True), (4096, True), (512, False)):
+        sh = dsp.Signal(None, x.copy(), fs)
+        sd = dsp.Signal.from_planar_f32(backend._planar_f32(x), fs)
+        for s in (sh, sd):
+            s.set_spectrogram_parameters(window_length_samples=W, padding=pad)
+        th, fh, st_h = sh.get_spectrogram()
+        td, fd, st_d = sd.get_spectrogram()
+        assert np.array_equal(st_h, st_d) and np.array_equal(th, td) and np.array_equal(fh, fd)
+        _, _, handle = sd.get_spectrogram(on_device=True)
+        assert isinstance(handle, backend.DeviceSTFT) and handle.shape == st_h.shape
+        assert np.array_equal(handle.to_host(), st_h)
+        back_h = dsp.transforms.istft(st_h, original_signal=sh)
+        back_d = dsp.transforms.istft(handle, original_signal=sd)
+        assert back_d.on_device and not back_d._has_host_copy and len(back_d) == len(sd)
+        assert relmax(back_d.time_data, back_h.time_data) < 2e-7  # (the host path narrows complex128 -> complex64 the same way)
+        assert relmax(back_d.time_data[W:-W], x[W:-W]) < 2e-6
+        assert not sd._has_host_copy
+
+
+def test_device_resident_filtering_keeps_the_bands_on_the_device():
+    """Filter.filter_signal and FilterBank.filter_signal (three modes) over a device-resident signal: outputs are
+    device-resident signals / a MultiBandSignal of device-resident bands (slices of one buffer), equal to the host path and
+    1e-6 against the oracle; time_data / get_all_time_data materialise on demand; assigning time_data drops the device copy."""
+    rng = np.random.default_rng(44)
+    n, n_ch, fs = 50000, 3, 48000
+    x = rng.standard_normal((n, n_ch)) * 0.2
+    filters = [dsp.Filter.fir_filter(1200, [300.0 * (k + 1), 900.0 * (k + 1)], FilterPassType.Bandpass, fs) for k in range(4)]
+    taps = [f.ba[0] for f in filters]
+    sh = dsp.Signal(None, x.copy(), fs)
+    sd = dsp.Signal.from_planar_f32(backend._planar_f32(x), fs)
+    yh = filters[0].filter_signal(sh)
+    yd = filters[0].filter_signal(sd)
+    assert yd.on_device and not yd._has_host_copy and type(yd) is dsp.Signal
+    assert np.array_equal(yd.time_data, yh.time_data)
+    assert relmax(yd.time_data, orc.lfilter_fir(taps[0], x)) < TOL
+    fb = dsp.FilterBank(filters)
+    for mode in (FilterBankMode.Parallel, FilterBankMode.Sequential, FilterBankMode.Summed):
+        oh = fb.filter_signal(sh, mode)
+        od = fb.filter_signal(sd, mode)
+        if mode == FilterBankMode.Parallel:
+            assert od.on_device and od.number_of_bands == 4 and all(not b._has_host_copy for b in od.bands)
+            owners = {id(b.device_samples.owner) for b in od.bands}
+            assert len(owners) == 1  # one output buffer, four slices
+            all_d, _ = od.get_all_time_data()
+            all_h, _ = oh.get_all_time_data()
+            assert np.array_equal(all_d, all_h)
+            assert all(not b._has_host_copy for b in od.bands)  # the bulk download did not pin a second copy
+            assert np.array_equal(od.bands[2].time_data, oh.bands[2].time_data) and od.bands[2]._has_host_copy
+            ref = orc.filterbank_fir(taps, x, "Parallel")
+            assert relmax(all_d, np.transpose(ref, (0, 2, 1))) < TOL
+            coll = od.collapse()
+            assert relmax(coll.time_data, oh.collapse().time_data) < 1e-12
+        else:
+            assert od.on_device and not od._has_host_copy
+            assert np.array_equal(od.time_data, oh.time_data)
+    # an impulse response constrains its amplitude: its filter output is inspected on the host, like the reference's
+    ir = dsp.ImpulseResponse(None, x[:, :1].copy() * 0.1, fs).to_device()
+    out = filters[1].filter_signal(ir)
+    assert type(out) is dsp.ImpulseResponse and not out.on_device
+    # copies share the device samples; assigning new samples drops them
+    c = sd.copy()
+    assert c.on_device and c.device_samples is sd.device_samples
+    c.time_data = x[:100]
+    assert not c.on_device and c.time_data.shape == (100, n_ch) and sd.on_device
+
+
+def test_device_resident_spectral_deconvolve():
+    """spectral_deconvolve of device-resident signals (fast length: everything on the device) against the host path."""
+    fs = 48000
+    for n, n_cy, padding in ((8192, 2, False), (16384, 3, True), (4096, 1, False)):
+        from dsptoolbox_amd.generators import exponential_sweep
+        rng = np.random.default_rng(n)
+        x = exponential_sweep(n, fs)[:, None]
+        h = rng.standard_normal((n_cy, 64)) * np.exp(-np.arange(64) / 10.0)
+        y = np.stack([np.convolve(x[:, 0], h[c])[:n] for c in range(n_cy)], axis=1)
+        xh, yh = dsp.Signal(None, x.copy(), fs), dsp.Signal(None, y.copy(), fs)
+        xd = dsp.Signal.from_planar_f32(backend._planar_f32(x), fs)
+        yd = dsp.Signal.from_planar_f32(backend._planar_f32(y), fs)
+        ir_h = dsp.transfer_functions.spectral_deconvolve(yh, xh, padding=padding, keep_original_length=padding)
+        ir_d = dsp.transfer_functions.spectral_deconvolve(yd, xd, padding=padding, keep_original_length=padding)
+        assert type(ir_d) is dsp.ImpulseResponse and ir_d.on_device and not ir_d._has_host_copy
+        assert ir_d.spectrum_method == SpectrumMethod.FFT and len(ir_d) == len(ir_h)
+        assert relmax(ir_d.time_data, ir_h.time_data) < 3e-7
+        ref = orc.spectral_deconvolve(y, x, fs, padding=padding, keep_original_length=padding)
+        assert relmax(ir_d.time_data, ref) < TOL
+        assert not yd._has_host_copy and not xd._has_host_copy
