@@ -688,8 +688,11 @@ def measure(args, ctx, dist, workload: str, steps: int, warmup: int, strong: boo
         # the STEP against the fp32 matrix peak; the two kernels' HBM fractions follow under "kernels"
         flops = (alg_parts["gemm_flops"] + alg_parts["fft_flops"]) / div
         tf = flops / (step_ms * 1e-3) / 1e12
+        step_gbs = alg_parts["step"] / div / (step_ms * 1e-3) / 1e9
         roof = dict(bound="mfma", achieved=tf, peak=MFMA_F32_PEAK_TFLOPS, unit="TFLOP/s", frac=tf / MFMA_F32_PEAK_TFLOPS,
                     traffic=None, algorithmic_flops_per_step=flops, time_base="step (both kernels), HIP events",
+                    # the same step by BYTES (samples in, matrices out: SURVEY 8(d)'s fused ideal) against the HBM roofline
+                    step_bytes_gbs=step_gbs, step_bytes_frac=step_gbs / HBM_PEAK_GBS,
                     dominant_kernel_hbm=hbm)
     else:
         roof = hbm
@@ -803,6 +806,7 @@ def workload_entry(args, ctx, dist, name: str):
     else:
         ent["traffic_ratio"] = None
     if roof["bound"] == "mfma":
+        ent["step_bytes_frac"] = roof.get("step_bytes_frac")
         ent["kernels_hbm_frac"] = {k: v["frac"] for k, v in roof.get("kernels", {}).items()}
         if "gemm" in roof and "frac_of_bf16_peak" in roof["gemm"]:
             ent["executed_bf16_frac"] = roof["gemm"]["frac_of_bf16_peak"]

@@ -113,6 +113,9 @@ def build_library(force: bool = False, verbose: bool = True) -> str:
                 return LIB_PATH
             hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
             tmp = LIB_PATH + f".tmp{os.getpid()}"
+            # the hash of what is about to be compiled: taken now, not after the two minutes hipcc runs (a source
+            # edited meanwhile would otherwise be recorded as built)
+            hash_at_start = _source_hash()
             cmd = [hipcc] + FLAGS + REMARK_FLAGS + ["-o", tmp] + SOURCES + ["-ldl", "-pthread"]
             if verbose:
                 print(" ".join(cmd), file=sys.stderr, flush=True)
@@ -148,7 +151,7 @@ def build_library(force: bool = False, verbose: bool = True) -> str:
                     json.dump(res, fh, indent=1, sort_keys=True)
                 os.replace(tmp, LIB_PATH)
                 with open(HASH_PATH, "w") as fh:
-                    fh.write(_source_hash() + "\n")
+                    fh.write(hash_at_start + "\n")
                 LAST_BUILD = "compiled"
             finally:
                 if os.path.exists(tmp):

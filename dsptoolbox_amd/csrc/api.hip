@@ -33,6 +33,7 @@
 #include "kernels_welch16384.hpp"
 #include "kernels_welch_long.hpp"
 #include "kernels_stft_long.hpp"
+#include "kernels_welch2048h.hpp"
 #include "kernels_istft_long.hpp"
 #include "kernels_welch_f64.hpp"
 #include "kernels_stft_any.hpp"
@@ -49,6 +50,7 @@ struct ds_ctx {
     hipStream_t stream = nullptr;
     hipStream_t side = nullptr;  // second stream for a kernel that may run beside the main one
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipEvent_t ev_chunk[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // csm_chunked
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::string err;
     std::map<int, float2*> tw;  // twiddle tables by length
@@ -214,6 +216,8 @@ extern "C" void ds_destroy(ds_ctx* c) {
     (void)hipStreamDestroy(c->stream);
     if (c->side) (void)hipStreamDestroy(c->side);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    for (auto e : c->ev_chunk)
+        if (e) (void)hipEventDestroy(e);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     delete c;
 }
@@ -1254,6 +1258,62 @@ static int welch4096_run(ds_ctx* c, const float* x, int n_cx, int64_t ldx, const
     return DS_OK;
 }
 
+// window 2048 at 50 % overlap: two 2048-point pair transforms per pass of the 4096-point register machine
+// (kernels_welch2048h.hpp).  y == nullptr: auto spectra of x only (psd in `coh`).
+static bool welch2048h_applies(const ds_ctx* c, int W, int hop, int average, int64_t n_samples, int n_frames) {
+    return c && W == 2048 && hop == 1024 && average == DS_AVG_MEAN && !c->cfg.welch_generic && !c->cfg.w2048_wave &&
+           welch2048h::fits(n_samples, n_frames);
+}
+static int welch2048h_run(ds_ctx* c, const float* x, int n_cx, int64_t ldx, const float* y, int n_cy, int64_t ldy,
+                          int64_t n_samples, int n_frames, const float* window, int detrend, int mode, int amp_sqrt,
+                          double norm_scale, double factor, int halve_edges, float2* tf, float* coh, int kind = 0) {
+    namespace wh = welch2048h;
+    namespace w4 = welch4096;
+    const bool auto_only = kind == 1;
+    if (!x || !window || (!auto_only && !y)) return fail(c, DS_ERR_ARG, "ds_welch: null argument");
+    if (!auto_only && n_cx != 1 && n_cx != n_cy) return fail(c, DS_ERR_ARG, "ds_welch_tf: one input channel, or one per output channel");
+    if (n_cx <= 0 || n_samples <= 0 || n_frames <= 0 || ldx < n_samples || (!auto_only && (n_cy <= 0 || ldy < n_samples)))
+        return fail(c, DS_ERR_ARG, "ds_welch: bad shape");
+    if (kind == 0 && (mode < DS_TF_H1 || mode > DS_TF_H3)) return fail(c, DS_ERR_ARG, "welch: unsupported transfer function type");
+    if (!c->w4_tables) {
+        std::vector<float2> h;
+        w4::host_tables(h);
+        CHK(upload_table_fwd(c, &c->w4_tables, h));
+    }
+    const int nf = frames_to_visit(n_samples, wh::HOP, n_frames);
+    const int n_out = auto_only ? n_cx : n_cy;
+    wh::Plan pl = wh::plan(nf, n_out, auto_only ? 0 : n_cx, c->cfg.welch_chunks);
+    CHK(reserve(c, &c->ws, &c->ws_bytes, pl.bytes + 4096));
+    Carver cv(c->ws);
+    float2* xs = auto_only ? nullptr : cv.take<float2>((size_t)n_cx * pl.n_passes * wh::PASS);
+    float* px = auto_only ? nullptr : cv.take<float>((size_t)n_cx * pl.n_passes * wh::NBW);
+    float* psx = auto_only ? nullptr : cv.take<float>((size_t)pl.n_chunks * n_cx * wh::NBW);
+    float2* pxy = auto_only ? nullptr : cv.take<float2>((size_t)pl.n_chunks * n_cy * wh::NBW);
+    float* pyy = cv.take<float>((size_t)pl.n_chunks * n_out * wh::NBW);
+    // (Args::n_pairs counts passes of four frames here)
+    w4::Args ax{x, n_samples, ldx, 1, wh::HOP, nf, pl.n_passes, detrend, pl.n_chunks, 0, window, c->w4_tables, xs, px, pxy, pyy, psx};
+    ax.n_cx = n_cx;
+    if (auto_only) {
+        ax.n_ch = n_cx;
+        w4::place_remainder(ax, n_cx);
+        CHK(launch(c, "welch2048_main@4k", wh::k_y2h<true>, dim3(pl.n_chunks * n_cx), w4::NT, wh::LDS_BYTES, ax));
+        WelchFinArgs f{pyy, nullptr, nullptr, pl.n_chunks, pl.n_chunks, n_cx, 0, 1, 0,
+                       FinishPar{norm_scale / (double)n_frames, factor, halve_edges, amp_sqrt, wh::NBW}, nullptr, coh};
+        return launch_finish(c, dim3((unsigned)(((int64_t)wh::NBW * n_cx + 63) / 64)), f);
+    }
+    w4::Args ay = ax;
+    ay.sig = y;
+    ay.ld = ldy;
+    ay.n_ch = n_cy;
+    w4::place_remainder(ay, n_cy);
+    CHK(launch(c, "welch2048_x", wh::k_x2h, dim3(pl.n_passes * n_cx), w4::NT, wh::LDS_BYTES, ax));
+    if (n_cx > 1) CHK(launch(c, "welch2048_pxsum", wh::k_px_sum, dim3(pl.n_chunks, n_cx), 256, 0, ay));
+    CHK(launch(c, "welch2048_main@4k", wh::k_y2h<false>, dim3(pl.n_chunks * n_cy), w4::NT, wh::LDS_BYTES, ay));
+    WelchFinArgs f{psx, pxy, pyy, pl.n_chunks, pl.n_chunks, n_cx, n_cy, kind, mode,
+                   FinishPar{norm_scale / (double)n_frames, factor, halve_edges, amp_sqrt, wh::NBW}, tf, coh};
+    return launch_finish(c, dim3((unsigned)(((int64_t)wh::NBW * n_cy + 63) / 64)), f);
+}
+
 // window 8192, one input channel: two 4096-point register transforms per frame pair
 // (kernels_welch8192.hpp)
 static int welch8192_run(ds_ctx* c, const float* x, int n_cx, int64_t ldx, const float* y, int n_cy, int64_t ldy,
@@ -1689,6 +1749,9 @@ extern "C" int ds_welch_tf_dev(ds_ctx* c, const float* x, int n_cx, int64_t ldx,
         welch8k::buf_fits(n_samples, n_frames, hop))
         return welch8192_run(c, x, n_cx, ldx, y, n_cy, ldy, n_samples, hop, n_frames, window, detrend, mode,
                              amp_sqrt, norm_scale, factor, halve_edges, (float2*)tf, coh);
+    if ((n_cx == 1 || n_cx == n_cy) && welch2048h_applies(c, W, hop, average, n_samples, n_frames))
+        return welch2048h_run(c, x, n_cx, ldx, y, n_cy, ldy, n_samples, n_frames, window, detrend, mode, amp_sqrt, norm_scale,
+                              factor, halve_edges, (float2*)tf, coh);
     // 256 ... 2048-sample windows (1024: the reference's default): one input channel or one per output channel
     if (c && (W == 2048 || W == 1024 || W == 512 || W == 256) && (n_cx == 1 || n_cx == n_cy) && average == DS_AVG_MEAN &&
         !no1k && welch1k::buf_fits(n_samples, n_cy, ldy)) {
@@ -1928,6 +1991,9 @@ extern "C" int ds_welch_psd_dev(ds_ctx* c, const float* x, int n_cx, int64_t ldx
     if (c && W == 4096 && average == DS_AVG_MEAN && !c->cfg.no_welch4096 && !no1k)
         return welch4096_psd_run(c, x, n_cx, ldx, n_samples, hop, n_frames, window, detrend, amp_sqrt,
                                  norm_scale, factor, halve_edges, psd);
+    if (welch2048h_applies(c, W, hop, average, n_samples, n_frames))
+        return welch2048h_run(c, x, n_cx, ldx, nullptr, 0, 0, n_samples, n_frames, window, detrend, 0, amp_sqrt, norm_scale,
+                              factor, halve_edges, nullptr, psd, 1);
     if (c && (W == 2048 || W == 1024 || W == 512 || W == 256) && average == DS_AVG_MEAN && !no1k &&
         welch1k::buf_fits(n_samples, n_cx, ldx)) {
         auto run = W == 2048 ? welch_wave_psd_run<2048>
@@ -1963,6 +2029,9 @@ static int welch_csd_dev(ds_ctx* c, const float* x, const float* y, int n_ch, in
         if (W == 8192 && welch8k::buf_fits(n_samples, n_frames, hop))
             return welch8192_run(c, x, n_ch, ld, y, n_ch, ld, n_samples, hop, n_frames, window, detrend, DS_TF_H1,
                                  amp_sqrt, norm_scale, factor, halve_edges, (float2*)csd, nullptr, 2);
+        if (welch2048h_applies(c, W, hop, average, n_samples, n_frames))
+            return welch2048h_run(c, x, n_ch, ld, y, n_ch, ld, n_samples, n_frames, window, detrend, DS_TF_H1, amp_sqrt,
+                                  norm_scale, factor, halve_edges, (float2*)csd, nullptr, 2);
         if ((W == 2048 || W == 1024 || W == 512 || W == 256) && welch1k::buf_fits(n_samples, n_ch, ld)) {
             auto run = W == 2048 ? welch_wave_run<2048>
                                  : (W == 1024 ? welch_wave_run<1024> : (W == 512 ? welch_wave_run<512> : welch_wave_run<256>));
@@ -1978,6 +2047,47 @@ static int welch_csd_dev(ds_ctx* c, const float* x, const float* y, int n_ch, in
 }
 
 // ---- CSM -------------------------------------------------------------------
+// frame f of a chunk that starts at frame f0 is frame f0 + f of the signal: the chunk's transform reads x + f0 hop
+static bool pad_ok_for_chunks(int64_t n_samples, int hop, int n_frames) {
+    return (int64_t)(n_frames - 1) * hop < n_samples;  // every chunk starts inside the signal
+}
+static int csm_chunked(ds_ctx* c, const float* x, int n_ch, int64_t ld, int64_t n_samples, int W, int hop, int n_frames,
+                       const float* window, int detrend, int amp_sqrt, double norm_scale, double factor, int halve_edges,
+                       int K, float2* csm) {
+    const int nb = W / 2 + 1;
+    const size_t part_elems = (size_t)nb * n_ch * n_ch;
+    CHK(reserve(c, &c->ws, &c->ws_bytes, Carver::pad(sizeof(float2) * (size_t)nb * n_frames * n_ch) + Carver::pad(sizeof(float2) * part_elems)));
+    Carver cv(c->ws);
+    float2* X = cv.take<float2>((size_t)nb * n_frames * n_ch);
+    float2* part = cv.take<float2>(part_elems);
+    if (c->ev_chunk[0] == nullptr)
+        for (auto& e : c->ev_chunk) HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    hipStream_t main_stream = c->stream;
+    // the side stream starts behind everything already queued on the main one (the previous call's product reads X)
+    HIPCHK(c, hipEventRecord(c->ev_fork, main_stream));
+    HIPCHK(c, hipStreamWaitEvent(c->side, c->ev_fork, 0));
+    int rc = DS_OK;
+    for (int k = 0; k < K && rc == DS_OK; ++k) {
+        const int f0 = (int)((int64_t)k * n_frames / K), f1 = (int)((int64_t)(k + 1) * n_frames / K), fk = f1 - f0;
+        float2* Xk = X + (size_t)nb * f0 * n_ch;  // chunk k: [nb][fk][n_ch]
+        rc = ds_stft_r2c_dev(c, x + (int64_t)f0 * hop, n_samples - (int64_t)f0 * hop, n_ch, ld, W, hop, W, 0, fk, window, detrend,
+                             1.0f, 1.0f, 0, (ds_c32*)Xk);
+        if (rc != DS_OK) break;
+        HIPCHK(c, hipEventRecord(c->ev_chunk[k], main_stream));
+        HIPCHK(c, hipStreamWaitEvent(c->side, c->ev_chunk[k], 0));
+        CsmArgs a{Xk, n_ch, fk, FinishPar{norm_scale / (double)n_frames, factor, halve_edges, amp_sqrt, nb}, csm, 0};
+        a.part_in = k > 0 ? part : nullptr;
+        a.part_out = k + 1 < K ? part : nullptr;
+        c->stream = c->side;  // launch() enqueues on the context's stream
+        rc = launch(c, "csm_gemm@b3", csmb3::k_csm_gemm64_b3, dim3(nb - 1), 256, 0, a);
+        c->stream = main_stream;
+    }
+    // the main stream goes on behind the last product
+    HIPCHK(c, hipEventRecord(c->ev_join, c->side));
+    HIPCHK(c, hipStreamWaitEvent(main_stream, c->ev_join, 0));
+    return rc;
+}
+
 static int csm_dev(ds_ctx* c, const float* x, int n_ch, int64_t ld, int64_t n_samples, int W, int hop,
                    int n_frames, const float* window, int detrend, int average, int amp_sqrt,
                    double norm_scale, double factor, int halve_edges, int bin_start, int bin_count,
@@ -2022,6 +2132,18 @@ static int csm_dev(ds_ctx* c, const float* x, int n_ch, int64_t ld, int64_t n_sa
                         (float2*)csm};
         CHK(launch(c, "csm_median", k_csm_median, dim3((nb + bpb - 1) / bpb, n_ch * (n_ch + 1) / 2), 256, lds, m));
         return DS_OK;
+    }
+    // Round 5: the 64-microphone shape in frame chunks on two streams.  Transform and product are both streams of the
+    // spectrogram X (written once, read once: 4.9 x the algorithmic bytes of the step, and each kernel alone reaches
+    // 0.4 of the HBM roofline); with the frames cut into chunks the transform of chunk k + 1 (main stream) runs beside
+    // the product of chunk k (side stream), the products carrying their raw fp32 sums from chunk to chunk
+    // (CsmArgs::part_in / part_out: 8.5 MB per hand-over against 66 MB of spectrogram per chunk).
+    {
+        const int K = std::min(c->cfg.csm_chunks, n_frames / 64);  // >= 64 frames per chunk
+        if (K >= 2 && !big && all_bins && n_ch <= 64 && nb >= 3 && !c->cfg.csm_generic && !c->cfg.csm_f32 &&
+            csmb3::fits(n_ch, n_frames) && pad_ok_for_chunks(n_samples, hop, n_frames))
+            return csm_chunked(c, x, n_ch, ld, n_samples, W, hop, n_frames, window, detrend, amp_sqrt, norm_scale, factor,
+                               halve_edges, K, (float2*)csm);
     }
     // the STFT buffer X[b][f][c] (+ the four-step scratch for long windows) in the workspace
     size_t bytes = Carver::pad(sizeof(float2) * (size_t)nb * n_frames * n_ch);
@@ -2643,6 +2765,11 @@ static int fir4k_run(ds_ctx* c, const float* x, int n_ch, int64_t ldx, int64_t n
     if (c->cfg.fir_chunks > 0) chunks = c->cfg.fir_chunks;
     chunks = std::min(chunks, n_blocks);
     f4::Args a{x, n_samples, ldx, ld_y, n_ch, n_filt, n_blocks, chunks, c->w4_tables, hp, y};
+    if (c->cfg.fir_stage) {  // round-5 experiment: stores through a per-wave LDS strip (profiles/r05_fir_staged_stores.txt)
+        if (P == 1)
+            return launch(c, "fir@4k_p1_staged", f4::k_fir<1, true>, dim3((unsigned)(pairs * chunks)), f4::NT, f4::LDS_BYTES + f4::STAGE_BYTES, a);
+        return launch(c, "fir@4k_p2_staged", f4::k_fir<2, true>, dim3((unsigned)(pairs * chunks)), f4::NT, f4::LDS_BYTES + f4::STAGE_BYTES, a);
+    }
     if (P == 1) return launch(c, "fir@4k_p1", f4::k_fir<1>, dim3((unsigned)(pairs * chunks)), f4::NT, f4::LDS_BYTES, a);
     return launch(c, "fir@4k_p2", f4::k_fir<2>, dim3((unsigned)(pairs * chunks)), f4::NT, f4::LDS_BYTES, a);
 }

@@ -13,12 +13,18 @@ struct ds_config {
     bool welch_generic = false;   // DSPTOOLBOX_AMD_WELCH_GENERIC: generic LDS kernels instead of the register kernels
                                   //   for windows of 8 ... 16384 other than 4096 (and for cross spectra)
     bool no_welch4096 = false;    // DSPTOOLBOX_AMD_NO_WELCH4096=1: ... and for 4096-sample windows too
+    bool w2048_wave = false;      // DSPTOOLBOX_AMD_W2048_WAVE=1: 2048-sample windows at 50 % overlap on the wave / team kernels
+                                  //   (kernels_welch1024.hpp) instead of two transforms per pass of the 4096-point machine
     bool w4_two_per_cu = false;   // DSPTOOLBOX_AMD_W4_TWO_PER_CU=1: round 1's welch4096::k_y instead of k_y3
     bool stft_generic = false;    // DSPTOOLBOX_AMD_STFT_GENERIC: k_stft<N> instead of the wave / frame kernels
     bool istft_fused = true;      // DSPTOOLBOX_AMD_ISTFT_FUSED=0: transform and overlap-add as two launches
     bool istft_wave = true;       // DSPTOOLBOX_AMD_ISTFT_WAVE=0: no wave-level inverse transform (256 ... 2048)
     bool istft_one_ch = false;    // DSPTOOLBOX_AMD_ISTFT_CT=1: one channel per workgroup in k_istft
     bool csm_generic = false;     // DSPTOOLBOX_AMD_CSM_GENERIC: one workgroup per bin and tile pair
+    int csm_chunks = 1;           // DSPTOOLBOX_AMD_CSM_CHUNKS = 2 ... 8: frame chunks of the <= 64-channel matrix (transform of chunk
+                                  //   k + 1 beside the product of chunk k on a second stream).  Measured, not adopted: 0.22 / 0.24 /
+                                  //   0.29 ms at 2 / 4 / 8 chunks against 0.16 ms for one transform, then one product
+                                  //   (profiles/r05_csm_chunks_two_streams.txt)
     bool csm_f32 = false;         // DSPTOOLBOX_AMD_CSM_F32: fp32 matrix instructions instead of bf16 triples
     bool deconv_generic = false;  // DSPTOOLBOX_AMD_DECONV_GENERIC: k_deconv<8192> instead of deconv8k
     bool deconv_2percu = false;   // DSPTOOLBOX_AMD_DECONV_2PERCU: the 512-thread deconv8k kernel
@@ -26,6 +32,7 @@ struct ds_config {
     bool deconv_4percu = true;    // DSPTOOLBOX_AMD_DECONV_4PERCU=0: k_deconv3 (three per CU) instead of k_deconv3q
     bool fir_generic = false;     // DSPTOOLBOX_AMD_FIR_GENERIC: k_fir<16384> instead of fir16k
     int fir4k_min_taps = 1025;    // DSPTOOLBOX_AMD_FIR_4K: 0 never fir4k, 1 always, n > 1 from n taps on
+    bool fir_stage = false;       // DSPTOOLBOX_AMD_FIR_STAGE=1: fir4k's stores through a per-wave LDS strip (16-byte stores; measured, not faster)
     bool fir_direct = true;       // DSPTOOLBOX_AMD_FIR_DIRECT=0: no direct float64 sum for a signal shorter than the filter
     bool finish_wide = false;     // DSPTOOLBOX_AMD_FINISH_WIDE=1: k_welch_finish by 64-bit loads (the path of partial slabs >= 4 GiB)
     // ---- tuning overrides (0 = the built-in choice) ------------------------------------------------
@@ -49,6 +56,7 @@ struct ds_config {
         };
         g.welch_generic = set("DSPTOOLBOX_AMD_WELCH_GENERIC");
         g.no_welch4096 = is("DSPTOOLBOX_AMD_NO_WELCH4096", '1');
+        g.w2048_wave = is("DSPTOOLBOX_AMD_W2048_WAVE", '1');
         g.w4_two_per_cu = is("DSPTOOLBOX_AMD_W4_TWO_PER_CU", '1');
         g.stft_generic = set("DSPTOOLBOX_AMD_STFT_GENERIC");
         g.istft_fused = !(set("DSPTOOLBOX_AMD_ISTFT_FUSED") && num("DSPTOOLBOX_AMD_ISTFT_FUSED") == 0);
@@ -56,12 +64,14 @@ struct ds_config {
         g.istft_one_ch = set("DSPTOOLBOX_AMD_ISTFT_CT") && num("DSPTOOLBOX_AMD_ISTFT_CT") == 1;
         g.csm_generic = set("DSPTOOLBOX_AMD_CSM_GENERIC");
         g.csm_f32 = set("DSPTOOLBOX_AMD_CSM_F32");
+        if (num("DSPTOOLBOX_AMD_CSM_CHUNKS") >= 1) g.csm_chunks = std::min(8, num("DSPTOOLBOX_AMD_CSM_CHUNKS"));
         g.deconv_generic = set("DSPTOOLBOX_AMD_DECONV_GENERIC");
         g.deconv_2percu = set("DSPTOOLBOX_AMD_DECONV_2PERCU");
         g.deconv_persist = !(set("DSPTOOLBOX_AMD_DECONV_PERSIST") && num("DSPTOOLBOX_AMD_DECONV_PERSIST") == 0);
         g.deconv_4percu = !(set("DSPTOOLBOX_AMD_DECONV_4PERCU") && num("DSPTOOLBOX_AMD_DECONV_4PERCU") == 0);
         g.finish_wide = is("DSPTOOLBOX_AMD_FINISH_WIDE", '1');
         g.fir_generic = set("DSPTOOLBOX_AMD_FIR_GENERIC");
+        g.fir_stage = is("DSPTOOLBOX_AMD_FIR_STAGE", '1');
         g.fir_direct = !(set("DSPTOOLBOX_AMD_FIR_DIRECT") && num("DSPTOOLBOX_AMD_FIR_DIRECT") == 0);
         if (const char* e = getenv("DSPTOOLBOX_AMD_FIR_4K")) {
             if (e[0] == '0')

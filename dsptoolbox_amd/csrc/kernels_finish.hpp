@@ -396,6 +396,11 @@ struct CsmArgs {
     int b0;       // first bin of this call (generic kernel: a bin range for the multi-GPU split)
     int n_groups; // k_csm_group_b3 / k_csm_offdiag_b3: groups of 64 channels (0: not used)
     int n_groups_bins;  // k_csm_offdiag_b3: bins of this call (its grid is padded to whole XCD rounds)
+    // Frame chunks (round 5: the transform of chunk k + 1 runs beside the product of chunk k on a second stream): the
+    // raw fp32 sums of the lower triangle, [bin][i][j] with the matrix's own strides.  part_in: added to this call's
+    // sums; part_out: this call stores its sums there INSTEAD of finishing them (the last chunk has part_out == null).
+    const float2* part_in = nullptr;
+    float2* part_out = nullptr;
 };
 
 // Combine the four waves' partial 32x32 tiles (fp64, through LDS), apply the Welch finish and
@@ -464,6 +469,21 @@ __device__ __forceinline__ void csm_tile_reduce_store(CsmRed& red, int I, int J,
         // part selects the branch of the square root of a negative real element (+i for the lower
         // element, its conjugate for the mirror, as the reference's sqrt of its Hermitian matrix gives)
         gy[rr] = up ? 0.f - gy[rr] : gy[rr];
+    }
+    if (p.part_in || p.part_out) {  // (uniform) frame chunks: carry the raw sums between the calls
+        const int64_t pb = (int64_t)(b - p.b0) * p.n_ch * p.n_ch;
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const bool live = gi[rr] < C && gj[rr] < C && gi[rr] >= gj[rr];
+            const int64_t at = pb + (int64_t)gi[rr] * p.n_ch + gj[rr];
+            if (p.part_in && live) {
+                const float2 q = p.part_in[at];
+                gx[rr] += q.x;
+                gy[rr] += q.y;
+            }
+            if (p.part_out && live) p.part_out[at] = make_float2(gx[rr], gy[rr]);
+        }
+        if (p.part_out) return;
     }
     const double e = p.fin.halve_edges ? ((b == 0 || b == p.fin.nb - 1) ? 0.5 * p.fin.factor : p.fin.factor) : 1.0;
     double vx[4], vy[4];
@@ -536,6 +556,7 @@ __device__ __forceinline__ void csm_epilogue64(CsmRed& red, float2* G, const f32
         csm_tile_reduce_store<ILV, true>(red, 1, 1, diag_m, b, p, G, C);
     }
     __syncthreads();
+    if (p.part_out) return;  // a frame chunk that is not the last: its sums went to part_out, nothing is finished yet
     float2* out = p.csm + (int64_t)(b - p.b0) * Ct * Ct + (int64_t)c0 * Ct + c0;
     const int col = threadIdx.x & 63;
     if (col < C)

@@ -272,13 +272,18 @@ struct Args {
     float* y;          // [(f n_ch + c) ld_y + n]
 };
 
+// STAGE (round 5 experiment; DSPTOOLBOX_AMD_FIR_STAGE=1): the 2 x 8 four-byte stores of a thread
+// (256 contiguous bytes per wave instruction) go through a per-wave LDS strip instead -- 16 ds_write_b32, 4
+// ds_read_b128 -- and leave as 2 x 2 sixteen-byte stores (four 256-byte runs per wave instruction).
+constexpr int STAGE_BYTES = 4 * 2 * 8 * 64 * 4;  // waves x channels x groups of 256 samples x lanes x float
 // grid = ceil(n_ch / 2) * n_chunks
-template <int P>
+template <int P, bool STAGE = false>
 __global__ __launch_bounds__(NT, P == 1 ? 3 : 2) void k_fir(Args p) {
     static_assert(P == 1 || P == 2, "one or two partitions of 2049 taps");
     extern __shared__ __align__(16) float2 lds[];
     float2* buf = lds;
     float2* tw2 = lds + 16 * w4::L1S;
+    float* strip = reinterpret_cast<float*>(reinterpret_cast<char*>(lds) + LDS_BYTES) + (threadIdx.x >> 6) * (2 * 8 * 64);
     const int tid = threadIdx.x;
     const int cp = (int)blockIdx.x / p.n_chunks, q = (int)blockIdx.x - cp * p.n_chunks;
     const int b0 = (int)((int64_t)q * p.n_blocks / p.n_chunks), b1 = (int)((int64_t)(q + 1) * p.n_blocks / p.n_chunks);
@@ -358,10 +363,31 @@ __global__ __launch_bounds__(NT, P == 1 ? 3 : 2) void k_fir(Args p) {
             float* __restrict__ ya = p.y + ((int64_t)f * p.n_ch + ca) * p.ld_y;
             const __amdgpu_buffer_rsrc_t oa = __builtin_amdgcn_make_buffer_rsrc(ya, 0, (int)sig_bytes, 0x00020000);
             const __amdgpu_buffer_rsrc_t ob = __builtin_amdgcn_make_buffer_rsrc(ya + p.ld_y, 0, vb ? (int)sig_bytes : 0, 0x00020000);
+            if constexpr (STAGE) {
+                const int l = tid & 63, g = l >> 4, q4 = 4 * (l & 15);
 #pragma unroll
-            for (int m = 0; m < 8; ++m) {
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[8 + m].x), oa, out_off + 1024 * m, 0, 0);
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[8 + m].y), ob, out_off + 1024 * m, 0, 0);
+                for (int m = 0; m < 8; ++m) {
+                    strip[m * 64 + l] = v[8 + m].x;
+                    strip[(8 + m) * 64 + l] = v[8 + m].y;
+                }
+                w4::wave_sync();
+                // lane (g, q): samples 4 q .. 4 q + 3 of this wave's 64 in the groups m = g and m = 4 + g
+                const int so = 4 * (b * HOP + (tid & ~63) + q4);
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) {
+                    const int m = 4 * jj + g;
+                    const float4 a4 = *reinterpret_cast<const float4*>(strip + m * 64 + q4);
+                    const float4 b4 = *reinterpret_cast<const float4*>(strip + (8 + m) * 64 + q4);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, a4), oa, so + 1024 * m, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, b4), ob, so + 1024 * m, 0, 0);
+                }
+                w4::wave_sync();  // the strip is rewritten by the next filter
+            } else {
+#pragma unroll
+                for (int m = 0; m < 8; ++m) {
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[8 + m].x), oa, out_off + 1024 * m, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[8 + m].y), ob, out_off + 1024 * m, 0, 0);
+                }
             }
         }
         if (P == 2) {

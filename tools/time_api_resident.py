@@ -48,7 +48,7 @@ for W in (4096, 1024):
     m_h = timed(lambda: dsp.transfer_functions.compute_transfer_function(Y, X, W, H1), reps=5, warm=1)
     m_d = timed(lambda: dsp.transfer_functions.compute_transfer_function(Yd, Xd, W, H1), reps=200, warm=20)
     print(f"compute_transfer_function 64 + 1 ch x 2^20, window {W}:  host arrays {m_h[0]:8.3f} ms   resident {m_d[0]:8.3f} ms (min {m_d[1]:.3f})")
-assert not Yd._has_host_copy
+assert not Xd._has_host_copy  # (Yd came from a host array and keeps it)
 
 rng = np.random.default_rng(1)
 mic = rng.standard_normal((512000, 64)) * 0.1

@@ -33,11 +33,11 @@ for W in sizes:
         ctx.check(ctx.lib.ds_welch_tf_dev(ctx.handle, C.c_void_p(d_x.ptr), 1, n, C.c_void_p(d_y.ptr), n_cy, n, n, W,
                                           hop, n_frames, C.c_void_p(d_w.ptr), 1, 0, 1, amp, ns, fac, phys,
                                           C.c_void_p(d_tf.ptr), C.c_void_p(d_coh.ptr)), "welch")
-    for _ in range(3):
+    for _ in range(300):  # past the clock ramp of an idle chip (profiles/r05_clock_ramp.txt)
         step()
     ctx.sync()
     t0 = time.perf_counter()
-    K = 20
+    K = 200
     for _ in range(K):
         step()
     ctx.sync()
