@@ -2568,13 +2568,17 @@ def test_welch_2048_window_on_the_4096_machine(monkeypatch):
         xc = rng.standard_normal((n, C)) * 0.3
         y = np.stack([np.convolve(x1[:, 0], rng.standard_normal(6))[:n] for _ in range(C)], axis=1)
         y += 0.05 * rng.standard_normal((n, C)) + 0.1
+        # one input per output channel: responses to THOSE inputs (a transfer function between unrelated noises is
+        # itself noise, 1 / sqrt(frames) of nothing)
+        yc = np.stack([np.convolve(xc[:, c], rng.standard_normal(6))[:n] for c in range(C)], axis=1)
+        yc += 0.05 * rng.standard_normal((n, C)) + 0.1
         for det in (True, False):
             lo = 1 if det else 0
-            for xin in (x1, xc):
+            for xin, yout in ((x1, y), (xc, yc)):
                 ctx.routes()
-                tf, coh = backend.welch_transfer_function(y, xin, fs, W, "H1", detrend=det, precision="f32")
+                tf, coh = backend.welch_transfer_function(yout, xin, fs, W, "H1", detrend=det, precision="f32")
                 assert {"welch2048_x", "welch2048_main@4k"} <= ctx.routes(), ctx.routes()
-                rt, rc = orc.compute_transfer_function(y, xin, fs, W, "H1", detrend=det)
+                rt, rc = orc.compute_transfer_function(yout, xin, fs, W, "H1", detrend=det)
                 e = max(relmax(tf[lo:], rt[lo:]), relmax(coh[lo:], rc[lo:]))
                 worst = max(worst, e)
                 # (one to five frames: nothing averages the fp32 transform rounding down -- DESIGN section 2; the API
@@ -2583,10 +2587,10 @@ def test_welch_2048_window_on_the_4096_machine(monkeypatch):
             for sc in (SpectrumScaling.FFTBackward, SpectrumScaling.AmplitudeSpectralDensity):
                 ctx.routes()
                 a = backend._welch(y, None, fs, Window.Hann, W, 50, det, "mean", sc)
-                k = backend._welch(xc, y, fs, Window.Hann, W, 50, det, "mean", sc)
+                k = backend._welch(xc, yc, fs, Window.Hann, W, 50, det, "mean", sc)
                 assert "welch2048_main@4k" in ctx.routes()
                 ra = orc.welch(y, None, fs, "hann", W, 50, det, "mean", sc.name)
-                rk = orc.welch(xc, y, fs, "hann", W, 50, det, "mean", sc.name)
+                rk = orc.welch(xc, yc, fs, "hann", W, 50, det, "mean", sc.name)
                 e = max(relmax(np.atleast_2d(a.T).T[lo:], np.atleast_2d(ra.T).T[lo:]),
                         relmax(np.atleast_2d(k.T).T[lo:], np.atleast_2d(rk.T).T[lo:]))
                 worst = max(worst, e)
