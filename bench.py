@@ -770,9 +770,10 @@ def measure(args, ctx, dist, workload: str, steps: int, warmup: int, strong: boo
     out["preheat"] = dict(preheat, note="untimed steps in front of the W warm-up steps: the engine clock of an idle "
                                         "chip ramps for ~10 ms (profiles/r05_clock_ramp.txt)")
     if steady:
-        if "kernel_avg_ms" in steady:  # the same fraction over the longer region
-            steady["roofline_frac"] = (roof["dominant_kernel_hbm"]["frac"] * dom_ms / steady["kernel_avg_ms"]
-                                       if "dominant_kernel_hbm" in roof else roof["frac"] * dom_ms / steady["kernel_avg_ms"])
+        if roof["bound"] == "mfma":  # the same fraction over the longer region: flops of the step / its time / peak
+            steady["roofline_frac"] = roof["frac"] * step_ms / steady["step_event_ms"]
+        elif "kernel_avg_ms" in steady:
+            steady["roofline_frac"] = roof["frac"] * dom_ms / steady["kernel_avg_ms"]
         out["steady_state"] = steady
     if bcast_ms is not None:
         out["rccl_bcast_ms"] = bcast_ms

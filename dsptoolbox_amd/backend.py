@@ -440,8 +440,21 @@ class DeviceSTFT:
         self.buf, self.shape, self.power = buf, tuple(int(v) for v in shape), bool(power)
 
     def to_host(self) -> np.ndarray:
-        out = self.buf.to_array(self.shape, np.complex64)
-        return out.real.astype(np.float64) if self.power else _widen(out)
+        n = int(np.prod(self.shape))
+        if self.power or n < (1 << 20):
+            out = self.buf.to_array(self.shape, np.complex64)
+            return out.real.astype(np.float64) if self.power else _widen(out)
+        # a large spectrogram: page-locked chunks (the link's rate), each widened by the host threads while it is hot
+        ctx, lib = self.buf.ctx, load_library()
+        res = np.empty(self.shape, dtype=np.complex128)
+        flat = res.reshape(-1)
+        chunk = 4 << 20  # complex values: 32 MB down, 64 MB out
+        for i0 in range(0, n, chunk):
+            m = min(chunk, n - i0)
+            part = ctx.download_staged(self.buf.ptr + 8 * i0, (m,), np.complex64)
+            if lib.ds_host_widen_f64(_ptr(part), 2 * m, C.c_void_p(flat.ctypes.data + 16 * i0), 0) != 0:
+                flat[i0:i0 + m] = part
+        return res
 
     def __deepcopy__(self, memo):
         return self

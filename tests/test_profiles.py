@@ -25,7 +25,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 FILES = sorted(glob.glob(os.path.join(ROOT, "profiles", "r03_*_rocprofv3_summary.txt")) +
-               glob.glob(os.path.join(ROOT, "profiles", "r04_*_rocprofv3_summary.txt")))
+               glob.glob(os.path.join(ROOT, "profiles", "r04_*_rocprofv3_summary.txt")) +
+               glob.glob(os.path.join(ROOT, "profiles", "r05_*_rocprofv3_summary.txt")))
 
 
 def _parse(path):
@@ -38,7 +39,7 @@ def _parse(path):
 
 
 def test_profiles_of_rounds_3_and_4_are_committed():
-    for tag in ("r03", "r04"):
+    for tag in ("r03", "r04", "r05"):
         names = {os.path.basename(f).split("_rocprofv3")[0][4:] for f in FILES if os.path.basename(f).startswith(tag)}
         assert {"welch_h1", "welch_h1_1024", "fir_bank", "csm", "deconv"} <= names, (tag, names)
 
@@ -121,3 +122,61 @@ def test_default_line_carries_the_other_configs_and_the_ceiling():
             assert e["bound"] == "hbm" and e["peak"] == peak
             assert abs(e["frac"] - nbytes / (e["kernel_avg_ms"] * 1e-3) / unit / peak) < 1e-9, name
     assert line["workloads_wall_s"] < 120.0
+
+
+def test_round5_default_line_preheat_steady_state_and_the_new_workload_entries():
+    """the line `python3 bench.py` prints (traced in profiles/r05_welch_h1_*) says how long it preheated,
+    carries a second timed region of >= 2000 steps that agrees with the first, a deconvolution entry on the persistent
+    kernel with its parity on a regularised inverse, the byte-based fraction of the CSM step beside the flops fraction, and the
+    short-estimate (float64 route) timing; every kernel time agrees with the trace of that very run."""
+    path = os.path.join(ROOT, "profiles", "r05_welch_h1_rocprofv3_summary.txt")
+    line, stats = _parse(path)
+    roof = line["roofline"]
+    assert line["config"]["workload"].startswith("welch_h1") and roof["kernel"] == "welch4096_main"
+    assert line["preheat"]["steps"] >= 100 and 20.0 <= line["preheat"]["ms"] < 200.0
+    ss = line["steady_state"]
+    assert ss["steps"] >= 2000 and ss["kernel"] == "welch4096_main" and ss["kernel_brackets"] >= 400
+    assert abs(ss["roofline_frac"] - roof["algorithmic_per_launch"] / (ss["kernel_avg_ms"] * 1e-3) / 1e9 / 8000.0) < 1e-9
+    # past the clock ramp the short region reads what the long one reads (it read 15 % slow in BENCH_r04)
+    assert abs(ss["kernel_avg_ms"] - roof["kernel_avg_ms"]) < 0.03 * roof["kernel_avg_ms"]
+    assert abs(ss["ms_per_step"] - line["ms_per_step"]) < 0.05 * line["ms_per_step"]
+    avg_ns = _trace_avg_ns(stats, "welch4096_main")
+    assert avg_ns * 0.985 <= ss["kernel_avg_ms"] * 1e6 <= avg_ns + 6500.0
+    wl = line["workloads"]
+    assert set(wl) == {"welch_h1_1024", "fir_bank", "csm", "deconv", "short_estimate_api"}
+    alg = {"welch_h1_1024": 65 * 2**20 * 4 + 513 * 64 * 12, "fir_bank": 4429709440, "deconv": 134250504}
+    for name in ("welch_h1_1024", "fir_bank", "csm", "deconv"):
+        e = wl[name]
+        assert e["parity_rel_max_vs_oracle"] < 1e-6 and e["cpu_baseline"]["value"] > 0
+        avg_ns = _trace_avg_ns(stats, e["kernel"])
+        assert avg_ns * 0.95 <= e["kernel_avg_ms"] * 1e6 <= avg_ns * 1.05 + 6500.0, (name, e["kernel_avg_ms"], avg_ns)
+        if name == "csm":
+            assert abs(e["frac"] - 18448384000.0 / (e["step_event_ms"] * 1e-3) / 1e12 / 157.3) < 1e-9
+            assert abs(e["step_bytes_frac"] - 147881984.0 / (e["step_event_ms"] * 1e-3) / 1e9 / 8000.0) < 1e-9
+            assert 0.05 < e["step_bytes_frac"] < e["frac"]
+        else:
+            assert abs(e["frac"] - alg[name] / (e["kernel_avg_ms"] * 1e-3) / 1e9 / 8000.0) < 1e-9, name
+    # the deconvolution runs on the persistent kernel (k_rperm + k_deconv_p in the trace), parity on items spread over the batch
+    assert any("k_deconv_p" in k for k in stats) and any("k_rperm" in k for k in stats)
+    assert "regularised" in wl["deconv"]["workload"] and "spread over the batch" in wl["deconv"]["cpu_baseline"]["sample"]
+    assert wl["deconv"]["traffic_ratio"] < 1.1
+    se = wl["short_estimate_api"]
+    for k in ("f64_route_auto", "f32_kernels_forced"):
+        assert se[k]["ms_median"] > 0 and se[k]["parity_rel_max_vs_oracle"] < 1e-6
+    assert se["f64_route_auto"]["parity_rel_max_vs_oracle"] < 1e-12
+    assert line["workloads_wall_s"] < 150.0
+
+
+def test_round5_experiment_files_say_what_was_measured():
+    """The negative results of round 5 are files with their numbers, not sentences in DESIGN.md."""
+    need = {"r05_valu_cost_and_instruction_slope.txt": ("W4_AB", "722", "v_fmamk_f32"),
+            "r05_clock_ramp.txt": ("preheat", "round 0"),
+            "r05_deconv_persistent.txt": ("k_deconv_p", "k_rperm", "0.464"),
+            "r05_csm_chunks_two_streams.txt": ("NOT adopted", "0.2210"),
+            "r05_fir_staged_stores.txt": ("NOT adopted", "1.8142"),
+            "r05_api_resident.txt": ("resident", "compute_transfer_function"),
+            "r05_mid_windows.txt": ("2048", "welch2048h")}
+    for name, words in need.items():
+        text = open(os.path.join(ROOT, "profiles", name)).read()
+        for w in words:
+            assert w in text, (name, w)

@@ -4,7 +4,7 @@
 set -u
 export TMPDIR=/tmp
 cd /tmp && cd - > /dev/null
-echo "##### welch 2048 tests"; timeout -k 10 300 python3 -m pytest tests -m gpu -x -q -k "welch_2048" 2>&1 | tail -4
+echo "##### resident spectrogram to host"; timeout -k 10 200 python3 tools/time_api_resident.py 2>&1 | grep get_spectrogram
 tools/prof_all.sh r05 "welch_h1 welch_h1_1024 fir_bank csm deconv" 2>&1 | tail -8
 for W in welch_h1 fir_bank deconv; do
   echo "##### two ranks on one GPU, host broadcast: $W"

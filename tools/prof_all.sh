@@ -12,7 +12,8 @@ for W in $WORKLOADS; do
   OUT=gpurun_out/prof_${TAG}_$W
   rm -rf $OUT
   mkdir -p $OUT
-  CMD="python3 bench.py --workload $W --steps 10 --warmup 2 --no-cpu-baseline"
+  # (counter passes: per-dispatch averages, no need for the clock-ramp preheat or the 2000-step steady-state region)
+  CMD="python3 bench.py --workload $W --steps 10 --warmup 2 --no-cpu-baseline --preheat-ms 0 --steady-steps 0"
   rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_MFMA --output-format csv -d $OUT/pmc1 -- $CMD > $OUT/pmc1.log 2>&1
   rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc2 -- $CMD > $OUT/pmc2.log 2>&1
   rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc3 -- $CMD > $OUT/pmc3.log 2>&1
@@ -31,6 +32,8 @@ for W in $WORKLOADS; do
   echo "== bench line of the traced run (rocprofv3 --kernel-trace --stats -- $TRACE)" >> $OUT/summary.txt
   cat $OUT/bench_line.txt >> $OUT/summary.txt
   cp $OUT/summary.txt profiles/${TAG}_${W}_rocprofv3_summary.txt
+  # gpurun merges at most 64 MiB back: the per-dispatch CSVs have been condensed into summary.txt
+  rm -rf $OUT/pmc1 $OUT/pmc2 $OUT/pmc3 $OUT/pmc4 $OUT/pmc5 $OUT/pmc6 $OUT/trace
   echo "$W done"
 done
 echo done
