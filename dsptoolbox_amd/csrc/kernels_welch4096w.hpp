@@ -66,6 +66,9 @@ __device__ __forceinline__ void wave_sync() {
 #ifndef W4_NO_READ2
 #define W4_NO_READ2 1
 #endif
+#ifndef W4_TW2_REG
+#define W4_TW2_REG 0  // experiment (round 5): the W256 twiddles of pass 2 rebuilt from six per-thread values instead of 15 LDS reads
+#endif
 #ifndef W4_WIN_GLOBAL
 #define W4_WIN_GLOBAL 0  // experiment (tools/exp): window values by buffer loads (L1-resident 16 KB) instead of the LDS copy
 #endif
@@ -77,6 +80,10 @@ struct Tw6 {
     float2 b[3];  // W4096^(t k1), k1 = 4, 8, 12
 #else
     float2 w[15];
+#endif
+#if W4_TW2_REG
+    float2 c[3];  // W256^(n3 k2), k2 = 1, 2, 3
+    float2 d[3];  // W256^(n3 k2), k2 = 4, 8, 12
 #endif
 };
 
@@ -90,6 +97,13 @@ __device__ __forceinline__ void load_tw6(Tw6& tw, const float2* __restrict__ twt
 #else
 #pragma unroll
     for (int k1 = 1; k1 < 16; ++k1) tw.w[k1 - 1] = twt[(k1 - 1) * 256 + tid];
+#endif
+#if W4_TW2_REG
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        tw.c[j] = twt[15 * 256 + (j + 1) * 16 + (tid & 15)];        // tw2[k2 * 16 + n3]
+        tw.d[j] = twt[15 * 256 + 4 * (j + 1) * 16 + (tid & 15)];
+    }
 #endif
 }
 
@@ -289,10 +303,15 @@ __device__ __forceinline__ void fft4096_wi(float2 (&v)[16], const Tw6& tw, float
             // 16 reads issued, then 3 + 4 + 4 table reads behind the first three butterflies:
             // butterfly g needs the first 4 (g + 1) of the 16
             constexpr int g = decltype(gc)::value;
+#if W4_TW2_REG
+            lgkm_wait<12 - 4 * g>();
+#else
             lgkm_wait<(g == 0 ? 12 : 11)>();
+#endif
         },
         [&](int g) {
             W4_PIN();
+#if !W4_TW2_REG
             static_for<4>([&](auto jc) {
                 constexpr int j = decltype(jc)::value;
                 // (the compiler folds g; the offset must be a constant for the asm operand)
@@ -301,6 +320,7 @@ __device__ __forceinline__ void fft4096_wi(float2 (&v)[16], const Tw6& tw, float
                 if (g == 2) lds_rd64<(8 + j) * 16 * 8>(w2[8 + j], a_tw2);
                 if (g == 3) lds_rd64<(12 + j) * 16 * 8>(w2[12 + j], a_tw2);
             });
+#endif
 #if W4_XS_EARLY
             ld_b(g);
 #endif
@@ -315,7 +335,12 @@ __device__ __forceinline__ void fft4096_wi(float2 (&v)[16], const Tw6& tw, float
             for (int j = 0; j < 4; ++j) {
                 const int k2 = g + 4 * j;
                 float2 z = v[4 * g + j];
+#if W4_TW2_REG
+                if (g) z = cmul(z, tw.c[g - 1]);
+                if (j) z = cmul(z, tw.d[j - 1]);
+#else
                 if (k2) z = cmul(z, w2[k2]);
+#endif
                 W4_PIN();
                 if (W4_AB & 4)
                     asm volatile("" ::"v"(z.x), "v"(z.y));
