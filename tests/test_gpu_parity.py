@@ -2641,3 +2641,33 @@ def test_welch_2048_explicit_frame_count():
             tol = TOL if F >= 5 else 3e-5  # (one to three frames: nothing averages the fp32 transform rounding down)
             assert relmax(tf[:, c], sxy / sxx) < tol, (F, c)
             assert relmax(coh[:, c], np.abs(sxy)**2 / sxx / syy) < tol, (F, c)
+
+
+def test_deconvolve_persistent_kernel_edges():
+    """deconv8k::k_deconv_p through ds_deconv_dev: more units than the 2 x CUs workgroups of the persistent grid (every
+    workgroup takes a second unit: the prefetch and the zero-record descriptor past the last one), an odd channel count (the
+    last pair has one channel), inputs shorter than the transform (zero padded by the range check) and fewer output samples
+    than the transform; against numpy in float64.  Also the one-item call (a grid of one)."""
+    import ctypes as C
+    from dsptoolbox_amd._lib import DeviceBuffer, get_context
+    ctx = get_context()
+    rng = np.random.default_rng(8192)
+    n_fft = 8192
+    r = (rng.standard_normal(n_fft // 2 + 1) + 1j * rng.standard_normal(n_fft // 2 + 1)).astype(np.complex64)
+    r *= np.exp(-np.arange(n_fft // 2 + 1) / 2000.0).astype(np.float32)
+    rr = r.astype(np.complex128)
+    d_r = DeviceBuffer.from_array(ctx, r)
+    for items, n_ch, n, n_out in ((150, 5, 5000, 6000), (1, 2, 8192, 8192), (260, 4, 8192, 8192), (3, 1, 100, 8192)):
+        y = (rng.standard_normal((items, n_ch, n)) * 0.1).astype(np.float32)
+        d_y = DeviceBuffer.from_array(ctx, y)
+        d_o = DeviceBuffer(ctx, items * n_ch * n_out * 4)
+        ctx.routes()
+        ctx.check(ctx.lib.ds_deconv_dev(ctx.handle, C.c_void_p(d_y.ptr), items, n_ch, n, n, n_fft, C.c_void_p(d_r.ptr), 0, n_out,
+                                        n_out, C.c_void_p(d_o.ptr)), "ds_deconv_dev")
+        assert {"deconv_rperm", "deconv@8k_persist"} <= ctx.routes()
+        got = d_o.to_array((items, n_ch, n_out), np.float32)
+        ref = np.fft.irfft(np.fft.rfft(y.astype(np.float64), n_fft, axis=-1) * rr, n_fft, axis=-1)[..., :n_out]
+        assert relmax(got, ref) < TOL, (items, n_ch, n, n_out, relmax(got, ref))
+        for d in (d_y, d_o):
+            d.free()
+    d_r.free()
