@@ -342,8 +342,8 @@ def welch_transfer_function(output_td, input_td, fs_hz: int, window_length_sampl
 class _Borrowed:
     """A context-owned device buffer lent to one call: free() is a no-op."""
 
-    def __init__(self, buf: DeviceBuffer):
-        self.ptr, self.nbytes, self.ctx = buf.ptr, buf.nbytes, buf.ctx
+    def __init__(self, buf):  # a DeviceBuffer, or a DevicePlanar (device-resident samples)
+        self.ptr, self.nbytes, self.ctx = buf.ptr, getattr(buf, "nbytes", 0), buf.ctx
 
     def free(self):
         pass
@@ -655,8 +655,13 @@ def _spectrogram_band_power(x, fs_hz: int, window_length_samples: int, window_ty
     """STFT -> sum_b filters[band, b] |stft[b]|^2 (-> dB -> |DCT-II| over bands), everything on the
     device: the spectrogram never travels to the host.  band_filters (bands, B').
     -> (time_s, freqs_hz, out (bands, F, C) float64)."""
-    pl = _stft_plan(x, fs_hz, window_length_samples, window_type, overlap_percent, fft_length_samples,
-                    padding, scaling)
+    resident = isinstance(x, DevicePlanar)  # a device-resident signal: its samples are read in place
+    if resident:
+        pl = _stft_plan(_ShapeOnly(x.n_samples, x.n_ch), fs_hz, window_length_samples, window_type, overlap_percent,
+                        fft_length_samples, padding, scaling, planar=False)
+    else:
+        pl = _stft_plan(x, fs_hz, window_length_samples, window_type, overlap_percent, fft_length_samples,
+                        padding, scaling)
     filt = np.ascontiguousarray(band_filters, dtype=np.float32)
     assert filt.ndim == 2 and filt.shape[1] == pl["B"], (
         f"Shape of the mel filter matrix {filt.shape} does not match the STFT "
@@ -665,16 +670,17 @@ def _spectrogram_band_power(x, fs_hz: int, window_length_samples: int, window_ty
     nz = filt != 0
     b0 = np.where(nz.any(axis=1), nz.argmax(axis=1), 0).astype(np.int32)
     b1 = np.where(nz.any(axis=1), filt.shape[1] - nz[:, ::-1].argmax(axis=1), 0).astype(np.int32)
-    ctx = get_context()
+    ctx = x.ctx if resident else get_context()
     n_fc = pl["n_frames"] * pl["n_ch"]
-    d_x = DeviceBuffer.from_array(ctx, pl["xp"])
+    d_x = _Borrowed(x) if resident else DeviceBuffer.from_array(ctx, pl["xp"])
+    x_ld = x.ld if resident else pl["n"]
     d_w = DeviceBuffer.from_array(ctx, pl["w32"])
     d_s = DeviceBuffer(ctx, pl["B"] * n_fc * 8)
     d_f = DeviceBuffer.from_array(ctx, filt)
     d_b0, d_b1 = DeviceBuffer.from_array(ctx, b0), DeviceBuffer.from_array(ctx, b1)
     d_o = DeviceBuffer(ctx, n_bands * n_fc * 4)
     try:
-        ctx.check(ctx.lib.ds_stft_r2c_dev(ctx.handle, C.c_void_p(d_x.ptr), pl["n"], pl["n_ch"], pl["n"], pl["W"],
+        ctx.check(ctx.lib.ds_stft_r2c_dev(ctx.handle, C.c_void_p(d_x.ptr), pl["n"], pl["n_ch"], x_ld, pl["W"],
                                           pl["hop"], pl["nfft"], pl["pad_front"], pl["n_frames"],
                                           C.c_void_p(d_w.ptr), int(bool(detrend)), pl["scale"], pl["edge"],
                                           pl["power"], C.c_void_p(d_s.ptr)), "ds_stft_r2c_dev")

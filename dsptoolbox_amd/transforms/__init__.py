@@ -129,14 +129,16 @@ def mel_filterbank(f_hz, range_hz=None, n_bands: int = 40, normalize: bool = Tru
 def _band_power(signal: Signal, filters, f_hz_check, to_db: bool, dct_abs: bool):
     par = signal._spectrogram_parameters
     return backend._spectrogram_band_power(
-        signal.time_data, signal.sampling_rate_hz, par["window_length_samples"], par["window_type"],
+        signal.device_samples if signal.on_device else signal.time_data, signal.sampling_rate_hz,
+        par["window_length_samples"], par["window_type"],
         par["overlap_percent"], par["fft_length_samples"], par["detrend"], par["padding"], par["scaling"],
         filters, to_db, dct_abs)
 
 
 def _spectrogram_axes(signal: Signal):
     par = signal._spectrogram_parameters
-    pl = backend._stft_plan(signal.time_data, signal.sampling_rate_hz, par["window_length_samples"],
+    pl = backend._stft_plan(backend._ShapeOnly(len(signal), signal.number_of_channels), signal.sampling_rate_hz,
+                            par["window_length_samples"],
                             par["window_type"], par["overlap_percent"], par["fft_length_samples"],
                             par["padding"], par["scaling"], planar=False)  # axes only: no cast of the data
     return pl["time_s"], pl["freqs_hz"], pl["B"]

@@ -2671,3 +2671,21 @@ def test_deconvolve_persistent_kernel_edges():
         for d in (d_y, d_o):
             d.free()
     d_r.free()
+
+
+def test_device_resident_spectrogram_features():
+    """log_mel_spectrogram / mfcc / chroma_stft of a device-resident signal read its samples in place and give the host path's
+    numbers (same kernels: identical), without materialising time_data."""
+    rng = np.random.default_rng(77)
+    x = rng.standard_normal((30000, 2)) * 0.2
+    sh = dsp.Signal(None, x.copy(), 48000)
+    sd = dsp.Signal.from_planar_f32(backend._planar_f32(x), 48000)
+    for s in (sh, sd):
+        s.set_spectrogram_parameters(window_length_samples=1024)
+    th, fh, mh = dsp.transforms.log_mel_spectrogram(sh, generate_plot=False)[:3]
+    td, fd, md = dsp.transforms.log_mel_spectrogram(sd, generate_plot=False)[:3]
+    assert np.array_equal(mh, md) and np.array_equal(th, td) and not sd._has_host_copy
+    ch = dsp.transforms.chroma_stft(sh, plot_channel=-1)
+    cd = dsp.transforms.chroma_stft(sd, plot_channel=-1)
+    assert np.array_equal(ch[1], cd[1]) and np.array_equal(ch[2], cd[2])
+    assert not sd._has_host_copy
