@@ -2634,7 +2634,8 @@ extern "C" int ds_deconv_dev(ds_ctx* c, const float* y, int n_items, int n_ch, i
         // transforms, the inverse spectrum from a permuted copy (k_rperm + k_deconv_p); DSPTOOLBOX_AMD_DECONV_PERSIST=0
         // keeps the one-unit-per-workgroup kernels below
         const int64_t n_units = (int64_t)((n_ch + 1) / 2) * n_items;
-        if (c->cfg.deconv_persist && !c->cfg.deconv_2percu && n_units < ((int64_t)1 << 31) && c->n_cu > 0) {
+        // (n_units + grid stays an int inside the kernel: u + gridDim.x is formed for the prefetch past the last unit)
+        if (c->cfg.deconv_persist && !c->cfg.deconv_2percu && n_units < ((int64_t)1 << 31) - 4096 && c->n_cu > 0) {
             if (!c->deconv_rperm) HIPCHK(c, hipMalloc((void**)&c->deconv_rperm, sizeof(float2) * deconv8k::RPERM_LEN));
             CHK(launch(c, "deconv_rperm", deconv8k::k_rperm, dim3(32), 256, 0, deconv8k::RpArgs{(const float2*)r, c->deconv_rperm}));
             deconv8k::PArgs pa{a8, c->deconv_rperm, (int)n_units};
