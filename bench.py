@@ -530,6 +530,32 @@ def pmc_summary(workload: str, kernel_hints):
     return {}, None
 
 
+def pmc_kernel_current(workload: str, kernel_hints):
+    """Were the committed counters taken on the machine code that runs now?  The summary file records a fingerprint
+    of each profiled kernel (tools/prof_summary.py, "== kernel code"); this compares the dominant kernel's with the
+    library in use.  True / False, or None when either side has no fingerprint (an older file, no c++filt)."""
+    import glob
+    import re
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_{workload}_rocprofv3_summary.txt")))
+    if not files:
+        return None
+    text = open(files[-1]).read()
+    if "== kernel code (" not in text:
+        return None
+    sect = text.split("== kernel code (", 1)[1].split("\n==", 1)[0]
+    recorded = {m.group(2).strip(): m.group(1) for m in re.finditer(r"^\s+([0-9a-f]{16})\s+(\S.*)$", sect, re.M)}
+    from dsptoolbox_amd import _build
+    now = _build.demangled_fingerprints()
+    if not now:
+        return None
+    for hint in kernel_hints:
+        for name, h in recorded.items():
+            if hint in name:
+                cur = [v for d, v in now.items() if d[:60] == name]
+                return len(cur) == 1 and cur[0] == h
+    return None
+
+
 # ---------------------------------------------------------------------------
 EVENT_STRIDE = 4  # the dominant kernel is bracketed at every 4th launch of the timed region
 
@@ -703,6 +729,7 @@ def measure(args, ctx, dist, workload: str, steps: int, warmup: int, strong: boo
         # read (MI355X_MICROARCH.md, HBM section), hence the factor 2
         roof["traffic"] = (2.0 * pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024.0
         roof["traffic_source"] = src + " (2*FETCH_SIZE + WRITE_SIZE) KiB"
+        current = pmc_kernel_current(workload, hints)
         if alg_parts:  # both kernels of the step against the step's algorithmic bytes
             tot = 0.0
             for h in (("k_stft",), ("k_csm_gemm",)):
@@ -710,6 +737,14 @@ def measure(args, ctx, dist, workload: str, steps: int, warmup: int, strong: boo
                 tot += (2.0 * kp.get("FETCH_SIZE", 0.0) + kp.get("WRITE_SIZE", 0.0)) * 1024.0
             roof["traffic"] = tot
             roof["traffic_source"] = src + " (2*FETCH_SIZE + WRITE_SIZE) KiB, transform + Gram kernel"
+            both = [pmc_kernel_current(workload, h) for h in (("k_stft",), ("k_csm_gemm",))]
+            current = None if None in both else all(both)
+        # the counters are a committed file, not this run: the file carries a fingerprint of the
+        # machine code they were taken on; a kernel rebuilt since then gets no traffic figure
+        roof["traffic_kernel_current"] = current
+        if current is False:
+            roof["traffic_stale"] = dict(traffic=roof["traffic"], note="counters of an older build of this kernel: re-run tools/prof_all.sh")
+            roof["traffic"] = None
     if "SQ_INSTS_VALU" in pmc:
         # the ceiling the vector pipe puts on this kernel: wave-level VALU instructions of one
         # launch x 2 cycles (wave64 on a SIMD-32) over 1024 SIMDs; at the 2.4 GHz maximum clock --

@@ -91,6 +91,60 @@ def _without_remarks(text: str) -> str:
     return "".join(keep)
 
 
+def kernel_fingerprints(lib_path: str = LIB_PATH) -> dict:
+    """{mangled kernel name: first 16 hex digits of the sha256 of its machine code} from the gfx950 code object inside
+    the library (the uncompressed clang offload bundle in .hip_fatbin; plain ELF64 parsing, no tools).  What a profile
+    file records beside its counters, so that a reader can tell whether they were taken on the kernel that runs now
+    (bench.py: roofline.traffic_kernel_current)."""
+    import hashlib
+    import struct
+    blob = open(lib_path, "rb").read()
+    start = blob.find(b"__CLANG_OFFLOAD_BUNDLE__")
+    if start < 0:
+        return {}
+    n_entries = struct.unpack_from("<Q", blob, start + 24)[0]
+    pos, elf = start + 32, None
+    for _ in range(n_entries):
+        off, size, id_len = struct.unpack_from("<QQQ", blob, pos)
+        ident = blob[pos + 24:pos + 24 + id_len]
+        pos += 24 + id_len
+        if b"gfx950" in ident and size:
+            elf = blob[start + off:start + off + size]
+    if elf is None or elf[:4] != b"\x7fELF":
+        return {}
+    shoff, = struct.unpack_from("<Q", elf, 0x28)
+    shentsize, shnum, _ = struct.unpack_from("<HHH", elf, 0x3A)
+    secs = [struct.unpack_from("<IIQQQQIIQQ", elf, shoff + i * shentsize) for i in range(shnum)]
+    out = {}
+    for name, typ, flags, addr, offset, size, link, info, align, entsize in secs:
+        if typ != 2:  # SHT_SYMTAB
+            continue
+        str_off = secs[link][4]
+        for i in range(size // 24):
+            st_name, st_info, _, st_shndx, st_value, st_size = struct.unpack_from("<IBBHQQ", elf, offset + 24 * i)
+            if (st_info & 0xF) != 2 or st_size == 0 or st_shndx == 0 or st_shndx >= shnum:  # STT_FUNC, defined
+                continue
+            sec = secs[st_shndx]
+            code = elf[sec[4] + st_value - sec[3]:sec[4] + st_value - sec[3] + st_size]
+            end = elf.index(b"\0", str_off + st_name)
+            out[elf[str_off + st_name:end].decode()] = hashlib.sha256(code).hexdigest()[:16]
+    return out
+
+
+def demangled_fingerprints(lib_path: str = LIB_PATH) -> dict:
+    """{demangled kernel name as rocprofv3 prints it: fingerprint}; {} without c++filt."""
+    fp = kernel_fingerprints(lib_path)
+    if not fp:
+        return {}
+    names = sorted(fp)
+    try:
+        out = subprocess.run(["c++filt"], input="\n".join(names), stdout=subprocess.PIPE, stderr=subprocess.DEVNULL,
+                             text=True, check=True).stdout.splitlines()
+    except (OSError, subprocess.CalledProcessError):
+        return {}
+    return {d: fp[m] for m, d in zip(names, out)} if len(out) == len(names) else {}
+
+
 LAST_BUILD = None  # "compiled" or "reused" (the library's source hash matched): what build_library last did
 
 

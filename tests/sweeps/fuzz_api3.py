@@ -88,8 +88,15 @@ for it in range(n_cases):
             mode = str(rng.choice(["H1", "H3"]))
             tf, coh = backend.welch_transfer_function(y, x, fs, W, mode)
             rt, rc = orc.compute_transfer_function(y, x, fs, W, mode)
-            e = max(orc.rel_max(tf[1:], rt[1:]), orc.rel_max(coh[1:], rc[1:]))
+            e_tf, e_coh = orc.rel_max(tf[1:], rt[1:]), orc.rel_max(coh[1:], rc[1:])
+            e = max(e_tf, e_coh)
             lim = 1e-6
+            if e > lim:  # where: an estimate is ill-conditioned in float64 too where the coherence is small
+                d = np.abs(tf[1:] - rt[1:]) if e_tf >= e_coh else np.abs(coh[1:] - rc[1:])
+                b, ch = np.unravel_index(np.argmax(d), d.shape)
+                info = info + (mode, f"e_tf={e_tf:.2e} e_coh={e_coh:.2e} worst bin {b + 1} ch {ch} "
+                                     f"coh_ref there={rc[b + 1, ch]:.4f} |tf_ref| there={abs(rt[b + 1, ch]):.3e} "
+                                     f"max|tf_ref|={np.abs(rt[1:]).max():.3e} min coh_ref={rc[1:].min():.2e}")
     except Exception as ex:  # noqa: BLE001
         fails.append((kind, info, repr(ex)[:200]))
         continue

@@ -180,3 +180,38 @@ def test_round5_experiment_files_say_what_was_measured():
         text = open(os.path.join(ROOT, "profiles", name)).read()
         for w in words:
             assert w in text, (name, w)
+
+
+def test_kernel_fingerprints_of_the_built_library():
+    """dsptoolbox_amd._build.kernel_fingerprints: one fingerprint per kernel of the gfx950 code object, the hot kernels
+    among them; two template instances of one kernel differ."""
+    sys.path.insert(0, ROOT)
+    from dsptoolbox_amd import _build
+    if not os.path.exists(_build.LIB_PATH):
+        pytest.skip("library not built")
+    fp = _build.kernel_fingerprints()
+    assert len(fp) > 200 and all(re.fullmatch(r"[0-9a-f]{16}", v) for v in fp.values())
+    for token in _build.NO_SCRATCH:
+        assert any(token in k for k in fp), token
+    y3 = sorted(v for k, v in fp.items() if "welch40964k_y3" in k)
+    assert len(y3) == 2 and y3[0] != y3[1]
+    dm = _build.demangled_fingerprints()
+    assert dm.get("void welch4096::k_y3<false>(welch4096::Args)") in y3
+
+
+@pytest.mark.parametrize("workload,hints", [("welch_h1", ("welch4096::k_y3<",)), ("welch_h1_1024", ("welch1k::k_y<",)),
+                                            ("fir_bank", ("fir4k::k_fir<",)), ("csm", ("k_stft",)), ("csm", ("k_csm_gemm",)),
+                                            ("deconv", ("k_deconv_p",))])
+def test_committed_counters_belong_to_the_kernels_that_run_now(workload, hints):
+    """roofline.traffic comes from a committed counter file, so the file must have been taken on
+    the machine code of today's library.  The summary records each profiled kernel's fingerprint ("== kernel code");
+    bench.py prints roofline.traffic_kernel_current from the same comparison and drops a stale traffic figure."""
+    sys.path.insert(0, ROOT)
+    import bench
+    from dsptoolbox_amd import _build
+    if not os.path.exists(_build.LIB_PATH) or not _build.demangled_fingerprints():
+        pytest.skip("library not built (or no c++filt)")
+    cur = bench.pmc_kernel_current(workload, hints)
+    if cur is None:
+        pytest.skip("the latest summary of this workload predates the fingerprints")
+    assert cur is True, f"profiles/*_{workload}_rocprofv3_summary.txt was taken on another build of {hints[0]}: re-run tools/prof_all.sh"

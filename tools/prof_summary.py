@@ -36,3 +36,19 @@ for k in acc:
     print(k)
     for c, (s, n) in sorted(acc[k].items()):
         print(f"    {c:28s} {s / n:18.1f}  (n={n})")
+
+# which machine code the counters above were taken on: bench.py compares these with the library it runs
+# (roofline.traffic_kernel_current) and drops the traffic figure of a kernel that has changed since
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+try:
+    from dsptoolbox_amd import _build
+    fps = _build.demangled_fingerprints()
+except Exception as ex:  # noqa: BLE001
+    fps = {}
+    print("== kernel code: not available (", repr(ex)[:100], ")")
+if fps:
+    print("== kernel code (sha256[:16] of the gfx950 machine code of the kernels above: dsptoolbox_amd._build.kernel_fingerprints)")
+    for k in acc:
+        hit = sorted(h for d, h in fps.items() if d[:60] == k)
+        if len(hit) == 1:
+            print(f"    {hit[0]}  {k}")
