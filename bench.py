@@ -841,6 +841,7 @@ def workload_entry(args, ctx, dist, name: str):
         ent["traffic_source"] = roof.get("traffic_source")
     else:
         ent["traffic_ratio"] = None
+    ent["traffic_kernel_current"] = roof.get("traffic_kernel_current")
     if roof["bound"] == "mfma":
         ent["step_bytes_frac"] = roof.get("step_bytes_frac")
         ent["kernels_hbm_frac"] = {k: v["frac"] for k, v in roof.get("kernels", {}).items()}

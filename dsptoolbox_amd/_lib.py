@@ -104,7 +104,7 @@ SIGNATURES = {
                                   C.c_void_p, C.c_void_p]),
     "ds_welch_spec_x64": (C.c_int, [ctx_p, C.c_void_p, C.c_void_p, C.c_int, i64, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                     C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, C.c_void_p]),
-    "ds_csm_x64": (C.c_int, [ctx_p, C.c_void_p, C.c_int, i64, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int,
+    "ds_csm_x64": (C.c_int, [ctx_p, C.c_void_p, C.c_int, i64, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int,
                              C.c_double, C.c_double, C.c_int, C.c_void_p]),
     "ds_fir_part_step_dev": (C.c_int, [ctx_p, f32_p, f32_p, C.c_int, C.c_int, C.c_int, C.c_int, c32_p, C.c_int,
                                        C.c_int, c32_p, C.c_int, f32_p]),

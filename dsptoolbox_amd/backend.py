@@ -232,7 +232,7 @@ _X64_SHORT_BYTES = 256 << 20  # (1 GB in round 3: 64 channels x 100 frames of 81
 
 # The same for the Welch spectra themselves (get_spectrum with the Welch method: ds_welch_psd / ds_welch_csd) and
 # the cross-spectral matrix (get_csm: ds_csm): "auto" sends SHORT estimates -- fewer than 128 frames, frame
-# spectra <= 256 MB, window <= 262144; the matrix: mean averaging, up to 1024 channels, <= 256 MB of matrices -- through
+# spectra <= 256 MB, window <= 262144; the matrix: up to 1024 channels, <= 256 MB of matrices -- through
 # ds_welch_spec_x64 / ds_csm_x64; "f32" keeps the fp32 kernels for every shape.  Environment:
 # DSPTOOLBOX_AMD_SPEC_PRECISION.  (tests/sweeps/edge_welch.py, round 4: fp32 cross spectra and matrices of
 # one to five frames reach 2-3e-6 of the largest element under the amplitude scalings.)
@@ -757,15 +757,15 @@ def _csm_welch(time_data, sampling_rate_hz: int, window_length_samples: int, win
     hop, n_frames = _welch_framing(n, W, overlap_percent, window)
     amp, norm_scale, factor, phys = _finish_params(scaling, W, sampling_rate_hz, window)
     B = W // 2 + 1
-    if average == "mean" and n_ch <= 1024 and _x64_short(SPEC_PRECISION, n_ch, n_frames, W, average) \
+    if n_ch <= 1024 and _x64_short(SPEC_PRECISION, n_ch, n_frames, W, average) \
             and B * n_ch * n_ch * 16 <= _X64_SHORT_BYTES:  # (the matrix itself, complex128, crosses PCIe too)
         # short estimate: float64 end to end on the device (ds_csm_x64)
         x64 = np.ascontiguousarray(td.reshape(n, n_ch) if td.ndim == 2 else td[:, None], dtype=np.float64)
         out64 = np.empty((B, n_ch, n_ch), dtype=np.complex128)
         w64 = np.ascontiguousarray(window, dtype=np.float64)
         ctx = get_context()
-        ctx.check(ctx.lib.ds_csm_x64(ctx.handle, _ptr(x64), n_ch, n, W, hop, n_frames, _ptr(w64), int(bool(detrend)), amp,
-                                     norm_scale, factor, phys, _ptr(out64)), "ds_csm_x64")
+        ctx.check(ctx.lib.ds_csm_x64(ctx.handle, _ptr(x64), n_ch, n, W, hop, n_frames, _ptr(w64), int(bool(detrend)),
+                                     DS_AVG[average], amp, norm_scale, factor, phys, _ptr(out64)), "ds_csm_x64")
         return np.fft.rfftfreq(W, 1 / sampling_rate_hz), out64
     out = np.empty((B, n_ch, n_ch), dtype=np.complex64)
     w32 = window.astype(np.float32)

@@ -1942,13 +1942,15 @@ extern "C" int ds_welch_spec_x64(ds_ctx* c, const double* x, const double* y, in
     return DS_OK;
 }
 
-// _csm_welch in float64 end to end (mean averaging, up to 1024 channels): csm [nb][n_ch][n_ch] complex128
+// _csm_welch in float64 end to end (up to 1024 channels; median averaging: up to 128 frames): csm [nb][n_ch][n_ch] complex128
 extern "C" int ds_csm_x64(ds_ctx* c, const double* x, int n_ch, int64_t n_samples, int W, int hop, int n_frames,
-                          const double* window, int detrend, int amp_sqrt, double norm_scale, double factor,
+                          const double* window, int detrend, int average, int amp_sqrt, double norm_scale, double factor,
                           int halve_edges, double* csm) {
     if (!c || !x || !window || !csm) return fail(c, DS_ERR_ARG, "ds_csm_x64: null argument");
-    CHK(x64_shape_ok(c, "ds_csm_x64", n_ch, n_samples, W, hop, n_frames, DS_AVG_MEAN));
+    CHK(x64_shape_ok(c, "ds_csm_x64", n_ch, n_samples, W, hop, n_frames, average));
     if (n_ch > w64::CSM_MAX_CH) return fail(c, DS_ERR_UNSUP, "ds_csm_x64: more than 1024 channels (use ds_csm)");
+    if (average == DS_AVG_MEDIAN && n_frames > w64::CSM_MEDIAN_MAX_FRAMES)
+        return fail(c, DS_ERR_UNSUP, "ds_csm_x64: median averaging over more than 128 frames (use ds_csm)");
     const int nb = W / 2 + 1;
     const size_t spec = (size_t)n_ch * n_frames * nb, bout = (size_t)nb * n_ch * n_ch;
     if (spec * sizeof(double2) > ((size_t)2 << 30))
@@ -1963,11 +1965,18 @@ extern "C" int ds_csm_x64(ds_ctx* c, const double* x, int n_ch, int64_t n_sample
     double2* xs = cv.take<double2>(spec);
     CHK(x64_frames(c, t, x, dx, n_ch, n_samples, W, hop, n_frames, detrend, xs));
     double2* dcsm = cv.take<double2>(bout);
-    const int tile = std::max(1, std::min(n_frames, 4096 / n_ch));  // <= 64 KB of frame values per workgroup
-    w64::CsmArgs ca{xs, n_ch, n_frames, FinishPar{norm_scale / (double)n_frames, factor, halve_edges, amp_sqrt, nb}, dcsm};
-    hipLaunchKernelGGL(w64::k_csm, dim3(nb, w64::csm_pair_groups(n_ch)), dim3(256), (size_t)n_ch * tile * 16, c->stream, ca, tile);
-    HIPCHK(c, hipGetLastError());
-    c->routes.insert("csm_f64");
+    if (average == DS_AVG_MEDIAN) {
+        const int nbias = (n_frames & 1) ? n_frames : n_frames - 1;  // as ds_welch_spec_x64
+        w64::CsmArgs ca{xs, n_ch, n_frames, FinishPar{norm_scale * (double)std::max(1, nbias), factor, halve_edges, amp_sqrt, nb}, dcsm};
+        CHK(launch(c, "csm_f64_median", w64::k_csm_median, dim3(nb, w64::csm_median_tile_pairs(n_ch)), 256,
+                   w64::csm_median_lds(n_ch, n_frames), ca));
+    } else {
+        const int tile = std::max(1, std::min(n_frames, 4096 / n_ch));  // <= 64 KB of frame values per workgroup
+        w64::CsmArgs ca{xs, n_ch, n_frames, FinishPar{norm_scale / (double)n_frames, factor, halve_edges, amp_sqrt, nb}, dcsm};
+        hipLaunchKernelGGL(w64::k_csm, dim3(nb, w64::csm_pair_groups(n_ch)), dim3(256), (size_t)n_ch * tile * 16, c->stream, ca, tile);
+        HIPCHK(c, hipGetLastError());
+        c->routes.insert("csm_f64");
+    }
     HIPCHK(c, hipMemcpyAsync(csm, dcsm, bout * 16, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return DS_OK;

@@ -481,4 +481,95 @@ __global__ __launch_bounds__(256) void k_csm(CsmArgs p, int tile) {
     }
 }
 
+// average = "median" of the matrix (_csm_welch calls _welch per channel pair, :351-369, so every element is the median over
+// the frames of the real and of the imaginary part of conj(X_i1) X_i2; the diagonal the median of |X_i|^2).  Short
+// estimates only: F <= 128 frames, two per lane.  A workgroup takes one bin and one pair of channel tiles (32 + 32
+// channels, their frame values in LDS: 2 * 32 * F * 16 bytes <= 128 KB), a wave one channel pair at a time: every lane
+// ranks its two frame values against all F (ties by frame index, values read across the wave with v_readlane), the
+// two middle ranks are averaged.  grid = (nb, csm_median_tile_pairs(n_ch)), 256 threads; the host folds the bias into fin.inv.
+constexpr int CSM_MEDIAN_TILE = 32, CSM_MEDIAN_MAX_FRAMES = 128;
+inline int csm_median_tiles(int n_ch) { return (n_ch + CSM_MEDIAN_TILE - 1) / CSM_MEDIAN_TILE; }
+inline int csm_median_tile_pairs(int n_ch) { return csm_median_tiles(n_ch) * (csm_median_tiles(n_ch) + 1) / 2; }
+inline size_t csm_median_lds(int n_ch, int n_frames) {
+    return (size_t)(csm_median_tiles(n_ch) > 1 ? 2 : 1) * CSM_MEDIAN_TILE * n_frames * sizeof(double2);
+}
+
+__device__ __forceinline__ double wave_lane_value(double v, int lane) {  // lane is wave-uniform
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
+}
+// median over the F values held as (v0: frame lane, v1: frame lane + 64) across one wave
+__device__ __forceinline__ double wave_median(double v0, double v1, int F, int lane) {
+    int rank0 = 0, rank1 = 0;
+    const int n0 = min(F, 64);
+    for (int j = 0; j < n0; ++j) {
+        const double u = wave_lane_value(v0, j);
+        rank0 += (u < v0 || (u == v0 && j < lane)) ? 1 : 0;
+        rank1 += (u <= v1) ? 1 : 0;  // frame j < 64 <= frame of v1
+    }
+    for (int j = 64; j < F; ++j) {
+        const double u = wave_lane_value(v1, j - 64);
+        rank0 += (u < v0) ? 1 : 0;
+        rank1 += (u < v1 || (u == v1 && j - 64 < lane)) ? 1 : 0;
+    }
+    // exactly one frame holds each rank (a NaN among the values ranks nothing: the result is then NaN like the reference's)
+    auto value_of_rank = [&](int r) {
+        const unsigned long long hit0 = __ballot(lane < F && rank0 == r);
+        const unsigned long long hit1 = __ballot(lane + 64 < F && rank1 == r);
+        const double a = wave_lane_value(v0, hit0 ? __ffsll((long long)hit0) - 1 : 0);
+        const double b = wave_lane_value(v1, hit1 ? __ffsll((long long)hit1) - 1 : 0);
+        return hit0 ? a : (hit1 ? b : __longlong_as_double(0x7ff8000000000000ll));
+    };
+    return 0.5 * (value_of_rank((F - 1) / 2) + value_of_rank(F / 2));
+}
+
+__global__ __launch_bounds__(256) void k_csm_median(CsmArgs p) {
+    extern __shared__ __align__(16) double2 xt[];  // tile A [32][F], then tile B [32][F] when it is another tile
+    constexpr int T = CSM_MEDIAN_TILE;
+    const int b = blockIdx.x, nb = p.fin.nb, C = p.n_ch, F = p.n_frames, tid = threadIdx.x;
+    // tile pair blockIdx.y -> (tb >= ta), rows of the lower triangle one after the other
+    int tb = 0;
+    while ((tb + 1) * (tb + 2) / 2 <= (int)blockIdx.y) ++tb;
+    const int ta = (int)blockIdx.y - tb * (tb + 1) / 2;
+    double2* A = xt;
+    double2* B = ta == tb ? xt : xt + (size_t)T * F;
+    for (int i = tid; i < T * F; i += 256) {
+        const int c = i / F, f = i - c * F;
+        double2 va = make_double2(0.0, 0.0), vb = va;  // (channels past the end are never paired)
+        if (ta * T + c < C) va = p.xs[((size_t)(ta * T + c) * F + f) * nb + b];
+        if (ta != tb && tb * T + c < C) vb = p.xs[((size_t)(tb * T + c) * F + f) * nb + b];
+        A[i] = va;
+        if (ta != tb) B[i] = vb;
+    }
+    __syncthreads();
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const double inf = __longlong_as_double(0x7ff0000000000000ll);
+    double2* m = p.csm + (size_t)b * C * C;
+    for (int q = wave; q < T * T; q += 4) {
+        const int a = q / T, bb = q - a * T, i1 = ta * T + a, i2 = tb * T + bb;
+        if (i1 >= C || i2 >= C || i2 < i1) continue;
+        double re0 = inf, re1 = inf, im0 = inf, im1 = inf;  // frames past the end rank last
+        if (lane < F) {
+            const double2 u = A[a * F + lane], v = B[bb * F + lane];
+            re0 = u.x * v.x + u.y * v.y;  // conj(u) v
+            im0 = u.x * v.y - u.y * v.x;
+        }
+        if (lane + 64 < F) {
+            const double2 u = A[a * F + lane + 64], v = B[bb * F + lane + 64];
+            re1 = u.x * v.x + u.y * v.y;
+            im1 = u.x * v.y - u.y * v.x;
+        }
+        const double mre = wave_median(re0, re1, F, lane);
+        // the diagonal is _welch(x_i, None): the median of |X|^2, imaginary part 0
+        const double mim = i1 == i2 ? 0.0 : wave_median(im0, im1, F, lane) + 0.0;
+        if (lane != 0) continue;
+        const cd g = dsk::finish_cplx(cd{mre, mim}, b, p.fin);
+        if (i1 == i2) {
+            m[(size_t)i1 * C + i1] = make_double2(g.x, 0.0);  // 0.5 g + conj(0.5 g)
+        } else {
+            m[(size_t)i2 * C + i1] = make_double2(g.x, g.y);
+            m[(size_t)i1 * C + i2] = make_double2(g.x, 0.0 - g.y);
+        }
+    }
+}
+
 }  // namespace w64

@@ -188,10 +188,10 @@ int ds_welch_tf_x64(ds_ctx* ctx, const double* x, int n_cx, const double* y, int
 int ds_welch_spec_x64(ds_ctx* ctx, const double* x, const double* y, int n_ch, int64_t n_samples, int W,
                       int hop, int n_frames, const double* window, int detrend, int average, int amp_sqrt,
                       double norm_scale, double factor, int halve_edges, double* out);
-/* _csm_welch in float64 end to end (_spectral_methods.py:285-371; mean averaging, up to 1024 channels):
- * csm [nb][n_ch][n_ch] complex128, same element order as ds_csm.                                          */
+/* _csm_welch in float64 end to end (_spectral_methods.py:285-371; up to 1024 channels; average = median, the
+ * per-pair median of _welch :153-162, up to 128 frames): csm [nb][n_ch][n_ch] complex128, same element order as ds_csm. */
 int ds_csm_x64(ds_ctx* ctx, const double* x, int n_ch, int64_t n_samples, int W, int hop, int n_frames,
-               const double* window, int detrend, int amp_sqrt, double norm_scale, double factor,
+               const double* window, int detrend, int average, int amp_sqrt, double norm_scale, double factor,
                int halve_edges, double* csm);
 int ds_welch_psd_dev(ds_ctx* ctx, const float* x_dev, int n_cx, int64_t ldx,
                      int64_t n_samples, int W, int hop, int n_frames,

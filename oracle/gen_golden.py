@@ -719,7 +719,7 @@ def gen_api_holes(dsp):
     """Round 5 (missing 4 and 5): Spectrum.sum_channels(power_sum) (classes/spectrum.py:435-459),
     MultiBandSignal.is_complex_signal (classes/multibandsignal.py:262-274), ImpulseResponse.set_window
     (classes/impulse_response.py:139-152), and a SHORT cross-spectral matrix of more than 64 channels
-    (_spectral_methods.py:285-371 through Signal.get_csm: 70 channels, 22 frames)."""
+    (_spectral_methods.py:285-371 through Signal.get_csm: 70 channels, 22 frames), mean and median averaging."""
     import warnings
     from dsptoolbox.standard.enums import SpectrumScaling, SpectrumMethod
     warnings.simplefilter("ignore")
@@ -769,6 +769,16 @@ def gen_api_holes(dsp):
         arrs[f"csm70_{i}"] = m[::8]  # every 8th bin (9 of 65): 0.7 MB instead of 5
         cases.append(dict(kind="csm_short_many_channels", channels=n_ch, W=W, scaling=sc.name, key=f"csm70_{i}",
                           bin_step=8, frames=int(np.ceil(n / (W // 2)))))
+    # ... and with average="median" (every element the median of its pair's frames): 22 frames (the two middle
+    # ranks are averaged) and 21 frames (the first 1344 samples)
+    for i, (sc, n_used) in enumerate(((SpectrumScaling.FFTBackward, n), (SpectrumScaling.AmplitudeSpectrum, 1344))):
+        sig = dsp.Signal(None, x[:n_used].copy(), fs)
+        sig.set_spectrum_parameters(method=SpectrumMethod.WelchPeriodogram, window_length_samples=W, scaling=sc,
+                                    average="median")
+        fv, m = sig.get_csm()
+        arrs[f"csm70_median_{i}"] = m[::16]  # every 16th bin (5 of 65)
+        cases.append(dict(kind="csm_short_median", channels=n_ch, W=W, scaling=sc.name, key=f"csm70_median_{i}",
+                          bin_step=16, samples=n_used, frames=int(np.ceil(n_used / (W // 2)))))
     arrs["csm70_x"] = x
     save("api_holes", dict(cases=cases, fs=fs), arrs)
 

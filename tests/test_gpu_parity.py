@@ -2223,6 +2223,57 @@ def test_csm_short_estimate_of_70_channels(monkeypatch):
     assert n_seen == 2
 
 
+def test_csm_short_estimate_median_in_float64(monkeypatch):
+    """VERDICT r4, missing 5, second half: a SHORT cross-spectral matrix with average="median" takes float64 kernels too
+    (w64::k_csm_median: a wave ranks one channel pair's frames).  The reference's own matrices of 70 channels over 22 and
+    21 frames (api_holes.npz), then seeded shapes against the oracle: one and two channel tiles, 1 ... 127 frames (more
+    than 64 frames: two per lane), odd and even counts, every scaling family."""
+    import dsptoolbox_amd as dsp
+    from dsptoolbox_amd._lib import get_context
+    from dsptoolbox_amd.standard.enums import SpectrumMethod
+    monkeypatch.setattr(backend, "SPEC_PRECISION", "auto")
+    meta, z = load_golden("api_holes")
+    ctx = get_context()
+    n_seen = 0
+    for c in meta["cases"]:
+        if c["kind"] != "csm_short_median":
+            continue
+        sig = dsp.Signal(None, z["csm70_x"][:c["samples"]].copy(), meta["fs"])
+        sig.set_spectrum_parameters(method=SpectrumMethod.WelchPeriodogram, window_length_samples=c["W"],
+                                    scaling=SpectrumScaling[c["scaling"]], average="median")
+        ctx.routes()
+        f, m = sig.get_csm()
+        assert ctx.routes() == {"welch_f64_frames", "csm_f64_median"}
+        assert m.shape == (c["W"] // 2 + 1, c["channels"], c["channels"]) and m.dtype == np.complex128
+        e = relmax(m[::c["bin_step"]][1:], z[c["key"]][1:])
+        assert e < 1e-11, (c, e)
+        assert np.array_equal(m[1:], np.conj(np.swapaxes(m[1:], 1, 2)))
+        n_seen += 1
+    assert n_seen == 2
+    rng = np.random.default_rng(91)
+    worst = 0.0
+    for C, W, n_frames, det, sc in ((2, 64, 1, False, SpectrumScaling.FFTBackward), (5, 256, 2, True, SpectrumScaling.PowerSpectrum),
+                                    (33, 64, 9, True, SpectrumScaling.AmplitudeSpectralDensity),
+                                    (7, 128, 64, False, SpectrumScaling.PowerSpectralDensity),
+                                    (3, 32, 65, True, SpectrumScaling.FFTForward), (40, 16, 127, True, SpectrumScaling.FFTOrthogonal),
+                                    (4, 4096, 6, True, SpectrumScaling.AmplitudeSpectrum)):
+        n = (n_frames - 1) * (W // 2) + 3
+        x = 0.2 * rng.standard_normal((n, C)) + 0.3 * rng.standard_normal(n)[:, None]
+        ctx.routes()
+        f, m = backend._csm_welch(x, 48000, W, Window.Hann, 50, det, "median", sc)
+        assert ctx.routes() == {"welch_f64_frames", "csm_f64_median"}, (C, W, n_frames)
+        rf, rm = orc.csm_welch(x, 48000, W, "hann", 50, det, "median", sc.name)
+        lo = 1 if det else 0
+        worst = max(worst, relmax(m[lo:], rm[lo:]))
+    assert worst < 1e-11, worst
+    with pytest.raises(NotImplementedError, match="more than 128 frames"):  # the C entry point itself: two frames a lane
+        x = np.zeros((129 * 8, 2))
+        out = np.empty((9, 2, 2), dtype=np.complex128)
+        w = np.ones(16)
+        ctx.check(ctx.lib.ds_csm_x64(ctx.handle, x.ctypes.data, 2, x.shape[0], 16, 8, 129, w.ctypes.data, 0, 1, 0, 1.0, 1.0, 0,
+                                     out.ctypes.data), "ds_csm_x64")
+
+
 @pytest.mark.parametrize("W", [32768, 65536, 131072, 262144])
 def test_short_estimates_with_long_windows_hold_1e6(W, monkeypatch):
     """The same for windows of 2^15 ... 2^18 samples -- where estimates are short almost by definition (a 2^20-sample

@@ -476,6 +476,9 @@ def test_api_holes_host_side():
         elif c["kind"] == "csm_short_many_channels":
             f, m = orc.csm_welch(z["csm70_x"], fs, c["W"], "hann", 50, True, "mean", c["scaling"])
             close(m[::c["bin_step"]], z[c["key"]], 1e-12)
+        elif c["kind"] == "csm_short_median":
+            f, m = orc.csm_welch(z["csm70_x"][:c["samples"]], fs, c["W"], "hann", 50, True, "median", c["scaling"])
+            close(m[::c["bin_step"]][1:], z[c["key"]][1:], 1e-12)
 
 
 def test_gen_golden_writes_every_fixture():
