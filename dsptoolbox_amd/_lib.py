@@ -69,6 +69,8 @@ SIGNATURES = {
                              C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, c32_p]),
     "ds_welch_csd": (C.c_int, [ctx_p, f32_p, f32_p, C.c_int, i64, C.c_int, C.c_int, C.c_int, f32_p,
                                C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, c32_p]),
+    "ds_welch_csd_f64": (C.c_int, [ctx_p, C.c_void_p, C.c_void_p, C.c_int, i64, C.c_int, C.c_int, C.c_int, f32_p,
+                                   C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, c32_p]),
     "ds_band_power_dev": (C.c_int, [ctx_p, c32_p, C.c_int, i64, f32_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                     C.c_int, f32_p]),
     "ds_band_power": (C.c_int, [ctx_p, c32_p, C.c_int, i64, f32_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,

@@ -195,6 +195,13 @@ def _welch(x, y, fs_hz: int, window_type, window_length_samples: int, overlap_pe
                                            _ptr(out)), "ds_welch_psd_f64")
         res = out.astype(np.complex128 if avg else np.float64)
         return res if multi else res[:, 0]
+    if not auto and _fusable(x) and _fusable(y):
+        n, n_ch = x.shape
+        out = np.empty((B, n_ch), dtype=np.complex64)
+        ctx.check(ctx.lib.ds_welch_csd_f64(ctx.handle, _ptr(x), _ptr(y), n_ch, n, W, hop, n_frames, _ptr(w32),
+                                           int(bool(detrend)), avg, amp, norm_scale, factor, phys,
+                                           _ptr(out)), "ds_welch_csd_f64")
+        return _widen(out)
     xp = _planar_f32(x)
     n_ch, n = xp.shape
     if auto:
@@ -218,7 +225,7 @@ def _welch(x, y, fs_hz: int, window_type, window_length_samples: int, overlap_pe
 # (transfer_functions.compute_transfer_function): "auto" takes the float64 route
 # (ds_welch_tf_x64: float64 transforms, sums and finish, the reference's own precision) when the
 # problem is small -- frame spectra of all channels <= 64 MB, window <= 262144 (median averaging: at
-# most 4096 frames) -- or when it is SHORT: fewer than 128 frames (and <= 1 GB of frame spectra), where
+# most 4096 frames) -- or when it is SHORT: fewer than 128 frames (and <= 1.25 GB of frame spectra), where
 # an fp32 estimate has too few frames to average its transform rounding down (the two sweep cases of
 # round 2 that reached 1.1e-6 / 1.8e-6 in the coherence had 98 and 110 frames of 8192 samples: they are
 # tests now) --
@@ -227,12 +234,13 @@ def _welch(x, y, fs_hz: int, window_type, window_length_samples: int, overlap_pe
 TF_PRECISION = os.environ.get("DSPTOOLBOX_AMD_TF_PRECISION", "auto")
 _X64_AUTO_BYTES = 64 << 20
 _X64_MAX_WINDOW = 262144  # (16384 until round 4: k_frames_cls / k_split of kernels_welch_f64.hpp carry it to the reference's limit)
-_X64_SHORT_BYTES = 256 << 20  # (1 GB in round 3: 64 channels x 100 frames of 8192 samples took the slow route)
+_X64_SHORT_BYTES = 1280 << 20  # frame spectra of a short estimate (transfer functions, auto / cross spectra): see _short_bytes
+_X64_MATRIX_BYTES = 256 << 20  # ... of a short cross-spectral matrix (float64 pair sums grow with channels^2), and of the matrix itself
 
 
 # The same for the Welch spectra themselves (get_spectrum with the Welch method: ds_welch_psd / ds_welch_csd) and
 # the cross-spectral matrix (get_csm: ds_csm): "auto" sends SHORT estimates -- fewer than 128 frames, frame
-# spectra <= 256 MB, window <= 262144; the matrix: up to 1024 channels, <= 256 MB of matrices -- through
+# spectra <= 1.25 GB, window <= 262144; the matrix: up to 1024 channels, <= 256 MB of frame spectra and of matrices -- through
 # ds_welch_spec_x64 / ds_csm_x64; "f32" keeps the fp32 kernels for every shape.  Environment:
 # DSPTOOLBOX_AMD_SPEC_PRECISION.  (tests/sweeps/edge_welch.py, round 4: fp32 cross spectra and matrices of
 # one to five frames reach 2-3e-6 of the largest element under the amplitude scalings.)
@@ -240,22 +248,25 @@ SPEC_PRECISION = os.environ.get("DSPTOOLBOX_AMD_SPEC_PRECISION", "auto")
 
 
 def _short_bytes(W: int) -> int:
-    """Byte cap of a short estimate's frame spectra on the float64 route: 256 MB, five times that for windows beyond 16384
-    samples -- their frames are few by nature and the fp32 rounding of a 2^15 ... 2^18-point transform is the largest
-    (tests/sweeps/fuzz_long_windows.py: 37 frames of 65536 samples, 16 channels, 310 MB: coherence 1.2e-6 on fp32).  At 50 %
-    overlap the frame spectra of a signal are 16 bytes per sample whatever the window, so 1.25 GB is 64 + 1 channels x 2^20
-    samples: 4 ... 19 ms of float64 kernels there (tools/dbg/x64_long_time.py) beside ~15 ms of host conversion and PCIe."""
-    return _X64_SHORT_BYTES if W <= 16384 else 5 * _X64_SHORT_BYTES
+    """Byte cap of a short estimate's frame spectra on the float64 route: 1.25 GB for every window (at 50 % overlap the frame
+    spectra of a signal are 16 bytes per sample whatever the window, so this is 64 + 1 channels x 2^20 samples).  It was 256 MB up
+    to 16384-sample windows until round 5 (the float64 KERNELS are 5-8 x slower than the fp32 ones: 3.5 against 0.4 ms at
+    1 GB); measured end to end through this host API with the reference's float64 arrays (tools/x64_cap_time.py,
+    profiles/r05_sweeps.txt) the float64 route costs the same or less -- 13.4 against 12.6 ms at 1 GB of 8192-sample frames, 8.8
+    against 22.6 ms and 3.7 against 6.2 ms at 0.5 / 0.3 GB of 16384-sample frames: the arrays cross PCIe as they are instead of
+    through a host cast -- and the estimates of 45 ... 61 frames of 8192 / 16384 samples that the randomized sweeps found at
+    1.0-1.7e-6 in the coherence on the fp32 kernels (20 + 20 and 33 + 33 channels: 320-530 MB) now take it."""
+    return _X64_SHORT_BYTES
 
 
-def _x64_short(precision, n_spectra: int, n_frames: int, W: int, average: str) -> bool:
+def _x64_short(precision, n_spectra: int, n_frames: int, W: int, average: str, cap: int | None = None) -> bool:
     """Does a SHORT estimate of `n_spectra` channel spectra take the float64 route?"""
     assert precision in ("auto", "f32"), "DSPTOOLBOX_AMD_SPEC_PRECISION: 'auto' or 'f32'"
     if precision != "auto" or W > _X64_MAX_WINDOW or n_frames >= 128:
         return False
     if average != "mean" and n_frames > 4096:
         return False
-    return n_spectra * n_frames * (W // 2 + 1) * 16 <= _short_bytes(W)
+    return n_spectra * n_frames * (W // 2 + 1) * 16 <= (_short_bytes(W) if cap is None else cap)
 
 
 def _tf_x64_applies(precision, n_cx: int, n_cy: int, n_frames: int, W: int, average: str) -> bool:
@@ -757,8 +768,8 @@ def _csm_welch(time_data, sampling_rate_hz: int, window_length_samples: int, win
     hop, n_frames = _welch_framing(n, W, overlap_percent, window)
     amp, norm_scale, factor, phys = _finish_params(scaling, W, sampling_rate_hz, window)
     B = W // 2 + 1
-    if n_ch <= 1024 and _x64_short(SPEC_PRECISION, n_ch, n_frames, W, average) \
-            and B * n_ch * n_ch * 16 <= _X64_SHORT_BYTES:  # (the matrix itself, complex128, crosses PCIe too)
+    if n_ch <= 1024 and _x64_short(SPEC_PRECISION, n_ch, n_frames, W, average, cap=_X64_MATRIX_BYTES) \
+            and B * n_ch * n_ch * 16 <= _X64_MATRIX_BYTES:  # (the matrix itself, complex128, crosses PCIe too)
         # short estimate: float64 end to end on the device (ds_csm_x64)
         x64 = np.ascontiguousarray(td.reshape(n, n_ch) if td.ndim == 2 else td[:, None], dtype=np.float64)
         out64 = np.empty((B, n_ch, n_ch), dtype=np.complex128)
@@ -778,7 +789,7 @@ def _csm_welch(time_data, sampling_rate_hz: int, window_length_samples: int, win
         ctx.check(ctx.lib.ds_csm(ctx.handle, _ptr(xp), n_ch, n, W, hop, n_frames, _ptr(w32),
                                  int(bool(detrend)), DS_AVG[average], amp, norm_scale, factor, phys,
                                  _ptr(out)), "ds_csm")
-    return np.fft.rfftfreq(W, 1 / sampling_rate_hz), out.astype(np.complex128)
+    return np.fft.rfftfreq(W, 1 / sampling_rate_hz), _widen(out)
 
 
 class DeviceCSM:
@@ -792,7 +803,7 @@ class DeviceCSM:
         self.n_bins = len(freqs_hz)
 
     def to_host(self) -> np.ndarray:
-        return self.buf.to_array((self.n_bins, self.n_ch, self.n_ch), np.complex64).astype(np.complex128)
+        return _widen(self.buf.to_array((self.n_bins, self.n_ch, self.n_ch), np.complex64))
 
     def free(self):
         self.buf.free()

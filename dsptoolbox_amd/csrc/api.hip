@@ -3294,11 +3294,11 @@ extern "C" int ds_welch_psd_f64(ds_ctx* c, const double* x, int n_cx, int64_t n_
                           norm_scale, factor, halve_edges, psd);
 }
 
-extern "C" int ds_welch_csd(ds_ctx* c, const float* x, const float* y, int n_ch, int64_t n_samples,
-                            int W, int hop, int n_frames, const float* window, int detrend,
-                            int average, int amp_sqrt, double norm_scale, double factor,
-                            int halve_edges, ds_c32* csd) {
-    if (!c || !x || !y || !window || !csd) return fail(c, DS_ERR_ARG, "ds_welch_csd: null argument");
+// x / y: planar float32 [n_ch][n_samples], or x64 / y64: the reference's (n_samples, n_ch) float64 arrays as they are
+static int welch_csd_host(ds_ctx* c, const float* x, const float* y, const double* x64, const double* y64, int n_ch,
+                          int64_t n_samples, int W, int hop, int n_frames, const float* window, int detrend, int average,
+                          int amp_sqrt, double norm_scale, double factor, int halve_edges, ds_c32* csd) {
+    if (!c || (!x && !x64) || (!y && !y64) || !window || !csd) return fail(c, DS_ERR_ARG, "ds_welch_csd: null argument");
     if (n_ch <= 0 || n_samples <= 0 || W <= 0) return fail(c, DS_ERR_ARG, "ds_welch_csd: bad shape");
     size_t nx = (size_t)n_ch * n_samples, no = (size_t)(W / 2 + 1) * n_ch;
     CHK(stage_reserve(c, 2 * Carver::pad(nx * 4) + Carver::pad((size_t)W * 4) + Carver::pad(no * 8)));
@@ -3307,12 +3307,32 @@ extern "C" int ds_welch_csd(ds_ctx* c, const float* x, const float* y, int n_ch,
     float* dy = cv.take<float>(nx);
     float* dw = cv.take<float>(W);
     float2* dc = cv.take<float2>(no);
-    CHK(ds_upload(c, dx, x, nx * 4));
-    CHK(ds_upload(c, dy, y, nx * 4));
+    if (x64) {
+        CHK(upload_planar_f64(c, x64, n_samples, n_ch, dx, n_samples));
+        CHK(upload_planar_f64(c, y64, n_samples, n_ch, dy, n_samples));
+    } else {
+        CHK(ds_upload(c, dx, x, nx * 4));
+        CHK(ds_upload(c, dy, y, nx * 4));
+    }
     CHK(ds_upload(c, dw, window, (size_t)W * 4));
     CHK(welch_csd_dev(c, dx, dy, n_ch, n_samples, n_samples, W, hop, n_frames, dw, detrend, average,
                       amp_sqrt, norm_scale, factor, halve_edges, (ds_c32*)dc));
     return ds_download(c, csd, dc, no * 8);
+}
+extern "C" int ds_welch_csd(ds_ctx* c, const float* x, const float* y, int n_ch, int64_t n_samples,
+                            int W, int hop, int n_frames, const float* window, int detrend,
+                            int average, int amp_sqrt, double norm_scale, double factor,
+                            int halve_edges, ds_c32* csd) {
+    return welch_csd_host(c, x, y, nullptr, nullptr, n_ch, n_samples, W, hop, n_frames, window, detrend, average, amp_sqrt,
+                          norm_scale, factor, halve_edges, csd);
+}
+extern "C" int ds_welch_csd_f64(ds_ctx* c, const double* x, const double* y, int n_ch, int64_t n_samples,
+                                int W, int hop, int n_frames, const float* window, int detrend,
+                                int average, int amp_sqrt, double norm_scale, double factor,
+                                int halve_edges, ds_c32* csd) {
+    if (!x || !y) return fail(c, DS_ERR_ARG, "ds_welch_csd_f64: null argument");
+    return welch_csd_host(c, nullptr, nullptr, x, y, n_ch, n_samples, W, hop, n_frames, window, detrend, average, amp_sqrt,
+                          norm_scale, factor, halve_edges, csd);
 }
 
 static int csm_host(ds_ctx* c, const float* x, const double* x64, int n_ch, int64_t n_samples, int W, int hop,

@@ -206,6 +206,12 @@ int ds_welch_csd(ds_ctx* ctx, const float* x, const float* y, int n_ch,
                  int64_t n_samples, int W, int hop, int n_frames, const float* window,
                  int detrend, int average, int amp_sqrt, double norm_scale, double factor,
                  int halve_edges, ds_c32* csd);
+/* ... taking the reference's (n_samples, n_ch) float64 C-order arrays as they are (cast + transpose in host threads
+ * straight into page-locked upload chunks, like ds_welch_psd_f64 / ds_welch_tf_f64)                                  */
+int ds_welch_csd_f64(ds_ctx* ctx, const double* x, const double* y, int n_ch,
+                     int64_t n_samples, int W, int hop, int n_frames, const float* window,
+                     int detrend, int average, int amp_sqrt, double norm_scale, double factor,
+                     int halve_edges, ds_c32* csd);
 
 /* ---- band powers of a spectrogram: replaces np.tensordot(mel_filters, |stft|^2) + to_db in
  * log_mel_spectrogram / mfcc, transforms/transforms.py:181-184, 421-429.

@@ -178,14 +178,19 @@ def test_compute_transfer_function_validation():
 
 def test_precision_routing_rules():
     """Which estimates the host mirror sends through the float64 kernels: short ones (fewer than 128
-    frames, frame spectra up to 256 MB) for every window the reference allows -- 2^18 samples since round 4 --, small
+    frames, frame spectra up to 1.25 GB; matrices 256 MB) for every window the reference allows -- 2^18 samples since round 4 --, small
     transfer-function problems, nothing under "f32"; median averaging up to 4096 frames; "f64" raises where the route ends."""
     assert backend._x64_short("auto", 2, 5, 262144, "mean") and backend._x64_short("auto", 3, 1, 32768, "median")
     assert not backend._x64_short("auto", 2, 5, 524288, "mean")       # beyond the reference's longest window
     assert not backend._x64_short("auto", 64, 127, 262144, "mean")    # 17 GB of frame spectra
-    assert backend._x64_short("auto", 10, 13, 262144, "mean")         # 272 MB: long windows have a 1.25 GB cap ...
+    assert backend._x64_short("auto", 10, 13, 262144, "mean")         # 272 MB: the cap is 1.25 GB ...
     assert backend._tf_x64_applies("auto", 1, 64, 8, 262144, "mean")     # ... = 64 + 1 channels x 2^20 samples
-    assert not backend._x64_short("auto", 64, 100, 8192, "mean")      # ... 420 MB of 8192-sample frames stay on fp32 (256 MB)
+    # ... for every window since round 5 (it was 256 MB up to 16384 samples: end to end the float64 route costs no more,
+    # tools/x64_cap_time.py): 420 MB of 8192-sample frames, and the 20 + 20 channels x 61 frames of 16384 samples of the sweeps
+    assert backend._x64_short("auto", 64, 100, 8192, "mean") and backend._tf_x64_applies("auto", 20, 20, 61, 16384, "mean")
+    assert backend._x64_short("auto", 64, 127, 16384, "mean") and not backend._x64_short("auto", 128, 127, 16384, "mean")  # 1.0 / 2.0 GB
+    # the matrix keeps 256 MB (its float64 pair sums grow with the square of the channel count)
+    assert not backend._x64_short("auto", 64, 100, 8192, "mean", cap=backend._X64_MATRIX_BYTES)
     assert not backend._x64_short("auto", 2, 128, 1024, "mean") and not backend._x64_short("f32", 2, 5, 1024, "mean")
     assert backend._tf_x64_applies("auto", 1, 3, 7, 131072, "mean") and backend._tf_x64_applies("auto", 1, 2, 2000, 256, "mean")
     assert not backend._tf_x64_applies("auto", 1, 64, 511, 4096, "mean")  # the headline shape stays on the fp32 kernels

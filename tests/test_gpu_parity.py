@@ -1362,7 +1362,16 @@ def test_fused_float64_upload_is_the_same_computation():
         psd_a = backend._welch(y, None, 48000, Window.Hann, 1024, 50, True, "mean", SpectrumScaling.FFTBackward)
         psd_b = backend._welch(yf, None, 48000, Window.Hann, 1024, 50, True, "mean", SpectrumScaling.FFTBackward)
         assert np.array_equal(psd_a, psd_b, equal_nan=True), (n, c)
+        # cross spectra of two such arrays: ds_welch_csd_f64 (round 5) against numpy's cast + ds_welch_csd
+        from dsptoolbox_amd._lib import get_context
+        y2 = np.ascontiguousarray(y[:, ::-1]) + 0.1 * x
+        get_context().routes()
+        csd_a = backend._welch(y, y2, 48000, Window.Hann, 1024, 50, True, "mean", SpectrumScaling.PowerSpectralDensity)
+        csd_b = backend._welch(yf, np.asfortranarray(y2), 48000, Window.Hann, 1024, 50, True, "mean", SpectrumScaling.PowerSpectralDensity)
+        assert csd_a.dtype == np.complex128 and np.array_equal(csd_a, csd_b, equal_nan=True), (n, c)
         if c <= 8:
+            rk = orc.welch(y, y2, 48000, "hann", 1024, 50, True, "mean", "PowerSpectralDensity")
+            assert relmax(csd_a[1:], rk[1:]) < TOL
             for sc in (SpectrumScaling.FFTBackward, SpectrumScaling.AmplitudeSpectrum, SpectrumScaling.PowerSpectrum):
                 t_a, f_a, st_a = backend._stft(y, 48000, 1024, Window.Hann, 50, None, False, True, sc)
                 t_b, f_b, st_b = backend._stft(yf, 48000, 1024, Window.Hann, 50, None, False, True, sc)
@@ -2221,6 +2230,37 @@ def test_csm_short_estimate_of_70_channels(monkeypatch):
         assert np.array_equal(m, np.conj(np.swapaxes(m, 1, 2)))
         n_seen += 1
     assert n_seen == 2
+
+
+def test_sweep_shapes_over_the_old_byte_cap_take_float64(monkeypatch):
+    """profiles/r05_sweeps.txt: paired-input estimates of 45 ... 61 frames of 8192 / 16384 samples read 1.0-1.7e-6 in the
+    coherence at a null of the response on the fp32 kernels, and their 320-530 MB of frame spectra were over the 256 MB cap of
+    the short-estimate rule.  The cap is 1.25 GB for every window now: through the reference-shaped API such an estimate
+    takes the float64 kernels (a response with a prescribed null at the Nyquist bin; 20 + 20 channels, 61 frames of 16384)."""
+    import dsptoolbox_amd as dsp
+    from dsptoolbox_amd._lib import get_context
+    from dsptoolbox_amd.transfer_functions import TransferFunctionType
+    monkeypatch.setattr(backend, "TF_PRECISION", "auto")
+    rng = np.random.default_rng(306)
+    W, C, n = 16384, 20, 495295
+    x = rng.standard_normal((n, C)) * 0.4
+    h = rng.standard_normal((8, C)) * 0.5 + 1.0
+    sign = (-1.0) ** np.arange(8)
+    h[7] -= (sign @ h - 0.01) / sign[7]  # the response at the Nyquist bin: 0.01 (its maximum is ~3)
+    y = np.stack([np.convolve(x[:, j], h[:, j])[:n] for j in range(C)], axis=1) + 0.01 * rng.standard_normal((n, C))
+    hop, n_frames = backend._welch_framing(n, W, 50.0, backend._window_array(Window.Hann, W))
+    assert n_frames == 61 and 2 * C * n_frames * (W // 2 + 1) * 16 > (256 << 20)
+    xs, ys = dsp.Signal(None, x, 48000), dsp.Signal(None, y, 48000)
+    xs.set_spectrum_parameters(window_length_samples=W)
+    ctx = get_context()
+    ctx.routes()
+    sp = dsp.transfer_functions.compute_transfer_function(ys, xs, W, TransferFunctionType.H1)
+    seen = ctx.routes()
+    assert seen and all(r.startswith("welch_f64") for r in seen), seen
+    rt, rc = orc.compute_transfer_function(y, x, 48000, W, "H1")
+    e_tf, e_coh = relmax(np.asarray(sp.spectral_data)[1:], rt[1:]), relmax(np.asarray(sp.coherence)[1:], rc[1:])
+    assert e_tf < 1e-11 and e_coh < 1e-11, (e_tf, e_coh)
+    assert rc[W // 2].min() < 0.6  # (the null is there: on the fp32 kernels this is where the 1e-6 goes)
 
 
 def test_csm_short_estimate_median_in_float64(monkeypatch):

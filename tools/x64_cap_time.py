@@ -34,3 +34,36 @@ for W, n, C, ov in ((16384, 495295, 20, 50.0), (16384, 743700, 33, 25.0), (8192,
         ctx.profile_enable(False)
         print(f"W {W:6d} {C:3d}+{C:3d} ch {frames:4d} frames {mb:7.0f} MB of frame spectra  {prec}: {best:7.1f} ms end to end, "
               f"kernels {sum(v[0] for v in rep.values()):7.2f} ms", flush=True)
+
+# the same question for the Welch spectra themselves and for the cross-spectral matrix (backend._welch / _csm_welch):
+# "auto" with the cap lifted against "f32"
+from dsptoolbox_amd.standard.enums import SpectrumScaling, Window  # noqa: E402
+
+backend._X64_SHORT_BYTES = 1 << 40
+for W, n, C in ((8192, 2**19, 64), (4096, 2**18, 64), (16384, 2**19, 33), (1024, 2**16, 64)):
+    y = rng.standard_normal((n, C))
+    x = rng.standard_normal((n, C))
+    frames = int(np.ceil(n / (W // 2)))
+    for what in ("psd", "csd", "csm"):
+        mb = (2 if what == "csd" else 1) * C * frames * (W // 2 + 1) * 16 / 2**20
+        for prec in ("auto", "f32"):
+            backend.SPEC_PRECISION = prec
+            best = 1e9
+            for _ in range(3):
+                t0 = time.perf_counter()
+                if what == "csm":
+                    backend._csm_welch(y, 48000, W, Window.Hann, 50, True, "mean", SpectrumScaling.FFTBackward)
+                else:
+                    backend._welch(y, x if what == "csd" else None, 48000, Window.Hann, W, 50, True, "mean", SpectrumScaling.FFTBackward)
+                best = min(best, (time.perf_counter() - t0) * 1e3)
+            ctx.routes()
+            ctx.profile_enable(True)
+            if what == "csm":
+                backend._csm_welch(y, 48000, W, Window.Hann, 50, True, "mean", SpectrumScaling.FFTBackward)
+            else:
+                backend._welch(y, x if what == "csd" else None, 48000, Window.Hann, W, 50, True, "mean", SpectrumScaling.FFTBackward)
+            ctx.sync()
+            rep = ctx.profile_report()
+            ctx.profile_enable(False)
+            print(f"{what} W {W:6d} {C:3d} ch {frames:4d} frames {mb:7.0f} MB of frame spectra  {prec:4s}: {best:7.1f} ms end to end, "
+                  f"kernels {sum(v[0] for v in rep.values()):7.2f} ms  routes {sorted(ctx.routes())[:3]}", flush=True)
