@@ -239,6 +239,19 @@ class Context:
         size = max(4096, 1 << (n - 1).bit_length())
         pool = self.__dict__.setdefault("_result_pool", {})
         lst = pool.setdefault(size, [])
+        if len(lst) > 64:
+            # many results of this size were alive at once (a caller keeping hundreds of spectra): of the blocks whose
+            # arrays are gone by now all but 16 go back to the driver instead of staying page-locked for good
+            keep, spare = [], 0
+            for q, b in lst:
+                if sys.getrefcount(b) <= 3:  # the tuple, the loop variable, getrefcount's argument
+                    spare += 1
+                    if spare > 16:
+                        self.lib.ds_host_free(self.handle, C.c_void_p(q))
+                        continue
+                keep.append((q, b))
+            del q, b
+            lst[:] = keep
         blk = None
         for cand in lst:
             if sys.getrefcount(cand[1]) <= 2:  # the tuple in the list and getrefcount's argument
@@ -248,10 +261,7 @@ class Context:
             p = C.c_void_p()
             self.check(self.lib.ds_host_alloc(self.handle, C.byref(p), size), "ds_host_alloc")
             blk = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(size,))
-            if len(lst) < 16:
-                lst.append((p.value, blk))
-            else:  # (more live results than the pool keeps: this block is simply never reused; freed with the context)
-                self.__dict__.setdefault("_result_overflow", []).append(p.value)
+            lst.append((p.value, blk))
         self.check(self.lib.ds_download(self.handle, blk.ctypes.data, C.c_void_p(dptr), n), "ds_download")
         return blk[:n].view(dtype).reshape(shape)
 

@@ -2232,6 +2232,31 @@ def test_csm_short_estimate_of_70_channels(monkeypatch):
     assert n_seen == 2
 
 
+def test_result_pool_gives_page_locked_blocks_back():
+    """Context.download_result: the array returned owns a block of the context's page-locked pool until the last view of it
+    is gone; a caller that kept many results alive does not leave their blocks page-locked for good (all but 16 spare
+    ones go back to the driver at the next call)."""
+    import gc
+    from dsptoolbox_amd._lib import DeviceBuffer, get_context
+    ctx = get_context()
+    src = np.arange(3000, dtype=np.float32)
+    d = DeviceBuffer.from_array(ctx, src)
+    size = 1 << (src.nbytes - 1).bit_length()
+    held = [ctx.download_result(d.ptr, (3000,), np.float32) for _ in range(90)]
+    assert all(np.array_equal(h, src) for h in held[::9])
+    assert len({h.ctypes.data for h in held}) == 90  # ninety different blocks
+    pool = ctx._result_pool[size]
+    n_before = len(pool)
+    assert n_before >= 90
+    view = held[5][10:20]  # a view keeps its block
+    del held
+    gc.collect()
+    again = ctx.download_result(d.ptr, (3000,), np.float32)
+    assert np.array_equal(again, src) and np.array_equal(view, src[10:20])
+    assert len(pool) <= 16 + 2, (n_before, len(pool))  # sixteen spare ones, the view's, this one's
+    d.free()
+
+
 def test_sweep_shapes_over_the_old_byte_cap_take_float64(monkeypatch):
     """profiles/r05_sweeps.txt: paired-input estimates of 45 ... 61 frames of 8192 / 16384 samples read 1.0-1.7e-6 in the
     coherence at a null of the response on the fp32 kernels, and their 320-530 MB of frame spectra were over the 256 MB cap of

@@ -40,7 +40,10 @@ for W, n, C, ov in ((16384, 495295, 20, 50.0), (16384, 743700, 33, 25.0), (8192,
 from dsptoolbox_amd.standard.enums import SpectrumScaling, Window  # noqa: E402
 
 backend._X64_SHORT_BYTES = 1 << 40
-for W, n, C in ((8192, 2**19, 64), (4096, 2**18, 64), (16384, 2**19, 33), (1024, 2**16, 64)):
+# (100 frames of 4096 samples x 64 channels is the advisor's example of a shape the fp32 register kernels handle in well
+# under a millisecond: what does the CALL cost on either route?)
+for W, n, C in ((8192, 2**19, 64), (4096, 2**18, 64), (16384, 2**19, 33), (1024, 2**16, 64), (4096, 100 * 2048, 64), (1024, 100 * 512, 64),
+                (8192, 100 * 4096, 64)):
     y = rng.standard_normal((n, C))
     x = rng.standard_normal((n, C))
     frames = int(np.ceil(n / (W // 2)))
