@@ -778,9 +778,11 @@ def _csm_welch(time_data, sampling_rate_hz: int, window_length_samples: int, win
         ctx.check(ctx.lib.ds_csm_x64(ctx.handle, _ptr(x64), n_ch, n, W, hop, n_frames, _ptr(w64), int(bool(detrend)),
                                      DS_AVG[average], amp, norm_scale, factor, phys, _ptr(out64)), "ds_csm_x64")
         return np.fft.rfftfreq(W, 1 / sampling_rate_hz), out64
-    out = np.empty((B, n_ch, n_ch), dtype=np.complex64)
     w32 = window.astype(np.float32)
     ctx = get_context()
+    # the complex64 matrices land in the context's page-locked staging buffer (the link's full rate, no first-touch faults of
+    # a fresh array) and are widened out of it into the complex128 array the caller gets
+    out = ctx.staging(B * n_ch * n_ch * 8).view(np.complex64).reshape(B, n_ch, n_ch)
     if fused:
         ctx.check(ctx.lib.ds_csm_f64(ctx.handle, _ptr(td), n_ch, n, W, hop, n_frames, _ptr(w32),
                                      int(bool(detrend)), DS_AVG[average], amp, norm_scale, factor, phys,
@@ -803,7 +805,7 @@ class DeviceCSM:
         self.n_bins = len(freqs_hz)
 
     def to_host(self) -> np.ndarray:
-        return _widen(self.buf.to_array((self.n_bins, self.n_ch, self.n_ch), np.complex64))
+        return _widen(self.ctx.download_staged(self.buf.ptr, (self.n_bins, self.n_ch, self.n_ch), np.complex64))
 
     def free(self):
         self.buf.free()
