@@ -545,6 +545,9 @@ def pmc_kernel_current(workload: str, kernel_hints):
     sect = text.split("== kernel code (", 1)[1].split("\n==", 1)[0]
     recorded = {m.group(2).strip(): m.group(1) for m in re.finditer(r"^\s+([0-9a-f]{16})\s+(\S.*)$", sect, re.M)}
     from dsptoolbox_amd import _build
+    m = re.search(r"^== compiler of the profiled library: (.*)$", text, re.M)
+    if m and m.group(1).strip() != _build.compiler_id():
+        return None  # a library built by another compiler: the fingerprints say nothing either way
     now = _build.demangled_fingerprints()
     if not now:
         return None

@@ -131,6 +131,17 @@ def kernel_fingerprints(lib_path: str = LIB_PATH) -> dict:
     return out
 
 
+def compiler_id() -> str:
+    """First two lines of `hipcc --version` (HIP and clang versions): kernel fingerprints are only comparable between
+    libraries built by the same compiler.  "" when hipcc cannot be run."""
+    try:
+        out = subprocess.run([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"), "--version"], stdout=subprocess.PIPE,
+                             stderr=subprocess.STDOUT, text=True, timeout=60).stdout.splitlines()
+    except (OSError, subprocess.SubprocessError):
+        return ""
+    return " | ".join(l.strip() for l in out[:2])
+
+
 def demangled_fingerprints(lib_path: str = LIB_PATH) -> dict:
     """{demangled kernel name as rocprofv3 prints it: fingerprint}; {} without c++filt."""
     fp = kernel_fingerprints(lib_path)

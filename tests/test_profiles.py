@@ -220,5 +220,5 @@ def test_committed_counters_belong_to_the_kernels_that_run_now(workload, hints):
         pytest.skip("library not built (or no c++filt)")
     cur = bench.pmc_kernel_current(workload, hints)
     if cur is None:
-        pytest.skip("the latest summary of this workload predates the fingerprints")
+        pytest.skip("the latest summary of this workload predates the fingerprints, or the library here was built by another compiler")
     assert cur is True, f"profiles/*_{workload}_rocprofv3_summary.txt was taken on another build of {hints[0]}: re-run tools/prof_all.sh"

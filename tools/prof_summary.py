@@ -47,6 +47,7 @@ except Exception as ex:  # noqa: BLE001
     fps = {}
     print("== kernel code: not available (", repr(ex)[:100], ")")
 if fps:
+    print("== compiler of the profiled library:", _build.compiler_id())
     print("== kernel code (sha256[:16] of the gfx950 machine code of the kernels above: dsptoolbox_amd._build.kernel_fingerprints)")
     for k in acc:
         hit = sorted(h for d, h in fps.items() if d[:60] == k)
