@@ -960,6 +960,11 @@ def main():
             t0 = time.perf_counter()
             out["workloads"][name] = workload_entry(args, ctx, dist, name)
             out["workloads"][name]["wall_s_including_setup_and_cpu_leg"] = time.perf_counter() - t0
+        # config 2 with detrend on AND off (the line itself is --detrend 1: the reference's default)
+        keep = args.detrend
+        args.detrend = 0 if keep else 1
+        out["workloads"]["welch_h1_detrend_" + ("off" if keep else "on")] = workload_entry(args, ctx, dist, "welch_h1")
+        args.detrend = keep
         out["workloads"]["short_estimate_api"] = short_estimate_entry()
         out["workloads_wall_s"] = time.perf_counter() - t_all
     print(json.dumps(out), flush=True)

@@ -511,7 +511,9 @@ __device__ __forceinline__ double wave_median(double v0, double v1, int F, int l
         rank0 += (u < v0) ? 1 : 0;
         rank1 += (u < v1 || (u == v1 && j - 64 < lane)) ? 1 : 0;
     }
-    // exactly one frame holds each rank (a NaN among the values ranks nothing: the result is then NaN like the reference's)
+    // exactly one frame holds each rank for finite values (ties by frame index); NaN samples are outside the contract --
+    // they compare false everywhere, so the ranks of the other frames close up and a finite order statistic comes out
+    // where numpy's median would say NaN
     auto value_of_rank = [&](int r) {
         const unsigned long long hit0 = __ballot(lane < F && rank0 == r);
         const unsigned long long hit1 = __ballot(lane + 64 < F && rank1 == r);
