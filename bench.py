@@ -50,7 +50,7 @@ FS = 48000
 # bench kernel name (ds_profile_*) -> how rocprofv3's kernel trace names the same kernel
 KERNEL_HINTS = {"welch4096_main": ("welch4096::k_y3<", "welch4096::k_y<"),
                 "welch1024_main": ("welch1k::k_y<",), "welch_yacc": ("k_yacc",),
-                "fir": ("fir4k::k_fir<", "fir16k::k_fir<true>", "fir16k::k_fir", "k_fir<"),
+                "fir": ("fir4k::k_fir3<", "fir4k::k_fir<", "fir16k::k_fir<true>", "fir16k::k_fir", "k_fir<"),
                 "csm_gemm": ("k_csm_fused", "k_csm_gemm"), "stft": ("k_stft_wave", "k_stft"),
                 "deconv": ("k_deconv_p", "k_deconv3", "k_deconv")}
 

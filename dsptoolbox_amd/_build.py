@@ -22,7 +22,7 @@ RES_PATH = os.path.join(LIB_DIR, "kernel_resources.json")
 NO_SCRATCH = [
     "welch40964k_y3", "welch40964k_x3", "welch40963k_y", "welch40963k_x",
     "stft1k11k_stft_wave", "stft4k6k_stft", "stft4k7k_istft", "stft4k10k_stft_dif", "welch1k3k_y", "welch1k3k_x", "welch8k3k_y", "welch8k3k_x", "welch16k3k_y", "welch16k3k_x", "welchl4k_yc", "welchl4k_xc", "stftl10k_stft_cls",
-    "fir16k5k_firILb1E", "fir4k5k_firILi1E", "fir4k5k_firILi2E", "deconv8k10k_deconv_p", "k_csm_gemm64",
+    "fir16k5k_firILb1E", "fir4k5k_firILi1E", "fir4k5k_firILi2E", "fir4k6k_fir3ILi0E", "deconv8k10k_deconv_p", "k_csm_gemm64",
 ]
 
 
@@ -131,9 +131,10 @@ def kernel_fingerprints(lib_path: str = LIB_PATH) -> dict:
     return out
 
 
-def compiler_id() -> str:
-    """First two lines of `hipcc --version` (HIP and clang versions): kernel fingerprints are only comparable between
-    libraries built by the same compiler.  "" when hipcc cannot be run."""
+INFO_PATH = os.path.join(LIB_DIR, "build_info.json")
+
+
+def _run_compiler_id() -> str:
     try:
         out = subprocess.run([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"), "--version"], stdout=subprocess.PIPE,
                              stderr=subprocess.STDOUT, text=True, timeout=60).stdout.splitlines()
@@ -142,11 +143,7 @@ def compiler_id() -> str:
     return " | ".join(l.strip() for l in out[:2])
 
 
-def demangled_fingerprints(lib_path: str = LIB_PATH) -> dict:
-    """{demangled kernel name as rocprofv3 prints it: fingerprint}; {} without c++filt."""
-    fp = kernel_fingerprints(lib_path)
-    if not fp:
-        return {}
+def _run_demangle(fp: dict) -> dict:
     names = sorted(fp)
     try:
         out = subprocess.run(["c++filt"], input="\n".join(names), stdout=subprocess.PIPE, stderr=subprocess.DEVNULL,
@@ -154,6 +151,44 @@ def demangled_fingerprints(lib_path: str = LIB_PATH) -> dict:
     except (OSError, subprocess.CalledProcessError):
         return {}
     return {d: fp[m] for m, d in zip(names, out)} if len(out) == len(names) else {}
+
+
+def write_build_info() -> dict:
+    """lib/build_info.json: the compiler (first two lines of `hipcc --version`), the source hash of the library beside it and
+    {demangled kernel name: fingerprint}.  Written where the library is BUILT (build_library after a compile,
+    __graft_entry__.build() when the file is missing or belongs to another library) -- it runs hipcc and c++filt, and a
+    process that has initialised the GPU (bench.py; anything under rocprofv3) must not start programs: hipcc --version alone
+    runs rocm_agent_enumerator, a python script, and a GPU box refuses that exec.  Readers use build_info()."""
+    import json
+    info = dict(source_hash=open(HASH_PATH).read().strip() if os.path.exists(HASH_PATH) else "",
+                compiler=_run_compiler_id(), fingerprints=_run_demangle(kernel_fingerprints()))
+    with open(INFO_PATH, "w") as fh:
+        json.dump(info, fh, indent=1, sort_keys=True)
+    return info
+
+
+def build_info() -> dict:
+    """The record write_build_info left for the library in the tree ({} if there is none or it is another library's).
+    No program is started."""
+    import json
+    try:
+        with open(INFO_PATH) as fh:
+            info = json.load(fh)
+        with open(HASH_PATH) as fh:
+            return info if info.get("source_hash") == fh.read().strip() else {}
+    except (OSError, ValueError):
+        return {}
+
+
+def compiler_id() -> str:
+    """The compiler of the library in the tree (kernel fingerprints are only comparable between libraries built by the same
+    one); "" when not recorded."""
+    return build_info().get("compiler", "")
+
+
+def demangled_fingerprints() -> dict:
+    """{demangled kernel name as rocprofv3 prints it: fingerprint} of the library in the tree; {} when not recorded."""
+    return build_info().get("fingerprints", {})
 
 
 LAST_BUILD = None  # "compiled" or "reused" (the library's source hash matched): what build_library last did
@@ -217,6 +252,7 @@ def build_library(force: bool = False, verbose: bool = True) -> str:
                 os.replace(tmp, LIB_PATH)
                 with open(HASH_PATH, "w") as fh:
                     fh.write(hash_at_start + "\n")
+                write_build_info()
                 LAST_BUILD = "compiled"
             finally:
                 if os.path.exists(tmp):

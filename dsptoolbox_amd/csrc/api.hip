@@ -1550,7 +1550,10 @@ static int welch_long_run(ds_ctx* c, const float* x, int n_cx, int64_t ldx, cons
     ay.n_ch = n_cy;
     ay.b = by;
     CHK(dif(ay, n_cy));
-    CHK(launch(c, "welch_long_main", wl::k_yc<false>, dim3((unsigned)(pl.n_chunks * n_cy * R)), wl::NT, wl::LDS_BYTES, ay));
+    if (c->cfg.welch_long_3percu)
+        CHK(launch(c, "welch_long_main@jit", wl::k_yc<false, true>, dim3((unsigned)(pl.n_chunks * n_cy * R)), wl::NT, wl::LDS_BYTES, ay));
+    else
+        CHK(launch(c, "welch_long_main", wl::k_yc<false>, dim3((unsigned)(pl.n_chunks * n_cy * R)), wl::NT, wl::LDS_BYTES, ay));
     CHK(launch(c, "welch_long_fold", wl::k_fold<false>, fold_grid, 256, 0, ay));
     WelchFinArgs f{psx, pxy, pyy, pl.n_chunks, pl.n_chunks, n_cx, n_cy, kind, mode,
                    FinishPar{norm_scale / (double)n_frames, factor, halve_edges, amp_sqrt, nb}, tf, coh};
@@ -2748,8 +2751,9 @@ static int fir_long(ds_ctx* c, const float* x, int n_ch, int64_t ldx, int64_t n_
     return DS_OK;
 }
 
-// Up to 4097 taps: uniformly partitioned overlap-save on the 4096-point register transform, three (one
-// partition) or two (two partitions) independent workgroups per CU (kernels_fir4k.hpp).
+// Up to 4097 taps: uniformly partitioned overlap-save on the 4096-point register transform, three independent
+// workgroups per CU (kernels_fir4k.hpp; two partitions: k_fir3 since round 5, DSPTOOLBOX_AMD_FIR_3PERCU=0 keeps the
+// two-per-CU k_fir<2> with its tap-spectrum prefetch).
 // DSPTOOLBOX_AMD_FIR_4K=0 keeps the block kernels below (A/B); =1 also sends the short filters here.
 static int fir4k_run(ds_ctx* c, const float* x, int n_ch, int64_t ldx, int64_t n_samples, const float* taps,
                      int n_filt, int n_taps, float* y, int64_t ld_y) {
@@ -2771,7 +2775,8 @@ static int fir4k_run(ds_ctx* c, const float* x, int n_ch, int64_t ldx, int64_t n
     const int n_blocks = (int)((n_samples + f4::HOP - 1) / f4::HOP);
     // every workgroup resident at once (3 or 2 per CU): a run of blocks each, one extra forward
     // transform per run with two partitions
-    int chunks = std::max(1, (P == 1 ? 768 : 512) / pairs);
+    const bool three = P == 2 && c->cfg.fir_3percu && !c->cfg.fir_stage;
+    int chunks = std::max(1, ((P == 1 || three) ? 768 : 512) / pairs);
     if (c->cfg.fir_chunks > 0) chunks = c->cfg.fir_chunks;
     chunks = std::min(chunks, n_blocks);
     f4::Args a{x, n_samples, ldx, ld_y, n_ch, n_filt, n_blocks, chunks, c->w4_tables, hp, y};
@@ -2781,6 +2786,7 @@ static int fir4k_run(ds_ctx* c, const float* x, int n_ch, int64_t ldx, int64_t n
         return launch(c, "fir@4k_p2_staged", f4::k_fir<2, true>, dim3((unsigned)(pairs * chunks)), f4::NT, f4::LDS_BYTES + f4::STAGE_BYTES, a);
     }
     if (P == 1) return launch(c, "fir@4k_p1", f4::k_fir<1>, dim3((unsigned)(pairs * chunks)), f4::NT, f4::LDS_BYTES, a);
+    if (three) return launch(c, "fir@4k_p2_3percu", f4::k_fir3<0>, dim3((unsigned)(pairs * chunks)), f4::NT, f4::LDS_BYTES, a);
     return launch(c, "fir@4k_p2", f4::k_fir<2>, dim3((unsigned)(pairs * chunks)), f4::NT, f4::LDS_BYTES, a);
 }
 

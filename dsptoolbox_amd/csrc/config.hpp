@@ -33,6 +33,11 @@ struct ds_config {
     bool fir_generic = false;     // DSPTOOLBOX_AMD_FIR_GENERIC: k_fir<16384> instead of fir16k
     int fir4k_min_taps = 1025;    // DSPTOOLBOX_AMD_FIR_4K: 0 never fir4k, 1 always, n > 1 from n taps on
     bool fir_stage = false;       // DSPTOOLBOX_AMD_FIR_STAGE=1: fir4k's stores through a per-wave LDS strip (16-byte stores; measured, not faster)
+    bool welch_long_3percu = false;  // DSPTOOLBOX_AMD_WELCH_LONG_3PERCU=1: the long-window cross loop (welchl::k_yc) without the next class sequence in
+                                  //   flight through the transform: 152 instead of 174 registers, three workgroups per CU instead of two
+    bool fir_3percu = true;       // DSPTOOLBOX_AMD_FIR_3PERCU=0: two-partition filters (2050 ... 4097 taps) on fir4k::k_fir<2> (two workgroups per CU,
+                                  //   the next filter's tap spectra in flight through the transform) instead of k_fir3 (three per CU, the tap
+                                  //   spectra requested at the top of each filter's pass: 1.66-1.68 against 1.74-1.76 ms on the bench shape)
     bool fir_direct = true;       // DSPTOOLBOX_AMD_FIR_DIRECT=0: no direct float64 sum for a signal shorter than the filter
     bool finish_wide = false;     // DSPTOOLBOX_AMD_FINISH_WIDE=1: k_welch_finish by 64-bit loads (the path of partial slabs >= 4 GiB)
     // ---- tuning overrides (0 = the built-in choice) ------------------------------------------------
@@ -72,6 +77,8 @@ struct ds_config {
         g.finish_wide = is("DSPTOOLBOX_AMD_FINISH_WIDE", '1');
         g.fir_generic = set("DSPTOOLBOX_AMD_FIR_GENERIC");
         g.fir_stage = is("DSPTOOLBOX_AMD_FIR_STAGE", '1');
+        g.fir_3percu = !(set("DSPTOOLBOX_AMD_FIR_3PERCU") && num("DSPTOOLBOX_AMD_FIR_3PERCU") == 0);
+        g.welch_long_3percu = is("DSPTOOLBOX_AMD_WELCH_LONG_3PERCU", '1');
         g.fir_direct = !(set("DSPTOOLBOX_AMD_FIR_DIRECT") && num("DSPTOOLBOX_AMD_FIR_DIRECT") == 0);
         if (const char* e = getenv("DSPTOOLBOX_AMD_FIR_4K")) {
             if (e[0] == '0')

@@ -397,6 +397,99 @@ __global__ __launch_bounds__(NT, P == 1 ? 3 : 2) void k_fir(Args p) {
     }
 }
 
+// ---- two partitions at THREE workgroups per CU (round 5; default, DSPTOOLBOX_AMD_FIR_3PERCU=0 keeps k_fir<2>) -------------
+// k_fir<2> holds the next filter's two tap spectra in flight through the whole inverse transform (64 registers: 214 in
+// all, two workgroups per CU).  Here both are requested at the top of the filter's pass (PF = 0) -- the L2 round trip is
+// covered by the two other workgroups of the CU --: 162 registers, no scratch, the same arithmetic, loads and stores
+// per pass.  Measured on the bench shape (32 x 4097 taps, 8 x 2^22 samples; same box, alternating, three repetitions):
+// 1.664-1.681 ms against 1.739-1.761 ms.  Keeping part of the prefetch does not pay: the first PF = 2 / 4 sixteen-byte
+// values of the first partition still requested in the call-outs of the second transform pass (165 / 168 registers) gave
+// 1.745-1.769 / 1.710-1.725 ms (profiles/r05_one_more_workgroup.txt); PF = 6 spills.
+template <int PF>
+__global__ __launch_bounds__(NT, 3) void k_fir3(Args p) {
+    extern __shared__ __align__(16) float2 lds[];
+    float2* buf = lds;
+    float2* tw2 = lds + 16 * w4::L1S;
+    const int tid = threadIdx.x;
+    const int cp = (int)blockIdx.x / p.n_chunks, q = (int)blockIdx.x - cp * p.n_chunks;
+    const int b0 = (int)((int64_t)q * p.n_blocks / p.n_chunks), b1 = (int)((int64_t)(q + 1) * p.n_blocks / p.n_chunks);
+    const int ca = 2 * cp, cb = ca + 1;
+    const bool vb = cb < p.n_ch;
+    const uint32_t sig_bytes = (uint32_t)(p.n_samples * 4);
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x + (int64_t)ca * p.ldx), 0, (int)sig_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x + (int64_t)(vb ? cb : ca) * p.ldx), 0, vb ? (int)sig_bytes : 0, 0x00020000);
+    w4::Tw6 tw;
+    w4::load_tw6(tw, p.twt, tid);
+    tw2[tid] = p.twt[15 * 256 + tid];
+    float2* tw2p = lds + 16 * w4::L1S + 256;
+    fill_tw2p(tw2p, p.twt, tid);
+    auto forward = [&](float2 (&v)[16], int b) {
+        const int off0 = 4 * ((b - 1) * HOP + tid);
+#pragma unroll
+        for (int n1 = 0; n1 < 16; ++n1)
+            v[n1] = make_float2(w4::ld_sample(ra, off0 + 1024 * n1), w4::ld_sample(rb, off0 + 1024 * n1));
+        w4::fft4096_w(v, tw, buf, tw2, tid);
+    };
+    float2 xp[16];
+    forward(xp, b0 - 1);
+    const __amdgpu_buffer_rsrc_t hrs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float4*>(p.hp), 0, (int)((uint32_t)p.n_filt * 2 * (8 * 256 * 16)), 0x00020000);
+    auto ld_h = [&](int byte_off) {
+        return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(hrs, byte_off, 0, 0));
+    };
+    const int hq = 16 * tid;
+    for (int b = b0; b < b1; ++b) {
+        float2 xc[16];
+        forward(xc, b);
+        const int out_off = 4 * (b * HOP + tid);
+        float4 h0[8];
+#pragma unroll
+        for (int g = 0; g < PF; ++g) h0[g] = ld_h(hq + 4096 * g);
+        for (int f = 0; f < p.n_filt; ++f) {
+            const int hf = hq + f * (2 * 8 * 4096);
+            float4 h1[8];
+#pragma unroll
+            for (int g = 0; g < 8; ++g) h1[g] = ld_h(hf + 4096 * (8 + g));
+#pragma unroll
+            for (int g = PF; g < 8; ++g) h0[g] = ld_h(hf + 4096 * g);
+            float2 v[16];
+#pragma unroll
+            for (int g = 0; g < 8; ++g) {
+                v[2 * g] = cmul(xc[2 * g], make_float2(h0[g].x, h0[g].y));
+                v[2 * g + 1] = cmul(xc[2 * g + 1], make_float2(h0[g].z, h0[g].w));
+            }
+#pragma unroll
+            for (int g = 0; g < 8; ++g) {
+                const float2 a = xp[2 * g], c = xp[2 * g + 1];
+                v[2 * g].x = fmaf(a.x, h1[g].x, fmaf(-a.y, h1[g].y, v[2 * g].x));
+                v[2 * g].y = fmaf(a.x, h1[g].y, fmaf(a.y, h1[g].x, v[2 * g].y));
+                v[2 * g + 1].x = fmaf(c.x, h1[g].z, fmaf(-c.y, h1[g].w, v[2 * g + 1].x));
+                v[2 * g + 1].y = fmaf(c.x, h1[g].w, fmaf(c.y, h1[g].z, v[2 * g + 1].y));
+            }
+            const int hn = hq + min(f + 1, p.n_filt - 1) * (2 * 8 * 4096);
+            ifft4096_wi(
+                v, tw, buf, tw2p, tid, [&](int) {},
+                [&](int g) {
+                    if (2 * g < PF) {
+                        h0[2 * g] = ld_h(hn + 4096 * (2 * g));
+                        h0[2 * g + 1] = ld_h(hn + 4096 * (2 * g + 1));
+                    }
+                });
+            float* __restrict__ ya = p.y + ((int64_t)f * p.n_ch + ca) * p.ld_y;
+            const __amdgpu_buffer_rsrc_t oa = __builtin_amdgcn_make_buffer_rsrc(ya, 0, (int)sig_bytes, 0x00020000);
+            const __amdgpu_buffer_rsrc_t ob = __builtin_amdgcn_make_buffer_rsrc(ya + p.ld_y, 0, vb ? (int)sig_bytes : 0, 0x00020000);
+#pragma unroll
+            for (int m = 0; m < 8; ++m) {
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[8 + m].x), oa, out_off + 1024 * m, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[8 + m].y), ob, out_off + 1024 * m, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < 16; ++s) xp[s] = xc[s];
+    }
+}
+
 // Byte offsets are formed in 32-bit signed arithmetic (4 * sample index) and a NEGATIVE offset is how the zeros
 // in front of the signal are read (the range check sees a huge unsigned number): signals below 2^29 samples.
 // (A wrapped negative register offset whose IMMEDIATE part carries it back over zero inside a wave was seen to

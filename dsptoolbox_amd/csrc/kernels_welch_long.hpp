@@ -212,8 +212,10 @@ __global__ __launch_bounds__(256) void k_px_sum(Args p) {
 
 // ---- output channels: one workgroup per (chunk, channel, class).  grid = n_chunks * n_ch * R ------------------
 // AUTO: auto spectra only (ds_welch_psd): no input spectra, no cross sums.
-template <bool AUTO = false>
-__global__ __launch_bounds__(NT, AUTO ? 3 : 2) void k_yc(Args p) {  // (the cross loop needs 177 registers: the next sequence is 32 of them)
+// JIT (round 5 experiment, DSPTOOLBOX_AMD_WELCH_LONG_3PERCU=1): the cross loop without the next sequence in flight through
+// the transform -- its sixteen loads are issued at the top of the pair's pass, three workgroups per CU cover the round trip.
+template <bool AUTO = false, bool JIT = false>
+__global__ __launch_bounds__(NT, (AUTO || JIT) ? 3 : 2) void k_yc(Args p) {  // (the cross loop needs 177 registers: the next sequence is 32 of them)
     extern __shared__ __align__(16) float2 lds[];
     float2* buf = lds;
     float2* tw2 = lds + 16 * w4::L1S;
@@ -246,7 +248,7 @@ __global__ __launch_bounds__(NT, AUTO ? 3 : 2) void k_yc(Args p) {  // (the cros
         return __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(rs, byte_off, 0, 0));
     };
     float2 nx[16];
-    if (p0 < p1) {
+    if (!JIT && p0 < p1) {
 #pragma unroll
         for (int n1 = 0; n1 < 16; ++n1) nx[n1] = ld8(brs, 8 * (tid + 256 * n1));
     }
@@ -255,8 +257,13 @@ __global__ __launch_bounds__(NT, AUTO ? 3 : 2) void k_yc(Args p) {  // (the cros
     const int pstep = (int)(pair_stride * 8);  // bytes between consecutive pairs (R <= 64: 2 MB)
     for (int pr = p0; pr < p1; ++pr) {
         float2 v[16];
+        if (JIT) {
 #pragma unroll
-        for (int n1 = 0; n1 < 16; ++n1) v[n1] = nx[n1];
+            for (int n1 = 0; n1 < 16; ++n1) v[n1] = ld8(brs, (pr - p0) * pstep + 8 * (tid + 256 * n1));
+        } else {
+#pragma unroll
+            for (int n1 = 0; n1 < 16; ++n1) v[n1] = nx[n1];
+        }
         float2 xw[16];
         // the next pair's sequence (behind the chunk's last pair the range check returns zeros that nobody uses)
         const int boff = (pr + 1 - p0) * pstep + 8 * tid;
@@ -264,8 +271,10 @@ __global__ __launch_bounds__(NT, AUTO ? 3 : 2) void k_yc(Args p) {  // (the cros
         w4::fft4096_wi(
             v, tw, buf, tw2, tid,
             [&](int g) {
+                if (!JIT) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) nx[4 * g + j] = ld8(brs, boff + 2048 * (4 * g + j));
+                    for (int j = 0; j < 4; ++j) nx[4 * g + j] = ld8(brs, boff + 2048 * (4 * g + j));
+                }
             },
             [&](int g) {
                 if (!AUTO) {

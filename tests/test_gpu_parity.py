@@ -2460,7 +2460,7 @@ SWITCH_ROUTES = [
     # (environment, golden subset, launch names (ds_routes) that must / must not appear)
     ({}, [lambda: _welch_golden_body(), lambda: _welch4096_golden(), lambda: test_stft_golden(), lambda: _csm_golden_body(),
           lambda: test_deconvolve_batch_8192(), lambda: test_fir_bank_4097_taps(), lambda: test_istft_golden_and_round_trip("istft")],
-     {"welch1024_main", "welch4096_main@3", "stft@wave", "csm_gemm@b3", "deconv@8k_persist", "fir@4k_p2", "istft@wave"}, set()),
+     {"welch1024_main", "welch4096_main@3", "stft@wave", "csm_gemm@b3", "deconv@8k_persist", "fir@4k_p2_3percu", "istft@wave"}, {"fir@4k_p2"}),
     ({}, [lambda: test_welch_long_windows_golden()], {"welch_long_main", "welch8192_main"}, {"welch16384_main"}),
     ({"DSPTOOLBOX_AMD_WELCH_GENERIC": "1"}, [lambda: _welch_golden_body(), lambda: test_welch_long_windows_golden()],
      {"welch_xspec"}, {"welch1024_main", "welch8192_main", "welch16384_main", "welch_long_main"}),
@@ -2482,10 +2482,14 @@ SWITCH_ROUTES = [
      {"deconv@8k_persist", "deconv@8k_4percu"}),
     ({"DSPTOOLBOX_AMD_FIR_GENERIC": "1", "DSPTOOLBOX_AMD_FIR_4K": "0"},
      [lambda: test_fir_golden(), lambda: test_fir_16k_blocks_vs_oracle(4097, 12288 * 3, 2)], {"fir@generic"},
-     {"fir@4k_p1", "fir@4k_p2", "fir@16k", "fir@16k_ragged"}),
+     {"fir@4k_p1", "fir@4k_p2", "fir@4k_p2_3percu", "fir@16k", "fir@16k_ragged"}),
+    ({"DSPTOOLBOX_AMD_FIR_3PERCU": "0"}, [lambda: test_fir_bank_4097_taps(), lambda: test_fir_golden(), lambda: _fir_short_signal_on_the_fft_routes()],
+     {"fir@4k_p2"}, {"fir@4k_p2_3percu"}),
+    # (the auto-spectrum loop has three workgroups per CU anyway and keeps its launch name)
+    ({"DSPTOOLBOX_AMD_WELCH_LONG_3PERCU": "1"}, [lambda: test_welch_long_windows_golden()], {"welch_long_main@jit"}, set()),
     ({"DSPTOOLBOX_AMD_FIR_4K": "0"}, [lambda: test_fir_golden(), lambda: test_fir_16k_blocks_vs_oracle(4097, 12288 * 3, 2),
                                       lambda: test_fir_16k_blocks_vs_oracle(4097, 5000, 5),
-                                      lambda: test_fir_bank_4097_taps()], {"fir@16k_ragged", "fir@direct_f64"}, {"fir@4k_p1", "fir@4k_p2"}),
+                                      lambda: test_fir_bank_4097_taps()], {"fir@16k_ragged", "fir@direct_f64"}, {"fir@4k_p1", "fir@4k_p2", "fir@4k_p2_3percu"}),
     ({"DSPTOOLBOX_AMD_FIR_4K": "1"}, [lambda: test_fir_golden(), lambda: test_fir_one_and_two_tap_filters()], {"fir@4k_p1"}, set()),
     ({"DSPTOOLBOX_AMD_CSM_CHUNKS": "3"}, [_csm_frame_chunks_vs_oracle, lambda: _csm_golden_body()], {"csm_gemm@b3"}, set()),
     ({"DSPTOOLBOX_AMD_FIR_STAGE": "1"}, [lambda: test_fir_bank_4097_taps(), lambda: test_fir_golden(), lambda: test_fir_one_and_two_tap_filters()],
@@ -2493,7 +2497,7 @@ SWITCH_ROUTES = [
     ({"DSPTOOLBOX_AMD_W2048_WAVE": "1"}, [lambda: _welch_golden_body()], set(), {"welch2048_main@4k"}),
     ({"DSPTOOLBOX_AMD_FINISH_WIDE": "1"}, [lambda: _welch_golden_body(), lambda: _welch4096_golden(), lambda: test_welch_long_windows_golden()],
      {"welch_finish@wide"}, {"welch_finish"}),
-    ({"DSPTOOLBOX_AMD_FIR_DIRECT": "0"}, [lambda: test_fir_golden(), lambda: _fir_short_signal_on_the_fft_routes()], {"fir@4k_p2"},
+    ({"DSPTOOLBOX_AMD_FIR_DIRECT": "0"}, [lambda: test_fir_golden(), lambda: _fir_short_signal_on_the_fft_routes()], {"fir@4k_p2_3percu"},
      {"fir@direct_f64"}),
     ({"DSPTOOLBOX_AMD_STFT_GENERIC": "1"}, [lambda: test_stft_and_csm_long_windows_vs_oracle()], set(), {"stft@long", "stft_long_dif"}),
     ({"DSPTOOLBOX_AMD_ISTFT_FUSED": "0"}, [lambda: test_istft_golden_and_round_trip("istft")], {"istft_ola"},
