@@ -19,8 +19,10 @@ from dsptoolbox_amd.standard.enums import SpectrumScaling, Window  # noqa: E402
 from oracle import dsp_oracle as orc  # noqa: E402
 
 warnings.simplefilter("ignore")
-KINDS = ("psd", "csd", "csm", "tf", "coh")
-LIMIT = {"f32": dict(psd=1e-6, csd=5e-6, csm=5e-6, tf=2e-5, coh=2e-5), "auto": {k: 1e-6 for k in KINDS}}
+KINDS = ("psd", "csd", "csm", "csm_median", "tf", "coh")
+# (a median picks single-frame values: the fp32 matrix of one to five frames is only good to ~1e-5; round 5 gave the API's route
+# a float64 median matrix kernel)
+LIMIT = {"f32": dict(psd=1e-6, csd=5e-6, csm=5e-6, csm_median=5e-5, tf=2e-5, coh=2e-5), "auto": {k: 1e-6 for k in KINDS}}
 
 
 def rel(a, b, lo):
@@ -59,6 +61,9 @@ def sweep(mode: str):
                         if C > 1:
                             _, m = backend._csm_welch(y, 48000, W, Window.Hann, 50, det, "mean", sc)
                             note("csm", rel(m, orc.csm_welch(y, 48000, W, "hann", 50, det, "mean", sc.name)[1], lo), case)
+                            if W <= 1024:  # (the oracle's pair loop of median Welch calls)
+                                _, m = backend._csm_welch(y, 48000, W, Window.Hann, 50, det, "median", sc)
+                                note("csm_median", rel(m, orc.csm_welch(y, 48000, W, "hann", 50, det, "median", sc.name)[1], lo), case)
                     for xin in (x, x[:, :1]):
                         yy = y if xin.shape[1] == C else np.stack(
                             [np.convolve(x[:, 0], rng.standard_normal(5))[:n] for _ in range(C)], axis=1)
