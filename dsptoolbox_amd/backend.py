@@ -752,6 +752,9 @@ def _istft(stft, nfft: int, W: int, step: int, window, scale: float, frame_offse
     return _interleaved_f64(out)
 
 
+_STAGED_RESULT_BYTES = 512 << 20  # largest result that goes through the context's page-locked staging buffer (which stays allocated)
+
+
 def _csm_welch(time_data, sampling_rate_hz: int, window_length_samples: int, window_type,
                overlap_percent, detrend: bool, average: str, scaling: SpectrumScaling):
     """-> (f (B,), csm (B, C, C) complex128)."""
@@ -782,7 +785,10 @@ def _csm_welch(time_data, sampling_rate_hz: int, window_length_samples: int, win
     ctx = get_context()
     # the complex64 matrices land in the context's page-locked staging buffer (the link's full rate, no first-touch faults of
     # a fresh array) and are widened out of it into the complex128 array the caller gets
-    out = ctx.staging(B * n_ch * n_ch * 8).view(np.complex64).reshape(B, n_ch, n_ch)
+    # (up to 512 MB; a larger result -- hundreds of channels -- comes back into an ordinary array)
+    nbytes = B * n_ch * n_ch * 8
+    out = (ctx.staging(nbytes).view(np.complex64).reshape(B, n_ch, n_ch) if nbytes <= _STAGED_RESULT_BYTES
+           else np.empty((B, n_ch, n_ch), dtype=np.complex64))
     if fused:
         ctx.check(ctx.lib.ds_csm_f64(ctx.handle, _ptr(td), n_ch, n, W, hop, n_frames, _ptr(w32),
                                      int(bool(detrend)), DS_AVG[average], amp, norm_scale, factor, phys,
@@ -805,7 +811,10 @@ class DeviceCSM:
         self.n_bins = len(freqs_hz)
 
     def to_host(self) -> np.ndarray:
-        return _widen(self.ctx.download_staged(self.buf.ptr, (self.n_bins, self.n_ch, self.n_ch), np.complex64))
+        shape = (self.n_bins, self.n_ch, self.n_ch)
+        if self.n_bins * self.n_ch * self.n_ch * 8 > _STAGED_RESULT_BYTES:
+            return _widen(self.buf.to_array(shape, np.complex64))
+        return _widen(self.ctx.download_staged(self.buf.ptr, shape, np.complex64))
 
     def free(self):
         self.buf.free()
