@@ -212,7 +212,7 @@ def test_kernel_fingerprints_of_the_built_library():
 
 
 @pytest.mark.parametrize("workload,hints", [("welch_h1", ("welch4096::k_y3<",)), ("welch_h1_1024", ("welch1k::k_y<",)),
-                                            ("fir_bank", ("fir4k::k_fir<",)), ("csm", ("k_stft",)), ("csm", ("k_csm_gemm",)),
+                                            ("fir_bank", ("fir4k::k_fir3<",)), ("csm", ("k_stft",)), ("csm", ("k_csm_gemm",)),
                                             ("deconv", ("k_deconv_p",))])
 def test_committed_counters_belong_to_the_kernels_that_run_now(workload, hints):
     """roofline.traffic comes from a committed counter file, so the file must have been taken on
